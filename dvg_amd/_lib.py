@@ -1,0 +1,92 @@
+"""ctypes binding of libdvg_hip.so (the C ABI declared in include/dvg_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is
+absent, `lib()` raises.  Nothing in here touches a GPU; loading works on a CPU-only
+box (the HIP runtime is only initialised by the first kernel launch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdvg_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_l = C.c_long
+
+# name -> (restype, argtypes); must list EVERY symbol of include/dvg_hip.h
+# (tests/test_abi.py parses the header and cross-checks this table).
+SIGNATURES = {
+    "dvg_abi_version": (_i, []),
+    "dvg_last_error": (C.c_char_p, []),
+    "dvg_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_pack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_unpack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_unpack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_conv_stats_rows": (_i, [_i, _i, _i, _i, _i]),
+    "dvg_conv_first_stats_rows": (_i, [_i, _i, _i, _i]),
+    "dvg_conv3x3_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_conv3x3_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_convT3x3_last": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_conv4x4s2_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_conv4x4s2_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_convT4x4s2_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_convT4x4s2_last": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_channel_stats_rows": (_i, [_l]),
+    "dvg_channel_stats": (_i, [_p, _p, _l, _i, _p]),
+    "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p]),
+    "dvg_bn_act_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_gemm_nt_bias_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "dvg_gp_lds_bytes": (C.c_size_t, [_i, _i, _i]),
+    "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _p]),
+    "dvg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class DvgLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the kernel library; raise loudly when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DvgLibraryError(
+                f"{LIB_PATH} not found: the HIP kernel library has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dvg_amd/csrc`). "
+                "There is no CPU/eager fallback for the DVG hot path.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise DvgLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise DvgLibraryError(f"{LIB_PATH} lacks symbol {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+        return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    """Translate a DVG_ERR_* status into a RuntimeError (SURVEY.md §8(b) 'Errors')."""
+    if code != 0:
+        msg = lib().dvg_last_error()
+        raise RuntimeError(f"libdvg_hip {what} failed (code {code}): {msg.decode() if msg else '?'}")

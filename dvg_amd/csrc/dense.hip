@@ -1,0 +1,247 @@
+// Dense ends of the encoder/decoder and the recurrent latent predictor.
+//
+//  * gemm_nt: out = act((a . w^T) * scale + shift) for small M (= batch).  Used for
+//    the encoder head (4x4 valid conv on a 4x4 map = GEMM with K = 16*512,
+//    vgg_64.py:44-48), the decoder stem (1x1 -> 4x4 transposed conv = GEMM with
+//    N = 16*512, vgg_64.py:65-69) and the nn.Linear layers of lstm.py:50,53-55.
+//    HBM/L2-bound on the weight matrix; split-K spreads the K = 8192 head over
+//    the chip.
+//  * lstm_cell: one nn.LSTMCell step (lstm.py:51,68-70).  A wave owns an
+//    8 (batch) x 8 (2 hidden units x 4 gates) block of gate pre-activations with
+//    K split across its 64 lanes; a 63-shuffle butterfly transpose-reduce leaves
+//    exactly one finished pre-activation per lane, and three more shuffles bring
+//    the i,f,g,o of one (batch, unit) together for the state update.
+#include "dvg_common.h"
+
+namespace dvg {
+
+// ------------------------------------------------------------------------------------
+// gemm_nt
+// ------------------------------------------------------------------------------------
+struct GemmParams {
+    const float* a;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    float* out;
+    float* ws;
+    int M, N, K, lda, ldo, period, splitk, kper, act;
+    float slope;
+    int vec;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
+    constexpr int BK = 16, LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[BK * LD];
+    __shared__ __attribute__((aligned(16))) float Ws[BK * LD];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, z = blockIdx.z;
+    const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
+    const int tx = tid & 15, ty = tid >> 4;
+    const int lr = tid >> 2, lq = tid & 3;  // loader: row 0..63, k-quad 0..3
+
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+        const int kk = k0 + lq * 4;
+        if (m0 + lr < p.M) {
+            const float* ap = p.a + (size_t)(m0 + lr) * p.lda + kk;
+            if (p.vec && kk + 3 < kend) av = *reinterpret_cast<const f32x4*>(ap);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < kend) av[e] = ap[e];
+        }
+        if (n0 + lr < p.N) {
+            const float* wp = p.w + (size_t)(n0 + lr) * p.K + kk;
+            if (p.vec && kk + 3 < kend) wv = *reinterpret_cast<const f32x4*>(wp);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < kend) wv[e] = wp[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[(lq * 4 + e) * LD + lr] = av[e];
+            Ws[(lq * 4 + e) * LD + lr] = wv[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[k * LD + ty * 4]);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Ws[k * LD + tx * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], w4[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= p.N) continue;
+            if (p.splitk > 1) {
+                p.ws[((size_t)z * p.M + m) * p.N + n] = acc[i][j];
+            } else {
+                const int c = n % p.period;
+                const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
+                p.out[(size_t)m * p.ldo + n] = apply_act(acc[i][j] * sc + sf, p.act, p.slope);
+            }
+        }
+    }
+}
+
+__global__ void gemm_splitk_reduce_kernel(const GemmParams p) {
+    const long total = (long)p.M * p.N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = i / p.N, n = i % p.N;
+        float s = 0.f;
+        for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * total + i];
+        const int c = n % p.period;
+        const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
+        p.out[(size_t)m * p.ldo + n] = apply_act(s * sc + sf, p.act, p.slope);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// lstm_cell
+// ------------------------------------------------------------------------------------
+template <int NN>
+__device__ __forceinline__ void butterfly_step(float (&v)[64], int lane) {
+    // lanes with bit NN set keep the upper NN values, the others the lower NN; the
+    // half that is not kept goes to the partner lane (lane ^ NN).
+    const bool up = (lane & NN) != 0;
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        const float keep = up ? v[i + NN] : v[i];
+        const float send = up ? v[i] : v[i + NN];
+        v[i] = keep + __shfl_xor(send, NN);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ x, const float* __restrict__ h,
+                                                        const float* __restrict__ c,
+                                                        const float* __restrict__ w_ih,
+                                                        const float* __restrict__ w_hh,
+                                                        const float* __restrict__ b_ih,
+                                                        const float* __restrict__ b_hh, float* __restrict__ h_out,
+                                                        float* __restrict__ c_out, float* __restrict__ gates_out,
+                                                        int B, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 2;
+    const int b0 = blockIdx.y * 32 + wave * 8;
+    if (b0 >= B) return;  // whole wave out of range (wave-uniform; no barriers below)
+
+    float v[64];  // v[b*8 + jj*4 + g]
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = 0.f;
+
+    for (int k0 = lane * 4; k0 < H; k0 += 256) {
+        f32x4 xv[8], hv[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b0 + b < B) {
+                xv[b] = *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + b) * H + k0);
+                hv[b] = *reinterpret_cast<const f32x4*>(h + (size_t)(b0 + b) * H + k0);
+            } else {
+                xv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                hv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = (r & 3) * H + j0 + (r >> 2);
+            const f32x4 wi = *reinterpret_cast<const f32x4*>(w_ih + (size_t)row * H + k0);
+            const f32x4 wh = *reinterpret_cast<const f32x4*>(w_hh + (size_t)row * H + k0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float s = v[b * 8 + r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(xv[b][e], wi[e], s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(hv[b][e], wh[e], s);
+                v[b * 8 + r] = s;
+            }
+        }
+    }
+    // 64 partial sums per lane -> one finished sum per lane (value index == lane)
+    butterfly_step<32>(v, lane);
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+
+    const int b = lane >> 3, jj = (lane >> 2) & 1, g = lane & 3;
+    const int j = j0 + jj;
+    const float pre = v[0] + b_ih[g * H + j] + b_hh[g * H + j];
+    const float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
+    const int q = lane & ~3;
+    const float gi = __shfl(a, q), gf = __shfl(a, q + 1), gg = __shfl(a, q + 2), go = __shfl(a, q + 3);
+    if (b0 + b < B) {
+        if (gates_out) gates_out[(size_t)(b0 + b) * 4 * H + g * H + j] = a;
+        if (g == 0) {
+            const float cn = gf * c[(size_t)(b0 + b) * H + j] + gi * gg;
+            c_out[(size_t)(b0 + b) * H + j] = cn;
+            h_out[(size_t)(b0 + b) * H + j] = go * tanhf(cn);
+        }
+    }
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float* scale, const float* shift, float* out,
+                                    float* workspace, int M, int N, int K, int lda, int ldo, int period, int splitk,
+                                    int act, float slope, void* stream) {
+    DVG_REQUIRE(a && w && out, DVG_ERR_NULL, "dvg_gemm_nt_bias_act: NULL pointer");
+    DVG_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldo >= N, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad shape");
+    DVG_REQUIRE(period > 0 && period <= N && N % period == 0, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad period");
+    DVG_REQUIRE(splitk >= 1 && splitk <= 256, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad splitk");
+    DVG_REQUIRE(splitk == 1 || workspace != nullptr, DVG_ERR_NULL, "dvg_gemm_nt_bias_act: workspace needed");
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad act");
+    GemmParams p{a, w, scale, shift, out, workspace, M, N, K, lda, ldo, period, splitk, 0, act, slope, 0};
+    int kper = (K + splitk - 1) / splitk;
+    kper = ((kper + 15) / 16) * 16;
+    p.kper = kper;
+    p.splitk = (K + kper - 1) / kper;  // drop empty splits
+    p.vec = (K % 4 == 0 && lda % 4 == 0 && aligned16(a) && aligned16(w)) ? 1 : 0;
+    dim3 grid((N + 63) / 64, (M + 63) / 64, p.splitk);
+    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (int e = check_launch("dvg_gemm_nt_bias_act")) return e;
+    if (p.splitk > 1) {
+        const long total = (long)M * N;
+        const unsigned g = (unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("dvg_gemm_nt_bias_act(reduce)");
+    }
+    return DVG_OK;
+}
+
+extern "C" int dvg_lstm_cell(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                             const float* b_ih, const float* b_hh, float* h_out, float* c_out, float* gates_out,
+                             int B, int H, void* stream) {
+    DVG_REQUIRE(x && h && c && w_ih && w_hh && b_ih && b_hh && h_out && c_out, DVG_ERR_NULL,
+                "dvg_lstm_cell: NULL pointer");
+    DVG_REQUIRE(B > 0 && H > 0 && H % 64 == 0, DVG_ERR_SHAPE, "dvg_lstm_cell: H=%d must be a multiple of 64", H);
+    DVG_REQUIRE(h_out != h && c_out != c && h_out != x, DVG_ERR_SHAPE, "dvg_lstm_cell: in-place state update");
+    DVG_REQUIRE(aligned16(x) && aligned16(h) && aligned16(w_ih) && aligned16(w_hh), DVG_ERR_ALIGN,
+                "dvg_lstm_cell: alignment");
+    dim3 grid(H / 2, (B + 31) / 32);
+    hipLaunchKernelGGL(lstm_cell_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, h, c, w_ih, w_hh, b_ih, b_hh,
+                       h_out, c_out, gates_out, B, H);
+    return check_launch("dvg_lstm_cell");
+}

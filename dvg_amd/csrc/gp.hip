@@ -1,0 +1,242 @@
+// Batched sparse variational GP "trigger" (gp_models.py:10-24 + the gpytorch 0.3.x
+// WhitenedVariationalStrategy / GaussianLikelihood / MultivariateNormal arithmetic
+// reached from train.py:225-226,283-284 and generate_frames.py:131,170,229,273,291).
+// Equations of record: DESIGN.md section "GP".
+//
+// One workgroup per latent dimension d (D = 90 independent 1-D GPs).  Everything —
+// RBF covariance assembly over [Z ; x], the MxM and BxB Cholesky factorisations,
+// the triangular solves, predictive mean / covariance, the KL term and the
+// reparameterised sample — stays in LDS (<= ~120 KB at M = 40, B = 128; 33 KB at
+// B = 64).  The factorisations are wave-synchronous (lane = matrix row, row
+// broadcasts through LDS, no workgroup barriers inside the O(n^3) loops) while the
+// other three waves assemble W = L_S^T K_Zx in parallel.
+#include "dvg_common.h"
+
+namespace dvg {
+
+struct GpParams {
+    const float* h;         // [B][D]
+    const float* z;         // [D][M]
+    const float* var_mean;  // [D][M]
+    const float* chol_var;  // [D][M][M]
+    const float* mean_const;
+    const float* outputscale;
+    const float* lengthscale;
+    const float* noise;  // [D] or nullptr
+    const float* eps;    // [D][B] or nullptr
+    float* mean;         // [D][B]
+    float* var;          // [D][B]
+    float* sample;       // [D][B]
+    float* cov;          // [D][B][B]
+    float* kl;           // [D]
+    int B, D, M, train_mode;
+    float jitter;
+};
+
+// In-place lower Cholesky of the n x n matrix A (row stride ld) by ONE wave:
+// lane owns rows lane and lane+64.  Left-looking by columns: column j needs rows'
+// dot products with row j over the already finished columns.
+__device__ void wave_cholesky(float* A, int n, int ld, int lane) {
+    for (int j = 0; j < n; ++j) {
+        float s0 = 0.f, s1 = 0.f;
+        const int i0 = lane, i1 = lane + 64;
+        const bool a0 = i0 >= j && i0 < n, a1 = i1 >= j && i1 < n;
+        if (a0) s0 = A[i0 * ld + j];
+        if (a1) s1 = A[i1 * ld + j];
+        for (int k = 0; k < j; ++k) {
+            const float ljk = A[j * ld + k];
+            if (a0) s0 = fmaf(-A[i0 * ld + k], ljk, s0);
+            if (a1) s1 = fmaf(-A[i1 * ld + k], ljk, s1);
+        }
+        // the diagonal element lives in lane j%64, slot j/64
+        float d = __shfl((j < 64) ? s0 : s1, j & 63);
+        d = sqrtf(fmaxf(d, 1e-12f));
+        const float inv = 1.f / d;
+        if (a0) A[i0 * ld + j] = (i0 == j) ? d : s0 * inv;
+        if (a1) A[i1 * ld + j] = (i1 == j) ? d : s1 * inv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
+    // 256 threads; scratch >= 4 floats
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.M, B = p.B;
+    const int LM = M + 1;   // row stride of the MxM matrices
+    const int LB = B + 2;   // row stride of the M x (B+1) matrices
+    const int LS = B + 1;   // row stride of Sigma
+    float* L = sm;                 // [M][LM]   K_ZZ + jitter -> its Cholesky factor
+    float* Ls = L + M * LM;        // [M][LM]   variational Cholesky factor (lower)
+    float* AK = Ls + M * LM;       // [M][LB]   [K_Zx | m-c] -> L^-1 [K_Zx | m-c]
+    float* Wm = AK + M * LB;       // [M][LB]   L_S^T K_Zx
+    float* zs = Wm + M * LB;       // [M]
+    float* xs = zs + M;            // [B]
+    float* mu = xs + B;            // [B]
+    float* red = mu + B;           // [8]
+    float* Sg = red + 8;           // [B][LS]   predictive covariance (only when needed)
+
+    const float s = p.outputscale[d];
+    const float ell = p.lengthscale[d];
+    const float ninv = -0.5f / (ell * ell);
+    const float c0 = p.mean_const[d];
+    const float noise = p.noise ? p.noise[d] : 0.f;
+    const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
+
+    for (int i = tid; i < M; i += 256) zs[i] = p.z[(size_t)d * M + i];
+    for (int b = tid; b < B; b += 256) xs[b] = p.h[(size_t)b * p.D + d];
+    __syncthreads();
+    for (int i = tid; i < M * M; i += 256) {
+        const int r = i / M, q = i % M;
+        const float dz = zs[r] - zs[q];
+        L[r * LM + q] = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
+    }
+    for (int i = tid; i < M * (B + 1); i += 256) {
+        const int r = i / (B + 1), b = i % (B + 1);
+        float v;
+        if (b < B) {
+            const float dx = zs[r] - xs[b];
+            v = s * expf(dx * dx * ninv);
+        } else {
+            v = p.var_mean[(size_t)d * M + r] - c0;
+        }
+        AK[r * LB + b] = v;
+    }
+    __syncthreads();
+
+    // wave 0: chol(K_ZZ).  waves 1-3: W = L_S^T K_Zx (needs the un-solved K_Zx).
+    if (wave == 0) {
+        wave_cholesky(L, M, LM, lane);
+    } else {
+        for (int i = tid - 64; i < M * B; i += 192) {
+            const int r = i / B, b = i % B;
+            float acc = 0.f;
+            for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], AK[j * LB + b], acc);
+            Wm[r * LB + b] = acc;
+        }
+    }
+    __syncthreads();
+
+    // forward substitution, one thread per column of [K_Zx | m-c]
+    for (int col = tid; col < B + 1; col += 256) {
+        for (int i = 0; i < M; ++i) {
+            float acc = AK[i * LB + col];
+            for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], AK[j * LB + col], acc);
+            AK[i * LB + col] = acc / L[i * LM + i];
+        }
+    }
+    __syncthreads();
+
+    // predictive mean and marginal variance
+    for (int b = tid; b < B; b += 256) {
+        float m = 0.f, qa = 0.f, qw = 0.f;
+        for (int i = 0; i < M; ++i) {
+            const float a = AK[i * LB + b], w = Wm[i * LB + b];
+            m = fmaf(a, AK[i * LB + B], m);
+            qa = fmaf(a, a, qa);
+            qw = fmaf(w, w, qw);
+        }
+        m += c0;
+        mu[b] = m;
+        if (p.mean) p.mean[(size_t)d * B + b] = m;
+        if (p.var) {
+            float dd = s - qa;
+            if (p.train_mode) dd = fmaxf(dd, 0.f);
+            p.var[(size_t)d * B + b] = qw + dd + noise;
+        }
+    }
+
+    if (p.kl != nullptr) {
+        // KL(q(u)||p(u)) = 0.5 [ -log|K| - log|S'| + tr(S'K) + (m-c)^T K^-1 (m-c) - M ],
+        // tr(S'K) = || L^T L_S ||_F^2,  (m-c)^T K^-1 (m-c) = || L^-1 (m-c) ||^2
+        float part = 0.f;
+        for (int i = tid; i < M * M; i += 256) {
+            const int r = i / M, q = i % M;
+            float acc = 0.f;
+            for (int k = (r > q ? r : q); k < M; ++k) acc = fmaf(L[k * LM + r], Ls[k * LM + q], acc);
+            part = fmaf(acc, acc, part);
+        }
+        for (int i = tid; i < M; i += 256) {
+            const float v = AK[i * LB + B];
+            part = fmaf(v, v, part);
+            part -= 2.f * logf(L[i * LM + i]);
+            part -= 2.f * logf(fabsf(Ls[i * LM + i]));
+        }
+        const float tot = block_sum(part, red, tid);
+        if (tid == 0) p.kl[d] = 0.5f * (tot - (float)M);
+    }
+
+    if (need_cov) {
+        __syncthreads();
+        for (int i = tid; i < B * B; i += 256) {
+            const int r = i / B, q = i % B;
+            float acc = 0.f;
+            for (int k = 0; k < M; ++k) {
+                acc = fmaf(Wm[k * LB + r], Wm[k * LB + q], acc);
+                acc = fmaf(-AK[k * LB + r], AK[k * LB + q], acc);
+            }
+            const float dx = xs[r] - xs[q];
+            acc += s * expf(dx * dx * ninv);
+            if (r == q) acc += noise;
+            Sg[r * LS + q] = acc;
+            if (p.cov) p.cov[((size_t)d * B + r) * B + q] = acc;
+        }
+        __syncthreads();
+        if (p.sample != nullptr) {
+            if (wave == 0) wave_cholesky(Sg, B, LS, lane);
+            __syncthreads();
+            for (int b = tid; b < B; b += 256) {
+                float acc = mu[b];
+                for (int j = 0; j <= b; ++j) acc = fmaf(Sg[b * LS + j], p.eps[(size_t)d * B + j], acc);
+                p.sample[(size_t)d * B + b] = acc;
+            }
+        }
+    }
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
+    size_t f = (size_t)2 * M * (M + 1) + (size_t)2 * M * (B + 2) + M + 2 * (size_t)B + 8;
+    if (need_cov) f += (size_t)B * (B + 1);
+    return f * 4;
+}
+
+extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_mean, const float* chol_var,
+                              const float* mean_const, const float* outputscale, const float* lengthscale,
+                              const float* noise, const float* eps, float* mean, float* var, float* sample,
+                              float* cov, float* kl, int B, int D, int M, int train_mode, float jitter,
+                              void* stream) {
+    DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
+                "dvg_gp_predict: NULL input");
+    DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
+                "dvg_gp_predict: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
+    DVG_REQUIRE(sample == nullptr || eps != nullptr, DVG_ERR_NULL, "dvg_gp_predict: sample needs eps");
+    const int need_cov = (cov != nullptr) || (sample != nullptr);
+    const size_t lds = dvg_gp_lds_bytes(B, M, need_cov);
+    DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gp_predict_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
+               B, D, M, train_mode, jitter};
+    hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("dvg_gp_predict");
+}

@@ -1,0 +1,273 @@
+// Weight re-layout, layout converters, train-mode BatchNorm helpers.
+// All HBM-bound elementwise / reduction kernels: 16-byte accesses, grid-stride.
+#include "dvg_common.h"
+
+namespace dvg {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// packed[t][co][ci]  <->  w[co][ci][kh][kw] (conv)  or  w[ci][co][KH-1-kh][KW-1-kw] (convT)
+template <bool TRANSPOSED, bool UNPACK>
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
+                                   int kw) {
+    const long total = (long)cout * cin * kh * kw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the packed tensor [t][co][ci]
+        const int ci = i % cin;
+        long r = i / cin;
+        const int co = r % cout;
+        const int t = r / cout;
+        const int a = t / kw, b = t % kw;
+        long j;
+        if (!TRANSPOSED) j = (((long)co * cin + ci) * kh + a) * kw + b;
+        else j = (((long)ci * cout + co) * kh + (kh - 1 - a)) * kw + (kw - 1 - b);
+        if (!UNPACK) dst[i] = src[j];
+        else dst[j] = src[i];
+    }
+}
+
+// [N][C][HW] <-> [N][HW][C] through a 32x33 LDS tile
+template <bool TO_NHWC>
+__global__ void layout_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* xs = x + (size_t)n * C * HW;
+    float* ys = y + (size_t)n * C * HW;
+    if (TO_NHWC) {
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, p = p0 + tx;
+            tile[i][tx] = (c < C && p < HW) ? xs[(size_t)c * HW + p] : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int p = p0 + i, c = c0 + tx;
+            if (c < C && p < HW) ys[(size_t)p * C + c] = tile[tx][i];
+        }
+    } else {
+        for (int i = ty; i < 32; i += 8) {
+            const int p = p0 + i, c = c0 + tx;
+            tile[i][tx] = (c < C && p < HW) ? xs[(size_t)p * C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, p = p0 + tx;
+            if (c < C && p < HW) ys[(size_t)c * HW + p] = tile[tx][i];
+        }
+    }
+}
+
+// per-channel sum / sum of squares of an NHWC tensor viewed as [rows][C]:
+// grid.x slabs of rows, each writes one partial row [2][C] (deterministic).
+__global__ void channel_stats_kernel(const float* __restrict__ u, float* __restrict__ partial, long rows, int C,
+                                     int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            const float v = u[r * C + c];
+            s1 += v;
+            s2 += v * v;
+        }
+        partial[(size_t)blockIdx.x * 2 * C + c] = s1;
+        partial[(size_t)blockIdx.x * 2 * C + C + c] = s2;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, int C, double count, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrows; ++r) {
+        s1 += (double)partial[(size_t)r * 2 * C + c];
+        s2 += (double)partial[(size_t)r * 2 * C + C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = act(u*scale+shift), float4 over channels
+__global__ void bn_act_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                              const float* __restrict__ shift, float* __restrict__ y, long n4, int C4, int act,
+                              float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k] * sc[k] + sf[k], act, slope);
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// scalar variant for channel counts that are not a multiple of 4 (the (N,90) encoder head)
+__global__ void bn_act_scalar_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ y, long n, int C, int act,
+                                     float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        y[i] = apply_act(u[i] * scale[c] + shift[c], act, slope);
+    }
+}
+
+// same + fused 2x2 max-pool: one thread per (pooled pixel, 4 channels)
+__global__ void bn_act_pool_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ y,
+                                   float* __restrict__ y_pool, int N, int H, int W, int C4, int act, float slope) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const long total = (long)N * Hp * Wp * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        long r = i / C4;
+        const int xp = r % Wp; r /= Wp;
+        const int yp = r % Hp;
+        const int n = r / Hp;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        f32x4 mx;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const size_t off = ((((size_t)n * H + 2 * yp + dy) * W + 2 * xp + dx) * C4 + c4);
+                f32x4 v = reinterpret_cast<const f32x4*>(u)[off];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k] * sc[k] + sf[k], act, slope);
+                reinterpret_cast<f32x4*>(y)[off] = v;
+                if (dy == 0 && dx == 0) mx = v;
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], v[k]);
+            }
+        reinterpret_cast<f32x4*>(y_pool)[i] = mx;
+    }
+}
+
+static inline unsigned grid_for(long n, int block = 256, int cap = 2048) {
+    long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_abi_version(void) { return 1; }
+extern "C" const char* dvg_last_error(void) { return err_buf(); }
+
+#define PACK_ENTRY(NAME, TR, UN, A0, A1)                                                                        \
+    extern "C" int NAME(const float* src, float* dst, int A0, int A1, int kh, int kw, void* stream) {          \
+        DVG_REQUIRE(src && dst, DVG_ERR_NULL, #NAME ": NULL pointer");                                          \
+        DVG_REQUIRE(cout > 0 && cin > 0 && kh > 0 && kw > 0, DVG_ERR_SHAPE, #NAME ": bad shape");               \
+        const long total = (long)cout * cin * kh * kw;                                                          \
+        hipLaunchKernelGGL((pack_weight_kernel<TR, UN>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, \
+                           src, dst, cout, cin, kh, kw);                                                        \
+        return check_launch(#NAME);                                                                             \
+    }
+PACK_ENTRY(dvg_pack_conv_weight, false, false, cout, cin)
+PACK_ENTRY(dvg_pack_convT_weight, true, false, cin, cout)
+PACK_ENTRY(dvg_unpack_conv_weight, false, true, cout, cin)
+PACK_ENTRY(dvg_unpack_convT_weight, true, true, cin, cout)
+
+extern "C" int dvg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+    DVG_REQUIRE(x && y, DVG_ERR_NULL, "dvg_nchw_to_nhwc: NULL pointer");
+    DVG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N < 65536, DVG_ERR_SHAPE, "dvg_nchw_to_nhwc: bad shape");
+    const int HW = H * W;
+    hipLaunchKernelGGL((layout_kernel<true>), dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
+                       x, y, C, HW);
+    return check_launch("dvg_nchw_to_nhwc");
+}
+extern "C" int dvg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+    DVG_REQUIRE(x && y, DVG_ERR_NULL, "dvg_nhwc_to_nchw: NULL pointer");
+    DVG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N < 65536, DVG_ERR_SHAPE, "dvg_nhwc_to_nchw: bad shape");
+    const int HW = H * W;
+    hipLaunchKernelGGL((layout_kernel<false>), dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0,
+                       (hipStream_t)stream, x, y, C, HW);
+    return check_launch("dvg_nhwc_to_nchw");
+}
+
+extern "C" int dvg_channel_stats_rows(long rows) {
+    // number of partial rows dvg_channel_stats writes for a [rows][C] tensor
+    long rpb = (rows + 1023) / 1024;
+    if (rpb < 16) rpb = 16;
+    return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, void* stream) {
+    DVG_REQUIRE(u && stats_partial, DVG_ERR_NULL, "dvg_channel_stats: NULL pointer");
+    DVG_REQUIRE(rows > 0 && C > 0, DVG_ERR_SHAPE, "dvg_channel_stats: bad shape");
+    long rpb = (rows + 1023) / 1024;
+    if (rpb < 16) rpb = 16;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
+                       (hipStream_t)stream, u, stats_partial, rows, C, (int)rpb);
+    return check_launch("dvg_channel_stats");
+}
+
+extern "C" int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma, const float* beta,
+                               float* scale, float* shift, float* running_mean, float* running_var,
+                               float* save_mean, float* save_invstd, int C, double count, float eps, float momentum,
+                               void* stream) {
+    DVG_REQUIRE(stats_partial && scale && shift, DVG_ERR_NULL, "dvg_bn_finalize: NULL pointer");
+    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats_partial, nrows,
+                       gamma, beta, scale, shift, running_mean, running_var, save_mean, save_invstd, C, count, eps,
+                       momentum);
+    return check_launch("dvg_bn_finalize");
+}
+
+extern "C" int dvg_bn_act_apply(const float* u, const float* scale, const float* shift, float* y, float* y_pool, int N,
+                                int H, int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(u && scale && shift && y, DVG_ERR_NULL, "dvg_bn_act_apply: NULL pointer");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, DVG_ERR_SHAPE, "dvg_bn_act_apply: bad shape");
+    if (C % 4 != 0) {
+        DVG_REQUIRE(y_pool == nullptr, DVG_ERR_SHAPE, "dvg_bn_act_apply: pool needs C %% 4 == 0");
+        const long n = (long)N * H * W * C;
+        hipLaunchKernelGGL(bn_act_scalar_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u,
+                           scale, shift, y, n, C, act, slope);
+        return check_launch("dvg_bn_act_apply");
+    }
+    DVG_REQUIRE(aligned16(u) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(y_pool),
+                DVG_ERR_ALIGN, "dvg_bn_act_apply: alignment");
+    if (y_pool) {
+        DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_bn_act_apply: pool needs even H,W");
+        const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+        hipLaunchKernelGGL(bn_act_pool_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u,
+                           scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+    } else {
+        const long n4 = (long)N * H * W * (C / 4);
+        hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u, scale,
+                           shift, y, n4, C / 4, act, slope);
+    }
+    return check_launch("dvg_bn_act_apply");
+}

@@ -1,0 +1,258 @@
+"""Layer-level fused blocks: nn parameter containers in, HIP kernels underneath.
+
+The model classes (dvg_amd/models/*) keep the reference's attribute tree
+(nn.Conv2d / nn.BatchNorm2d / nn.LSTMCell objects as *parameter holders*, so
+state_dict keys, `init_weights` and whole-module pickles stay compatible —
+SURVEY.md §8(b)), but their forward never calls those modules: it calls the
+functions below, which repack the weights once (cached on parameter version) and
+launch the kernels of libdvg_hip.so.
+
+Eval mode folds conv bias + BatchNorm running statistics into one per-channel
+(scale, shift) pair consumed by the conv epilogue.  Train mode runs the conv with
+a statistics epilogue, finalises the batch statistics on device and applies
+BN + activation (+ 2x2 max-pool) in one elementwise pass.
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH
+
+_cache: "weakref.WeakKeyDictionary[nn.Module, dict]" = weakref.WeakKeyDictionary()
+
+
+def _slot(mod: nn.Module) -> dict:
+    d = _cache.get(mod)
+    if d is None:
+        d = {}
+        _cache[mod] = d
+    return d
+
+
+def _ver(*ts) -> tuple:
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+
+def packed_weight(conv: nn.Module) -> torch.Tensor:
+    """[taps][Cout][Cin] repack of a Conv2d / ConvTranspose2d weight, cached per parameter version."""
+    slot = _slot(conv)
+    key = _ver(conv.weight)
+    hit = slot.get("wp")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if isinstance(conv, nn.ConvTranspose2d):
+        wp = ops.pack_convT_weight(conv.weight)
+    else:
+        wp = ops.pack_conv_weight(conv.weight)
+    slot["wp"] = (key, wp)
+    return wp
+
+
+def gemm_weight(conv: nn.Module, kind: str) -> torch.Tensor:
+    """Weights of the two dense ends as [N][K] GEMM operands in NHWC flatten order.
+
+    kind == "head": Conv2d(512,dim,4,1,0) on a 4x4 map (vgg_64.py:44):
+        W[n][ (h*4+w)*512 + c ] = w[n][c][h][w]
+    kind == "stem": ConvTranspose2d(dim,512,4,1,0) on a 1x1 map (vgg_64.py:65):
+        W[ (h*4+w)*512 + c ][k] = w[k][c][h][w]
+    """
+    slot = _slot(conv)
+    key = _ver(conv.weight)
+    hit = slot.get("gw")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = conv.weight.detach()
+    if kind == "head":
+        n, c, kh, kw = w.shape
+        gw = w.permute(0, 2, 3, 1).reshape(n, kh * kw * c).contiguous()
+    else:
+        k, c, kh, kw = w.shape
+        gw = w.permute(2, 3, 1, 0).reshape(kh * kw * c, k).contiguous()
+    slot["gw"] = (key, gw)
+    return gw
+
+
+def folded_affine(conv: nn.Module, bn: nn.BatchNorm2d):
+    """Eval-mode BN folded with the conv bias: y = conv_nobias(x)*scale + shift."""
+    slot = _slot(bn)
+    key = _ver(conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    hit = slot.get("fold")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight * inv) if bn.weight is not None else inv
+        bias = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        shift = (bias - bn.running_mean) * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias
+        scale, shift = scale.contiguous(), shift.contiguous()
+    slot["fold"] = (key, scale, shift)
+    return scale, shift
+
+
+def _needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
+    res = ops.bn_finalize(stats, bn.weight.detach() if bn.weight is not None else None,
+                          bn.bias.detach() if bn.bias is not None else None,
+                          bn.running_mean if bn.track_running_stats else None,
+                          bn.running_var if bn.track_running_stats else None, count, bn.eps,
+                          bn.momentum if bn.momentum is not None else 0.1, save=save)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return res
+
+
+# --------------------------------------------------------------------------------------
+# blocks (forward).  x / skip are NHWC-in-memory; outputs likewise.
+# --------------------------------------------------------------------------------------
+def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2):
+    """vgg_layer (vgg_64.py:5-15) with optional fused cat/upsample on the input and
+    fused 2x2 max-pool on the output."""
+    if _needs_grad(x, skip, conv.weight, bn.weight):
+        from .autograd import conv_block_autograd
+        return conv_block_autograd("conv3", conv, bn, x, skip, upsample=upsample, pool=pool, act=act, slope=slope)
+    wp = packed_weight(conv)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.conv3x3(x, skip, wp, sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
+    u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,
+                        act=ACT_NONE, stats=True)
+    n, _, h, w = u.shape
+    sc, sh = _train_bn(bn, st, n * h * w)
+    return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, pool=pool, inplace=True)
+
+
+def conv3_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
+    """vgg_layer(nc, 64) on the raw frame (vgg_64.py:23)."""
+    if _needs_grad(x_nchw, conv.weight, bn.weight):
+        from .autograd import conv_block_autograd
+        return conv_block_autograd("conv3_first", conv, bn, x_nchw, None, act=act, slope=slope)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.conv3x3_first(x_nchw, conv.weight, sc, sh, act=act, slope=slope)
+    u, st = ops.conv3x3_first(x_nchw, conv.weight, None, conv.bias.detach() if conv.bias is not None else None,
+                              act=ACT_NONE, stats=True)
+    n, _, h, w = u.shape
+    sc, sh = _train_bn(bn, st, n * h * w)
+    return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
+
+
+def conv4s2_bn_act(conv, bn, x, *, act=ACT_LRELU, slope=0.2):
+    """dcgan_conv (dcgan_64.py:4-14)."""
+    if _needs_grad(x, conv.weight, bn.weight):
+        from .autograd import conv_block_autograd
+        return conv_block_autograd("conv4s2", conv, bn, x, None, act=act, slope=slope)
+    wp = packed_weight(conv)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.conv4x4s2(x, wp, sc, sh, act=act, slope=slope)
+    u, st = ops.conv4x4s2(x, wp, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE,
+                          stats=True)
+    n, _, h, w = u.shape
+    sc, sh = _train_bn(bn, st, n * h * w)
+    return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
+
+
+def conv4s2_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
+    """dcgan_conv(nc, 64) on the raw frame (dcgan_64.py:34)."""
+    if _needs_grad(x_nchw, conv.weight, bn.weight):
+        from .autograd import conv_block_autograd
+        return conv_block_autograd("conv4s2_first", conv, bn, x_nchw, None, act=act, slope=slope)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.conv4x4s2_first(x_nchw, conv.weight, sc, sh, act=act, slope=slope)
+    u, st = ops.conv4x4s2_first(x_nchw, conv.weight, None, conv.bias.detach() if conv.bias is not None else None,
+                                act=ACT_NONE, stats=True)
+    n, _, h, w = u.shape
+    sc, sh = _train_bn(bn, st, n * h * w)
+    return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
+
+
+def convT4s2_bn_act(conv, bn, x, skip=None, *, act=ACT_LRELU, slope=0.2):
+    """dcgan_upconv on cat([x, skip]) (dcgan_64.py:16-26,84-86)."""
+    if _needs_grad(x, skip, conv.weight, bn.weight):
+        from .autograd import conv_block_autograd
+        return conv_block_autograd("convT4s2", conv, bn, x, skip, act=act, slope=slope)
+    wp = packed_weight(conv)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.convT4x4s2(x, skip, wp, sc, sh, act=act, slope=slope)
+    u, st = ops.convT4x4s2(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE,
+                           stats=True)
+    n, _, h, w = u.shape
+    sc, sh = _train_bn(bn, st, n * h * w)
+    return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
+
+
+def head_bn_tanh(conv, bn, x):
+    """Encoder head Conv2d(512,dim,4,1,0)+BN+Tanh on a 4x4 NHWC map (vgg_64.py:44-48): (N,dim)."""
+    if _needs_grad(x, conv.weight, bn.weight):
+        from .autograd import dense_block_autograd
+        return dense_block_autograd("head", conv, bn, x, act=ACT_TANH)
+    n, c, h, w = x.shape
+    if (h, w) != tuple(conv.kernel_size):
+        raise RuntimeError(f"encoder head expects a {conv.kernel_size} map, got {(h, w)}")
+    gw = gemm_weight(conv, "head")
+    a = x.permute(0, 2, 3, 1).reshape(n, h * w * c)  # NHWC buffer viewed as [N][K]; no copy
+    k = a.shape[1]
+    splitk = max(1, min(64, k // 256))
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        return ops.gemm_nt(a, gw, sc, sh, act=ACT_TANH, splitk=splitk)
+    u = ops.gemm_nt(a, gw, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE, splitk=splitk)
+    st = ops.channel_stats(u)
+    sc, sh = _train_bn(bn, st, n)
+    return ops.bn_act_apply(_as_nhwc_vec(u), sc, sh, act=ACT_TANH, inplace=True).reshape(n, u.shape[1])
+
+
+def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2):
+    """Decoder stem ConvTranspose2d(dim,512,4,1,0)+BN+LReLU (vgg_64.py:65-69): (N,dim) -> NHWC (N,512,4,4)."""
+    if _needs_grad(vec, conv.weight, bn.weight):
+        from .autograd import dense_block_autograd
+        return dense_block_autograd("stem", conv, bn, vec, act=act, slope=slope)
+    dim, cout, kh, kw = conv.weight.shape
+    vec = vec.reshape(-1, dim)
+    n = vec.shape[0]
+    gw = gemm_weight(conv, "stem")
+    out = ops.nhwc_empty(n, cout, kh, kw, vec.device)
+    out2d = out.permute(0, 2, 3, 1).reshape(n, kh * kw * cout)
+    if not bn.training:
+        sc, sh = folded_affine(conv, bn)
+        ops.gemm_nt(vec, gw, sc, sh, act=act, slope=slope, period=cout, out=out2d)
+        return out
+    ops.gemm_nt(vec, gw, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE, period=cout,
+                out=out2d)
+    st = ops.channel_stats(out2d.view(n * kh * kw, cout))
+    sc, sh = _train_bn(bn, st, n * kh * kw)
+    return ops.bn_act_apply(out, sc, sh, act=act, slope=slope, inplace=True)
+
+
+def _as_nhwc_vec(u2d):
+    n, c = u2d.shape
+    return u2d.view(n, 1, 1, c).permute(0, 3, 1, 2)
+
+
+def convT3_last(conv, x, *, act=ACT_SIGMOID):
+    """ConvTranspose2d(64,nc,3,1,1)+Sigmoid (vgg_64.py:88-92): NHWC in, NCHW frame out."""
+    if _needs_grad(x, conv.weight):
+        from .autograd import last_layer_autograd
+        return last_layer_autograd("convT3", conv, x, None, act=act)
+    return ops.convT3x3_last(x, conv.weight, conv.bias.detach() if conv.bias is not None else None,
+                             conv.weight.shape[1], act=act)
+
+
+def convT4s2_last(conv, x, skip, *, act=ACT_TANH):
+    """ConvTranspose2d(128,nc,4,2,1)+Tanh on cat([x,skip]) (dcgan_64.py:75-79,87)."""
+    if _needs_grad(x, skip, conv.weight):
+        from .autograd import last_layer_autograd
+        return last_layer_autograd("convT4s2", conv, x, skip, act=act)
+    return ops.convT4x4s2_last(x, skip, conv.weight, conv.bias.detach() if conv.bias is not None else None,
+                               conv.weight.shape[1], act=act)

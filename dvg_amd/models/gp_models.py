@@ -1,0 +1,209 @@
+"""models.gp_models counterpart: the batched sparse variational GP "trigger".
+
+`GPRegressionLayer1(num_dims=90, num_inducing_points=40)` keeps the reference
+constructor (gp_models.py:10-11) and the gpytorch-0.3.x state_dict key names
+(SURVEY.md §8(b)), but contains no gpytorch: the arithmetic that gpytorch's
+WhitenedVariationalStrategy / GaussianLikelihood / MultivariateNormal /
+VariationalELBO performed for the reference call sites (train.py:101-112,225-232,
+283-284; generate_frames.py:67-72,131,170,229,273,291) is stated in DESIGN.md
+("GP: equations of record") and runs as ONE `dvg_gp_predict` launch per call:
+RBF assembly, both Cholesky factorisations, solves, predictive moments, KL and the
+reparameterised sample, one workgroup per latent dimension.
+
+`GaussianLikelihood` and `VariationalELBO` are the minimal stand-ins for
+`gpytorch.likelihoods.GaussianLikelihood(batch_size=D)` (train.py:102) and
+`gpytorch.mlls.VariationalELBO(likelihood, gp, num_data, combine_terms=True)`
+(train.py:112).  Parity for this module is *unpinned* (no gpytorch, no reference
+tests): it is validated against oracle/dvg_oracle.py's fp64 restatement.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+JITTER = 1e-3        # lazy_tensor.add_jitter() default of gpytorch 0.3.x
+NOISE_FLOOR = 1e-4   # GaussianLikelihood noise constraint GreaterThan(1e-4)
+
+
+class _Holder(nn.Module):
+    """Parameter container (never called)."""
+
+
+class GPPrediction:
+    """What the reference code reads off a gpytorch MultivariateNormal: `.mean` (D,B),
+    `.variance` (D,B), `.rsample()` (D,B), `.covariance_matrix` (D,B,B).  Evaluation is lazy
+    so that `likelihood(gp_layer(x)).rsample()` is a single kernel launch."""
+
+    def __init__(self, layer: "GPRegressionLayer1", h: torch.Tensor, noise=None, training=False):
+        self._layer, self._h, self._noise, self._training = layer, h, noise, training
+        self._res = None
+        self._cov = None
+
+    # -- evaluation ------------------------------------------------------------------
+    def _run(self, eps=None, want_cov=False):
+        lay = self._layer
+        if self._training and lay._grad_needed(self._h):
+            from ..autograd import gp_train_autograd
+            return gp_train_autograd(lay, self._h, self._noise)
+        s, ell, c = lay.hypers()
+        return ops.gp_predict(self._h, lay.variational_strategy.inducing_points,
+                              lay.variational_strategy.variational_distribution.variational_mean,
+                              lay.variational_strategy.variational_distribution.chol_variational_covar, c, s, ell,
+                              noise=self._noise, eps=eps, want_cov=want_cov, want_kl=self._training,
+                              train_mode=self._training, jitter=JITTER)
+
+    def _moments(self):
+        if self._res is None:
+            self._res = self._run()
+        return self._res
+
+    @property
+    def mean(self):
+        return self._moments()["mean"]
+
+    @property
+    def variance(self):
+        return self._moments()["var"]
+
+    @property
+    def kl(self):
+        return self._moments()["kl"]
+
+    @property
+    def covariance_matrix(self):
+        if self._training:
+            raise RuntimeError("train-mode prediction carries a diagonal covariance only (gpytorch 0.3.x)")
+        if self._cov is None:
+            r = self._run(want_cov=True)
+            self._res, self._cov = r, r["cov"]
+        return self._cov
+
+    def rsample(self, base_samples: torch.Tensor = None):
+        """mean + chol(Sigma) eps;  eps ~ N(0,I) (D,B) from the global torch RNG unless given."""
+        d, b = self._layer.num_dims, self._h.shape[0]
+        eps = base_samples if base_samples is not None else torch.randn(d, b, device=self._h.device)
+        if self._training:
+            m = self._moments()
+            return m["mean"] + torch.sqrt(m["var"]) * eps
+        r = self._run(eps=eps)
+        if self._res is None:
+            self._res = r
+        return r["sample"]
+
+    sample = rsample
+
+    def with_noise(self, noise):
+        return GPPrediction(self._layer, self._h, noise, self._training)
+
+
+class GPRegressionLayer1(nn.Module):
+    """D independent 1-D sparse variational GPs, M learnable inducing points each
+    (gp_models.py:10-24): constant mean, ScaleKernel(RBFKernel), Cholesky variational
+    distribution, whitened variational strategy."""
+
+    def __init__(self, num_dims=90, num_inducing_points=40):
+        super().__init__()
+        D, M = num_dims, num_inducing_points
+        self.num_dims, self.num_inducing_points = D, M
+        vs = _Holder()
+        vs.inducing_points = nn.Parameter(torch.rand(D, M, 1))                    # gp_models.py:13
+        vd = _Holder()
+        vd.variational_mean = nn.Parameter(torch.zeros(D, M))
+        vd.chol_variational_covar = nn.Parameter(torch.eye(M).repeat(D, 1, 1))
+        vs.variational_distribution = vd
+        vs.register_buffer("variational_params_initialized", torch.tensor(0))
+        self.variational_strategy = vs
+        self.mean_module = _Holder()
+        self.mean_module.constant = nn.Parameter(torch.zeros(D, 1))                # ConstantMean(batch_size=D)
+        self.covar_module = _Holder()
+        self.covar_module.raw_outputscale = nn.Parameter(torch.zeros(D))           # ScaleKernel(batch_size=D)
+        self.covar_module.base_kernel = _Holder()
+        self.covar_module.base_kernel.raw_lengthscale = nn.Parameter(torch.zeros(D, 1, 1))  # RBFKernel(batch_size=D)
+
+    # -- hyper-parameters ---------------------------------------------------------------
+    def hypers(self):
+        s = F.softplus(self.covar_module.raw_outputscale).reshape(-1)
+        ell = F.softplus(self.covar_module.base_kernel.raw_lengthscale).reshape(-1)
+        return s, ell, self.mean_module.constant.reshape(-1)
+
+    def _grad_needed(self, h):
+        return torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    @torch.no_grad()
+    def initialize_variational_dist(self):
+        """First-call initialisation of gpytorch's WhitenedVariationalStrategy: variational
+        mean <- prior mean, chol_variational_covar <- chol((K_ZZ + jitter I)^-1) in fp64, so
+        the GP starts at its prior."""
+        vs = self.variational_strategy
+        s, ell, c = [t.double() for t in self.hypers()]
+        z = vs.inducing_points.squeeze(-1).double()
+        diff = z.unsqueeze(-1) - z.unsqueeze(-2)
+        kzz = s.view(-1, 1, 1) * torch.exp(-0.5 * diff * diff / ell.view(-1, 1, 1) ** 2)
+        kzz = kzz + JITTER * torch.eye(z.shape[1], dtype=torch.float64, device=z.device)
+        # one-off 40x40 fp64 inverse per latent dim at initialisation time (host of the path, not
+        # on it): done on the CPU so that no BLAS/solver library is pulled onto the device
+        ls = torch.linalg.cholesky(torch.linalg.inv(kzz.cpu())).to(z.device)
+        vs.variational_distribution.chol_variational_covar.copy_(ls.to(torch.float32))
+        vs.variational_distribution.variational_mean.copy_(c.view(-1, 1).expand_as(
+            vs.variational_distribution.variational_mean).to(torch.float32))
+        vs.variational_params_initialized.fill_(1)
+
+    def forward(self, x):
+        """x: (D,B,1) as produced by `h.transpose(0,1).view(D,B,1)` (train.py:225) — a strided view
+        that shares storage with h — or directly h (B,D)."""
+        if not int(self.variational_strategy.variational_params_initialized.item()):
+            self.initialize_variational_dist()
+        if x.dim() == 3:
+            if x.shape[0] != self.num_dims or x.shape[2] != 1:
+                raise RuntimeError(f"GP input must be ({self.num_dims},B,1), got {tuple(x.shape)}")
+            h = x.squeeze(-1).transpose(0, 1)
+        else:
+            h = x
+        if h.shape[1] != self.num_dims:
+            raise RuntimeError(f"GP input must carry {self.num_dims} latent dims, got {tuple(h.shape)}")
+        return GPPrediction(self, h, None, self.training)
+
+
+class GaussianLikelihood(nn.Module):
+    """gpytorch.likelihoods.GaussianLikelihood(batch_size=D): homoskedastic noise per latent
+    dim, sigma^2 = softplus(raw_noise) + 1e-4; `likelihood(pred)` adds it to the predictive
+    (co)variance (generate_frames.py:131,170)."""
+
+    def __init__(self, batch_size=1):
+        super().__init__()
+        self.noise_covar = _Holder()
+        self.noise_covar.raw_noise = nn.Parameter(torch.zeros(batch_size, 1))
+
+    @property
+    def noise(self):
+        return F.softplus(self.noise_covar.raw_noise).reshape(-1) + NOISE_FLOOR
+
+    def forward(self, pred: GPPrediction) -> GPPrediction:
+        return pred.with_noise(self.noise)
+
+    def expected_log_prob(self, target, pred: GPPrediction):
+        """E_q(f)[log N(y | f, sigma^2)] summed over the B points -> (D,)."""
+        mean, var = pred.mean, pred.variance
+        nz = self.noise.view(-1, 1)
+        res = -0.5 * ((target - mean) ** 2 + var) / nz - 0.5 * torch.log(nz) - 0.5 * math.log(2 * math.pi)
+        return res.sum(-1)
+
+
+class VariationalELBO(nn.Module):
+    """gpytorch.mlls.VariationalELBO(likelihood, model, num_data, combine_terms=True)
+    (train.py:112): `mll(pred, target)` -> (D,) = E log-lik / B - KL / num_data."""
+
+    def __init__(self, likelihood, model, num_data, combine_terms=True):
+        super().__init__()
+        self.likelihood, self.model, self.num_data, self.combine_terms = likelihood, model, num_data, combine_terms
+
+    def forward(self, pred: GPPrediction, target: torch.Tensor):
+        b = target.shape[-1]
+        ll = self.likelihood.expected_log_prob(target, pred) / b
+        kl = pred.kl / self.num_data
+        return ll - kl if self.combine_terms else (ll, kl)

@@ -1,0 +1,337 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+arithmetic op of the hot path is a kernel of libdvg_hip.so.  Activations travel as
+(N,C,H,W) tensors with channels_last strides, i.e. NHWC in memory.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2 = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor — the DVG hot path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+
+
+def nhwc_empty(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    """(N,C,H,W)-shaped view of a fresh NHWC buffer."""
+    return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def is_nhwc(t: torch.Tensor) -> bool:
+    if t.dim() != 4:
+        return False
+    n, c, h, w = t.shape
+    return t.stride() == (h * w * c, 1, w * c, c) or (c == 1 and t.is_contiguous()) or \
+        (h == 1 and w == 1 and t.is_contiguous())
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` (N,C,H,W) as an NHWC-in-memory tensor, converting with the layout kernel if needed."""
+    _dev_f32(t, "to_nhwc")
+    if is_nhwc(t):
+        return t
+    src = t if t.is_contiguous() else t.contiguous()
+    n, c, h, w = src.shape
+    out = nhwc_empty(n, c, h, w, t.device)
+    check(lib().dvg_nchw_to_nhwc(_p(src), _p(out), n, c, h, w, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous NCHW copy of an NHWC-in-memory tensor."""
+    _dev_f32(t, "to_nchw")
+    if t.is_contiguous():
+        return t
+    if not is_nhwc(t):
+        return t.contiguous()
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), device=t.device, dtype=torch.float32)
+    check(lib().dvg_nhwc_to_nchw(_p(t), _p(out), n, c, h, w, _stream()), "nhwc_to_nchw")
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------------
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    _dev_f32(w, "pack_conv_weight")
+    w = w.detach().contiguous()
+    co, ci, kh, kw = w.shape
+    out = torch.empty((kh * kw, co, ci), device=w.device, dtype=torch.float32)
+    check(lib().dvg_pack_conv_weight(_p(w), _p(out), co, ci, kh, kw, _stream()), "pack_conv_weight")
+    return out
+
+
+def pack_convT_weight(w: torch.Tensor) -> torch.Tensor:
+    _dev_f32(w, "pack_convT_weight")
+    w = w.detach().contiguous()
+    ci, co, kh, kw = w.shape
+    out = torch.empty((kh * kw, co, ci), device=w.device, dtype=torch.float32)
+    check(lib().dvg_pack_convT_weight(_p(w), _p(out), ci, co, kh, kw, _stream()), "pack_convT_weight")
+    return out
+
+
+def unpack_conv_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
+    t, co, ci = wp.shape
+    out = torch.empty((co, ci, kh, kw), device=wp.device, dtype=torch.float32)
+    check(lib().dvg_unpack_conv_weight(_p(wp.contiguous()), _p(out), co, ci, kh, kw, _stream()), "unpack_conv_weight")
+    return out
+
+
+def unpack_convT_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
+    t, co, ci = wp.shape
+    out = torch.empty((ci, co, kh, kw), device=wp.device, dtype=torch.float32)
+    check(lib().dvg_unpack_convT_weight(_p(wp.contiguous()), _p(out), ci, co, kh, kw, _stream()),
+          "unpack_convT_weight")
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# conv blocks.  All take / return NHWC-in-memory (N,C,H,W) tensors.
+# `stats=True` returns (y, stats_partial) with stats_partial [rows][2][Cout].
+# ----------------------------------------------------------------------------------
+def _stats_buf(rows: int, cout: int, device):
+    if rows <= 0:
+        raise RuntimeError("unsupported shape for fused BN statistics")
+    return torch.empty((rows, 2, cout), device=device, dtype=torch.float32)
+
+
+def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0.2, pool=False, stats=False):
+    _dev_f32(x, "conv3x3.x")
+    assert is_nhwc(x), "conv3x3: x must be NHWC in memory"
+    n, c1, hx, wx = x.shape
+    h, w = (hx * 2, wx * 2) if upsample else (hx, wx)
+    c2 = 0
+    if skip is not None:
+        _dev_f32(skip, "conv3x3.skip")
+        assert is_nhwc(skip), "conv3x3: skip must be NHWC in memory"
+        c2 = skip.shape[1]
+        if tuple(skip.shape) != (n, c2, h, w):
+            raise RuntimeError(f"conv3x3: skip shape {tuple(skip.shape)} does not match {(n, c2, h, w)}")
+    taps, cout, cin = wp.shape
+    if taps != 9 or cin != c1 + c2:
+        raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
+    y = nhwc_empty(n, cout, h, w, x.device)
+    yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
+    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV3, n, h, w, cout), cout, x.device) if stats else None
+    check(lib().dvg_conv3x3_bn_act(_p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
+                                   c2, cout, int(upsample), act, slope, _stream()), "conv3x3_bn_act")
+    out = (y, yp) if pool else y
+    return (out, st) if stats else out
+
+
+def conv3x3_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
+    _dev_f32(x_nchw, "conv3x3_first.x")
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    n, nc, h, wd = x.shape
+    w = w.detach()
+    cout = w.shape[0]
+    if tuple(w.shape) != (cout, nc, 3, 3) or not w.is_contiguous():
+        raise RuntimeError("conv3x3_first: weight must be contiguous (Cout,nc,3,3)")
+    y = nhwc_empty(n, cout, h, wd, x.device)
+    st = _stats_buf(lib().dvg_conv_first_stats_rows(3, n, h, wd), cout, x.device) if stats else None
+    check(lib().dvg_conv3x3_first(_p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
+                                  _stream()), "conv3x3_first")
+    return (y, st) if stats else y
+
+
+def convT3x3_last(x, w, bias, nc, *, act=ACT_SIGMOID):
+    _dev_f32(x, "convT3x3_last.x")
+    assert is_nhwc(x)
+    n, cin, h, wd = x.shape
+    w = w.detach()
+    if tuple(w.shape) != (cin, nc, 3, 3) or not w.is_contiguous():
+        raise RuntimeError("convT3x3_last: weight must be contiguous (Cin,nc,3,3)")
+    y = torch.empty((n, nc, h, wd), device=x.device, dtype=torch.float32)
+    check(lib().dvg_convT3x3_last(_p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, nc, act, _stream()), "convT3x3_last")
+    return y
+
+
+def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
+    _dev_f32(x, "conv4x4s2.x")
+    assert is_nhwc(x)
+    n, cin, h, w = x.shape
+    taps, cout, cin_w = wp.shape
+    if taps != 16 or cin_w != cin:
+        raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
+    y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
+    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV4S2, n, h, w, cout), cout, x.device) if stats else None
+    check(lib().dvg_conv4x4s2_bn_act(_p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, cin, cout, act,
+                                     slope, _stream()), "conv4x4s2_bn_act")
+    return (y, st) if stats else y
+
+
+def conv4x4s2_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
+    _dev_f32(x_nchw, "conv4x4s2_first.x")
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    n, nc, h, wd = x.shape
+    w = w.detach()
+    cout = w.shape[0]
+    if tuple(w.shape) != (cout, nc, 4, 4) or not w.is_contiguous():
+        raise RuntimeError("conv4x4s2_first: weight must be contiguous (Cout,nc,4,4)")
+    y = nhwc_empty(n, cout, h // 2, wd // 2, x.device)
+    st = _stats_buf(lib().dvg_conv_first_stats_rows(4, n, h, wd), cout, x.device) if stats else None
+    check(lib().dvg_conv4x4s2_first(_p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
+                                    _stream()), "conv4x4s2_first")
+    return (y, st) if stats else y
+
+
+def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
+    _dev_f32(x, "convT4x4s2.x")
+    assert is_nhwc(x)
+    n, c1, h, w = x.shape
+    c2 = 0
+    if skip is not None:
+        assert is_nhwc(skip)
+        c2 = skip.shape[1]
+        if tuple(skip.shape) != (n, c2, h, w):
+            raise RuntimeError("convT4x4s2: skip shape mismatch")
+    taps, cout, cin = wp.shape
+    if taps != 16 or cin != c1 + c2:
+        raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
+    y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
+    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONVT4S2, n, h, w, cout), cout, x.device) if stats else None
+    check(lib().dvg_convT4x4s2_bn_act(_p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, c1, c2,
+                                      cout, act, slope, _stream()), "convT4x4s2_bn_act")
+    return (y, st) if stats else y
+
+
+def convT4x4s2_last(x, skip, w, bias, nc, *, act=ACT_TANH):
+    _dev_f32(x, "convT4x4s2_last.x")
+    assert is_nhwc(x)
+    n, c1, h, wd = x.shape
+    c2 = 0
+    if skip is not None:
+        assert is_nhwc(skip)
+        c2 = skip.shape[1]
+    w = w.detach()
+    if tuple(w.shape) != (c1 + c2, nc, 4, 4) or not w.is_contiguous():
+        raise RuntimeError("convT4x4s2_last: weight must be contiguous (Cin,nc,4,4)")
+    y = torch.empty((n, nc, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
+    check(lib().dvg_convT4x4s2_last(_p(x), _p(skip), _p(w), _p(bias), _p(y), n, h, wd, c1, c2, nc, act, _stream()),
+          "convT4x4s2_last")
+    return y
+
+
+# ----------------------------------------------------------------------------------
+# BatchNorm (train mode) helpers
+# ----------------------------------------------------------------------------------
+def channel_stats(u2d: torch.Tensor) -> torch.Tensor:
+    """u2d: [rows][C] contiguous -> partial stats [r][2][C]."""
+    _dev_f32(u2d, "channel_stats")
+    rows, c = u2d.shape
+    r = lib().dvg_channel_stats_rows(rows)
+    st = torch.empty((r, 2, c), device=u2d.device, dtype=torch.float32)
+    check(lib().dvg_channel_stats(_p(u2d), _p(st), rows, c, _stream()), "channel_stats")
+    return st
+
+
+def bn_finalize(stats_partial, gamma, beta, running_mean, running_var, count, eps, momentum, save=False):
+    rows, _, c = stats_partial.shape
+    dev = stats_partial.device
+    scale = torch.empty(c, device=dev, dtype=torch.float32)
+    shift = torch.empty(c, device=dev, dtype=torch.float32)
+    sm = torch.empty(c, device=dev, dtype=torch.float32) if save else None
+    si = torch.empty(c, device=dev, dtype=torch.float32) if save else None
+    check(lib().dvg_bn_finalize(_p(stats_partial), rows, _p(gamma), _p(beta), _p(scale), _p(shift), _p(running_mean),
+                                _p(running_var), _p(sm), _p(si), c, float(count), eps, momentum, _stream()),
+          "bn_finalize")
+    return (scale, shift, sm, si) if save else (scale, shift)
+
+
+def bn_act_apply(u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, inplace=True):
+    """u NHWC (N,C,H,W); returns y (and pooled y)."""
+    assert is_nhwc(u)
+    n, c, h, w = u.shape
+    y = u if inplace else nhwc_empty(n, c, h, w, u.device)
+    yp = nhwc_empty(n, c, h // 2, w // 2, u.device) if pool else None
+    check(lib().dvg_bn_act_apply(_p(u), _p(scale), _p(shift), _p(y), _p(yp), n, h, w, c, act, slope, _stream()),
+          "bn_act_apply")
+    return (y, yp) if pool else y
+
+
+# ----------------------------------------------------------------------------------
+# dense / recurrent
+# ----------------------------------------------------------------------------------
+def gemm_nt(a, w, scale, shift, *, act=ACT_NONE, slope=0.0, period=None, splitk=1, out=None):
+    """out[m][n] = act((sum_k a[m][k] w[n][k]) * scale[n%period] + shift[n%period])."""
+    _dev_f32(a, "gemm_nt.a")
+    _dev_f32(w, "gemm_nt.w")
+    if a.dim() != 2 or a.stride(1) != 1:
+        a = a.contiguous().view(a.shape[0], -1)
+    w = w if w.is_contiguous() else w.contiguous()
+    m, k = a.shape
+    n, kw = w.shape
+    if kw != k:
+        raise RuntimeError(f"gemm_nt: K mismatch {k} vs {kw}")
+    if period is None:
+        period = n
+    if out is None:
+        out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    ws = torch.empty((splitk, m, n), device=a.device, dtype=torch.float32) if splitk > 1 else None
+    check(lib().dvg_gemm_nt_bias_act(_p(a), _p(w), _p(scale), _p(shift), _p(out), _p(ws), m, n, k, a.stride(0),
+                                     out.stride(0), period, splitk, act, slope, _stream()), "gemm_nt_bias_act")
+    return out
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=False):
+    for t, nm in ((x, "x"), (h, "h"), (c, "c")):
+        _dev_f32(t, "lstm_cell." + nm)
+    b, hid = h.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    h = h if h.is_contiguous() else h.contiguous()
+    c = c if c.is_contiguous() else c.contiguous()
+    if tuple(x.shape) != (b, hid) or tuple(w_ih.shape) != (4 * hid, hid) or tuple(w_hh.shape) != (4 * hid, hid):
+        raise RuntimeError("lstm_cell: shape mismatch (input size must equal hidden size)")
+    h_out = torch.empty_like(h)
+    c_out = torch.empty_like(c)
+    gates = torch.empty((b, 4 * hid), device=h.device, dtype=torch.float32) if want_gates else None
+    check(lib().dvg_lstm_cell(_p(x), _p(h), _p(c), _p(w_ih.detach()), _p(w_hh.detach()), _p(b_ih.detach()),
+                              _p(b_hh.detach()), _p(h_out), _p(c_out), _p(gates), b, hid, _stream()), "lstm_cell")
+    return (h_out, c_out, gates) if want_gates else (h_out, c_out)
+
+
+# ----------------------------------------------------------------------------------
+# GP
+# ----------------------------------------------------------------------------------
+def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *, noise=None, eps=None,
+               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3):
+    """h [B][D] (any strides); returns dict(mean [D][B], var, sample, cov, kl)."""
+    _dev_f32(h, "gp_predict.h")
+    h = h if h.is_contiguous() else h.contiguous()
+    b, d = h.shape
+    m = z.shape[1]
+    dev = h.device
+    mean = torch.empty((d, b), device=dev, dtype=torch.float32)
+    var = torch.empty((d, b), device=dev, dtype=torch.float32) if want_var else None
+    sample = torch.empty((d, b), device=dev, dtype=torch.float32) if eps is not None else None
+    cov = torch.empty((d, b, b), device=dev, dtype=torch.float32) if want_cov else None
+    kl = torch.empty((d,), device=dev, dtype=torch.float32) if want_kl else None
+    if eps is not None:
+        eps = eps.contiguous()
+        if tuple(eps.shape) != (d, b):
+            raise RuntimeError(f"gp_predict: eps must be ({d},{b})")
+    args = [t.detach().contiguous().view(-1) for t in (z, var_mean, chol_var, mean_const, outputscale, lengthscale)]
+    if args[0].numel() != d * m or args[2].numel() != d * m * m or args[3].numel() != d:
+        raise RuntimeError("gp_predict: parameter shapes do not match (D,M)")
+    nz = None if noise is None else noise.detach().contiguous().view(-1)
+    check(lib().dvg_gp_predict(_p(h), *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov),
+                               _p(kl), b, d, m, int(train_mode), jitter, _stream()), "gp_predict")
+    return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}

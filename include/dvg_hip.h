@@ -1,0 +1,255 @@
+/*
+ * dvg_hip.h — C ABI of libdvg_hip.so, the MI355X (gfx950) kernel library behind
+ * the DVG frame-prediction hot path.
+ *
+ * The reference (shgaurav1/DVG) has no FFI / plugin boundary of its own: every
+ * device op is an implicit torch.nn / gpytorch call.  Each entry
+ * point below therefore names the reference *call site* it replaces.  Citations
+ * are file:line into the reference tree.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise;
+ *   - activations are NHWC ("channels last"): x[n][y][x][c]; the Python side
+ *     exposes them as (N,C,H,W) torch tensors with channels_last strides;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns 0 on success, a DVG_ERR_* code otherwise and never
+ *     throws; dvg_last_error() gives a thread-local message;
+ *   - all shape checks happen on the host BEFORE a kernel is launched: a call
+ *     that fails a check launches nothing.
+ *   - no function allocates, frees or synchronises: graph-capture safe.
+ */
+#ifndef DVG_HIP_H
+#define DVG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVG_OK 0
+#define DVG_ERR_SHAPE 1   /* unsupported / inconsistent shape            */
+#define DVG_ERR_NULL 2    /* required pointer is NULL                    */
+#define DVG_ERR_HIP 3     /* a HIP runtime call / kernel launch failed   */
+#define DVG_ERR_ALIGN 4   /* pointer not 16-byte aligned                 */
+
+/* activation codes for the fused epilogues */
+#define DVG_ACT_NONE 0
+#define DVG_ACT_LRELU 1   /* LeakyReLU(slope)   vgg_64.py:11, dcgan_64.py:10 */
+#define DVG_ACT_TANH 2    /* vgg_64.py:47, dcgan_64.py:45,78, lstm.py:55     */
+#define DVG_ACT_SIGMOID 3 /* vgg_64.py:91                                     */
+
+int dvg_abi_version(void);
+const char* dvg_last_error(void);
+
+/* ------------------------------------------------------------------ *
+ * Weight re-layout (one launch per parameter, cached by the caller).
+ * ------------------------------------------------------------------ */
+
+/* Conv2d weight (Cout,Cin,KH,KW) [vgg_64.py:8, dcgan_64.py:8] ->
+ * packed [KH*KW][Cout][Cin] (Cin contiguous = implicit-GEMM K order).     */
+int dvg_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin,
+                         int kh, int kw, void* stream);
+
+/* ConvTranspose2d weight (Cin,Cout,KH,KW) [vgg_64.py:88, dcgan_64.py:20,76]
+ * -> packed [KH*KW][Cout][Cin] with the kernel spatially FLIPPED, i.e. the
+ * weight of the equivalent direct correlation.                             */
+int dvg_pack_convT_weight(const float* w_iohw, float* w_packed, int cin, int cout,
+                          int kh, int kw, void* stream);
+
+/* Inverse of the two packs (used by the backward pass to scatter dW back). */
+int dvg_unpack_conv_weight(const float* w_packed, float* w_oihw, int cout, int cin,
+                           int kh, int kw, void* stream);
+int dvg_unpack_convT_weight(const float* w_packed, float* w_iohw, int cin, int cout,
+                            int kh, int kw, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Encoder / decoder blocks
+ * ------------------------------------------------------------------ */
+
+/* vgg_layer = Conv2d(nin,nout,3,1,1)+BatchNorm2d+LeakyReLU(0.2)  (vgg_64.py:5-15)
+ * as ONE fp32-MFMA implicit GEMM (M = N*H*W pixels, N = Cout, K = 9*Cin):
+ *
+ *   u        = conv3x3(in) + 0            (bias is folded into `shift`)
+ *   y        = act(u * scale[c] + shift[c])
+ *   y_pool   = maxpool2x2(y)              (optional; nn.MaxPool2d(2,2) vgg_64.py:49)
+ *
+ * `in` is either `x` (N,H,W,C1) or, when `upsample_x` != 0, the channel concat
+ *   cat([nearest_up2(x), skip], C)   (vgg_64.py:93,98-105)
+ * with x given at (N,H/2,W/2,C1) and skip at (N,H,W,C2); the concat and the
+ * up-sampling are done by the tile loader and never materialised.
+ * With skip == NULL, C2 must be 0.  When upsample_x == 0 and skip != NULL the
+ * input is cat([x, skip]) at full resolution.
+ *
+ * scale/shift: [Cout] (eval-mode BN folded with the conv bias); either may be
+ * NULL (=1 / =0).
+ *
+ * stats (optional, train-mode BN): float[rows][2][Cout] with
+ * rows = dvg_conv_stats_rows(mode, N, H, W, Cout); every workgroup writes the
+ * per-channel sum(u') and sum(u'^2) of its own pixel tile, where
+ * u' = u*scale+shift BEFORE the activation (callers pass scale=NULL,
+ * shift=bias, act=NONE to obtain the raw conv output and its statistics).
+ * Deterministic (no atomics); dvg_bn_finalize reduces the rows.
+ *
+ * Requirements: C1 % 32 == 0, C2 % 32 == 0, Cout % 64 == 0, H % 8 == 0,
+ * W % 8 == 0, all pointers 16-byte aligned.                                 */
+#define DVG_MODE_CONV3 0
+#define DVG_MODE_CONV4S2 1
+#define DVG_MODE_CONVT4S2 2
+/* rows of the `stats` partial buffer for the implicit-GEMM convs (H,W = the
+ * H,W passed to the conv entry point); -1 if the shape is unsupported.        */
+int dvg_conv_stats_rows(int mode, int N, int H, int W, int Cout);
+/* same for the first-layer kernels (ks = 3 or 4)                              */
+int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
+
+int dvg_conv3x3_bn_act(const float* x, const float* skip, const float* w_packed,
+                       const float* scale, const float* shift, float* y,
+                       float* y_pool, float* stats, int N, int H, int W, int C1,
+                       int C2, int Cout, int upsample_x, int act, float slope,
+                       void* stream);
+
+/* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
+ * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.
+ * x is NCHW (N,nc,H,W) exactly as the caller's frame tensor (utils.py:90-91);
+ * w is the ORIGINAL (Cout,nc,3,3) weight; y is NHWC (N,H,W,Cout).
+ * Cout % 64 == 0.  stats as above (optional).                                */
+int dvg_conv3x3_first(const float* x_nchw, const float* w_oihw, const float* scale,
+                      const float* shift, float* y, float* stats, int N, int H,
+                      int W, int nc, int Cout, int act, float slope, void* stream);
+
+/* Last decoder layer: ConvTranspose2d(Cin,nc,3,1,1)+Sigmoid (vgg_64.py:88-92),
+ * nc in {1..4}.  x NHWC (N,H,W,Cin), w the ORIGINAL (Cin,nc,3,3) weight,
+ * bias [nc], y NCHW (N,nc,H,W).  Cin % 4 == 0, Cin <= 128.                    */
+int dvg_convT3x3_last(const float* x, const float* w_iohw, const float* bias,
+                      float* y_nchw, int N, int H, int W, int Cin, int nc, int act,
+                      void* stream);
+
+/* dcgan_conv = Conv2d(nin,nout,4,2,1)+BN+LReLU (dcgan_64.py:4-14) as implicit
+ * GEMM, K = 16*Cin.  x NHWC (N,H,W,Cin) -> y NHWC (N,H/2,W/2,Cout).
+ * w_packed [16][Cout][Cin].  Cin % 32 == 0, Cout % 64 == 0, H,W % 16 == 0 or
+ * H == W == 8.  stats as for dvg_conv3x3_bn_act.                              */
+int dvg_conv4x4s2_bn_act(const float* x, const float* w_packed, const float* scale,
+                         const float* shift, float* y, float* stats, int N, int H,
+                         int W, int Cin, int Cout, int act, float slope,
+                         void* stream);
+
+/* First dcgan layer Conv2d(nc,Cout,4,2,1)+BN+LReLU, nc in {1..4}
+ * (dcgan_64.py:34).  x NCHW, w ORIGINAL (Cout,nc,4,4), y NHWC (N,H/2,W/2,Cout). */
+int dvg_conv4x4s2_first(const float* x_nchw, const float* w_oihw, const float* scale,
+                        const float* shift, float* y, float* stats, int N, int H,
+                        int W, int nc, int Cout, int act, float slope, void* stream);
+
+/* dcgan_upconv = ConvTranspose2d(nin,nout,4,2,1)+BN+LReLU on cat([x, skip])
+ * (dcgan_64.py:16-26,84-87) as four parity-class implicit GEMMs (K = 4*Cin).
+ * x NHWC (N,H,W,C1), skip NHWC (N,H,W,C2) or NULL; w_packed = the
+ * dvg_pack_convT_weight layout [16][Cout][C1+C2]; y NHWC (N,2H,2W,Cout).
+ * C1,C2 % 32 == 0, Cout % 64 == 0, H,W % 8 == 0 (or H == W == 4).             */
+int dvg_convT4x4s2_bn_act(const float* x, const float* skip, const float* w_packed,
+                          const float* scale, const float* shift, float* y,
+                          float* stats, int N, int H, int W, int C1, int C2,
+                          int Cout, int act, float slope, void* stream);
+
+/* Last dcgan layer ConvTranspose2d(C1+C2,nc,4,2,1)+Tanh|Sigmoid on cat([x,skip])
+ * (dcgan_64.py:75-79; dcgan_128.py:80-84).  w ORIGINAL (C1+C2,nc,4,4),
+ * y NCHW (N,nc,2H,2W).                                                        */
+int dvg_convT4x4s2_last(const float* x, const float* skip, const float* w_iohw,
+                        const float* bias, float* y_nchw, int N, int H, int W,
+                        int C1, int C2, int nc, int act, void* stream);
+
+/* Per-channel sum / sum-of-squares of a [rows][C] (NHWC) tensor, written as
+ * dvg_channel_stats_rows(rows) partial rows [2][C] (deterministic slab sums).
+ * Used for the small BN inputs (encoder head, decoder stem).                  */
+int dvg_channel_stats_rows(long rows);
+int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, void* stream);
+
+/* Train-mode BatchNorm2d finalisation (vgg_64.py:9; torch semantics: biased
+ * variance for normalisation, unbiased for the running estimate, eps 1e-5):
+ * reduces `nrows` partial rows [2][C] (double accumulation) over `count`
+ * elements per channel and produces
+ *   scale[c] = gamma[c] / sqrt(var_b[c] + eps),  shift[c] = beta[c] - mean[c]*scale[c]
+ * and, when running_mean/var != NULL, updates them with `momentum`.
+ * save_mean / save_invstd (optional) are kept for the backward pass.          */
+int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma,
+                    const float* beta, float* scale, float* shift, float* running_mean,
+                    float* running_var, float* save_mean, float* save_invstd,
+                    int C, double count, float eps, float momentum, void* stream);
+
+/* y = act(u*scale[c]+shift[c]) elementwise over an NHWC tensor of `npix`
+ * pixels (train-mode BN apply + activation), optional fused 2x2 max-pool
+ * output (H,W needed only then).  In-place (y == u) is allowed.               */
+int dvg_bn_act_apply(const float* u, const float* scale, const float* shift, float* y,
+                     float* y_pool, int N, int H, int W, int C, int act, float slope,
+                     void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Dense ends and the recurrent predictor
+ * ------------------------------------------------------------------ */
+
+/* out[m][n] = act( (sum_k a[m][k]*w[n][k]) * scale[n % period] + shift[n % period] )
+ * Small-M GEMM used for: encoder head Conv2d(512,dim,4,1,0)+BN+Tanh on the 4x4
+ * map (vgg_64.py:44-48; K = 8192), decoder stem ConvTranspose2d(dim,512,4,1,0)
+ * +BN+LReLU (vgg_64.py:65-69; N = 8192, period = 512), nn.Linear of lstm.py:50,
+ * 53-55.  a [M][K] (row stride lda), w [N][K], out [M][N] (row stride ldo).
+ * scale/shift may be NULL.  `workspace` must hold M*N*splitk floats when
+ * splitk > 1 (NULL allowed when splitk == 1).                                  */
+int dvg_gemm_nt_bias_act(const float* a, const float* w, const float* scale,
+                         const float* shift, float* out, float* workspace, int M,
+                         int N, int K, int lda, int ldo, int period, int splitk,
+                         int act, float slope, void* stream);
+
+/* One nn.LSTMCell step (lstm.py:51,68-70; gate order i,f,g,o):
+ *   g = W_ih x + b_ih + W_hh h + b_hh ; c' = sig(f)*c + sig(i)*tanh(g~) ;
+ *   h' = sig(o)*tanh(c')
+ * x,h,c,h_out,c_out: [B][H] contiguous; w_ih,w_hh: [4H][H]; b_ih,b_hh: [4H].
+ * In-place state update (h_out == h, c_out == c) is NOT allowed (every
+ * workgroup reads all of h).  gates_out (optional, [B][4H]) receives the
+ * post-activation gates (i,f,g~,o) for the backward pass.  H % 64 == 0.       */
+int dvg_lstm_cell(const float* x, const float* h, const float* c, const float* w_ih,
+                  const float* w_hh, const float* b_ih, const float* b_hh,
+                  float* h_out, float* c_out, float* gates_out, int B, int H,
+                  void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Sparse variational GP trigger (gp_models.py:10-24 + gpytorch 0.3.x
+ * WhitenedVariationalStrategy / GaussianLikelihood / MultivariateNormal;
+ * equations of record in DESIGN.md §GP).  One workgroup per latent dim.
+ * ------------------------------------------------------------------ */
+
+/* Predictive distribution q(f(x)) for D independent 1-D GPs, M inducing points.
+ *   h            [B][D]   latent codes; GP d sees column d (the reference's
+ *                         h.transpose(0,1).view(D,B,1), train.py:225)
+ *   z            [D][M]   inducing inputs
+ *   var_mean     [D][M]   variational mean m
+ *   chol_var     [D][M][M] variational Cholesky factor (lower part is used)
+ *   mean_const   [D], outputscale [D], lengthscale [D]  (already soft-plus'ed)
+ *   noise        [D] or NULL: likelihood noise added to the variance/covariance
+ *                (GaussianLikelihood.__call__, generate_frames.py:131,170)
+ * Outputs (any may be NULL):
+ *   mean [D][B]; var [D][B] (marginal variance; train-mode clamp at 0 when
+ *   `train_mode` != 0); sample [D][B] = mean + chol(Sigma)*eps with
+ *   eps [D][B] supplied by the caller (MultivariateNormal.rsample);
+ *   cov [D][B][B] full predictive covariance (eval mode only).
+ *   kl [D] (train mode: KL(q(u)||p(u))).
+ * Limits: M <= 64, B <= 128 and dvg_gp_lds_bytes(B, M, cov||sample) <= 160 KiB. */
+size_t dvg_gp_lds_bytes(int B, int M, int need_cov);
+int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
+                   const float* chol_var, const float* mean_const,
+                   const float* outputscale, const float* lengthscale,
+                   const float* noise, const float* eps, float* mean, float* var,
+                   float* sample, float* cov, float* kl, int B, int D, int M,
+                   int train_mode, float jitter, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Small elementwise helpers on the path
+ * ------------------------------------------------------------------ */
+
+/* (N,C,H,W) contiguous -> NHWC and back (skip tensors handed to / taken from
+ * callers that insist on contiguous NCHW).                                    */
+int dvg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int dvg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVG_HIP_H */

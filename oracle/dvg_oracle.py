@@ -1,0 +1,330 @@
+"""CPU ORACLE for the DVG frame-prediction hot path.  *** TEST INFRASTRUCTURE ONLY ***
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import
+this module, and only as the checker / reported baseline.  The product (dvg_amd/)
+never imports it and has no CPU fallback.
+
+It restates, with plain torch-CPU functional ops on explicit state_dicts (reference
+key names), what the reference's modules compute.  Each function cites the reference
+lines it follows (paths relative to the reference tree).
+
+Pinning:
+  * encoder / decoder / LSTM restatements are pinned against golden vectors produced
+    by the reference's own modules imported on CPU (tests/golden/make_golden.py,
+    committed with its outputs; checked by tests/test_oracle_golden.py).
+  * GP (gp_models.py + gpytorch): **parity unpinned** — gpytorch is not vendored in
+    the reference, not pinned by any manifest and not installable here.  The GP
+    functions below restate the gpytorch 0.3.x WhitenedVariationalStrategy /
+    GaussianLikelihood / VariationalELBO arithmetic as documented in DESIGN.md
+    ("GP: equations of record") and are self-checked in fp64 against closed-form
+    identities (tests/test_oracle_gp.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def _bn(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
+    """nn.BatchNorm2d (vgg_64.py:9, dcgan_64.py:9): batch statistics in train mode
+    (running stats updated in place, momentum 0.1), running statistics in eval mode."""
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], training, BN_MOMENTUM, BN_EPS)
+
+
+def vgg_layer(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
+    """vgg_64.py:5-15: Conv2d(nin,nout,3,1,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
+    y = F.conv2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=1, padding=1)
+    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+
+
+def dcgan_conv(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
+    """dcgan_64.py:4-14: Conv2d(nin,nout,4,2,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
+    y = F.conv2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=2, padding=1)
+    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+
+
+def dcgan_upconv(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
+    """dcgan_64.py:16-26: ConvTranspose2d(nin,nout,4,2,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
+    y = F.conv_transpose2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=2, padding=1)
+    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+
+
+def _count_blocks(sd: SD, stage: str) -> int:
+    n = 0
+    while f"{stage}.{n}.main.0.weight" in sd:
+        n += 1
+    return n
+
+
+# --------------------------------------------------------------------------------------
+# vgg encoder / decoder (64 and 128)
+# --------------------------------------------------------------------------------------
+def vgg_encoder(x: torch.Tensor, sd: SD, training: bool = False) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """vgg_64.py:51-57 (4 stages + c5 head) and vgg_128.py:56-63 (5 stages + c6 head):
+    stage -> skip, MaxPool2d(2,2) between stages, head = Conv2d(512,dim,4,1,0)+BN+Tanh."""
+    nstage = 4 if "c6.0.weight" not in sd else 5
+    head = f"c{nstage + 1}"
+    skips = []
+    h = x
+    for s in range(1, nstage + 1):
+        if s > 1:
+            h = F.max_pool2d(h, 2, 2)
+        for b in range(_count_blocks(sd, f"c{s}")):
+            h = vgg_layer(h, sd, f"c{s}.{b}", training)
+        skips.append(h)
+    h = F.max_pool2d(h, 2, 2)
+    h = F.conv2d(h, sd[head + ".0.weight"], sd[head + ".0.bias"])
+    h = torch.tanh(_bn(h, sd, head + ".1", training))
+    return h.reshape(-1, sd[head + ".0.weight"].shape[0]), skips
+
+
+def vgg_decoder(vec: torch.Tensor, skips: Sequence[torch.Tensor], sd: SD, training: bool = False) -> torch.Tensor:
+    """vgg_64.py:95-106 / vgg_128.py:107-120: upc1 = ConvTranspose2d(dim,512,4,1,0)+BN+LReLU;
+    then [nearest x2 -> cat(skip) -> vgg blocks] per stage; the last stage ends with
+    ConvTranspose2d(64,nc,3,1,1)+Sigmoid."""
+    nstage = len(skips)
+    dim = sd["upc1.0.weight"].shape[0]
+    d = F.conv_transpose2d(vec.reshape(-1, dim, 1, 1), sd["upc1.0.weight"], sd["upc1.0.bias"])
+    d = F.leaky_relu(_bn(d, sd, "upc1.1", training), 0.2)
+    for s in range(nstage):
+        stage = f"upc{s + 2}"
+        d = torch.cat([F.interpolate(d, scale_factor=2, mode="nearest"), skips[nstage - 1 - s]], 1)
+        for b in range(_count_blocks(sd, stage)):
+            d = vgg_layer(d, sd, f"{stage}.{b}", training)
+    last = f"upc{nstage + 1}"
+    nb = _count_blocks(sd, last)
+    d = F.conv_transpose2d(d, sd[f"{last}.{nb}.weight"], sd[f"{last}.{nb}.bias"], stride=1, padding=1)
+    return torch.sigmoid(d)
+
+
+# --------------------------------------------------------------------------------------
+# dcgan encoder / decoder (64 and 128)
+# --------------------------------------------------------------------------------------
+def dcgan_encoder(x: torch.Tensor, sd: SD, training: bool = False) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """dcgan_64.py:48-54 / dcgan_128.py:50-57: strided conv stages, every stage output is
+    a skip; head Conv2d(512,dim,4,1,0)+BN+Tanh."""
+    nstage = 4 if "c6.0.weight" not in sd else 5
+    head = f"c{nstage + 1}"
+    skips = []
+    h = x
+    for s in range(1, nstage + 1):
+        h = dcgan_conv(h, sd, f"c{s}", training)
+        skips.append(h)
+    h = F.conv2d(h, sd[head + ".0.weight"], sd[head + ".0.bias"])
+    h = torch.tanh(_bn(h, sd, head + ".1", training))
+    return h.reshape(-1, sd[head + ".0.weight"].shape[0]), skips
+
+
+def dcgan_decoder(vec: torch.Tensor, skips: Sequence[torch.Tensor], sd: SD, training: bool = False,
+                  final_act: str = "tanh") -> torch.Tensor:
+    """dcgan_64.py:81-88 (final Tanh, :75-79) / dcgan_128.py:86-94 (final Sigmoid, :80-84):
+    upc1 stem, then dcgan_upconv on cat([d, skip]) per stage, last layer
+    ConvTranspose2d(128,nc,4,2,1) + activation."""
+    nstage = len(skips)
+    dim = sd["upc1.0.weight"].shape[0]
+    d = F.conv_transpose2d(vec.reshape(-1, dim, 1, 1), sd["upc1.0.weight"], sd["upc1.0.bias"])
+    d = F.leaky_relu(_bn(d, sd, "upc1.1", training), 0.2)
+    for s in range(nstage - 1):
+        d = dcgan_upconv(torch.cat([d, skips[nstage - 1 - s]], 1), sd, f"upc{s + 2}", training)
+    last = f"upc{nstage + 1}"
+    d = F.conv_transpose2d(torch.cat([d, skips[0]], 1), sd[last + ".0.weight"], sd[last + ".0.bias"], stride=2,
+                           padding=1)
+    return torch.tanh(d) if final_act == "tanh" else torch.sigmoid(d)
+
+
+# --------------------------------------------------------------------------------------
+# lstm
+# --------------------------------------------------------------------------------------
+def lstm_init_hidden(batch: int, hidden: int, n_layers: int, dtype=torch.float32):
+    """lstm.py:58-63: zeros (h, c) per layer."""
+    return [(torch.zeros(batch, hidden, dtype=dtype), torch.zeros(batch, hidden, dtype=dtype))
+            for _ in range(n_layers)]
+
+
+def lstm_cell(x, hc, sd: SD, prefix: str):
+    """nn.LSTMCell (lstm.py:51,69), gate order i,f,g,o."""
+    h, c = hc
+    g = F.linear(x, sd[prefix + ".weight_ih"], sd[prefix + ".bias_ih"]) + \
+        F.linear(h, sd[prefix + ".weight_hh"], sd[prefix + ".bias_hh"])
+    i, f, gg, o = g.chunk(4, 1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    return h2, c2
+
+
+def lstm_step(x: torch.Tensor, sd: SD, hidden: list) -> torch.Tensor:
+    """lstm.py:65-72: embed -> n_layers LSTMCells (state mutated in `hidden`) -> Linear+Tanh."""
+    in_size = sd["embed.weight"].shape[1]
+    h_in = F.linear(x.reshape(-1, in_size), sd["embed.weight"], sd["embed.bias"])
+    for i in range(len(hidden)):
+        hidden[i] = lstm_cell(h_in, hidden[i], sd, f"lstm.{i}")
+        h_in = hidden[i][0]
+    return torch.tanh(F.linear(h_in, sd["output.0.weight"], sd["output.0.bias"]))
+
+
+def gaussian_lstm_step(x: torch.Tensor, sd: SD, hidden: list, eps: torch.Tensor):
+    """lstm.py:166-175 with the N(0,1) draw of :163 passed in as `eps`."""
+    in_size = sd["embed.weight"].shape[1]
+    h_in = F.linear(x.reshape(-1, in_size), sd["embed.weight"], sd["embed.bias"])
+    for i in range(len(hidden)):
+        hidden[i] = lstm_cell(h_in, hidden[i], sd, f"lstm.{i}")
+        h_in = hidden[i][0]
+    mu = F.linear(h_in, sd["mu_net.weight"], sd["mu_net.bias"])
+    logvar = F.linear(h_in, sd["logvar_net.weight"], sd["logvar_net.bias"])
+    return eps * torch.exp(0.5 * logvar) + mu, mu, logvar
+
+
+# --------------------------------------------------------------------------------------
+# GP: equations of record.  State keys follow gpytorch 0.3.x:
+#   variational_strategy.inducing_points (D,M,1)
+#   variational_strategy.variational_distribution.variational_mean (D,M)
+#   variational_strategy.variational_distribution.chol_variational_covar (D,M,M)
+#   mean_module.constant (D,1), covar_module.raw_outputscale (D),
+#   covar_module.base_kernel.raw_lengthscale (D,1,1); likelihood: noise_covar.raw_noise (D,1)
+# --------------------------------------------------------------------------------------
+GP_JITTER = 1e-3
+NOISE_FLOOR = 1e-4
+
+
+def softplus(x):
+    return F.softplus(x)
+
+
+def gp_hypers(sd: SD):
+    s = softplus(sd["covar_module.raw_outputscale"]).reshape(-1)
+    ell = softplus(sd["covar_module.base_kernel.raw_lengthscale"]).reshape(-1)
+    c = sd["mean_module.constant"].reshape(-1)
+    return s, ell, c
+
+
+def likelihood_noise(lsd: SD):
+    """GaussianLikelihood(batch_size=D) (train.py:102): softplus(raw_noise) + 1e-4 floor."""
+    return softplus(lsd["noise_covar.raw_noise"]).reshape(-1) + NOISE_FLOOR
+
+
+def rbf(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, ell: torch.Tensor) -> torch.Tensor:
+    """ScaleKernel(RBFKernel) (gp_models.py:17-19): a (D,Na), b (D,Nb) -> (D,Na,Nb)."""
+    diff = a.unsqueeze(-1) - b.unsqueeze(-2)
+    return s.view(-1, 1, 1) * torch.exp(-0.5 * diff * diff / (ell.view(-1, 1, 1) ** 2))
+
+
+def gp_prior_init(sd: SD) -> None:
+    """WhitenedVariationalStrategy.initialize_variational_dist (first call):
+    m <- prior mean, L_S <- chol((K_ZZ + jitter I)^-1) computed in fp64."""
+    s, ell, c = gp_hypers(sd)
+    z = sd["variational_strategy.inducing_points"].squeeze(-1)
+    M = z.shape[1]
+    kzz = rbf(z.double(), z.double(), s.double(), ell.double()) + GP_JITTER * torch.eye(M, dtype=torch.float64)
+    ls = torch.linalg.cholesky(torch.linalg.inv(kzz))
+    sd["variational_strategy.variational_distribution.variational_mean"] = c.view(-1, 1).expand(-1, M).clone().to(
+        z.dtype)
+    sd["variational_strategy.variational_distribution.chol_variational_covar"] = ls.to(z.dtype)
+
+
+def gp_predict(h: torch.Tensor, sd: SD, training: bool, noise: torch.Tensor = None, dtype=torch.float64) -> dict:
+    """gp_layer(h.transpose(0,1).view(D,B,1)) (train.py:225; generate_frames.py:170) and,
+    with `noise`, likelihood(gp_layer(...)) (generate_frames.py:131,170).
+    h: (B,D).  Returns mean (D,B), var (D,B), cov (D,B,B) [eval], kl (D) [train]."""
+    s, ell, c = [t.to(dtype) for t in gp_hypers(sd)]
+    z = sd["variational_strategy.inducing_points"].squeeze(-1).to(dtype)
+    m = sd["variational_strategy.variational_distribution.variational_mean"].to(dtype)
+    ls = torch.tril(sd["variational_strategy.variational_distribution.chol_variational_covar"].to(dtype))
+    x = h.to(dtype).t().contiguous()  # (D,B): GP d sees latent column d
+    D, M = z.shape
+    kzz = rbf(z, z, s, ell) + GP_JITTER * torch.eye(M, dtype=dtype)
+    L = torch.linalg.cholesky(kzz)
+    kzx = rbf(z, x, s, ell)
+    A = torch.linalg.solve_triangular(L, kzx, upper=False)
+    v = torch.linalg.solve_triangular(L, (m - c.view(-1, 1)).unsqueeze(-1), upper=False)
+    mean = c.view(-1, 1) + (A.transpose(1, 2) @ v).squeeze(-1)
+    W = ls.transpose(1, 2) @ kzx
+    out = {"mean": mean}
+    nz = torch.zeros(D, dtype=dtype) if noise is None else noise.to(dtype).reshape(-1)
+    if training:
+        var = (W * W).sum(1) + torch.clamp(s.view(-1, 1) - (A * A).sum(1), min=0.0)
+        out["var"] = var + nz.view(-1, 1)
+        logdet_k = 2.0 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(1)
+        logdet_s = 2.0 * torch.log(torch.abs(torch.diagonal(ls, dim1=1, dim2=2))).sum(1)
+        trace = ((ls @ ls.transpose(1, 2)) * kzz).sum((1, 2))
+        quad = (v.squeeze(-1) ** 2).sum(1)
+        out["kl"] = 0.5 * (-logdet_k - logdet_s + trace + quad - M)
+    else:
+        cov = W.transpose(1, 2) @ W + rbf(x, x, s, ell) - A.transpose(1, 2) @ A
+        cov = cov + nz.view(-1, 1, 1) * torch.eye(x.shape[1], dtype=dtype)
+        out["cov"] = cov
+        out["var"] = torch.diagonal(cov, dim1=1, dim2=2)
+    return out
+
+
+def gp_rsample(mean: torch.Tensor, cov: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+    """MultivariateNormal.rsample with the base sample passed in: mean + chol(cov) eps."""
+    Lc = torch.linalg.cholesky(cov)
+    return mean + (Lc @ eps.to(cov.dtype).unsqueeze(-1)).squeeze(-1)
+
+
+def variational_elbo(pred: dict, target: torch.Tensor, noise: torch.Tensor, num_data: int) -> torch.Tensor:
+    """VariationalELBO(likelihood, gp, num_data, combine_terms=True) (train.py:112,226):
+    (1/B) sum_n E_q[log N(y_n | f_n, sigma^2)] - KL/num_data, per latent dim -> (D,).
+    `pred` is the TRAIN-mode latent prediction WITHOUT likelihood noise;
+    target (D,B) = h_target.transpose(0,1)."""
+    mean, var = pred["mean"], pred["var"]
+    nz = noise.to(mean.dtype).view(-1, 1)
+    ll = -0.5 * ((target.to(mean.dtype) - mean) ** 2 + var) / nz - 0.5 * torch.log(nz) - 0.5 * math.log(2 * math.pi)
+    return ll.sum(-1) / mean.shape[-1] - pred["kl"] / num_data
+
+
+# --------------------------------------------------------------------------------------
+# latent / index bookkeeping and the rollout
+# --------------------------------------------------------------------------------------
+def normalize_data(sequence: torch.Tensor) -> List[torch.Tensor]:
+    """utils.py:86-95: (B,T,H,W,C) -> list of T tensors (B,C,H,W)."""
+    seq = sequence.transpose(0, 1).transpose(3, 4).transpose(2, 3)
+    return [seq[t].contiguous() for t in range(seq.shape[0])]
+
+
+def gp_trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
+    """generate_frames.py:165-171: GP sampling replaces the LSTM prediction at steps
+    i >= n_past with i % 15 == 0."""
+    return [i for i in range(n_past, n_eval) if i % period == 0]
+
+
+def rollout(x: Sequence[torch.Tensor], enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n_eval: int,
+            eps_by_step: Dict[int, torch.Tensor], last_frame_skip: bool = False, rnn_size: int = 256,
+            n_layers: int = 2, period: int = 15) -> List[torch.Tensor]:
+    """One sample of the make_gifs loop (generate_frames.py:143-177), all modules in eval
+    mode.  enc(x)->(h,skips), dec(vec,skips)->frame are closures over the encoder/decoder
+    restatements.  Returns the n_eval frames [x0, ...] (conditioning frames copied)."""
+    B = x[0].shape[0]
+    hidden = lstm_init_hidden(B, rnn_size, n_layers)
+    frames = [x[0]]
+    x_in = x[0]
+    skip = None
+    noise = likelihood_noise(lik_sd)
+    for i in range(1, n_eval):
+        h, sk = enc(x_in)
+        if last_frame_skip or i < n_past:
+            skip = sk
+        if i < n_past:
+            lstm_step(h, lstm_sd, hidden)  # output discarded (generate_frames.py:162)
+            x_in = x[i]
+        else:
+            h_pred = lstm_step(h, lstm_sd, hidden)
+            if i % period == 0:
+                p = gp_predict(h, gp_sd, training=False, noise=noise, dtype=torch.float64)
+                z = gp_rsample(p["mean"], p["cov"], eps_by_step[i]).t().to(h.dtype)
+                x_in = dec(z, skip)
+            else:
+                x_in = dec(h_pred, skip)
+        frames.append(x_in)
+    return frames

@@ -1,0 +1,68 @@
+"""Shared helpers for the parity tests (regenerate the seeded weights/inputs of make_golden.py)."""
+import importlib
+
+import torch
+
+from oracle import dvg_oracle as orc
+from oracle import params
+
+# tag -> (family, res, nc, batch, training, seed)   — must mirror tests/golden/make_golden.py:main()
+BACKBONE_CASES = {
+    "vgg_64/eval": ("vgg", 64, 1, 2, False, 100),
+    "vgg_64/train": ("vgg", 64, 1, 4, True, 110),
+    "dcgan_64/eval": ("dcgan", 64, 1, 2, False, 120),
+    "dcgan_64/train": ("dcgan", 64, 1, 4, True, 130),
+    "vgg_64_nc3/eval": ("vgg", 64, 3, 2, False, 140),
+    "dcgan_64_nc3/eval": ("dcgan", 64, 3, 2, False, 150),
+    "vgg_128/eval": ("vgg", 128, 3, 1, False, 160),
+    "dcgan_128/eval": ("dcgan", 128, 3, 2, False, 170),
+}
+
+
+def our_module(family, res):
+    return importlib.import_module(f"dvg_amd.models.{family}_{res}")
+
+
+def backbone_case(tag):
+    """Returns (enc_module, dec_module, enc_sd, dec_sd, x, vec) for a golden case, modules on CPU."""
+    family, res, nc, batch, training, seed = BACKBONE_CASES[tag]
+    mod = our_module(family, res)
+    enc, dec = mod.encoder(90, nc), mod.decoder(90, nc)
+    esd = params.fill_state_dict(enc.state_dict(), seed)
+    dsd = params.fill_state_dict(dec.state_dict(), seed + 1, params.decoder_transposed_keys(dec.state_dict(), family))
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    enc.train(training)
+    dec.train(training)
+    x = params.frames(seed + 2, batch, nc, res)
+    vec = params.normal(seed + 3, batch, 90, scale=0.5).tanh()
+    return enc, dec, esd, dsd, x, vec
+
+
+def oracle_backbone(tag, esd, dsd, x, vec):
+    """Oracle forward for a case; mutates copies of the state dicts in train mode (running stats)."""
+    family, res, nc, batch, training, seed = BACKBONE_CASES[tag]
+    esd = {k: v.clone() for k, v in esd.items()}
+    dsd = {k: v.clone() for k, v in dsd.items()}
+    if family == "vgg":
+        h, skips = orc.vgg_encoder(x, esd, training)
+        y = orc.vgg_decoder(vec, skips, dsd, training)
+        y_h = orc.vgg_decoder(h, skips, dsd, training)
+    else:
+        act = "tanh" if res == 64 else "sigmoid"
+        h, skips = orc.dcgan_encoder(x, esd, training)
+        y = orc.dcgan_decoder(vec, skips, dsd, training, act)
+        y_h = orc.dcgan_decoder(h, skips, dsd, training, act)
+    return h, skips, y, y_h, esd, dsd
+
+
+def summarize(t: torch.Tensor, k: int = 64):
+    f = t.detach().double().reshape(-1).cpu()
+    idx = torch.linspace(0, f.numel() - 1, k).long()
+    return torch.cat([torch.stack([f.sum(), f.abs().sum(), (f * f).sum()]), f[idx]]).numpy()
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max(|b|max, tiny): the 'relative on fp32 frames' figure of the north star."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))

@@ -1,0 +1,315 @@
+"""GPU parity tests: every kernel of libdvg_hip.so, through the C ABI, against the CPU oracle on the
+same seeded inputs, and the whole modules against the golden vectors produced by the REFERENCE.
+
+Tolerance: the north star asks for 1e-4 relative on fp32 frames; tests use REL = 1e-4 on
+max|a-b| / max|b| (and a tighter figure where noted).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.common import BACKBONE_CASES, backbone_case, oracle_backbone, rel_err, summarize
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    from dvg_amd import ops
+    return ops.to_nhwc(t.to(dev()))
+
+
+# ----------------------------------------------------------------------------------------
+# kernel level
+# ----------------------------------------------------------------------------------------
+def test_layout_roundtrip():
+    from dvg_amd import ops
+    x = params.normal(1, 3, 70, 9, 13).to(dev())
+    y = ops.to_nhwc(x)
+    assert ops.is_nhwc(y) and torch.equal(y, x)
+    assert torch.equal(ops.to_nchw(y), x) and ops.to_nchw(y).is_contiguous()
+
+
+def test_weight_pack_roundtrip_is_bit_exact():
+    from dvg_amd import ops
+    w = params.normal(2, 64, 32, 3, 3).to(dev())
+    wp = ops.pack_conv_weight(w)
+    assert torch.equal(wp, w.permute(2, 3, 0, 1).reshape(9, 64, 32))
+    assert torch.equal(ops.unpack_conv_weight(wp, 3, 3), w)
+    wt = params.normal(3, 32, 64, 4, 4).to(dev())
+    wtp = ops.pack_convT_weight(wt)
+    assert torch.equal(wtp, wt.flip(2, 3).permute(2, 3, 1, 0).reshape(16, 64, 32))
+    assert torch.equal(ops.unpack_convT_weight(wtp, 4, 4), wt)
+
+
+@pytest.mark.parametrize("N,H,W,C1,C2,Cout,up,pool", [
+    (2, 16, 16, 32, 0, 64, False, False),
+    (2, 16, 32, 64, 0, 128, False, True),     # 8x16 tiles, BN=64 fallback, pooled output
+    (3, 8, 8, 64, 0, 64, False, True),        # 8x8 tiles
+    (2, 16, 16, 32, 32, 64, True, False),     # fused nearest-up + cat
+    (1, 8, 8, 64, 64, 128, True, False),
+    (2, 32, 32, 32, 64, 64, False, False),    # cat without upsample
+    (64, 8, 8, 64, 0, 128, False, False),     # enough tiles for BN=128
+])
+def test_conv3x3_igemm(N, H, W, C1, C2, Cout, up, pool):
+    from dvg_amd import ops
+    hx, wx = (H // 2, W // 2) if up else (H, W)
+    x = params.normal(10, N, C1, hx, wx)
+    sk = params.normal(11, N, C2, H, W) if C2 else None
+    w = params.normal(12, Cout, C1 + C2, 3, 3, scale=1.0 / np.sqrt(9 * (C1 + C2)))
+    sc = 1.0 + 0.1 * params.normal(13, Cout)
+    sh = 0.1 * params.normal(14, Cout)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if sk is not None:
+        xin = torch.cat([xin, sk], 1)
+    ref = F.leaky_relu(F.conv2d(xin, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
+    wp = ops.pack_conv_weight(w.to(dev()))
+    out = ops.conv3x3(nhwc(x), None if sk is None else nhwc(sk), wp, sc.to(dev()), sh.to(dev()), upsample=up,
+                      pool=pool)
+    y, yp = out if pool else (out, None)
+    assert rel_err(y, ref) < 2e-5
+    if pool:
+        assert torch.equal(yp, F.max_pool2d(y, 2, 2)), "fused max-pool must be bit-exact w.r.t. its own y"
+        assert rel_err(yp, F.max_pool2d(ref, 2, 2)) < 2e-5
+
+
+def test_conv3x3_stats_epilogue():
+    from dvg_amd import ops
+    N, H, W, C, Cout = 4, 16, 16, 32, 64
+    x = params.normal(20, N, C, H, W)
+    w = params.normal(21, Cout, C, 3, 3, scale=0.1)
+    b = params.normal(22, Cout, scale=0.2)
+    u_ref = F.conv2d(x, w, b, 1, 1)
+    (u, st) = ops.conv3x3(nhwc(x), None, ops.pack_conv_weight(w.to(dev())), None, b.to(dev()), act=ops.ACT_NONE,
+                          stats=True)
+    assert rel_err(u, u_ref) < 2e-5
+    tot = st.double().sum(0).cpu()
+    np.testing.assert_allclose(tot[0].numpy(), u_ref.double().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(tot[1].numpy(), (u_ref.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-4)
+    gamma, beta = 1 + 0.1 * params.normal(23, Cout), 0.1 * params.normal(24, Cout)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    ref = F.batch_norm(u_ref, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    rmd, rvd = torch.zeros(Cout, device=dev()), torch.ones(Cout, device=dev())
+    sc, sh = ops.bn_finalize(st, gamma.to(dev()), beta.to(dev()), rmd, rvd, N * H * W, 1e-5, 0.1)
+    y, yp = ops.bn_act_apply(u, sc, sh, act=ops.ACT_LRELU, pool=True, inplace=False)
+    assert rel_err(y, F.leaky_relu(ref, 0.2)) < 2e-5
+    assert torch.equal(yp, F.max_pool2d(y, 2, 2))
+    assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+
+
+@pytest.mark.parametrize("nc,res", [(1, 64), (3, 64), (3, 128), (1, 24)])
+def test_first_layers(nc, res):
+    from dvg_amd import ops
+    x = params.frames(30, 2, nc, res)
+    for ks, st, fn in ((3, 1, ops.conv3x3_first), (4, 2, ops.conv4x4s2_first)):
+        w = params.normal(31, 64, nc, ks, ks, scale=0.3)
+        sc, sh = 1 + 0.1 * params.normal(32, 64), 0.1 * params.normal(33, 64)
+        ref = F.leaky_relu(F.conv2d(x, w, None, st, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
+        y, stt = fn(x.to(dev()), w.to(dev()), sc.to(dev()), sh.to(dev()), stats=True)
+        assert rel_err(y, ref) < 2e-5
+        pre = F.conv2d(x, w, None, st, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        np.testing.assert_allclose(stt.double().sum(0)[0].cpu().numpy(), pre.double().sum((0, 2, 3)).numpy(),
+                                   rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (2, 16, 16, 128, 256), (5, 8, 8, 256, 512),
+                                            (2, 64, 64, 64, 64)])
+def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
+    from dvg_amd import ops
+    x = params.normal(40, N, Cin, H, W)
+    w = params.normal(41, Cout, Cin, 4, 4, scale=1.0 / np.sqrt(16 * Cin))
+    sc, sh = 1 + 0.1 * params.normal(42, Cout), 0.1 * params.normal(43, Cout)
+    ref = F.leaky_relu(F.conv2d(x, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
+    y, st = ops.conv4x4s2(nhwc(x), ops.pack_conv_weight(w.to(dev())), sc.to(dev()), sh.to(dev()), stats=True)
+    assert rel_err(y, ref) < 2e-5
+    pre = F.conv2d(x, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    np.testing.assert_allclose(st.double().sum(0)[1].cpu().numpy(), (pre.double() ** 2).sum((0, 2, 3)).numpy(),
+                               rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,H,W,C1,C2,Cout", [(2, 4, 4, 512, 512, 256), (3, 8, 8, 256, 256, 128),
+                                              (2, 16, 16, 128, 128, 64), (2, 32, 32, 64, 0, 64)])
+def test_convT4x4s2_igemm(N, H, W, C1, C2, Cout):
+    from dvg_amd import ops
+    x = params.normal(50, N, C1, H, W)
+    sk = params.normal(51, N, C2, H, W) if C2 else None
+    w = params.normal(52, C1 + C2, Cout, 4, 4, scale=1.0 / np.sqrt(4 * (C1 + C2)))
+    sc, sh = 1 + 0.1 * params.normal(53, Cout), 0.1 * params.normal(54, Cout)
+    xin = x if sk is None else torch.cat([x, sk], 1)
+    pre = F.conv_transpose2d(xin, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    y, st = ops.convT4x4s2(nhwc(x), None if sk is None else nhwc(sk), ops.pack_convT_weight(w.to(dev())),
+                           sc.to(dev()), sh.to(dev()), stats=True)
+    assert rel_err(y, F.leaky_relu(pre, 0.2)) < 2e-5
+    np.testing.assert_allclose(st.double().sum(0)[0].cpu().numpy(), pre.double().sum((0, 2, 3)).numpy(), rtol=1e-4,
+                               atol=1e-2)
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_last_layers(nc):
+    from dvg_amd import ops
+    x = params.normal(60, 2, 64, 40, 64)
+    w = params.normal(61, 64, nc, 3, 3, scale=0.05)
+    b = params.normal(62, nc, scale=0.1)
+    ref = torch.sigmoid(F.conv_transpose2d(x, w, b, 1, 1))
+    y = ops.convT3x3_last(nhwc(x), w.to(dev()), b.to(dev()), nc)
+    assert rel_err(y, ref) < 2e-5 and y.is_contiguous()
+    x1, x2 = params.normal(63, 2, 64, 32, 32), params.normal(64, 2, 64, 32, 32)
+    w4 = params.normal(65, 128, nc, 4, 4, scale=0.05)
+    ref = torch.tanh(F.conv_transpose2d(torch.cat([x1, x2], 1), w4, b, 2, 1))
+    y = ops.convT4x4s2_last(nhwc(x1), nhwc(x2), w4.to(dev()), b.to(dev()), nc, act=ops.ACT_TANH)
+    assert rel_err(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,splitk,period", [(64, 90, 8192, 32, 90), (64, 8192, 90, 1, 512), (5, 256, 90, 1, 256),
+                                                 (50, 90, 256, 1, 90), (7, 33, 1000, 4, 11)])
+def test_gemm_nt(M, N, K, splitk, period):
+    from dvg_amd import ops
+    a = params.normal(70, M, K, scale=1 / np.sqrt(K))
+    w = params.normal(71, N, K)
+    sc, sh = 1 + 0.1 * params.normal(72, period), 0.1 * params.normal(73, period)
+    idx = torch.arange(N) % period
+    ref = torch.tanh((a.double() @ w.double().t()) * sc.double()[idx] + sh.double()[idx])
+    y = ops.gemm_nt(a.to(dev()), w.to(dev()), sc.to(dev()), sh.to(dev()), act=ops.ACT_TANH, period=period,
+                    splitk=splitk)
+    assert rel_err(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,H", [(64, 256), (5, 256), (50, 128), (33, 64)])
+def test_lstm_cell(B, H):
+    from dvg_amd import ops
+    x, h, c = params.normal(80, B, H, scale=0.5), params.normal(81, B, H, scale=0.5), params.normal(82, B, H, scale=0.5)
+    sd = {"l.weight_ih": params.normal(83, 4 * H, H, scale=1 / np.sqrt(H)),
+          "l.weight_hh": params.normal(84, 4 * H, H, scale=1 / np.sqrt(H)),
+          "l.bias_ih": params.normal(85, 4 * H, scale=0.1), "l.bias_hh": params.normal(86, 4 * H, scale=0.1)}
+    h_ref, c_ref = orc.lstm_cell(x.double(), (h.double(), c.double()), {k: v.double() for k, v in sd.items()}, "l")
+    d = dev()
+    h2, c2, gates = ops.lstm_cell(x.to(d), h.to(d), c.to(d), sd["l.weight_ih"].to(d), sd["l.weight_hh"].to(d),
+                                  sd["l.bias_ih"].to(d), sd["l.bias_hh"].to(d), want_gates=True)
+    assert rel_err(h2, h_ref) < 1e-5 and rel_err(c2, c_ref) < 1e-5
+    assert gates.shape == (B, 4 * H) and bool(torch.isfinite(gates).all())
+
+
+@pytest.mark.parametrize("B,D,M", [(64, 90, 40), (50, 90, 40), (16, 12, 40), (128, 8, 40), (7, 5, 64)])
+def test_gp_predict_eval_and_train(B, D, M):
+    from dvg_amd import ops
+    sd, lik = params.gp_state(90, D=D, M=M)
+    h = params.normal(91, B, D, scale=0.7).tanh()
+    noise = orc.likelihood_noise(lik)
+    s, ell, c = orc.gp_hypers(sd)
+    eps = params.normal(92, D, B)
+    d = dev()
+    args = [sd["variational_strategy.inducing_points"], sd["variational_strategy.variational_distribution.variational_mean"],
+            sd["variational_strategy.variational_distribution.chol_variational_covar"], c, s, ell]
+    args = [t.to(d) for t in args]
+    ev_ref = orc.gp_predict(h, sd, training=False, noise=noise)
+    r = ops.gp_predict(h.to(d), *args, noise=noise.to(d), eps=eps.to(d), want_cov=True)
+    scale = float(ev_ref["cov"].abs().max())
+    assert rel_err(r["mean"], ev_ref["mean"]) < 5e-4
+    assert float((r["cov"].double().cpu() - ev_ref["cov"]).abs().max()) < 2e-3 * scale
+    assert float((r["var"].double().cpu() - ev_ref["var"]).abs().max()) < 2e-3 * scale
+    # the sample must be consistent with the kernel's OWN covariance: mean + chol(cov) eps
+    own = orc.gp_rsample(r["mean"].double().cpu(), r["cov"].double().cpu(), eps.double())
+    assert float((r["sample"].double().cpu() - own).abs().max()) < 2e-3
+    tr_ref = orc.gp_predict(h, sd, training=True)
+    t = ops.gp_predict(h.to(d), *args, want_kl=True, train_mode=True)
+    assert rel_err(t["mean"], tr_ref["mean"]) < 5e-4
+    assert float((t["var"].double().cpu() - tr_ref["var"]).abs().max()) < 2e-3 * scale
+    assert rel_err(t["kl"], tr_ref["kl"]) < 2e-3
+
+
+def test_gp_index_bookkeeping_is_exact():
+    """(B,D) <-> (D,B,1) view bookkeeping (train.py:225): GP d must see column d of h, bit-exactly."""
+    from dvg_amd.models.gp_models import GPRegressionLayer1
+    D, B = 6, 9
+    gp = GPRegressionLayer1(D, 8).to(dev()).eval()
+    h = params.normal(95, B, D).to(dev())
+    a = gp(h.transpose(0, 1).view(D, B, 1))
+    b = gp(h)
+    assert torch.equal(a.mean, b.mean) and a.mean.shape == (D, B)
+    # permuting the batch permutes the prediction columns and nothing else
+    perm = torch.randperm(B, device=dev())
+    assert torch.allclose(gp(h[perm]).mean, a.mean[:, perm], atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------
+# module level: HIP path vs oracle and vs the REFERENCE's golden vectors
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", list(BACKBONE_CASES))
+def test_backbone_modules(tag, golden):
+    enc, dec, esd, dsd, x, vec = backbone_case(tag)
+    training = BACKBONE_CASES[tag][4]
+    with torch.no_grad():
+        h_ref, skips_ref, y_ref, y_h_ref, esd2, dsd2 = oracle_backbone(tag, esd, dsd, x, vec)
+        enc.to(dev()), dec.to(dev())
+        h, skips = enc(x.to(dev()))
+        y = dec([vec.to(dev()), skips])
+        y_h = dec([h, skips])
+    assert h.shape == h_ref.shape and y.shape == y_ref.shape
+    tol = REL if not training else 5e-4  # batch statistics amplify rounding differences a little
+    assert rel_err(h, h_ref) < tol, rel_err(h, h_ref)
+    for s, sr in zip(skips, skips_ref):
+        assert s.shape == sr.shape and rel_err(s, sr) < tol
+    assert rel_err(y, y_ref) < tol and rel_err(y_h, y_h_ref) < tol
+    # against the reference's own outputs
+    assert rel_err(h, torch.from_numpy(golden[f"{tag}/h"])) < tol
+    assert rel_err(y, torch.from_numpy(golden[f"{tag}/y"])) < tol
+    assert rel_err(y_h, torch.from_numpy(golden[f"{tag}/y_h"])) < tol
+    for i, s in enumerate(skips):
+        np.testing.assert_allclose(summarize(s)[3:], golden[f"{tag}/skip{i}"][3:], rtol=0,
+                                   atol=tol * float(np.abs(golden[f"{tag}/skip{i}"][3:]).max()) + 1e-6)
+    if training:
+        sd_e, sd_d = enc.state_dict(), dec.state_dict()
+        for k in golden.files:
+            if k.startswith(f"{tag}/enc/"):
+                assert rel_err(sd_e[k.split("/enc/")[1]], torch.from_numpy(golden[k])) < 1e-4, k
+            if k.startswith(f"{tag}/dec/"):
+                assert rel_err(sd_d[k.split("/dec/")[1]], torch.from_numpy(golden[k])) < 1e-4, k
+
+
+def test_lstm_module(golden):
+    import dvg_amd.models.lstm as ours
+    B = 5
+    net = ours.lstm(90, 90, 256, 2, B)
+    net.load_state_dict(params.fill_state_dict(net.state_dict(), 300))
+    net.to(dev())
+    net.hidden = net.init_hidden()
+    with torch.no_grad():
+        ys = [net(params.normal(310 + t, B, 90, scale=0.5).to(dev())) for t in range(3)]
+    assert rel_err(torch.stack(ys), torch.from_numpy(golden["lstm/y"])) < 1e-5
+    assert rel_err(net.hidden[1][0], torch.from_numpy(golden["lstm/h1"])) < 1e-5
+    assert rel_err(net.hidden[1][1], torch.from_numpy(golden["lstm/c1"])) < 1e-5
+
+
+def test_gaussian_lstm_module(golden):
+    import dvg_amd.models.lstm as ours
+    B = 5
+    net = ours.gaussian_lstm(90, 90, 256, 2, B)
+    net.load_state_dict(params.fill_state_dict(net.state_dict(), 310))
+    net.to(dev())
+    net.hidden = net.init_hidden()
+    g = golden["gaussian_lstm/y"]
+    with torch.no_grad():
+        for t in range(3):
+            z, mu, logvar = net(params.normal(320 + t, B, 90, scale=0.5).to(dev()))
+            assert rel_err(mu, torch.from_numpy(g[t, 1])) < 1e-5 and rel_err(logvar, torch.from_numpy(g[t, 2])) < 1e-5
+            assert z.shape == mu.shape and bool(torch.isfinite(z).all())
+
+
+def test_skip_tensors_are_not_recycled():
+    """SURVEY §8(b) ownership: skips returned by the encoder stay valid across later calls."""
+    enc, dec, esd, dsd, x, vec = backbone_case("dcgan_64/eval")
+    enc.to(dev())
+    with torch.no_grad():
+        h1, s1 = enc(x.to(dev()))
+        keep = [s.clone() for s in s1]
+        for _ in range(3):
+            enc(torch.rand_like(x).to(dev()))
+    assert all(torch.equal(a, b) for a, b in zip(s1, keep))
