@@ -1,0 +1,90 @@
+"""Synthetic stand-ins for the datasets of the reference (no network, no torchvision here).
+
+`SyntheticMovingMNIST` follows the trajectory logic of data/moving_mnist.py:38-91 exactly —
+`num_digits` 32x32 sprites on a 64x64 canvas, start ~ randint(32), velocity ~ randint(-4,5),
+the non-deterministic bounce rules (:56-84), additive compositing clipped at 1 (:90) — but the
+sprites come from a seeded in-repo generator instead of MNIST.  Frames are (T,H,W,1) float32 in
+[0,1]; a batch is (B,T,H,W,1), which `utils.normalize_data` turns into T x (B,1,H,W)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _sprites(rng: np.random.Generator, n: int, size: int = 32) -> np.ndarray:
+    """Digit-like blobs: a few thick random strokes, smoothed, values in [0,1]."""
+    out = np.zeros((n, size, size), np.float32)
+    yy, xx = np.mgrid[0:size, 0:size]
+    for i in range(n):
+        img = np.zeros((size, size), np.float32)
+        p = rng.uniform(6, size - 6, 2)
+        for _ in range(rng.integers(3, 6)):
+            q = np.clip(p + rng.normal(0, 7, 2), 4, size - 5)
+            for t in np.linspace(0, 1, 24):
+                c = p * (1 - t) + q * t
+                img = np.maximum(img, np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2) / (2 * 1.6 ** 2)))
+            p = q
+        out[i] = np.clip(img * 1.3, 0, 1)
+    return out
+
+
+class SyntheticMovingMNIST:
+    def __init__(self, seq_len=20, num_digits=2, image_size=64, seed=1, n_sprites=64, deterministic=False):
+        self.seq_len, self.num_digits, self.image_size = seq_len, num_digits, image_size
+        self.digit_size = 32
+        self.deterministic = deterministic
+        self.rng = np.random.default_rng(seed)
+        self.data = _sprites(self.rng, n_sprites, self.digit_size)
+        self.N = n_sprites
+
+    def __len__(self):
+        return 10000
+
+    def __getitem__(self, index):
+        rng, S, D = self.rng, self.image_size, self.digit_size
+        x = np.zeros((self.seq_len, S, S, 1), np.float32)
+        for _ in range(self.num_digits):
+            digit = self.data[rng.integers(self.N)]
+            sx, sy = int(rng.integers(S - D)), int(rng.integers(S - D))
+            dx, dy = int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
+            for t in range(self.seq_len):
+                if sy < 0:
+                    sy = 0
+                    if self.deterministic:
+                        dy = -dy
+                    else:
+                        dy, dx = int(rng.integers(1, 5)), int(rng.integers(-4, 5))
+                elif sy >= S - D:
+                    sy = S - D - 1
+                    if self.deterministic:
+                        dy = -dy
+                    else:
+                        dy, dx = int(rng.integers(-4, 0)), int(rng.integers(-4, 5))
+                if sx < 0:
+                    sx = 0
+                    if self.deterministic:
+                        dx = -dx
+                    else:
+                        dx, dy = int(rng.integers(1, 5)), int(rng.integers(-4, 5))
+                elif sx >= S - D:
+                    sx = S - D - 1
+                    if self.deterministic:
+                        dx = -dx
+                    else:
+                        dx, dy = int(rng.integers(-4, 0)), int(rng.integers(-4, 5))
+                x[t, sy:sy + D, sx:sx + D, 0] += digit
+                sy += dy
+                sx += dx
+        x[x > 1] = 1.0
+        return x
+
+    def batch(self, batch_size: int) -> torch.Tensor:
+        return torch.from_numpy(np.stack([self[i] for i in range(batch_size)]))  # (B,T,H,W,1)
+
+
+def synthetic_video(batch, seq_len, channels, res, seed=1) -> torch.Tensor:
+    """(B,T,H,W,C) U[0,1]-textured clips with temporal coherence, for the KTH/BAIR/UCF-shaped configs."""
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0, 1, (batch, 1, res, res, channels)).astype(np.float32)
+    drift = rng.normal(0, 0.05, (batch, seq_len, res, res, channels)).astype(np.float32).cumsum(1)
+    return torch.from_numpy(np.clip(base + drift, 0, 1))

@@ -18,6 +18,45 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (name, flops, bytes, ev0, ev1)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _run(name, flops, nbytes, fn, *args):
+    """Launch through the C ABI; with a KernelTimer installed, bracket the launch with events."""
+    if _timer is None:
+        check(fn(*args), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), name)
+    e1.record()
+    _timer.records.append((name, flops, nbytes, e0, e1))
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -131,8 +170,10 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
     st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV3, n, h, w, cout), cout, x.device) if stats else None
-    check(lib().dvg_conv3x3_bn_act(_p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
-                                   c2, cout, int(upsample), act, slope, _stream()), "conv3x3_bn_act")
+    _run("conv3x3_igemm", 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) +
+                                                                   n * h * w * cout + wp.numel()),
+         lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
+         c2, cout, int(upsample), act, slope, _stream())
     out = (y, yp) if pool else y
     return (out, st) if stats else out
 
@@ -147,8 +188,9 @@ def conv3x3_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fa
         raise RuntimeError("conv3x3_first: weight must be contiguous (Cout,nc,3,3)")
     y = nhwc_empty(n, cout, h, wd, x.device)
     st = _stats_buf(lib().dvg_conv_first_stats_rows(3, n, h, wd), cout, x.device) if stats else None
-    check(lib().dvg_conv3x3_first(_p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
-                                  _stream()), "conv3x3_first")
+    _run("conv3x3_first", 2.0 * n * h * wd * cout * 9 * nc, 4.0 * (x.numel() + n * h * wd * cout),
+         lib().dvg_conv3x3_first, _p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
+         _stream())
     return (y, st) if stats else y
 
 
@@ -160,7 +202,8 @@ def convT3x3_last(x, w, bias, nc, *, act=ACT_SIGMOID):
     if tuple(w.shape) != (cin, nc, 3, 3) or not w.is_contiguous():
         raise RuntimeError("convT3x3_last: weight must be contiguous (Cin,nc,3,3)")
     y = torch.empty((n, nc, h, wd), device=x.device, dtype=torch.float32)
-    check(lib().dvg_convT3x3_last(_p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, nc, act, _stream()), "convT3x3_last")
+    _run("convT3x3_last", 2.0 * n * h * wd * cin * 9 * nc, 4.0 * (x.numel() + y.numel()),
+         lib().dvg_convT3x3_last, _p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, nc, act, _stream())
     return y
 
 
@@ -173,8 +216,9 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
         raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
     y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
     st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV4S2, n, h, w, cout), cout, x.device) if stats else None
-    check(lib().dvg_conv4x4s2_bn_act(_p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, cin, cout, act,
-                                     slope, _stream()), "conv4x4s2_bn_act")
+    _run("conv4x4s2_igemm", 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin,
+         4.0 * (x.numel() + y.numel() + wp.numel()), lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift),
+         _p(y), _p(st), n, h, w, cin, cout, act, slope, _stream())
     return (y, st) if stats else y
 
 
@@ -188,8 +232,9 @@ def conv4x4s2_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=
         raise RuntimeError("conv4x4s2_first: weight must be contiguous (Cout,nc,4,4)")
     y = nhwc_empty(n, cout, h // 2, wd // 2, x.device)
     st = _stats_buf(lib().dvg_conv_first_stats_rows(4, n, h, wd), cout, x.device) if stats else None
-    check(lib().dvg_conv4x4s2_first(_p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
-                                    _stream()), "conv4x4s2_first")
+    _run("conv4x4s2_first", 2.0 * n * (h // 2) * (wd // 2) * cout * 16 * nc, 4.0 * (x.numel() + y.numel()),
+         lib().dvg_conv4x4s2_first, _p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
+         _stream())
     return (y, st) if stats else y
 
 
@@ -208,8 +253,9 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
     st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONVT4S2, n, h, w, cout), cout, x.device) if stats else None
-    check(lib().dvg_convT4x4s2_bn_act(_p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, c1, c2,
-                                      cout, act, slope, _stream()), "convT4x4s2_bn_act")
+    _run("convT4x4s2_igemm", 2.0 * n * h * w * cout * 16 * cin,
+         4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel()), lib().dvg_convT4x4s2_bn_act,
+         _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())
     return (y, st) if stats else y
 
 
@@ -225,8 +271,9 @@ def convT4x4s2_last(x, skip, w, bias, nc, *, act=ACT_TANH):
     if tuple(w.shape) != (c1 + c2, nc, 4, 4) or not w.is_contiguous():
         raise RuntimeError("convT4x4s2_last: weight must be contiguous (Cin,nc,4,4)")
     y = torch.empty((n, nc, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
-    check(lib().dvg_convT4x4s2_last(_p(x), _p(skip), _p(w), _p(bias), _p(y), n, h, wd, c1, c2, nc, act, _stream()),
-          "convT4x4s2_last")
+    _run("convT4x4s2_last", 2.0 * n * h * wd * (c1 + c2) * 16 * nc,
+         4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel()), lib().dvg_convT4x4s2_last, _p(x), _p(skip),
+         _p(w), _p(bias), _p(y), n, h, wd, c1, c2, nc, act, _stream())
     return y
 
 
@@ -286,8 +333,9 @@ def gemm_nt(a, w, scale, shift, *, act=ACT_NONE, slope=0.0, period=None, splitk=
     if out is None:
         out = torch.empty((m, n), device=a.device, dtype=torch.float32)
     ws = torch.empty((splitk, m, n), device=a.device, dtype=torch.float32) if splitk > 1 else None
-    check(lib().dvg_gemm_nt_bias_act(_p(a), _p(w), _p(scale), _p(shift), _p(out), _p(ws), m, n, k, a.stride(0),
-                                     out.stride(0), period, splitk, act, slope, _stream()), "gemm_nt_bias_act")
+    _run("gemm_nt", 2.0 * m * n * k, 4.0 * (m * k + n * k + m * n), lib().dvg_gemm_nt_bias_act, _p(a), _p(w),
+         _p(scale), _p(shift), _p(out), _p(ws), m, n, k, a.stride(0), out.stride(0), period, splitk, act, slope,
+         _stream())
     return out
 
 
@@ -303,8 +351,9 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=False):
     h_out = torch.empty_like(h)
     c_out = torch.empty_like(c)
     gates = torch.empty((b, 4 * hid), device=h.device, dtype=torch.float32) if want_gates else None
-    check(lib().dvg_lstm_cell(_p(x), _p(h), _p(c), _p(w_ih.detach()), _p(w_hh.detach()), _p(b_ih.detach()),
-                              _p(b_hh.detach()), _p(h_out), _p(c_out), _p(gates), b, hid, _stream()), "lstm_cell")
+    _run("lstm_cell", 2.0 * b * 4 * hid * 2 * hid, 4.0 * (8 * hid * hid + 5 * b * hid), lib().dvg_lstm_cell, _p(x),
+         _p(h), _p(c), _p(w_ih.detach()), _p(w_hh.detach()), _p(b_ih.detach()), _p(b_hh.detach()), _p(h_out),
+         _p(c_out), _p(gates), b, hid, _stream())
     return (h_out, c_out, gates) if want_gates else (h_out, c_out)
 
 
@@ -332,6 +381,7 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
     if args[0].numel() != d * m or args[2].numel() != d * m * m or args[3].numel() != d:
         raise RuntimeError("gp_predict: parameter shapes do not match (D,M)")
     nz = None if noise is None else noise.detach().contiguous().view(-1)
-    check(lib().dvg_gp_predict(_p(h), *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov),
-                               _p(kl), b, d, m, int(train_mode), jitter, _stream()), "gp_predict")
+    _run("gp_predict", 0.0, 4.0 * (b * d + d * m * (m + 2) + 3 * d * b), lib().dvg_gp_predict, _p(h),
+         *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov), _p(kl), b, d, m,
+         int(train_mode), jitter, _stream())
     return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}

@@ -1,0 +1,76 @@
+"""The inference rollout of generate_frames.py (the path the headline metric is quoted on).
+
+`sample_rollout` is ONE pass of the `for s in range(nsample)` body of make_gifs
+(generate_frames.py:143-177) with all five modules in eval mode:
+
+    for i in 1..n_eval-1:
+        h, skip = encoder(x_in)                 # skip kept only while i < n_past (or last_frame_skip)
+        i <  n_past: step the LSTM on h, discard its output, x_in = x[i]          (:159-164)
+        i >= n_past: h_pred = lstm(h)
+                     i % 15 == 0: x_in = decoder([likelihood(gp(h^T)).rsample()^T, skip])   (:168-171)
+                     else:        x_in = decoder([h_pred, skip])                            (:174)
+
+The reference also runs `encoder(x[i])` on conditioning steps and discards it (:160-161); in eval
+mode that call has no side effect, so it is skipped here.
+Index bookkeeping (row K of SURVEY.md §8) is integer logic kept in `trigger_steps` / the skip rule.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+
+def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
+    return [i for i in range(n_past, n_eval) if i % period == 0]
+
+
+@torch.no_grad()
+def sample_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x: Sequence[torch.Tensor], n_past: int,
+                   n_eval: int, last_frame_skip: bool = False, period: int = 15,
+                   eps_by_step: Optional[Dict[int, torch.Tensor]] = None) -> List[torch.Tensor]:
+    """Returns the n_eval frames [x0, ..] of one sample (conditioning frames are the inputs themselves)."""
+    frame_predictor.hidden = frame_predictor.init_hidden()
+    frames = [x[0]]
+    x_in = x[0]
+    skip = None
+    for i in range(1, n_eval):
+        h, sk = encoder(x_in)
+        if last_frame_skip or i < n_past:
+            skip = sk
+        if i < n_past:
+            frame_predictor(h)
+            x_in = x[i]
+        else:
+            h_pred = frame_predictor(h)
+            if period and i % period == 0:
+                pred = likelihood(gp_layer(h.transpose(0, 1).view(gp_layer.num_dims, h.shape[0], 1)))
+                z = pred.rsample(None if eps_by_step is None else eps_by_step[i])
+                x_in = decoder([z.transpose(0, 1), skip])
+            else:
+                x_in = decoder([h_pred, skip])
+        frames.append(x_in)
+    return frames
+
+
+@torch.no_grad()
+def posterior_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
+                      last_frame_skip=False) -> List[torch.Tensor]:
+    """generate_frames.py:110-134: the GP is fed the LSTM output and its predictive MEAN is decoded."""
+    frame_predictor.hidden = frame_predictor.init_hidden()
+    frames = [x[0]]
+    x_in = x[0]
+    skip = None
+    for i in range(1, n_eval):
+        h, sk = encoder(x_in)
+        if last_frame_skip or i < n_past:
+            skip = sk
+        if i < n_past:
+            frame_predictor(h)
+            x_in = x[i]
+        else:
+            h_pred = frame_predictor(h)
+            pred = likelihood(gp_layer(h_pred.transpose(0, 1).view(gp_layer.num_dims, h_pred.shape[0], 1)))
+            x_in = decoder([pred.mean.transpose(0, 1), skip])
+        frames.append(x_in)
+    return frames
