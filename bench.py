@@ -62,14 +62,28 @@ def calibrate_batchnorm(enc, dec, frame):
     enc.eval(), dec.eval()
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes show 256
+    logical CPUs but run the job under a 16-CPU cgroup quota; 256 threads on 16 CPUs thrash."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int):
     """The oracle (CPU restatement, parity-checked against the reference's modules) timed on the host
-    cores of this box: ONE full rollout of the same workload."""
+    cores of this box: ONE full rollout of the same workload (bounded: ~10-30 s of CPU work)."""
     import importlib
     from oracle import dvg_oracle as orc
     from oracle import params
     from dvg_amd.data import SyntheticMovingMNIST
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     m = importlib.import_module(f"dvg_amd.models.{model}_64")
     esd = params.fill_state_dict(m.encoder(90, 1).state_dict(), 1)
     dsd = params.fill_state_dict(m.decoder(90, 1).state_dict(), 2,
@@ -91,7 +105,7 @@ def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int):
         t0 = time.perf_counter()
         orc.rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps)
         dt = time.perf_counter() - t0
-    return {"value": round(batch * (n_eval - n_past) / dt, 2), "unit": "frames/s", "cores": os.cpu_count(),
+    return {"value": round(batch * (n_eval - n_past) / dt, 2), "unit": "frames/s", "cores": cores,
             "kind": "port", "sample": f"1 rollout of the same workload ({model}_64, B={batch}, "
                                       f"{n_past}-in/{n_eval - n_past}-out) = {dt:.1f} s of CPU work, torch-CPU fp32"}
 
