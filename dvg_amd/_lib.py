@@ -45,6 +45,21 @@ SIGNATURES = {
     "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_gp_lds_bytes": (C.c_size_t, [_i, _i, _i]),
     "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _p]),
+    "dvg_gp_bwd_lds_bytes": (C.c_size_t, [_i, _i]),
+    "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _p]),
+    "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
+    "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _p]),
+    "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "dvg_act_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
+    "dvg_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_colsum": (_i, [_p, _p, _i, _i, _p]),
+    "dvg_reduce_partials": (_i, [_p, _p, _i, _l, _p]),
+    "dvg_conv_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
+    "dvg_conv_wgrad": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_wgrad_thin_rows": (_i, [_i, _i, _i, _i]),
+    "dvg_wgrad_thin": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_lstm_gates_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

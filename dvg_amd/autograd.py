@@ -1,0 +1,291 @@
+"""torch.autograd glue for the training path (train.py:146-253).
+
+Each fused block of dvg_amd/fused.py has a Function whose forward AND backward are kernels of
+libdvg_hip.so; autograd only does the bookkeeping (which gradients are needed, when).
+
+Gradient recipe per conv block  y = act(BN(conv(cat(up(x), skip)) + b)):
+  1. dp  = (dy + maxpool-scatter(dy_pool)) * act'(y), per-channel sums       dvg_bn_act_bwd_reduce
+  2. du  = A*dp + B*u + C  (batch-statistics BN backward), dgamma, dbeta     dvg_bn_bwd_finalize / dvg_affine3_apply
+  3. dW  = MFMA GEMM over pixels (K split + deterministic reduce)             dvg_conv_wgrad / dvg_reduce_partials
+  4. dx  = the forward implicit-GEMM kernel with re-packed weights           dvg_conv3x3_bn_act / conv4x4s2 / convT4x4s2
+           (+ dvg_upsample2x_bwd when x entered through the fused nearest-x2)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def _bn_forward(bn, u, stats, count, act, slope, pool):
+    """Shared forward tail: batch (train) or running (eval) statistics -> y (, y_pool), mean, invstd."""
+    if bn.training:
+        scale, shift, mean, invstd = ops.bn_finalize(
+            stats, bn.weight.detach(), bn.bias.detach(), bn.running_mean if bn.track_running_stats else None,
+            bn.running_var if bn.track_running_stats else None, count, bn.eps,
+            bn.momentum if bn.momentum is not None else 0.1, save=True)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    else:
+        with torch.no_grad():
+            mean = bn.running_mean.clone()
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+            scale = (bn.weight.detach() * invstd).contiguous()
+            shift = (bn.bias.detach() - mean * scale).contiguous()
+    out = ops.bn_act_apply(u, scale, shift, act=act, slope=slope, pool=pool, inplace=False)
+    return out, mean, invstd
+
+
+class _ConvBlock(torch.autograd.Function):
+    """conv (+fused up/cat) + BatchNorm + activation (+ max-pool).  kinds: conv3, conv3_first, conv4s2,
+    conv4s2_first, convT4s2."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, gamma, beta, cfg):
+        kind, bn = cfg["kind"], cfg["bn"]
+        act, slope, pool, up = cfg["act"], cfg["slope"], cfg.get("pool", False), cfg.get("upsample", False)
+        b = bias.detach() if bias is not None else None
+        need_stats = bn.training
+        if kind == "conv3":
+            wp = ops.pack_conv_weight(weight)
+            r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
+        elif kind == "conv3_first":
+            r = ops.conv3x3_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
+        elif kind == "conv4s2":
+            r = ops.conv4x4s2(x, ops.pack_conv_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
+        elif kind == "conv4s2_first":
+            r = ops.conv4x4s2_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
+        elif kind == "convT4s2":
+            r = ops.convT4x4s2(x, skip, ops.pack_convT_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
+        else:
+            raise RuntimeError(kind)
+        u, st = r if need_stats else (r, None)
+        n, _, h, w = u.shape
+        out, mean, invstd = _bn_forward(bn, u, st, n * h * w, act, slope, pool)
+        y = out[0] if pool else out
+        ctx.save_for_backward(x, skip, weight, gamma, u, y, mean, invstd)
+        ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None)
+        return out if pool else y
+
+    @staticmethod
+    def backward(ctx, dy, dyp=None):
+        x, skip, weight, gamma, u, y, mean, invstd = ctx.saved_tensors
+        cfg = ctx.cfg
+        kind, act, slope, up = cfg["kind"], cfg["act"], cfg["slope"], cfg.get("upsample", False)
+        dy = None if dy is None else ops.to_nhwc(dy)
+        dyp = None if dyp is None else ops.to_nhwc(dyp)
+        if dy is None and dyp is None:
+            return (None,) * 7
+        du, dgamma, dbeta, dbias = ops.bn_act_bwd(dy, dyp, y, u, gamma.detach(), mean, invstd, cfg["count"], act=act,
+                                                  slope=slope, train=cfg["train"])
+        need_x, need_skip = ctx.needs_input_grad[0], skip is not None and ctx.needs_input_grad[1]
+        dx = dskip = None
+        c1 = x.shape[1]
+        if kind == "conv3":
+            dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, skip, du, upsample=up), 3, 3)
+            if need_x:  # dgrad = the same igemm with the flipped / transposed weights
+                wd = ops.pack_convT_weight(_c(weight.detach()[:, :c1]))
+                dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
+                dx = ops.upsample2x_bwd(dxu) if up else dxu
+            if need_skip:
+                dskip = ops.conv3x3(du, None, ops.pack_convT_weight(_c(weight.detach()[:, c1:])), None, None,
+                                    act=ACT_NONE)
+        elif kind == "conv4s2":
+            dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV4S2, x, None, du), 4, 4)
+            if need_x:
+                dx = ops.convT4x4s2(du, None, ops.pack_convT_weight(weight.detach()), None, None, act=ACT_NONE)
+        elif kind == "convT4s2":
+            dW = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, skip, du), 4, 4)
+            if need_x:
+                dx = ops.conv4x4s2(du, ops.pack_conv_weight(weight.detach()[:c1]), None, None, act=ACT_NONE)
+            if need_skip:
+                dskip = ops.conv4x4s2(du, ops.pack_conv_weight(weight.detach()[c1:]), None, None, act=ACT_NONE)
+        elif kind in ("conv3_first", "conv4s2_first"):
+            if need_x:
+                raise RuntimeError("gradients w.r.t. the input frames are not part of the DVG training path")
+            dW = ops.wgrad_thin(x, du, 3 if kind == "conv3_first" else 4)
+        else:
+            raise RuntimeError(kind)
+        return dx, dskip, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta, None
+
+
+def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, act, slope=0.2):
+    cfg = {"kind": kind, "bn": bn, "upsample": upsample, "pool": pool, "act": act, "slope": slope}
+    if kind in ("conv3", "conv4s2", "convT4s2"):
+        x = ops.to_nhwc(x)
+    return _ConvBlock.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, cfg)
+
+
+class _DenseBlock(torch.autograd.Function):
+    """Encoder head (Conv2d(512,dim,4,1,0)+BN+Tanh) and decoder stem (ConvTranspose2d(dim,512,4,1,0)+BN+LReLU)
+    as small-M GEMMs (vgg_64.py:44-48,65-69)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, cfg):
+        kind, bn, act, slope = cfg["kind"], cfg["bn"], cfg["act"], cfg["slope"]
+        b = bias.detach() if bias is not None else None
+        w = weight.detach()
+        if kind == "head":
+            n, c, h, wd = x.shape
+            a = x.permute(0, 2, 3, 1).reshape(n, h * wd * c)
+            gw = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()  # [dim][K]
+            u2 = ops.gemm_nt(a, gw, None, b, act=ACT_NONE, splitk=max(1, min(64, a.shape[1] // 256)))
+            rows, ch = n, w.shape[0]
+        else:
+            dim, cout, kh, kw = w.shape
+            a = _c(x.reshape(-1, dim))
+            n = a.shape[0]
+            gw = w.permute(2, 3, 1, 0).reshape(kh * kw * cout, dim).contiguous()  # [N_out][dim]
+            u2 = ops.gemm_nt(a, gw, None, b, act=ACT_NONE, period=cout).view(n * kh * kw, cout)
+            rows, ch = n * kh * kw, cout
+        u4 = u2.view(rows, 1, 1, ch).permute(0, 3, 1, 2)
+        st = ops.channel_stats(u2) if bn.training else None
+        y4, mean, invstd = _bn_forward(bn, u4, st, rows, act, slope, False)
+        ctx.save_for_backward(a, gw, gamma, u4, y4, mean, invstd)
+        ctx.cfg = dict(cfg, train=bn.training, rows=rows, ch=ch, xshape=tuple(x.shape), wshape=tuple(w.shape),
+                       has_bias=bias is not None)
+        if kind == "head":
+            return y4.reshape(rows, ch)
+        return y4.reshape(n, kh, kw, cout).permute(0, 3, 1, 2)  # NHWC-in-memory (N,512,4,4)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, gw, gamma, u4, y4, mean, invstd = ctx.saved_tensors
+        cfg = ctx.cfg
+        rows, ch, kind = cfg["rows"], cfg["ch"], cfg["kind"]
+        if kind == "head":
+            dy4 = _c(dy).view(rows, 1, 1, ch).permute(0, 3, 1, 2)
+        else:
+            dy4 = ops.to_nhwc(dy).permute(0, 2, 3, 1).reshape(rows, 1, 1, ch).permute(0, 3, 1, 2)
+        du4, dgamma, dbeta, dbias = ops.bn_act_bwd(dy4, None, y4, u4, gamma.detach(), mean, invstd, rows,
+                                                   act=cfg["act"], slope=cfg["slope"], train=cfg["train"])
+        if kind == "head":
+            du = du4.reshape(rows, ch)                                   # [N][dim]
+            dgw = ops.gemm_nt(ops.transpose2d(du), ops.transpose2d(a), None, None)   # [dim][K]
+            n, c, h, wd = cfg["xshape"]
+            dW = dgw.view(ch, h, wd, c).permute(0, 3, 1, 2).contiguous()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                da = ops.gemm_nt(du, ops.transpose2d(gw), None, None)   # [N][K]
+                dx = da.view(n, h, wd, c).permute(0, 3, 1, 2)
+        else:
+            dim, cout, kh, kw = cfg["wshape"]
+            n = rows // (kh * kw)
+            du = du4.reshape(n, kh * kw * cout)                          # [N][N_out]
+            dgw = ops.gemm_nt(ops.transpose2d(du), ops.transpose2d(a), None, None)   # [N_out][dim]
+            dW = dgw.view(kh, kw, cout, dim).permute(3, 2, 0, 1).contiguous()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm_nt(du, ops.transpose2d(gw), None, None).view(cfg["xshape"])
+        return dx, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta, None
+
+
+def dense_block_autograd(kind, conv, bn, x, *, act, slope=0.2):
+    cfg = {"kind": kind, "bn": bn, "act": act, "slope": slope}
+    if kind == "head":
+        x = ops.to_nhwc(x)
+    return _DenseBlock.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, cfg)
+
+
+class _LastLayer(torch.autograd.Function):
+    """ConvTranspose2d(C,nc,3,1,1)+Sigmoid (vgg_64.py:88-92) / ConvTranspose2d(C,nc,4,2,1)+Tanh on cat
+    (dcgan_64.py:75-79)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, cfg):
+        nc = weight.shape[1]
+        b = bias.detach() if bias is not None else None
+        if cfg["kind"] == "convT3":
+            y = ops.convT3x3_last(x, weight, b, nc, act=cfg["act"])
+        else:
+            y = ops.convT4x4s2_last(x, skip, weight, b, nc, act=cfg["act"])
+        ctx.save_for_backward(x, skip, weight, y)
+        ctx.cfg = dict(cfg, has_bias=bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, skip, weight, y = ctx.saved_tensors
+        cfg = ctx.cfg
+        ks = 3 if cfg["kind"] == "convT3" else 4
+        dpre = ops.act_bwd(dy, y, cfg["act"])
+        first = ops.conv3x3_first if ks == 3 else ops.conv4x4s2_first
+        c1 = x.shape[1]
+        w = weight.detach()
+        dx = dskip = None
+        if ctx.needs_input_grad[0]:   # adjoint of a transposed conv = plain conv with the same weight
+            dx = first(dpre, _c(w[:c1]), None, None, act=ACT_NONE)
+        if skip is not None and ctx.needs_input_grad[1]:
+            dskip = first(dpre, _c(w[c1:]), None, None, act=ACT_NONE)
+        dW = ops.wgrad_thin(dpre, x, ks)
+        if skip is not None:
+            dW = torch.cat([dW, ops.wgrad_thin(dpre, skip, ks)], 0)
+        db = dpre.sum((0, 2, 3)) if cfg["has_bias"] else None  # nc floats
+        return dx, dskip, dW, db, None
+
+
+def last_layer_autograd(kind, conv, x, skip, *, act):
+    x = ops.to_nhwc(x)
+    skip = None if skip is None else ops.to_nhwc(skip)
+    return _LastLayer.apply(x, skip, conv.weight, conv.bias, {"kind": kind, "act": act})
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _c(x)
+        y = ops.gemm_nt(x, weight.detach(), None, bias.detach() if bias is not None else None, act=act)
+        ctx.save_for_backward(x, weight, y)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act != ACT_NONE else _c(dy)
+        dx = ops.gemm_nt(dpre, ops.transpose2d(weight.detach()), None, None) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm_nt(ops.transpose2d(dpre), ops.transpose2d(x), None, None)
+        db = ops.colsum(dpre) if ctx.has_bias else None
+        return dx, dW, db, None
+
+
+def linear_autograd(x, weight, bias, act):
+    return _Linear.apply(x, weight, bias, act)
+
+
+class _LSTMCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
+        x, h, c = _c(x), _c(h), _c(c)
+        h2, c2, gates = ops.lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=True)
+        ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c2)
+        return h2, c2
+
+    @staticmethod
+    def backward(ctx, dh2, dc2):
+        x, h, c, w_ih, w_hh, gates, c2 = ctx.saved_tensors
+        dG, dc = ops.lstm_gates_bwd(dh2, dc2, gates, c, c2)
+        dGt = ops.transpose2d(dG)
+        dx = ops.gemm_nt(dG, ops.transpose2d(w_ih.detach()), None, None) if ctx.needs_input_grad[0] else None
+        dh = ops.gemm_nt(dG, ops.transpose2d(w_hh.detach()), None, None) if ctx.needs_input_grad[1] else None
+        dw_ih = ops.gemm_nt(dGt, ops.transpose2d(x), None, None)
+        dw_hh = ops.gemm_nt(dGt, ops.transpose2d(h), None, None)
+        db = ops.colsum(dG)
+        return dx, dh, (dc if ctx.needs_input_grad[2] else None), dw_ih, dw_hh, db, db
+
+
+def lstm_cell_autograd(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    return _LSTMCell.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
+
+
+# --------------------------------------------------------------------------------------
+# GP (train mode).  Forward = dvg_gp_predict (mean, marginal variance, KL); backward = dvg_gp_train_bwd.
+# --------------------------------------------------------------------------------------
+def gp_train_autograd(layer, h, noise):
+    from .gp_autograd import gp_train
+    return gp_train(layer, h, noise)

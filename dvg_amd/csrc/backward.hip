@@ -1,0 +1,481 @@
+// Backward (training) kernels that are HBM-bound: BatchNorm + activation + max-pool backward,
+// nearest-upsample backward, LSTM gate backward, column sums, and the weight gradient of the
+// thin first / last layers.  The MFMA weight-gradient kernel lives in wgrad.hip; data gradients
+// of the dense convs reuse conv_igemm.hip with re-packed weights.
+//
+// Reference: these implement what `loss.backward()` (train.py:170,194,240) asks autograd to do for
+// the modules of vgg_64.py:5-15,49,93, dcgan_64.py:4-26 and lstm.py:51,65-72.
+#include "dvg_common.h"
+
+namespace dvg {
+
+__device__ __forceinline__ float act_grad_from_y(float y, int act, float slope) {
+    switch (act) {
+        case DVG_ACT_LRELU: return y > 0.f ? 1.f : slope;  // slope > 0: sign(y) == sign(pre-activation)
+        case DVG_ACT_TANH: return 1.f - y * y;
+        case DVG_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// dp = (dy + maxpool_scatter(dyp)) * act'(y);   partial[blk] = { sum dp, sum dp*u } per channel
+// One thread = one 2x2 window (POOL) or one pixel, 4 channels.  blockDim = 256 = TC x TP with
+// TC = min(C/4, 256) channel quads; rows of TP pixels reduce through LDS (deterministic).
+// ---------------------------------------------------------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ dyp,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ u, float* __restrict__ dp,
+                                                                float* __restrict__ partial, int N, int H, int W,
+                                                                int C, int act, float slope, int units_per_block) {
+    __shared__ float red[2 * 256 * 4];
+    const int C4 = C >> 2;
+    const int TC = C4 < 256 ? C4 : 256;
+    const int TP = 256 / TC;
+    const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
+    const int Hu = POOL ? H >> 1 : H, Wu = POOL ? W >> 1 : W;
+    const long units = (long)N * Hu * Wu;  // windows or pixels
+    const long u0 = (long)blockIdx.x * units_per_block;
+    const long u1 = min(units, u0 + units_per_block);
+    for (int c4 = tc; c4 < C4; c4 += TC) {  // C4 > 256 only when C > 1024: not on this path, kept for safety
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        for (long w_ = u0 + tp; w_ < u1; w_ += TP) {
+            if (POOL) {
+                const int xp = w_ % Wu;
+                long r = w_ / Wu;
+                const int yp_ = r % Hu;
+                const int n = r / Hu;
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                if (dyp) g = reinterpret_cast<const f32x4*>(dyp)[w_ * C4 + c4];
+                size_t off[4];
+                f32x4 yv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    off[q] = (((size_t)n * H + 2 * yp_ + (q >> 1)) * W + 2 * xp + (q & 1)) * C4 + c4;
+                    yv[q] = reinterpret_cast<const f32x4*>(y)[off[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    if (dy) d = reinterpret_cast<const f32x4*>(dy)[off[q]];
+                    const f32x4 uv = reinterpret_cast<const f32x4*>(u)[off[q]];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // first maximum in scan order (0,0),(0,1),(1,0),(1,1) wins — nn.MaxPool2d semantics
+                        const float m = fmaxf(fmaxf(yv[0][k], yv[1][k]), fmaxf(yv[2][k], yv[3][k]));
+                        bool win = yv[q][k] == m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (e < q && yv[e][k] == m) win = false;
+                        const float t = (d[k] + (win ? g[k] : 0.f)) * act_grad_from_y(yv[q][k], act, slope);
+                        d[k] = t;
+                        s1[k] += t;
+                        s2[k] = fmaf(t, uv[k], s2[k]);
+                    }
+                    reinterpret_cast<f32x4*>(dp)[off[q]] = d;
+                }
+            } else {
+                const size_t off = (size_t)w_ * C4 + c4;
+                f32x4 d = reinterpret_cast<const f32x4*>(dy)[off];
+                const f32x4 yv = reinterpret_cast<const f32x4*>(y)[off];
+                const f32x4 uv = reinterpret_cast<const f32x4*>(u)[off];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = d[k] * act_grad_from_y(yv[k], act, slope);
+                    d[k] = t;
+                    s1[k] += t;
+                    s2[k] = fmaf(t, uv[k], s2[k]);
+                }
+                reinterpret_cast<f32x4*>(dp)[off] = d;
+            }
+        }
+        // reduce over the TP pixel rows
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[(tp * TC + tc) * 4 + k] = s1[k];
+            red[1024 + (tp * TC + tc) * 4 + k] = s2[k];
+        }
+        __syncthreads();
+        if (tp == 0) {
+            float* dst = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = 0.f, b = 0.f;
+                for (int r = 0; r < TP; ++r) {
+                    a += red[(r * TC + tc) * 4 + k];
+                    b += red[1024 + (r * TC + tc) * 4 + k];
+                }
+                dst[c4 * 4 + k] = a;
+                dst[C + c4 * 4 + k] = b;
+            }
+        }
+    }
+}
+
+// coefficients of du = A*dp + B*u + Cc, plus dgamma, dbeta, dbias
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ coefA, float* __restrict__ coefB,
+                                       float* __restrict__ coefC, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ dbias, int C, double count,
+                                       int train) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrows; ++r) {
+        s1 += (double)partial[(size_t)r * 2 * C + c];
+        s2 += (double)partial[(size_t)r * 2 * C + C + c];
+    }
+    const double mu = mean[c], is = invstd[c];
+    const double g = gamma ? gamma[c] : 1.0;
+    const double G = is * (s2 - mu * s1);  // sum dp * xhat
+    const double A = g * is;
+    if (dgamma) dgamma[c] = (float)G;
+    if (dbeta) dbeta[c] = (float)s1;
+    if (train) {
+        const double B = -A * is * G / count;
+        coefA[c] = (float)A;
+        coefB[c] = (float)B;
+        coefC[c] = (float)(-A * s1 / count - B * mu);
+        if (dbias) dbias[c] = 0.f;  // sum_c du == 0 identically under batch statistics
+    } else {
+        coefA[c] = (float)A;
+        coefB[c] = 0.f;
+        coefC[c] = 0.f;
+        if (dbias) dbias[c] = (float)(A * s1);
+    }
+}
+
+__global__ void affine3_kernel(const float* __restrict__ dp, const float* __restrict__ u,
+                               const float* __restrict__ A, const float* __restrict__ B,
+                               const float* __restrict__ Cc, float* __restrict__ du, long n4, int C4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const f32x4 d = reinterpret_cast<const f32x4*>(dp)[i];
+        const f32x4 uv = reinterpret_cast<const f32x4*>(u)[i];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(A + c), b = *reinterpret_cast<const f32x4*>(B + c),
+                    cc = *reinterpret_cast<const f32x4*>(Cc + c);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaf(a[k], d[k], fmaf(b[k], uv[k], cc[k]));
+        reinterpret_cast<f32x4*>(du)[i] = o;
+    }
+}
+
+__global__ void affine3_scalar_kernel(const float* __restrict__ dp, const float* __restrict__ u,
+                                      const float* __restrict__ A, const float* __restrict__ B,
+                                      const float* __restrict__ Cc, float* __restrict__ du, long n, int C) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        du[i] = fmaf(A[c], dp[i], fmaf(B[c], u[i], Cc[c]));
+    }
+}
+
+// scalar (C % 4 != 0) version of the reduce: dp = dy*act'(y); partial sums per channel
+__global__ __launch_bounds__(256) void act_bwd_reduce_scalar_kernel(const float* __restrict__ dy,
+                                                                    const float* __restrict__ y,
+                                                                    const float* __restrict__ u,
+                                                                    float* __restrict__ dp,
+                                                                    float* __restrict__ partial, long rows, int C,
+                                                                    int act, float slope, int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            const float t = dy[r * C + c] * act_grad_from_y(y[r * C + c], act, slope);
+            dp[r * C + c] = t;
+            s1 += t;
+            s2 = fmaf(t, u[r * C + c], s2);
+        }
+        partial[(size_t)blockIdx.x * 2 * C + c] = s1;
+        partial[(size_t)blockIdx.x * 2 * C + C + c] = s2;
+    }
+}
+
+// dpre = dy * act'(y) on a flat tensor (last layers: NCHW frames; nn.Linear+Tanh outputs)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dpre,
+                               long n, int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dpre[i] = dy[i] * act_grad_from_y(y[i], act, slope);
+}
+
+// nearest x2 upsample backward: dx[n][y][x][c] = sum of the 2x2 block of dxu
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dxu, float* __restrict__ dx, int N, int H, int W,
+                                      int C4) {
+    const long total = (long)N * H * W * C4;  // H,W = low resolution
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        long r = i / C4;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int n = r / H;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(
+                dxu)[(((size_t)n * 2 * H + 2 * y + (q >> 1)) * 2 * W + 2 * x + (q & 1)) * C4 + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += v[k];
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = s;
+    }
+}
+
+// out[c] = sum_r a[r][c]   (bias gradients; rows = batch)
+__global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += a[(size_t)r * C + c];
+    out[c] = s;
+}
+
+// out[i] = sum_s partial[s][i]
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 s = reinterpret_cast<const f32x4*>(partial)[i];
+        for (int k = 1; k < S; ++k) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)k * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+}
+
+// LSTM cell backward, elementwise part: from d(h'), d(c'), the saved activated gates, c and c'
+// produce the gate pre-activation gradients dG [B][4H] and dc_prev [B][H].
+__global__ void lstm_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc,
+                                      const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                      const float* __restrict__ c_new, float* __restrict__ dG,
+                                      float* __restrict__ dc_prev, int B, int H) {
+    const long total = (long)B * H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = i / H, j = i % H;
+        const float* g = gates + (size_t)b * 4 * H;
+        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+        const float tc = tanhf(c_new[i]);
+        const float dhv = dh ? dh[i] : 0.f;
+        const float dcv = (dc ? dc[i] : 0.f) + dhv * go * (1.f - tc * tc);
+        float* o = dG + (size_t)b * 4 * H;
+        o[j] = dcv * gg * gi * (1.f - gi);
+        o[H + j] = dcv * c_prev[i] * gf * (1.f - gf);
+        o[2 * H + j] = dcv * gi * (1.f - gg * gg);
+        o[3 * H + j] = dhv * tc * go * (1.f - go);
+        dc_prev[i] = dcv * gf;
+    }
+}
+
+// Weight gradient of the thin layers: inp NCHW (N,nc,Hi,Wi) [frame side], dout NHWC (N,Ho,Wo,C)
+//   dW[c][ci][a][b] = sum_{n,oy,ox} dout[n][oy][ox][c] * inp[n][ci][S*oy + a - 1][S*ox + b - 1]
+// This is the conv weight gradient of the first layers (dout = du) and, by adjointness, of the last
+// transposed layers (dout := the layer input x, inp := dpre).  Same tiling as conv_first_kernel:
+// lane = channel, one output row per wave, input taps are LDS broadcasts; per-block partial sums.
+template <int KS, int S>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict__ inp,
+                                                         const float* __restrict__ dout,
+                                                         float* __restrict__ partial, int N, int Hi, int Wi,
+                                                         int nc, int C) {
+    constexpr int TH = 4, TW = 32;
+    constexpr int HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
+    constexpr int NT = KS * KS;
+    __shared__ float tile[4 * HH * HW];
+    __shared__ float red[4 * 64];
+    const int Ho = (Hi + 2 - KS) / S + 1, Wo = (Wi + 2 - KS) / S + 1;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    const int cg = blockIdx.y;
+    int t = blockIdx.x;
+    const int tx_i = t % tiles_x; t /= tiles_x;
+    const int ty_i = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nc * HH * HW; i += 256) {
+        const int ci = i / (HH * HW), r = i % (HH * HW);
+        const int yy = iy0 + r / HW, xx = ix0 + r % HW;
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi) v = inp[(((size_t)n * nc + ci) * Hi + yy) * Wi + xx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int c = cg * 64 + lane;
+    float acc[4 * NT];
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) acc[i] = 0.f;
+    const int oy = oy0 + wave;
+    if (oy < Ho) {
+        for (int px = 0; px < TW; ++px) {
+            const int ox = ox0 + px;
+            if (ox >= Wo) break;
+            const float d = dout[(((size_t)n * Ho + oy) * Wo + ox) * C + c];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                if (ci < nc) {
+                    const float* tp = tile + ci * HH * HW + (wave * S) * HW + px * S;
+#pragma unroll
+                    for (int a = 0; a < KS; ++a)
+#pragma unroll
+                        for (int b = 0; b < KS; ++b) acc[ci * NT + a * KS + b] = fmaf(d, tp[a * HW + b], acc[ci * NT + a * KS + b]);
+                }
+            }
+        }
+    }
+    // reduce the 4 waves (rows) through LDS, one tap at a time; write partial[block][c][ci*NT + tap]
+    float* dst = partial + ((size_t)blockIdx.x * C + c) * (nc * NT);
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) {
+        if (i < nc * NT) {
+            __syncthreads();
+            red[wave * 64 + lane] = acc[i];
+            __syncthreads();
+            if (wave == 0) dst[i] = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+        }
+    }
+}
+
+static inline unsigned grid_for(long n, int block = 256, int cap = 4096) {
+    long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+static int bwd_units_per_block(long units) {
+    long upb = (units + 2047) / 2048;
+    if (upb < 16) upb = 16;
+    return (int)upb;
+}
+
+extern "C" int dvg_bn_act_bwd_rows(int N, int H, int W, int pool) {
+    const long units = pool ? (long)N * (H / 2) * (W / 2) : (long)N * H * W;
+    const int upb = bwd_units_per_block(units);
+    return (int)((units + upb - 1) / upb);
+}
+
+extern "C" int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const float* y, const float* u, float* dp,
+                                     float* partial, int N, int H, int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(y && u && dp && partial, DVG_ERR_NULL, "dvg_bn_act_bwd_reduce: NULL pointer");
+    DVG_REQUIRE(dy || dyp, DVG_ERR_NULL, "dvg_bn_act_bwd_reduce: no incoming gradient");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: bad shape");
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: bad act");
+    const int pool = dyp != nullptr;
+    if (C % 4 != 0) {
+        DVG_REQUIRE(!pool, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: pool needs C %% 4 == 0");
+        const long rows = (long)N * H * W;
+        const int rpb = bwd_units_per_block(rows);
+        hipLaunchKernelGGL(act_bwd_reduce_scalar_kernel, dim3((rows + rpb - 1) / rpb), dim3(C >= 256 ? 256 : 64), 0,
+                           (hipStream_t)stream, dy, y, u, dp, partial, rows, C, act, slope, rpb);
+        return check_launch("dvg_bn_act_bwd_reduce");
+    }
+    DVG_REQUIRE(C <= 1024 && (256 % (C / 4 < 256 ? C / 4 : 256)) == 0, DVG_ERR_SHAPE,
+                "dvg_bn_act_bwd_reduce: C/4 must divide 256 (C=%d)", C);
+    DVG_REQUIRE(aligned16(dy) && aligned16(dyp) && aligned16(y) && aligned16(u) && aligned16(dp), DVG_ERR_ALIGN,
+                "dvg_bn_act_bwd_reduce: alignment");
+    if (pool) DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: odd H/W with pool");
+    const long units = pool ? (long)N * (H / 2) * (W / 2) : (long)N * H * W;
+    const int upb = bwd_units_per_block(units);
+    const unsigned grid = (unsigned)((units + upb - 1) / upb);
+    if (pool)
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dyp, y,
+                           u, dp, partial, N, H, W, C, act, slope, upb);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dyp,
+                           y, u, dp, partial, N, H, W, C, act, slope, upb);
+    return check_launch("dvg_bn_act_bwd_reduce");
+}
+
+extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
+                                   const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                   float* dbeta, float* dbias, int C, double count, int train, void* stream) {
+    DVG_REQUIRE(partial && mean && invstd && coefA && coefB && coefC, DVG_ERR_NULL, "dvg_bn_bwd_finalize: NULL");
+    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nrows,
+                       gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train);
+    return check_launch("dvg_bn_bwd_finalize");
+}
+
+extern "C" int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B, const float* Cc,
+                                 float* du, long n, int C, void* stream) {
+    DVG_REQUIRE(dp && u && A && B && Cc && du, DVG_ERR_NULL, "dvg_affine3_apply: NULL pointer");
+    DVG_REQUIRE(n > 0 && C > 0 && n % C == 0, DVG_ERR_SHAPE, "dvg_affine3_apply: bad shape");
+    if (C % 4 == 0 && aligned16(dp) && aligned16(u) && aligned16(du) && aligned16(A) && aligned16(B) && aligned16(Cc))
+        hipLaunchKernelGGL(affine3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B, Cc,
+                           du, n / 4, C / 4);
+    else
+        hipLaunchKernelGGL(affine3_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B,
+                           Cc, du, n, C);
+    return check_launch("dvg_affine3_apply");
+}
+
+extern "C" int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope, void* stream) {
+    DVG_REQUIRE(dy && y && dpre, DVG_ERR_NULL, "dvg_act_bwd: NULL pointer");
+    DVG_REQUIRE(n > 0 && act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_act_bwd: bad args");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n, act,
+                       slope);
+    return check_launch("dvg_act_bwd");
+}
+
+extern "C" int dvg_upsample2x_bwd(const float* dxu, float* dx, int N, int H, int W, int C, void* stream) {
+    DVG_REQUIRE(dxu && dx, DVG_ERR_NULL, "dvg_upsample2x_bwd: NULL pointer");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DVG_ERR_SHAPE, "dvg_upsample2x_bwd: bad shape");
+    DVG_REQUIRE(aligned16(dxu) && aligned16(dx), DVG_ERR_ALIGN, "dvg_upsample2x_bwd: alignment");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dxu, dx, N, H, W, C / 4);
+    return check_launch("dvg_upsample2x_bwd");
+}
+
+extern "C" int dvg_colsum(const float* a, float* out, int rows, int C, void* stream) {
+    DVG_REQUIRE(a && out, DVG_ERR_NULL, "dvg_colsum: NULL pointer");
+    DVG_REQUIRE(rows > 0 && C > 0, DVG_ERR_SHAPE, "dvg_colsum: bad shape");
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, out, rows, C);
+    return check_launch("dvg_colsum");
+}
+
+extern "C" int dvg_reduce_partials(const float* partial, float* out, int S, long n, void* stream) {
+    DVG_REQUIRE(partial && out, DVG_ERR_NULL, "dvg_reduce_partials: NULL pointer");
+    DVG_REQUIRE(S > 0 && n > 0 && n % 4 == 0, DVG_ERR_SHAPE, "dvg_reduce_partials: n %% 4 != 0");
+    DVG_REQUIRE(aligned16(partial) && aligned16(out), DVG_ERR_ALIGN, "dvg_reduce_partials: alignment");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial, out,
+                       S, n / 4);
+    return check_launch("dvg_reduce_partials");
+}
+
+extern "C" int dvg_lstm_gates_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                                  const float* c_new, float* dG, float* dc_prev, int B, int H, void* stream) {
+    DVG_REQUIRE(gates && c_prev && c_new && dG && dc_prev, DVG_ERR_NULL, "dvg_lstm_gates_bwd: NULL pointer");
+    DVG_REQUIRE(dh || dc, DVG_ERR_NULL, "dvg_lstm_gates_bwd: no incoming gradient");
+    DVG_REQUIRE(B > 0 && H > 0, DVG_ERR_SHAPE, "dvg_lstm_gates_bwd: bad shape");
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh, dc,
+                       gates, c_prev, c_new, dG, dc_prev, B, H);
+    return check_launch("dvg_lstm_gates_bwd");
+}
+
+extern "C" int dvg_wgrad_thin_rows(int ks, int N, int Hi, int Wi) {
+    const int S = ks == 4 ? 2 : 1;
+    const int Ho = (Hi + 2 - ks) / S + 1, Wo = (Wi + 2 - ks) / S + 1;
+    return N * ((Ho + 3) / 4) * ((Wo + 31) / 32);
+}
+
+extern "C" int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, float* partial, int ks, int N, int Hi,
+                              int Wi, int nc, int C, void* stream) {
+    DVG_REQUIRE(inp_nchw && dout_nhwc && partial, DVG_ERR_NULL, "dvg_wgrad_thin: NULL pointer");
+    DVG_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && nc >= 1 && nc <= 4 && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_wgrad_thin: bad shape");
+    DVG_REQUIRE(ks == 3 || ks == 4, DVG_ERR_SHAPE, "dvg_wgrad_thin: ks must be 3 or 4");
+    const unsigned gx = (unsigned)dvg_wgrad_thin_rows(ks, N, Hi, Wi);
+    if (ks == 3)
+        hipLaunchKernelGGL((wgrad_thin_kernel<3, 1>), dim3(gx, C / 64), dim3(256), 0, (hipStream_t)stream, inp_nchw,
+                           dout_nhwc, partial, N, Hi, Wi, nc, C);
+    else
+        hipLaunchKernelGGL((wgrad_thin_kernel<4, 2>), dim3(gx, C / 64), dim3(256), 0, (hipStream_t)stream, inp_nchw,
+                           dout_nhwc, partial, N, Hi, Wi, nc, C);
+    return check_launch("dvg_wgrad_thin");
+}

@@ -205,6 +205,231 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Train-mode backward.  Forward (see gp_predict_kernel, train_mode = 1):
+//   K = Kzz + jitter I,  alpha = K^-1 (m - c),  P = K^-1 Kzx,  W = L_S^T Kzx
+//   mean_b = c + Kzx[:,b].alpha ;  q_b = Kzx[:,b].P[:,b] ;  var_b = |W[:,b]|^2 + max(s - q_b, 0)
+//   KL = 1/2 [ -log|K| - log|L_S L_S^T| + tr(L_S L_S^T K) + (m-c).alpha - M ]
+// Given gm = dL/dmean, gv = dL/dvar, gk = dL/dKL it returns dL/d{h column, z, m, L_S, c, s, ell}.
+// With tau = K^-1 Kzx gm, gq = -gv*[s-q>0], GW = 2 gv W:
+//   G2 = dL/dKzx = alpha gm^T + 2 P diag(gq) + L_S GW
+//   GK = dL/dK   = -tau alpha^T - P diag(gq) P^T + gk/2 (-K^-1 + L_S L_S^T - alpha alpha^T)
+//   dL_S = tril( Kzx GW^T + gk (K L_S - diag(1/L_S_ii)) ),  dm = tau + gk alpha,  dc = sum gm - sum dm
+// and the RBF chain rule maps (GK, G2) onto z, x, s, ell.  K^-1 is formed explicitly from L^-1
+// (M = 40: a 40x40 triangular inverse by forward substitution, one thread per column).
+// ---------------------------------------------------------------------------------------
+struct GpBwdParams {
+    const float* h; const float* z; const float* var_mean; const float* chol_var;
+    const float* mean_const; const float* outputscale; const float* lengthscale;
+    const float* gmean; const float* gvar; const float* gkl;   // upstream gradients (any may be nullptr)
+    float* dh; float* dz; float* dm; float* dls; float* dc; float* ds; float* dell;
+    int B, D, M;
+    float jitter;
+};
+
+__global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.M, B = p.B, LM = M + 1, LB = B + 2;
+    float* Kj = sm;               // [M][LM] K with jitter
+    float* L = Kj + M * LM;       // chol(K)
+    float* Li = L + M * LM;       // L^-1
+    float* Ki = Li + M * LM;      // K^-1
+    float* Ls = Ki + M * LM;      // variational factor
+    float* GK = Ls + M * LM;      // dL/dK
+    float* Kzx = GK + M * LM;     // [M][LB]
+    float* P = Kzx + M * LB;      // K^-1 Kzx
+    float* Wm = P + M * LB;       // W, then GW
+    float* G2 = Wm + M * LB;      // dL/dKzx
+    float* zs = G2 + M * LB;      // [M]
+    float* rr = zs + M;           // m - c
+    float* al = rr + M;           // alpha
+    float* tt = al + M;           // Kzx gm
+    float* tau = tt + M;          // K^-1 tt
+    float* xs = tau + M;          // [B]
+    float* gm = xs + B;
+    float* gv = gm + B;
+    float* gq = gv + B;
+    float* red = gq + B;          // [8]
+
+    const float s = p.outputscale[d], ell = p.lengthscale[d];
+    const float ninv = -0.5f / (ell * ell), c0 = p.mean_const[d];
+    const float gk = p.gkl ? p.gkl[d] : 0.f;
+
+    for (int i = tid; i < M; i += 256) {
+        zs[i] = p.z[(size_t)d * M + i];
+        rr[i] = p.var_mean[(size_t)d * M + i] - c0;
+    }
+    for (int b = tid; b < B; b += 256) {
+        xs[b] = p.h[(size_t)b * p.D + d];
+        gm[b] = p.gmean ? p.gmean[(size_t)d * B + b] : 0.f;
+        gv[b] = p.gvar ? p.gvar[(size_t)d * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < M * M; i += 256) {
+        const int r = i / M, q = i % M;
+        const float dz = zs[r] - zs[q];
+        const float v = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
+        Kj[r * LM + q] = v;
+        L[r * LM + q] = v;
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
+    }
+    for (int i = tid; i < M * B; i += 256) {
+        const int r = i / B, b = i % B;
+        const float dx = zs[r] - xs[b];
+        Kzx[r * LB + b] = s * expf(dx * dx * ninv);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        wave_cholesky(L, M, LM, lane);
+    } else {
+        for (int i = tid - 64; i < M * B; i += 192) {
+            const int r = i / B, b = i % B;
+            float acc = 0.f;
+            for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], Kzx[j * LB + b], acc);
+            Wm[r * LB + b] = acc;
+        }
+    }
+    __syncthreads();
+    // tt = Kzx gm (needs the chol barrier only for ordering of LDS reuse, not for its data)
+    for (int i = tid; i < M; i += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(Kzx[i * LB + b], gm[b], acc);
+        tt[i] = acc;
+    }
+    __syncthreads();
+    // P <- [Kzx | m-c | Kzx gm]; then K^-1 applied column-wise by two TRIANGULAR solves with L
+    // (an explicit fp32 K^-1 loses ~cond(K)*eps = 1e-3 and the c / s gradients cancel to 1e-2 of it).
+    for (int i = tid; i < M * (B + 2); i += 256) {
+        const int r = i / (B + 2), b = i % (B + 2);
+        P[r * LB + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : tt[r]);
+    }
+    __syncthreads();
+    if (tid < B + 2) {
+        const int col = tid;
+        for (int i = 0; i < M; ++i) {            // L y = b
+            float acc = P[i * LB + col];
+            for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], P[j * LB + col], acc);
+            P[i * LB + col] = acc / L[i * LM + i];
+        }
+        for (int i = M - 1; i >= 0; --i) {       // L^T x = y
+            float acc = P[i * LB + col];
+            for (int k = i + 1; k < M; ++k) acc = fmaf(-L[k * LM + i], P[k * LB + col], acc);
+            P[i * LB + col] = acc / L[i * LM + i];
+        }
+    } else if (tid >= 192 && tid - 192 < M) {
+        // meanwhile: L^-1 (only the KL trace term -gk/2 K^-1 needs the explicit inverse), one thread per column
+        const int j = tid - 192;
+        for (int i = 0; i < M; ++i) {
+            float acc = (i == j) ? 1.f : 0.f;
+            if (i < j) { Li[i * LM + j] = 0.f; continue; }
+            for (int k = j; k < i; ++k) acc = fmaf(-L[i * LM + k], Li[k * LM + j], acc);
+            Li[i * LM + j] = acc / L[i * LM + i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < M * M; i += 256) {
+        const int r = i / M, q = i % M;
+        float acc = 0.f;
+        for (int k = (r > q ? r : q); k < M; ++k) acc = fmaf(Li[k * LM + r], Li[k * LM + q], acc);
+        Ki[r * LM + q] = acc;
+    }
+    for (int i = tid; i < M; i += 256) {
+        al[i] = P[i * LB + B];
+        tau[i] = P[i * LB + B + 1];
+    }
+    __syncthreads();
+    float ds_part = 0.f;
+    for (int b = tid; b < B; b += 256) {
+        float q = 0.f;
+        for (int i = 0; i < M; ++i) q = fmaf(Kzx[i * LB + b], P[i * LB + b], q);
+        const float mask = (s - q > 0.f) ? 1.f : 0.f;
+        gq[b] = -gv[b] * mask;
+        ds_part += gv[b] * mask;
+    }
+    __syncthreads();
+    for (int i = tid; i < M * B; i += 256) {   // GW = 2 gv W (in place)
+        const int r = i / B, b = i % B;
+        Wm[r * LB + b] *= 2.f * gv[b];
+    }
+    __syncthreads();
+    for (int i = tid; i < M * B; i += 256) {
+        const int r = i / B, b = i % B;
+        float acc = gm[b] * al[r] + 2.f * gq[b] * P[r * LB + b];
+        for (int k = 0; k <= r; ++k) acc = fmaf(Ls[r * LM + k], Wm[k * LB + b], acc);
+        G2[r * LB + b] = acc;
+    }
+    for (int i = tid; i < M * M; i += 256) {
+        const int r = i / M, q = i % M;
+        float acc = -tau[r] * al[q];
+        for (int b = 0; b < B; ++b) acc = fmaf(-gq[b] * P[r * LB + b], P[q * LB + b], acc);
+        float sp = 0.f;
+        const int kmax = r < q ? r : q;
+        for (int k = 0; k <= kmax; ++k) sp = fmaf(Ls[r * LM + k], Ls[q * LM + k], sp);
+        acc += 0.5f * gk * (-Ki[r * LM + q] + sp - al[r] * al[q]);
+        GK[r * LM + q] = acc;
+        // dL_S (lower part)
+        float g = 0.f;
+        if (q <= r) {
+            for (int b = 0; b < B; ++b) g = fmaf(Kzx[r * LB + b], Wm[q * LB + b], g);
+            float kl = (r == q) ? -1.f / Ls[r * LM + r] : 0.f;
+            for (int k = q; k < M; ++k) kl = fmaf(Kj[r * LM + k], Ls[k * LM + q], kl);
+            g = fmaf(gk, kl, g);
+        }
+        p.dls[((size_t)d * M + r) * M + q] = g;
+    }
+    float dc_part = 0.f;
+    for (int i = tid; i < M; i += 256) {
+        const float dr = tau[i] + gk * al[i];
+        p.dm[(size_t)d * M + i] = dr;
+        dc_part -= dr;
+    }
+    for (int b = tid; b < B; b += 256) dc_part += gm[b];
+    __syncthreads();
+    // RBF chain rule
+    float ds_acc = 0.f, dl_acc = 0.f;
+    const float il2 = 1.f / (ell * ell), il3 = il2 / ell;
+    for (int i = tid; i < M * M; i += 256) {
+        const int r = i / M, q = i % M;
+        const float kp = Kj[r * LM + q] - (r == q ? p.jitter : 0.f);
+        const float dz = zs[r] - zs[q];
+        const float g = GK[r * LM + q] * kp;
+        ds_acc += g;
+        dl_acc = fmaf(g, dz * dz, dl_acc);
+    }
+    for (int i = tid; i < M * B; i += 256) {
+        const int r = i / B, b = i % B;
+        const float dx = zs[r] - xs[b];
+        const float g = G2[r * LB + b] * Kzx[r * LB + b];
+        ds_acc += g;
+        dl_acc = fmaf(g, dx * dx, dl_acc);
+    }
+    for (int i = tid; i < M; i += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < M; ++j) {
+            const float kp = Kj[i * LM + j] - (i == j ? p.jitter : 0.f);
+            acc = fmaf((GK[i * LM + j] + GK[j * LM + i]) * kp, -(zs[i] - zs[j]), acc);
+        }
+        for (int b = 0; b < B; ++b) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b]), acc);
+        p.dz[(size_t)d * M + i] = acc * il2;
+    }
+    for (int b = tid; b < B; b += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < M; ++i) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b], acc);
+        p.dh[(size_t)b * p.D + d] = acc * il2;
+    }
+    const float ds_tot = block_sum(ds_acc, red, tid);
+    const float dl_tot = block_sum(dl_acc, red, tid);
+    const float dc_tot = block_sum(dc_part, red, tid);
+    const float dsdir_tot = block_sum(ds_part, red, tid);
+    if (tid == 0) {
+        p.ds[d] = ds_tot / s + dsdir_tot;
+        p.dell[d] = dl_tot * il3;
+        p.dc[d] = dc_tot;
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -239,4 +464,33 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
                B, D, M, train_mode, jitter};
     hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("dvg_gp_predict");
+}
+
+extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) {
+    return ((size_t)6 * M * (M + 1) + (size_t)4 * M * (B + 2) + 5 * (size_t)M + 4 * (size_t)B + 8) * 4;
+}
+
+extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
+                                const float* mean_const, const float* outputscale, const float* lengthscale,
+                                const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
+                                float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
+                                float jitter, void* stream) {
+    DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
+                "dvg_gp_train_bwd: NULL input");
+    DVG_REQUIRE(dh && dz && dm && dls && dc && ds && dell, DVG_ERR_NULL, "dvg_gp_train_bwd: NULL output");
+    DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
+                "dvg_gp_train_bwd: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
+    const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
+    DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gp_train_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
+                  dh, dz, dm, dls, dc, ds, dell, B, D, M, jitter};
+    hipLaunchKernelGGL(gp_train_bwd_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("dvg_gp_train_bwd");
 }

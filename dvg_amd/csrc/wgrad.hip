@@ -1,0 +1,251 @@
+// fp32-MFMA weight gradient of the dense convolutions (train.py:170,194,240 `loss.backward()` for
+// the Conv2d / ConvTranspose2d of vgg_64.py:8, dcgan_64.py:8,20).
+//
+//   dW[tap][co][ci] = sum over (n, pixel pairs)  dOut[n][out pixel][co] * In[n][in pixel(tap)][ci]
+//
+// GEMM view per tap: M = Cout tile (64), N = Cin tile (64), K = pixels.  In NHWC both operands are
+// "k-major with the M/N index contiguous", which is exactly the f32 MFMA operand layout
+// (lane l supplies A[i=l&31][k=l>>5]), so fragments are single ds_read_b32 per lane with unit stride
+// across lanes: conflict-free without padding.  A workgroup stages one spatial tile of dOut and the
+// matching input tile WITH HALO in LDS and accumulates all taps of its group from it (the dOut
+// fragment is shared by every tap).  K is split across workgroups; partial sums go to
+// partial[split][tap][Cout][Cin] and are reduced by dvg_reduce_partials (deterministic, no atomics).
+// The input loader fuses nearest-upsample + concat exactly like the forward kernel.
+#include "dvg_common.h"
+
+namespace dvg {
+
+enum { W_CONV3 = 0, W_CONV4S2 = 1, W_CONVT4S2 = 2 };
+
+struct WgradParams {
+    const float* x;     // forward input, (N, H>>up, W>>up, C1)
+    const float* skip;  // concat input (N,H,W,C2) or nullptr
+    const float* dout;  // gradient w.r.t. the conv output, NHWC on the output grid
+    float* partial;     // [S][taps][Cout][Cin]
+    int N, H, W;        // forward INPUT grid
+    int C1, C2, Cout, upsample;
+    int tiles_y, tiles_x, tiles_n, tiles_total, tiles_per_split, S, n_co, n_ci;
+};
+
+template <int MODE, int TI, int TH, int TW>
+struct WCfg {
+    static constexpr int S = (MODE == W_CONV4S2) ? 2 : 1;
+    static constexpr int SPAN = (MODE == W_CONV4S2) ? 4 : 3;
+    static constexpr int HH = (TH - 1) * S + SPAN, HW = (TW - 1) * S + SPAN;
+    static constexpr int HP = TI * HH * HW;
+    static constexpr int P = TI * TH * TW;  // pixel pairs per tile (GEMM K per tile)
+    static constexpr int NTAPS_ALL = (MODE == W_CONV3) ? 9 : 16;
+    static constexpr int GT = (MODE == W_CONV3) ? 9 : (MODE == W_CONV4S2 ? 8 : 4);  // taps per workgroup
+    static constexpr int NG = NTAPS_ALL / GT + (MODE == W_CONV3 ? 0 : 0);           // groups: 1, 2, 4
+    static constexpr int LDS_BYTES = (P * 64 + HP * 64) * 4;
+    static_assert(P % 2 == 0, "P");
+};
+
+template <int MODE, int TI, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p) {
+    using C = WCfg<MODE, TI, TH, TW>;
+    constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, P = C::P, GT = C::GT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ad = smem;            // [P][64]   dOut tile, this co tile
+    float* Xh = smem + P * 64;   // [HP][64]  input halo tile, this ci tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kk = lane >> 5;
+
+    unsigned b = blockIdx.x;
+    const int cit = b % p.n_ci; b /= p.n_ci;
+    const int cot = b % p.n_co; b /= p.n_co;
+    const int grp = b % C::NG; b /= C::NG;
+    const int split = b;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    const int py = grp >> 1, px = grp & 1;  // CONVT: output parity of this group
+    const int Cin = p.C1 + p.C2;
+
+    int Ho, Wo;
+    if (MODE == W_CONV3) { Ho = p.H; Wo = p.W; }
+    else if (MODE == W_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
+    else { Ho = p.H * 2; Wo = p.W * 2; }
+
+    // which input tensor holds this ci tile
+    const float* src;
+    int Cs, cc, sh;
+    if (ci0 < p.C1) { src = p.x; Cs = p.C1; cc = ci0; sh = p.upsample; }
+    else { src = p.skip; Cs = p.C2; cc = ci0 - p.C1; sh = 0; }
+    const int Hs = p.H >> sh, Ws = p.W >> sh;
+
+    f32x16 acc[GT];
+#pragma unroll
+    for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.tiles_total, t_begin + p.tiles_per_split);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tx_i = t % p.tiles_x; t /= p.tiles_x;
+        const int ty_i = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * TI;
+        const int y0 = ty_i * TH, x0 = tx_i * TW;  // iteration grid: output grid (CONV3/CONV4S2), input grid (CONVT)
+        const int yin0 = y0 * S - 1, xin0 = x0 * S - 1;
+        __syncthreads();
+        // dOut tile
+        for (int idx = tid; idx < P * 16; idx += 256) {
+            const int pp = idx >> 4, q = idx & 15;
+            const int ti = pp / (TH * TW), r = pp % (TH * TW);
+            const int ty = r / TW, tx = r % TW;
+            const int n = n0 + ti;
+            int oy, ox;
+            if (MODE == W_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+            else { oy = y0 + ty; ox = x0 + tx; }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N)
+                v = *reinterpret_cast<const f32x4*>(p.dout + (((size_t)n * Ho + oy) * Wo + ox) * p.Cout + co0 + q * 4);
+            *reinterpret_cast<f32x4*>(&Ad[pp * 64 + q * 4]) = v;
+        }
+        // input halo tile
+        for (int idx = tid; idx < HP * 16; idx += 256) {
+            const int hp = idx >> 4, q = idx & 15;
+            const int ti = hp / (HH * HW), r = hp % (HH * HW);
+            const int hy = r / HW, hx = r % HW;
+            const int n = n0 + ti, yy = yin0 + hy, xx = xin0 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * Hs + (yy >> sh)) * Ws + (xx >> sh)) * Cs + cc +
+                                                    q * 4);
+            *reinterpret_cast<f32x4*>(&Xh[hp * 64 + q * 4]) = v;
+        }
+        __syncthreads();
+        const float* Ap = Ad + wr * 32 + l31;
+        const float* Xp = Xh + wc * 32 + l31;
+#pragma unroll 2
+        for (int k0 = 0; k0 < P; k0 += 2) {
+            const int pp = k0 + kk;
+            const int ti = pp / (TH * TW), r = pp % (TH * TW);
+            const int ty = r / TW, tx = r % TW;
+            const float a = Ap[pp * 64];
+            const int hb = ((ti * HH + ty * S) * HW + tx * S) * 64;
+#pragma unroll
+            for (int t2 = 0; t2 < GT; ++t2) {
+                int th, tw;
+                if (MODE == W_CONV3) { th = t2 / 3; tw = t2 % 3; }
+                else if (MODE == W_CONV4S2) { const int tap = grp * GT + t2; th = tap >> 2; tw = tap & 3; }
+                else { th = 1 + py - (t2 >> 1); tw = 1 + px - (t2 & 1); }
+                const float bv = Xp[hb + (th * HW + tw) * 64];
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t2], 0, 0, 0);
+            }
+        }
+    }
+    // write partial[split][tapw][co][ci]
+#pragma unroll
+    for (int t2 = 0; t2 < GT; ++t2) {
+        int tapw;
+        if (MODE == W_CONV3) tapw = t2;
+        else if (MODE == W_CONV4S2) tapw = grp * GT + t2;
+        else tapw = (2 + py - 2 * (t2 >> 1)) * 4 + (2 + px - 2 * (t2 & 1));
+        float* dst = p.partial + (((size_t)split * C::NTAPS_ALL + tapw) * p.Cout + co0 + wr * 32) * Cin + ci0 + wc * 32 + l31;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+            dst[(size_t)row * Cin] = acc[t2][reg];
+        }
+    }
+}
+
+template <int MODE, int TI, int TH, int TW>
+static int wlaunch(WgradParams p, int Hg, int Wg, hipStream_t stream) {
+    using C = WCfg<MODE, TI, TH, TW>;
+    if (Hg % TH || Wg % TW) return fail(DVG_ERR_SHAPE, "wgrad: tile does not divide shape");
+    p.tiles_y = Hg / TH;
+    p.tiles_x = Wg / TW;
+    p.tiles_n = (p.N + TI - 1) / TI;
+    p.tiles_total = p.tiles_y * p.tiles_x * p.tiles_n;
+    p.tiles_per_split = (p.tiles_total + p.S - 1) / p.S;
+    const unsigned grid = (unsigned)p.S * C::NG * p.n_co * p.n_ci;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_igemm_kernel<MODE, TI, TH, TW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_igemm_kernel<MODE, TI, TH, TW>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    return check_launch("wgrad_igemm");
+}
+
+// tile choice on the iteration grid (Hg,Wg); returns tiles_total via out params
+static int wgrad_tile(int mode, int Hg, int Wg, int* ti, int* th, int* tw) {
+    if (mode == W_CONV4S2) {
+        if (Hg >= 4 && Wg >= 8 && Hg % 4 == 0 && Wg % 8 == 0) { *ti = 1; *th = 4; *tw = 8; return 0; }
+        if (Hg == 4 && Wg == 4) { *ti = 2; *th = 4; *tw = 4; return 0; }
+        return -1;
+    }
+    if (Hg % 8 == 0 && Wg % 16 == 0) { *ti = 1; *th = 8; *tw = 16; return 0; }
+    if (Hg == 8 && Wg == 8) { *ti = 2; *th = 8; *tw = 8; return 0; }
+    if (Hg % 8 == 0 && Wg % 8 == 0) { *ti = 1; *th = 8; *tw = 8; return 0; }
+    if (Hg == 4 && Wg == 4) { *ti = 4; *th = 4; *tw = 4; return 0; }
+    return -1;
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+// number of K splits (= leading dimension of `partial`) the wgrad call will use
+extern "C" int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout) {
+    int Hg = H, Wg = W;
+    if (mode == W_CONV4S2) { Hg = H / 2; Wg = W / 2; }
+    int ti, th, tw;
+    if (wgrad_tile(mode, Hg, Wg, &ti, &th, &tw)) return -1;
+    if (Cin % 64 || Cout % 64) return -1;
+    const long tiles = (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw);
+    const int groups = mode == W_CONV3 ? 1 : (mode == W_CONV4S2 ? 2 : 4);
+    const long base = (long)(Cin / 64) * (Cout / 64) * groups;
+    long S = (768 + base - 1) / base;
+    if (S > tiles) S = tiles;
+    if (S < 1) S = 1;
+    // every split must own at least one tile
+    const long tps = (tiles + S - 1) / S;
+    S = (tiles + tps - 1) / tps;
+    return (int)S;
+}
+
+#define W_DISPATCH(MODE, TI_, TH_, TW_) \
+    if (ti == TI_ && th == TH_ && tw == TW_) return wlaunch<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
+
+extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const float* dout, float* partial, int N,
+                              int H, int W, int C1, int C2, int Cout, int upsample_x, void* stream) {
+    DVG_REQUIRE(x && dout && partial, DVG_ERR_NULL, "dvg_conv_wgrad: NULL pointer");
+    DVG_REQUIRE((skip != nullptr) == (C2 > 0), DVG_ERR_SHAPE, "dvg_conv_wgrad: skip pointer / C2 mismatch");
+    DVG_REQUIRE(mode >= 0 && mode <= 2, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad mode");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: empty shape");
+    DVG_REQUIRE(C1 > 0 && C1 % 64 == 0 && C2 % 64 == 0 && Cout % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_conv_wgrad: C1=%d C2=%d Cout=%d must be multiples of 64", C1, C2, Cout);
+    DVG_REQUIRE(aligned16(x) && aligned16(skip) && aligned16(dout) && aligned16(partial), DVG_ERR_ALIGN,
+                "dvg_conv_wgrad: alignment");
+    DVG_REQUIRE(!upsample_x || mode == W_CONV3, DVG_ERR_SHAPE, "dvg_conv_wgrad: upsample only with CONV3");
+    int Hg = H, Wg = W;
+    if (mode == W_CONV4S2) { Hg = H / 2; Wg = W / 2; }
+    int ti, th, tw;
+    DVG_REQUIRE(wgrad_tile(mode, Hg, Wg, &ti, &th, &tw) == 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: unsupported map %dx%d",
+                H, W);
+    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    p.S = dvg_conv_wgrad_splits(mode, N, H, W, C1 + C2, Cout);
+    DVG_REQUIRE(p.S > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad split");
+    p.n_co = Cout / 64;
+    p.n_ci = (C1 + C2) / 64;
+    if (mode == W_CONV3) {
+        W_DISPATCH(W_CONV3, 1, 8, 16)
+        W_DISPATCH(W_CONV3, 2, 8, 8)
+        W_DISPATCH(W_CONV3, 1, 8, 8)
+    } else if (mode == W_CONV4S2) {
+        W_DISPATCH(W_CONV4S2, 1, 4, 8)
+        W_DISPATCH(W_CONV4S2, 2, 4, 4)
+    } else {
+        W_DISPATCH(W_CONVT4S2, 1, 8, 16)
+        W_DISPATCH(W_CONVT4S2, 2, 8, 8)
+        W_DISPATCH(W_CONVT4S2, 1, 8, 8)
+        W_DISPATCH(W_CONVT4S2, 4, 4, 4)
+    }
+    return fail(DVG_ERR_SHAPE, "dvg_conv_wgrad: no kernel for tile (%d,%d,%d)", ti, th, tw);
+}

@@ -1,0 +1,41 @@
+"""Train-mode GP with gradients (train.py:164-169,225-232: the ELBO and the decoded GP mean both
+back-propagate into the GP parameters AND into the encoder through h).
+
+Forward: ONE `dvg_gp_predict` launch (mean, clamped marginal variance, KL).
+Backward: ONE `dvg_gp_train_bwd` launch producing the gradients w.r.t. h, the inducing points, the
+variational mean / Cholesky factor and the (soft-plus'ed) hyper-parameters; the soft-plus chain and
+the noise term live in ordinary autograd ops on 90-element vectors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class _GPTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, z, m, ls, c, s, ell, jitter):
+        r = ops.gp_predict(h, z, m, ls, c, s, ell, want_var=True, want_kl=True, train_mode=True, jitter=jitter)
+        ctx.save_for_backward(h, z, m, ls, c, s, ell)
+        ctx.jitter = jitter
+        return r["mean"], r["var"], r["kl"]
+
+    @staticmethod
+    def backward(ctx, dmean, dvar, dkl):
+        h, z, m, ls, c, s, ell = ctx.saved_tensors
+        g = ops.gp_train_bwd(h, z, m, ls, c, s, ell, dmean, dvar, dkl, ctx.jitter)
+        return g["dh"], g["dz"].view_as(z), g["dm"], g["dls"], g["dc"].view_as(c), g["ds"].view_as(s), \
+            g["dell"].view_as(ell), None
+
+
+def gp_train(layer, h, noise):
+    from .models.gp_models import JITTER
+    vs = layer.variational_strategy
+    s, ell, c = layer.hypers()
+    mean, var, kl = _GPTrain.apply(h if h.is_contiguous() else h.contiguous(), vs.inducing_points,
+                                   vs.variational_distribution.variational_mean,
+                                   vs.variational_distribution.chol_variational_covar, c, s, ell, JITTER)
+    if noise is not None:
+        var = var + noise.view(-1, 1)
+    return {"mean": mean, "var": var, "kl": kl, "sample": None, "cov": None}

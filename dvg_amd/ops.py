@@ -385,3 +385,127 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
          *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov), _p(kl), b, d, m,
          int(train_mode), jitter, _stream())
     return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}
+
+
+# ----------------------------------------------------------------------------------
+# backward (training) wrappers
+# ----------------------------------------------------------------------------------
+def transpose2d(a: torch.Tensor) -> torch.Tensor:
+    """[R][C] -> contiguous [C][R] with the LDS-tiled layout kernel (a (1,R,C) 'NCHW' -> 'NHWC' pass)."""
+    _dev_f32(a, "transpose2d")
+    a = a if a.is_contiguous() else a.contiguous()
+    r, c = a.shape
+    out = torch.empty((c, r), device=a.device, dtype=torch.float32)
+    check(lib().dvg_nchw_to_nhwc(_p(a), _p(out), 1, r, c, 1, _stream()), "transpose2d")
+    return out
+
+
+def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=True):
+    """BatchNorm(+act, +2x2 max-pool) backward.  dy/dyp/y/u NHWC-in-memory (N,C,H,W) tensors (2-D [rows][C]
+    tensors are passed as (rows,C,1,1)).  Returns (du, dgamma, dbeta, dbias)."""
+    n, c, h, w = y.shape
+    pool = dyp is not None
+    rows = lib().dvg_bn_act_bwd_rows(n, h, w, int(pool))
+    dev = y.device
+    partial = torch.empty((rows, 2, c), device=dev, dtype=torch.float32)
+    dp = torch.empty_like(u)
+    _run("bn_act_bwd_reduce", 0.0, 4.0 * 4 * y.numel(), lib().dvg_bn_act_bwd_reduce, _p(dy), _p(dyp), _p(y), _p(u),
+         _p(dp), _p(partial), n, h, w, c, act, slope, _stream())
+    coef = torch.empty((3, c), device=dev, dtype=torch.float32)
+    dgamma = torch.empty(c, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(c, device=dev, dtype=torch.float32)
+    dbias = torch.empty(c, device=dev, dtype=torch.float32)
+    check(lib().dvg_bn_bwd_finalize(_p(partial), rows, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]),
+                                    _p(coef[2]), _p(dgamma), _p(dbeta), _p(dbias), c, float(count), int(train),
+                                    _stream()), "bn_bwd_finalize")
+    _run("affine3_apply", 0.0, 4.0 * 3 * y.numel(), lib().dvg_affine3_apply, _p(dp), _p(u), _p(coef[0]), _p(coef[1]),
+         _p(coef[2]), _p(dp), dp.numel(), c, _stream())
+    return dp, dgamma, dbeta, dbias
+
+
+def conv_wgrad(mode, x, skip, du, *, upsample=False):
+    """Packed weight gradient [taps][Cout][Cin] of a dense conv (see dvg_conv_wgrad)."""
+    n, c1, hx, wx = x.shape
+    h, w = (hx * 2, wx * 2) if upsample else (hx, wx)
+    c2 = 0 if skip is None else skip.shape[1]
+    cout = du.shape[1]
+    cin = c1 + c2
+    taps = 9 if mode == MODE_CONV3 else 16
+    s = lib().dvg_conv_wgrad_splits(mode, n, h, w, cin, cout)
+    if s <= 0:
+        raise RuntimeError(f"conv_wgrad: unsupported shape N={n} H={h} W={w} Cin={cin} Cout={cout}")
+    partial = torch.empty((s, taps, cout, cin), device=x.device, dtype=torch.float32)
+    _run("conv_wgrad", 2.0 * du.numel() * taps * cin / (4 if mode == MODE_CONVT4S2 else 1),
+         4.0 * (x.numel() + du.numel() + partial.numel()), lib().dvg_conv_wgrad, mode, _p(x), _p(skip), _p(du),
+         _p(partial), n, h, w, c1, c2, cout, int(upsample), _stream())
+    if s == 1:
+        return partial[0]
+    out = torch.empty((taps, cout, cin), device=x.device, dtype=torch.float32)
+    check(lib().dvg_reduce_partials(_p(partial), _p(out), s, out.numel(), _stream()), "reduce_partials")
+    return out
+
+
+def wgrad_thin(inp_nchw, dout_nhwc, ks):
+    """dW (C, nc, ks, ks) of a thin layer (see dvg_wgrad_thin)."""
+    inp = inp_nchw if inp_nchw.is_contiguous() else inp_nchw.contiguous()
+    n, nc, hi, wi = inp.shape
+    c = dout_nhwc.shape[1]
+    assert is_nhwc(dout_nhwc)
+    rows = lib().dvg_wgrad_thin_rows(ks, n, hi, wi)
+    partial = torch.empty((rows, c, nc * ks * ks), device=inp.device, dtype=torch.float32)
+    _run("wgrad_thin", 2.0 * dout_nhwc.numel() * nc * ks * ks, 4.0 * (inp.numel() + dout_nhwc.numel()),
+         lib().dvg_wgrad_thin, _p(inp), _p(dout_nhwc), _p(partial), ks, n, hi, wi, nc, c, _stream())
+    out = torch.empty((c, nc, ks, ks), device=inp.device, dtype=torch.float32)
+    check(lib().dvg_reduce_partials(_p(partial), _p(out), rows, out.numel(), _stream()), "reduce_partials")
+    return out
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    y = y if y.is_contiguous() else y.contiguous()
+    out = torch.empty_like(y)
+    check(lib().dvg_act_bwd(_p(dy), _p(y), _p(out), y.numel(), act, slope, _stream()), "act_bwd")
+    return out
+
+
+def upsample2x_bwd(dxu):
+    assert is_nhwc(dxu)
+    n, c, h2, w2 = dxu.shape
+    dx = nhwc_empty(n, c, h2 // 2, w2 // 2, dxu.device)
+    check(lib().dvg_upsample2x_bwd(_p(dxu), _p(dx), n, h2 // 2, w2 // 2, c, _stream()), "upsample2x_bwd")
+    return dx
+
+
+def colsum(a):
+    a = a if a.is_contiguous() else a.contiguous()
+    rows, c = a.shape
+    out = torch.empty(c, device=a.device, dtype=torch.float32)
+    check(lib().dvg_colsum(_p(a), _p(out), rows, c, _stream()), "colsum")
+    return out
+
+
+def lstm_gates_bwd(dh, dc, gates, c_prev, c_new):
+    b, hid = c_prev.shape
+    dh = None if dh is None else (dh if dh.is_contiguous() else dh.contiguous())
+    dc = None if dc is None else (dc if dc.is_contiguous() else dc.contiguous())
+    dG = torch.empty((b, 4 * hid), device=c_prev.device, dtype=torch.float32)
+    dcp = torch.empty_like(c_prev)
+    check(lib().dvg_lstm_gates_bwd(_p(dh), _p(dc), _p(gates), _p(c_prev), _p(c_new), _p(dG), _p(dcp), b, hid,
+                                   _stream()), "lstm_gates_bwd")
+    return dG, dcp
+
+
+def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3):
+    """Gradients of the train-mode GP prediction (see dvg_gp_train_bwd)."""
+    h = h if h.is_contiguous() else h.contiguous()
+    b, d = h.shape
+    mm = z.shape[1]
+    dev = h.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    out = {"dh": f(b, d), "dz": f(d, mm), "dm": f(d, mm), "dls": f(d, mm, mm), "dc": f(d), "ds": f(d), "dell": f(d)}
+    args = [t.detach().contiguous().view(-1) for t in (z, m, ls, c, s, ell)]
+    g = [None if t is None else t.contiguous() for t in (gmean, gvar, gkl)]
+    check(lib().dvg_gp_train_bwd(_p(h), *[_p(t) for t in args], *[_p(t) for t in g], _p(out["dh"]), _p(out["dz"]),
+                                 _p(out["dm"]), _p(out["dls"]), _p(out["dc"]), _p(out["ds"]), _p(out["dell"]), b, d,
+                                 mm, jitter, _stream()), "gp_train_bwd")
+    return out

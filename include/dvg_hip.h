@@ -241,6 +241,80 @@ int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
                    int train_mode, float jitter, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Backward (training) entry points: what `loss.backward()` (train.py:170,194,240)
+ * runs for the modules above.  Data gradients of the dense convs reuse the
+ * forward implicit-GEMM kernels with re-packed weights:
+ *   dgrad(Conv2d 3x3)        = dvg_conv3x3_bn_act   with dvg_pack_convT_weight(W)
+ *   dgrad(Conv2d 4x4 s2)     = dvg_convT4x4s2_bn_act with dvg_pack_convT_weight(W)
+ *   dgrad(ConvTranspose 4x4) = dvg_conv4x4s2_bn_act with dvg_pack_conv_weight(W)
+ * ------------------------------------------------------------------ */
+
+/* BatchNorm + activation (+ 2x2 max-pool) backward, pass 1:
+ *   dp = (dy + scatter_maxpool(dyp)) * act'(y)          (written to `dp`, NHWC)
+ *   partial[r] = { sum dp, sum dp*u } per channel, r < dvg_bn_act_bwd_rows(...)
+ * y = forward output (post activation), u = conv output before BN.  dy or dyp
+ * may be NULL (not both); dyp != NULL selects the pooled variant.               */
+int dvg_bn_act_bwd_rows(int N, int H, int W, int pool);
+int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const float* y, const float* u,
+                          float* dp, float* partial, int N, int H, int W, int C, int act,
+                          float slope, void* stream);
+/* pass 2: per-channel coefficients of du = A*dp + B*u + Cc (train: batch-statistics
+ * BN backward; eval: plain affine), plus dgamma, dbeta, dbias (any may be NULL).  */
+int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
+                        const float* invstd, float* coefA, float* coefB, float* coefC,
+                        float* dgamma, float* dbeta, float* dbias, int C, double count,
+                        int train, void* stream);
+/* pass 3: du = A[c]*dp + B[c]*u + Cc[c] over n elements (n %% C == 0); du may alias dp. */
+int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B,
+                      const float* Cc, float* du, long n, int C, void* stream);
+/* dpre = dy * act'(y), flat tensors (last layers, nn.Linear+Tanh).               */
+int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope,
+                void* stream);
+/* nn.UpsamplingNearest2d(2) backward: dx (N,H,W,C) = 2x2 block sums of dxu (N,2H,2W,C). */
+int dvg_upsample2x_bwd(const float* dxu, float* dx, int N, int H, int W, int C, void* stream);
+/* out[c] = sum_r a[r][c]  (bias gradients)                                       */
+int dvg_colsum(const float* a, float* out, int rows, int C, void* stream);
+/* out[i] = sum_s partial[s][i], n %% 4 == 0                                       */
+int dvg_reduce_partials(const float* partial, float* out, int S, long n, void* stream);
+
+/* Weight gradient of the dense convs as an fp32-MFMA GEMM over pixels:
+ *   partial[s][tap][Cout][Cin], s < dvg_conv_wgrad_splits(...); reduce with
+ *   dvg_reduce_partials, then dvg_unpack_conv(T)_weight gives the nn layout.
+ * mode = DVG_MODE_*; x/skip/upsample_x describe the forward input exactly as in the
+ * forward call (H,W = forward input grid); dout = gradient w.r.t. the conv output.
+ * C1, C2, Cout multiples of 64.                                                  */
+int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout);
+int dvg_conv_wgrad(int mode, const float* x, const float* skip, const float* dout,
+                   float* partial, int N, int H, int W, int C1, int C2, int Cout,
+                   int upsample_x, void* stream);
+
+/* Weight gradient of the thin first / last layers (ks = 3: stride 1, ks = 4: stride 2, pad 1):
+ *   dW[c][ci][a][b] = sum dout[n][oy][ox][c] * inp[n][ci][S*oy+a-1][S*ox+b-1]
+ * inp NCHW (N,nc,Hi,Wi), dout NHWC (N,Ho,Wo,C); partial[rows][C][nc*ks*ks] with
+ * rows = dvg_wgrad_thin_rows(ks,N,Hi,Wi).  First layers: inp = frame, dout = du.
+ * Last (transposed) layers: inp = dpre (frame side), dout = the layer INPUT x.     */
+int dvg_wgrad_thin_rows(int ks, int N, int Hi, int Wi);
+int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, float* partial, int ks, int N,
+                   int Hi, int Wi, int nc, int C, void* stream);
+
+/* nn.LSTMCell backward, elementwise part: gate pre-activation gradients dG [B][4H] and
+ * dc_prev [B][H] from dh', dc' (either may be NULL), the saved activated gates, c, c'.
+ * The GEMM parts (dx = dG W_ih, dW_ih = dG^T x, ...) go through dvg_gemm_nt_bias_act. */
+int dvg_lstm_gates_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                       const float* c_new, float* dG, float* dc_prev, int B, int H, void* stream);
+
+/* Train-mode GP backward (gradients of dvg_gp_predict(train_mode=1) outputs mean / var
+ * (without likelihood noise) / kl): upstream gmean [D][B], gvar [D][B], gkl [D] (any may
+ * be NULL = zero) -> dh [B][D], dz [D][M], dm [D][M], dls [D][M][M] (lower), dc, ds, dell
+ * [D] w.r.t. the soft-plus'ed hyper-parameters.  One workgroup per latent dim, all in LDS. */
+size_t dvg_gp_bwd_lds_bytes(int B, int M);
+int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
+                     const float* mean_const, const float* outputscale, const float* lengthscale,
+                     const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
+                     float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
+                     float jitter, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Small elementwise helpers on the path
  * ------------------------------------------------------------------ */
 
