@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""generate_frames.py — counterpart of the reference's generate_frames.py on the MI355X kernel library.
+
+Same flags (generate_frames.py:17-41).  Loads `<model_dir>/<dataset>.pth` (falls back to the
+`model.pth` that train.py writes — the reference's two scripts disagree on the filename),
+takes `opt` from the checkpoint (:44), forces n_eval / n_future / batch_size like :47-49 unless
+overridden, and runs either
+
+  * `make_gifs` (:107-217): the posterior rollout (GP fed the LSTM output, predictive MEAN decoded) plus
+    `nsample` diverse rollouts where a GP sample replaces the LSTM prediction at steps with i % 15 == 0, or
+  * `GPtrigger_gen` (:249-300, `--gp_trigger`): per batch index, a 12-step warm-up that records the norm of
+    the GP predictive variance, then a variance-threshold trigger `value > mean + (2+0.01*depth)*std` over a
+    12-long sliding window decides per step between a GP sample and the LSTM path.
+
+Image/GIF writing and SSIM are out of scope: results (frames, per-sample PSNR, best-of-N
+index, trigger steps) are saved as tensors.  `--synthetic_ckpt` builds a randomly initialised checkpoint so
+the script can run without a trained model.
+"""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import utils  # noqa: E402
+from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
+from dvg_amd.rollout import posterior_rollout, sample_rollout  # noqa: E402
+from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--batch_size', default=50, type=int)
+    p.add_argument('--log_dir', default='logs_gp')
+    p.add_argument('--model_dir', default='')
+    p.add_argument('--name', default='')
+    p.add_argument('--data_root', default='./data/kth')
+    p.add_argument('--seed', default=1, type=int)
+    p.add_argument('--image_width', type=int, default=64)
+    p.add_argument('--channels', default=1, type=int)
+    p.add_argument('--gp_trigger', action='store_true', help='variance-threshold trigger (GPtrigger_gen)')
+    p.add_argument('--dataset', default='kth')
+    p.add_argument('--n_past', type=int, default=5)
+    p.add_argument('--n_future', type=int, default=100)
+    p.add_argument('--n_eval', type=int, default=105)
+    p.add_argument('--rnn_size', type=int, default=256)
+    p.add_argument('--predictor_rnn_layers', type=int, default=2)
+    p.add_argument('--z_dim', type=int, default=10)
+    p.add_argument('--g_dim', type=int, default=90)
+    p.add_argument('--model', default='dcgan')
+    p.add_argument('--data_threads', type=int, default=5)
+    p.add_argument('--last_frame_skip', action='store_true')
+    p.add_argument('--nsample', type=int, default=100)
+    p.add_argument('--nbatches', type=int, default=5)
+    p.add_argument('--trigger_indices', type=int, default=None, help='GPtrigger_gen: how many batch indices')
+    p.add_argument('--synthetic_ckpt', action='store_true')
+    return p
+
+
+def psnr(gt: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
+    """Per-sample PSNR (data range 1) over (C,H,W): the on-device stand-in for utils.eval_seq's psnr_metric."""
+    mse = ((gt - pred) ** 2).flatten(1).mean(1).clamp_min(1e-12)
+    return 10.0 * torch.log10(1.0 / mse)
+
+
+class Generator:
+    def __init__(self, opt, ckpt, device):
+        self.opt, self.dev = opt, device
+        self.encoder, self.decoder = ckpt['encoder'], ckpt['decoder']
+        self.frame_predictor = ckpt['frame_predictor']
+        self.likelihood = GaussianLikelihood(batch_size=opt.g_dim)
+        self.gp_layer = GPRegressionLayer1(opt.g_dim)
+        self.likelihood.load_state_dict(ckpt['likelihood'])
+        self.gp_layer.load_state_dict(ckpt['gp_layer'])
+        for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood):
+            m.to(device).eval()
+        self.frame_predictor.batch_size = opt.batch_size
+
+    def _gp(self, h):
+        return self.likelihood(self.gp_layer(h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)))
+
+    @torch.no_grad()
+    def make_gifs(self, x, nsample):
+        opt = self.opt
+        post = posterior_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood, x,
+                                 opt.n_past, opt.n_eval, opt.last_frame_skip)
+        B, T = x[0].shape[0], opt.n_eval - opt.n_past
+        score = torch.zeros(B, nsample, T, device=self.dev)
+        all_gen = []
+        for s in range(nsample):
+            frames = sample_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood,
+                                    x, opt.n_past, opt.n_eval, opt.last_frame_skip)
+            for t in range(T):
+                score[:, s, t] = psnr(x[opt.n_past + t], frames[opt.n_past + t])
+            all_gen.append(torch.stack(frames))
+        best = score.mean(2).argsort(1)[:, -1]   # generate_frames.py:188-189,207: np.argsort(mean)[-1]
+        return {'posterior': torch.stack(post), 'samples': torch.stack(all_gen), 'psnr': score, 'best': best}
+
+    @torch.no_grad()
+    def _generation(self, x_in, skip):
+        h = self.encoder(x_in)[0]
+        return self.decoder([self.frame_predictor(h), skip])
+
+    @torch.no_grad()
+    def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1):
+        """generate_frames.py:249-298.  Keeps the reference's bookkeeping verbatim: the warm-up records the
+        variance norm of sample `index` (:275) while `var_value` reads sample 3 (:230); the skip tensors are
+        those of input step 4 (`i < 5`, :268-269)."""
+        opt = self.opt
+        B = x[0].shape[0]
+        out = []
+        for index in range(B if n_index is None else n_index):
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+            ctx, triggers, gen_seq = [], [], []
+            x_in, skip = x[0], None
+            for i in range(warmup):
+                h, sk = self.encoder(x_in)
+                if i < 5:
+                    skip = sk
+                var = self._gp(h).variance            # (D,B)
+                ctx.append(float(var.t().norm(dim=1)[index]))
+                x_in = self._generation(x_in, skip)
+                gen_seq.append(x_in)
+            ctx = np.array(ctx)
+            for i in range(warmup, total):
+                h = self.encoder(x_in)[0]
+                pred = self._gp(h)
+                value = float(pred.variance.t().norm(dim=1)[min(3, B - 1)])
+                ctx = np.concatenate([ctx[1:], [value]])
+                threshold = np.mean(ctx) + (2 + 0.01 * depth) * np.std(ctx)
+                if value > threshold:
+                    x_in = self.decoder([pred.rsample().transpose(0, 1), skip])
+                    triggers.append(i)
+                else:
+                    x_in = self._generation(x_in, skip)
+                gen_seq.append(x_in)
+            out.append({'index': index, 'frames': torch.stack(gen_seq)[:, index].cpu(), 'triggers': triggers})
+        return out
+
+
+def synthetic_checkpoint(opt):
+    import importlib
+    import models.lstm as lstm_models
+    model = importlib.import_module(f"models.{opt.model}_{opt.image_width}")
+    enc, dec = model.encoder(opt.g_dim, opt.channels), model.decoder(opt.g_dim, opt.channels)
+    enc.apply(utils.init_weights), dec.apply(utils.init_weights)
+    fp = lstm_models.lstm(opt.g_dim, opt.g_dim, opt.rnn_size, opt.predictor_rnn_layers, opt.batch_size)
+    fp.apply(utils.init_weights)
+    gp, lik = GPRegressionLayer1(opt.g_dim), GaussianLikelihood(batch_size=opt.g_dim)
+    return {'encoder': enc, 'decoder': dec, 'frame_predictor': fp, 'likelihood': lik.state_dict(),
+            'gp_layer': gp.state_dict(), 'opt': opt}
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    assert torch.cuda.is_available(), "generate_frames.py needs a GPU: the DVG hot path has no CPU fallback"
+    device = torch.device('cuda', 0)
+    if args.synthetic_ckpt:
+        ckpt = synthetic_checkpoint(args)
+        opt = args
+    else:
+        path = '%s/%s.pth' % (args.model_dir, args.dataset)
+        if not os.path.exists(path):
+            path = '%s/model.pth' % args.model_dir
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        opt = ckpt['opt']
+        opt.n_eval, opt.n_future, opt.batch_size = args.n_eval, args.n_future, args.batch_size
+        opt.log_dir = args.log_dir
+    os.makedirs('%s/gen/' % opt.log_dir, exist_ok=True)
+    print("Random Seed: ", opt.seed)
+    random.seed(opt.seed)
+    torch.manual_seed(opt.seed)
+    torch.cuda.manual_seed_all(opt.seed)
+    gen = Generator(opt, ckpt, device)
+    if getattr(opt, 'dataset', 'smmnist') == 'smmnist':
+        ds = SyntheticMovingMNIST(seq_len=opt.n_eval, image_size=opt.image_width, seed=opt.seed + 7919)
+        batches = (ds.batch(opt.batch_size) for _ in range(args.nbatches))
+    else:
+        batches = (synthetic_video(opt.batch_size, opt.n_eval, opt.channels, opt.image_width, seed=opt.seed + k)
+                   for k in range(args.nbatches))
+    for i, seq in enumerate(batches):
+        test_x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
+        if args.gp_trigger:
+            res = gen.gp_trigger_gen(test_x, args.trigger_indices, total=opt.n_eval)
+            torch.save(res, '%s/gen/gp_trigger_%d.pt' % (opt.log_dir, i))
+            print('batch %d: trigger steps of index 0: %s' % (i, res[0]['triggers']))
+        else:
+            res = gen.make_gifs(test_x, args.nsample)
+            torch.save({'posterior': res['posterior'][:, 0].cpu(), 'best': res['best'].cpu(), 'psnr': res['psnr'].cpu(),
+                        'best_sample_0': res['samples'][int(res['best'][0]), :, 0].cpu()},
+                       '%s/gen/sample_lstm_%d.pt' % (opt.log_dir, i))
+            print('batch %d: mean PSNR of best-of-%d %.3f dB' % (
+                i, args.nsample, float(res['psnr'].mean(2).max(1).values.mean())))
+
+
+if __name__ == '__main__':
+    main()

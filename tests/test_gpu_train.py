@@ -1,0 +1,133 @@
+"""GPU: the step closures of train.py (row S of SURVEY.md §8) against the oracle's restatement of the same
+loss composition (train.py:239), and smoke runs of both entry-point scripts."""
+import copy
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dvg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(model, extra=()):
+    import train
+    argv = ["--model", model, "--batch_size", "4", "--n_past", "2", "--n_future", "2", "--n_eval", "4", "--niter", "1",
+            "--epoch_size", "1", "--dataset", "smmnist", "--no_save"] + list(extra)
+    o = train.build_parser().parse_args(argv)
+    o.ft = True
+    o.rank, o.world, o.local_batch = 0, 1, o.batch_size
+    return o
+
+
+def _oracle_loss(model, esd, dsd, lsd, gsd, lik, x, opt):
+    """train.py:200-239 on CPU with the oracle blocks (train-mode BN; running stats mutate like the reference)."""
+    enc = (lambda t: orc.vgg_encoder(t, esd, True)) if model == "vgg" else (lambda t: orc.dcgan_encoder(t, esd, True))
+    dec = (lambda v, s: orc.vgg_decoder(v, s, dsd, True)) if model == "vgg" else \
+        (lambda v, s: orc.dcgan_decoder(v, s, dsd, True, "tanh"))
+    hidden = orc.lstm_init_hidden(x[0].shape[0], opt.rnn_size, opt.predictor_rnn_layers)
+    noise = orc.likelihood_noise(lik)
+    mse = mse_latent = mse_gp = ae_mse = 0
+    max_ll = 0
+    skip = None
+    for i in range(1, opt.n_past + opt.n_future):
+        h, sk = enc(x[i - 1])
+        h_target = enc(x[i])[0]
+        if opt.last_frame_skip or i < opt.n_past:
+            skip = sk
+        h_pred = orc.lstm_step(h, lsd, hidden)
+        mse_latent = mse_latent + F.mse_loss(h_pred, h_target)
+        gp = orc.gp_predict(h, gsd, training=True, dtype=torch.float32)
+        max_ll = max_ll - orc.variational_elbo(gp, h_target.t(), noise, num_data=x[0].shape[0])
+        x_pred = dec(h_pred, skip)
+        ae_mse = ae_mse + F.mse_loss(dec(h_target, skip), x[i])
+        mse = mse + F.mse_loss(x_pred, x[i])
+        mse_gp = mse_gp + F.mse_loss(dec(gp["mean"].t().float(), skip), x[i])
+    return 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_train_model_loss_matches_oracle(model):
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    torch.manual_seed(3)
+    opt = _opt(model)
+    tr = train.Trainer(opt, torch.device("cuda:0"))
+    tr.train_mode()
+    seq = SyntheticMovingMNIST(seq_len=4, seed=5).batch(4)
+    x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
+    tr.gp_layer(torch.zeros(4, 90, device="cuda"))  # triggers the prior initialisation of the variational dist
+    cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}  # noqa: E731
+    esd, dsd, lsd, gsd, lik = cpu(tr.encoder), cpu(tr.decoder), cpu(tr.frame_predictor), cpu(tr.gp_layer), \
+        cpu(tr.likelihood)
+    ref = float(_oracle_loss(model, esd, dsd, lsd, gsd, lik, [t.cpu() for t in x], opt))
+    before = [p.detach().clone() for p in tr.encoder.parameters()]
+    tr.train_model(x)
+    assert math.isfinite(tr.last_loss)
+    assert abs(tr.last_loss - ref) < 2e-3 * abs(ref), (tr.last_loss, ref)
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.encoder.parameters())), "optimizer must step"
+    # BatchNorm running statistics saw the same number of train-mode calls as the reference would issue
+    assert int(tr.encoder.c1.main[1].num_batches_tracked if model == "dcgan" else
+               tr.encoder.c1[0].main[1].num_batches_tracked) == 2 * (opt.n_past + opt.n_future - 1)
+    # fine-tuning closures run and only touch what the reference lets them touch
+    enc_before = copy.deepcopy(tr.encoder.state_dict())
+    dec_before = copy.deepcopy(tr.decoder.state_dict())
+    v = tr.finetune_temporal_encoders(x)
+    assert math.isfinite(v)
+    for k, t in tr.decoder.state_dict().items():
+        assert torch.equal(t, dec_before[k])
+    for k, p in tr.encoder.named_parameters():
+        assert torch.equal(p, enc_before[k]), "train_frame_predictor / train_GP step only their own optimizers"
+
+
+def test_train_script_runs_and_checkpoint_drives_generate(tmp_path):
+    import generate_frames
+    import train
+    out = str(tmp_path)
+    tr = train.main(["--model", "dcgan", "--batch_size", "4", "--n_past", "2", "--n_future", "2", "--n_eval", "5",
+                     "--niter", "1", "--epoch_size", "2", "--dataset", "smmnist", "--output_path", out])
+    assert os.path.exists(os.path.join(out, "model.pth")) and os.path.exists(os.path.join(out, "sample_0.pt"))
+    generate_frames.main(["--model_dir", out, "--dataset", "smmnist", "--batch_size", "4", "--n_eval", "18",
+                          "--n_future", "16", "--nsample", "2", "--nbatches", "1", "--log_dir", out + "/logs"])
+    res = torch.load(os.path.join(out, "logs", "gen", "sample_lstm_0.pt"))
+    assert res["psnr"].shape == (4, 2, 16) and bool(torch.isfinite(res["psnr"]).all())
+    generate_frames.main(["--model_dir", out, "--dataset", "smmnist", "--batch_size", "4", "--n_eval", "20",
+                          "--gp_trigger", "--trigger_indices", "1", "--nbatches", "1", "--log_dir", out + "/logs"])
+    trig = torch.load(os.path.join(out, "logs", "gen", "gp_trigger_0.pt"))
+    assert trig[0]["frames"].shape[0] == 20 and all(12 <= t < 20 for t in trig[0]["triggers"])
+
+
+def test_rollout_matches_oracle_rollout():
+    """The metric path end to end: make_gifs sample loop, HIP vs oracle, same eps at the GP trigger step."""
+    from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1
+    from dvg_amd.models.lstm import lstm
+    from dvg_amd.rollout import sample_rollout
+    from oracle import params
+    from tests.common import backbone_case, rel_err
+    dev = torch.device("cuda:0")
+    enc, dec, esd, dsd, x0, _ = backbone_case("dcgan_64/eval")
+    B, n_past, n_eval = 2, 3, 17
+    xs = [params.frames(700 + t, B, 1, 64) for t in range(n_eval)]
+    fp = lstm(90, 90, 256, 2, B)
+    lsd = params.fill_state_dict(fp.state_dict(), 300)
+    fp.load_state_dict(lsd)
+    gsd, lik = params.gp_state(710)
+    gp, like = GPRegressionLayer1(90), GaussianLikelihood(batch_size=90)
+    gp.load_state_dict(gsd), like.load_state_dict(lik)
+    eps = {15: params.normal(720, 90, B)}
+    ref = orc.rollout(xs, lambda t: orc.dcgan_encoder(t, esd, False), lambda v, s: orc.dcgan_decoder(v, s, dsd, False),
+                      lsd, gsd, lik, n_past, n_eval, eps)
+    for m in (enc, dec, fp, gp, like):
+        m.to(dev).eval()
+    ours = sample_rollout(enc, dec, fp, gp, like, [t.to(dev) for t in xs], n_past, n_eval,
+                          eps_by_step={15: eps[15].to(dev)})
+    assert len(ours) == len(ref) == n_eval
+    for t in range(n_eval):
+        tol = 1e-4 if t < 15 else 5e-3   # after the GP sample the fp32 Cholesky noise is chained through the rollout
+        assert rel_err(ours[t], ref[t]) < tol, (t, rel_err(ours[t], ref[t]))

@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""train.py — counterpart of the reference's train.py on the MI355X kernel library.
+
+Same flags (train.py:17-46) and the same three step closures (`train_model` :200-248,
+`train_frame_predictor` :175-198, `train_GP_Frame_predictor` :146-172), loss weights (:239), optimisers
+(:95-106, lr hard-coded 0.002 like the reference; `--lr/--beta1/--optimizer/--z_dim/--name` stay accepted
+and unused), scheduler-before-epoch order (:347), log line (:368) and checkpoint dict (:380-388).
+
+Consciously fixed (each was unrunnable in the reference — SURVEY.md §5 quirks):
+  * the model family follows `--model` / `--image_width` instead of a hard-coded dcgan_64 (:75);
+  * `h.view(90, 50, 1)` (:164) uses `(g_dim, batch_size, 1)`;
+  * `--dataset smmnist` works (`--num_digits`), batches may be `x` or `(x, y)`;
+  * no `torch.cuda.empty_cache()` per timestep (:166,191,235);
+  * `--ft` / flags are real booleans (`--no_ft`).
+Added: data parallelism — launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`;
+`--batch_size` is the GLOBAL batch, split evenly over the ranks; gradients are averaged with one flat
+RCCL all-reduce per backward (dvg_amd/parallel.py); BatchNorm statistics are per replica.
+Datasets are synthetic here (no network / files offline): `smmnist` = seeded Moving-MNIST trajectories,
+other names = random textured clips of the right shape.
+"""
+import argparse
+import importlib
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import utils  # noqa: E402
+from dvg_amd import parallel  # noqa: E402
+from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
+from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1, VariationalELBO  # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--lr', default=0.002, type=float, help='learning rate (unused, as in the reference)')
+    p.add_argument('--beta1', default=0.9, type=float)
+    p.add_argument('--batch_size', default=50, type=int, help='GLOBAL batch size')
+    p.add_argument('--log_dir', default='logs')
+    p.add_argument('--model_dir', default='')
+    p.add_argument('--name', default='')
+    p.add_argument('--output_path', default='.')
+    p.add_argument('--data_root', default='path/to/data/')
+    p.add_argument('--optimizer', default='adam')
+    p.add_argument('--niter', type=int, default=601)
+    p.add_argument('--seed', default=1, type=int)
+    p.add_argument('--epoch_size', type=int, default=300)
+    p.add_argument('--image_width', type=int, default=64)
+    p.add_argument('--channels', default=1, type=int)
+    p.add_argument('--dataset', default='smmnist')
+    p.add_argument('--num_digits', type=int, default=2)
+    p.add_argument('--n_past', type=int, default=5)
+    p.add_argument('--no_ft', action='store_true', help='disable the temporal fine-tuning closures')
+    p.add_argument('--n_future', type=int, default=10)
+    p.add_argument('--n_eval', type=int, default=15)
+    p.add_argument('--rnn_size', type=int, default=256)
+    p.add_argument('--predictor_rnn_layers', type=int, default=2)
+    p.add_argument('--z_dim', type=int, default=10)
+    p.add_argument('--g_dim', type=int, default=90)
+    p.add_argument('--model', default='dcgan', help='dcgan | vgg')
+    p.add_argument('--data_threads', type=int, default=5)
+    p.add_argument('--last_frame_skip', action='store_true')
+    p.add_argument('--save_every', type=int, default=4)
+    p.add_argument('--no_save', action='store_true')
+    return p
+
+
+class Trainer:
+    """The module-level state of the reference script, as an object (so tests can drive single steps)."""
+
+    def __init__(self, opt, device):
+        self.opt, self.dev = opt, device
+        self.rank, self.world = opt.rank, opt.world
+        model = importlib.import_module(f"models.{opt.model}_{opt.image_width}")
+        import models.lstm as lstm_models
+        self.encoder = model.encoder(opt.g_dim, opt.channels)
+        self.decoder = model.decoder(opt.g_dim, opt.channels)
+        self.encoder.apply(utils.init_weights)
+        self.decoder.apply(utils.init_weights)
+        self.frame_predictor = lstm_models.lstm(opt.g_dim, opt.g_dim, opt.rnn_size, opt.predictor_rnn_layers,
+                                                opt.local_batch)
+        self.frame_predictor.apply(utils.init_weights)
+        self.gp_layer = GPRegressionLayer1(num_dims=opt.g_dim)
+        self.likelihood = GaussianLikelihood(batch_size=opt.g_dim)
+        self.modules = [self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood]
+        for m in self.modules:
+            m.to(device)
+        parallel.broadcast_parameters(self.modules)
+        self.frame_predictor_optimizer = torch.optim.Adam(self.frame_predictor.parameters(), lr=0.002)
+        self.encoder_optimizer = torch.optim.Adam(self.encoder.parameters(), lr=0.002)
+        self.decoder_optimizer = torch.optim.Adam(self.decoder.parameters(), lr=0.002)
+        self.optimizer = torch.optim.Adam([{'params': self.gp_layer.parameters()},
+                                           {'params': self.likelihood.parameters()}], lr=0.002)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[3, 5], gamma=0.1)
+        self.mll = VariationalELBO(self.likelihood, self.gp_layer, num_data=opt.local_batch, combine_terms=True)
+        self.mse_criterion = nn.MSELoss()
+        self.mse_latent_criterion = nn.MSELoss()
+        gp_params = list(self.gp_layer.parameters()) + list(self.likelihood.parameters())
+        self.red_all = parallel.FlatGradReducer(list(self.encoder.parameters()) + list(self.decoder.parameters()) +
+                                                list(self.frame_predictor.parameters()) + gp_params)
+        self.red_fp = parallel.FlatGradReducer(self.frame_predictor.parameters())
+        self.red_gp = parallel.FlatGradReducer(gp_params)
+
+    # ---- mode switches (train.py:342-346,372-374) -------------------------------------------
+    def train_mode(self):
+        for m in self.modules:
+            m.train()
+
+    def _gp_in(self, h):
+        return h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)
+
+    def _skip_rule(self, i, enc_out, skip):
+        """train.py:158-161,184-187,217-220: skip is refreshed only while i < n_past (or last_frame_skip)."""
+        if self.opt.last_frame_skip or i < self.opt.n_past:
+            return enc_out[0], enc_out[1]
+        return enc_out[0], skip
+
+    # ---- the three closures -------------------------------------------------------------------
+    def train_GP_Frame_predictor(self, x):
+        opt = self.opt
+        self.optimizer.zero_grad()
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        max_ll = 0
+        skip = None
+        for i in range(1, opt.n_past + opt.n_future):
+            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
+            h_target = self.encoder(x[i])[0].detach()
+            h_pred = self.gp_layer(self._gp_in(h))
+            max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
+        loss = max_ll.sum()
+        loss.backward()
+        self.red_gp.reduce()
+        self.optimizer.step()
+        return float(loss.detach()) / (opt.n_past + opt.n_future)
+
+    def train_frame_predictor(self, x):
+        opt = self.opt
+        self.frame_predictor.zero_grad()
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        mse_latent = 0
+        skip = None
+        for i in range(1, opt.n_past + opt.n_future):
+            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
+            h_target = self.encoder(x[i])[0]
+            h_pred = self.frame_predictor(h)
+            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+        mse_latent.backward()
+        self.red_fp.reduce()
+        self.frame_predictor_optimizer.step()
+        return float(mse_latent.detach()) / (opt.n_past + opt.n_future)
+
+    def train_model(self, x):
+        opt = self.opt
+        self.encoder.zero_grad()
+        self.decoder.zero_grad()
+        self.frame_predictor.zero_grad()
+        self.optimizer.zero_grad()  # the reference lets GP grads of the previous closure leak in; we do not
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        mse = mse_latent = mse_gp = ae_mse = 0
+        max_ll = 0
+        skip = None
+        for i in range(1, opt.n_past + opt.n_future):
+            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
+            h_target = self.encoder(x[i])[0]
+            h_pred = self.frame_predictor(h)
+            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+            gp_pred = self.gp_layer(self._gp_in(h))
+            max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
+            x_pred = self.decoder([h_pred, skip])
+            x_target_pred = self.decoder([h_target, skip])
+            ae_mse = ae_mse + self.mse_latent_criterion(x_target_pred, x[i])
+            x_pred_gp = self.decoder([gp_pred.mean.transpose(0, 1), skip])
+            mse = mse + self.mse_criterion(x_pred, x[i])
+            mse_gp = mse_gp + self.mse_latent_criterion(x_pred_gp, x[i])
+        loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
+        loss.backward()
+        self.red_all.reduce()
+        self.frame_predictor_optimizer.step()
+        self.encoder_optimizer.step()
+        self.decoder_optimizer.step()
+        self.optimizer.step()
+        v = float(mse_latent.detach()) / (opt.n_past + opt.n_future)
+        self.last_loss = float(loss.detach())
+        return v, v
+
+    def finetune_temporal_encoders(self, x):
+        return self.train_frame_predictor(x) + self.train_GP_Frame_predictor(x)
+
+    # ---- qualitative rollout of train.py:256-289 (tensors only; PNG/GIF writers are out of scope) ------
+    @torch.no_grad()
+    def plot(self, x, epoch, nsample=5):
+        opt = self.opt
+        gen_seq = []
+        for s in range(nsample):
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+            seq = [x[0]]
+            x_in = x[0]
+            skip = None
+            for i in range(1, opt.n_eval):
+                h, skip = self._skip_rule(i, self.encoder(x_in), skip)
+                if i < opt.n_past:
+                    self.frame_predictor(h)
+                    x_in = x[i]
+                else:
+                    h_pred = self.frame_predictor(h)
+                    if i == 10:  # train.py:281: the one GP-sampled step of the qualitative rollout
+                        x_in = self.decoder([self.likelihood(self.gp_layer(self._gp_in(h))).rsample().transpose(0, 1),
+                                             skip])
+                    else:
+                        x_in = self.decoder([h_pred, skip])
+                seq.append(x_in)
+            gen_seq.append(torch.stack(seq))
+        gen = torch.stack(gen_seq)                       # (S,T,B,C,H,W)
+        gt = torch.stack(list(x[:opt.n_eval]))           # (T,B,C,H,W)
+        sse = ((gen - gt.unsqueeze(0)) ** 2).sum((1, 3, 4, 5))   # (S,B) — train.py:303-310 best-of-N
+        return gen, sse.argmin(0)
+
+    def save(self, path):
+        torch.save({'encoder': self.encoder, 'decoder': self.decoder, 'frame_predictor': self.frame_predictor,
+                    'likelihood': self.likelihood.state_dict(), 'gp_layer': self.gp_layer.state_dict(),
+                    'gp_layer_optimizer': self.optimizer.state_dict(), 'opt': self.opt}, path)
+
+
+def make_batch_generator(opt, seq_len, seed):
+    if opt.dataset == 'smmnist':
+        ds = SyntheticMovingMNIST(seq_len=seq_len, num_digits=opt.num_digits, image_size=opt.image_width, seed=seed)
+        while True:
+            yield ds.batch(opt.local_batch)
+    k = 0
+    while True:
+        yield synthetic_video(opt.local_batch, seq_len, opt.channels, opt.image_width, seed=seed + k)
+        k += 1
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    opt.ft = not opt.no_ft
+    rank, world, local = parallel.init_distributed()
+    opt.rank, opt.world = rank, world
+    opt.local_batch = parallel.shard_batch(opt.batch_size, world)
+    if rank == 0:
+        print("Random Seed: ", opt.seed)
+    random.seed(opt.seed + rank)
+    np.random.seed(opt.seed + rank)
+    torch.manual_seed(opt.seed)          # identical init on every rank (also broadcast below)
+    assert torch.cuda.is_available(), "train.py needs a GPU: the DVG hot path has no CPU fallback"
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    torch.cuda.manual_seed_all(opt.seed)
+    if rank == 0:
+        print(opt)
+    tr = Trainer(opt, device)
+    torch.manual_seed(opt.seed + 1000 * rank)   # from here on: per-rank randomness (GP samples)
+    train_gen = make_batch_generator(opt, opt.n_past + opt.n_future, opt.seed + 17 * rank)
+    test_gen = make_batch_generator(opt, opt.n_eval, opt.seed + 7919 + 17 * rank)
+    dtype = torch.cuda.FloatTensor
+    for epoch in range(opt.niter):
+        tr.train_mode()
+        tr.scheduler.step()   # before the epoch, as train.py:347
+        epoch_mse = 0.0
+        t0 = time.time()
+        indices = 0.0
+        for i in range(opt.epoch_size):
+            x, _ = utils.normalize_data(opt, dtype, next(train_gen))
+            mse_ctrl, indices = tr.train_model(x)
+            temp_loss = tr.finetune_temporal_encoders(x) if opt.ft else 0
+            epoch_mse += mse_ctrl + temp_loss
+        torch.cuda.synchronize()
+        if rank == 0:
+            fps = opt.batch_size * (opt.n_past + opt.n_future - 1) * opt.epoch_size / (time.time() - t0)
+            print('[%02d] mse loss: %.5f (%d) %.5f' % (epoch, epoch_mse / opt.epoch_size,
+                                                       epoch * opt.epoch_size * opt.batch_size, indices))
+            print('     train frames/s: %.1f' % fps)
+        if epoch % opt.save_every == 0:
+            tr.frame_predictor.eval()
+            tr.gp_layer.eval()
+            tr.likelihood.eval()   # encoder / decoder stay in train mode, as train.py:372-374
+            test_x, _ = utils.normalize_data(opt, dtype, next(test_gen))
+            gen, best = tr.plot(test_x, epoch)
+            if rank == 0 and not opt.no_save:
+                os.makedirs(opt.output_path, exist_ok=True)
+                torch.save({'gen': gen[:, :, :min(opt.local_batch, 10)].cpu(), 'best': best.cpu()},
+                           '%s/sample_%d.pt' % (opt.output_path, epoch))
+                tr.save('%s/model.pth' % opt.output_path)
+        if epoch % 10 == 0 and rank == 0:
+            print('log dir: %s' % opt.log_dir)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return tr
+
+
+if __name__ == '__main__':
+    main()
