@@ -52,16 +52,16 @@ class _ConvBlock(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         need_stats = bn.training
         if kind == "conv3":
-            wp = ops.pack_conv_weight(weight)
+            wp = ops.pack_igemm_weight(weight)
             r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
         elif kind == "conv3_first":
             r = ops.conv3x3_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "conv4s2":
-            r = ops.conv4x4s2(x, ops.pack_conv_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
+            r = ops.conv4x4s2(x, ops.pack_igemm_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "conv4s2_first":
             r = ops.conv4x4s2_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "convT4s2":
-            r = ops.convT4x4s2(x, skip, ops.pack_convT_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
+            r = ops.convT4x4s2(x, skip, ops.pack_igemm_weight(weight, True), None, b, act=ACT_NONE, stats=need_stats)
         else:
             raise RuntimeError(kind)
         u, st = r if need_stats else (r, None)
@@ -89,22 +89,22 @@ class _ConvBlock(torch.autograd.Function):
         if kind == "conv3":
             dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, skip, du, upsample=up), 3, 3)
             if need_x:  # dgrad = the same igemm with the flipped / transposed weights
-                wd = ops.pack_convT_weight(_c(weight.detach()[:, :c1]))
+                wd = ops.pack_igemm_weight(_c(weight.detach()[:, :c1]), True)
                 dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
                 dx = ops.upsample2x_bwd(dxu) if up else dxu
             if need_skip:
-                dskip = ops.conv3x3(du, None, ops.pack_convT_weight(_c(weight.detach()[:, c1:])), None, None,
+                dskip = ops.conv3x3(du, None, ops.pack_igemm_weight(_c(weight.detach()[:, c1:]), True), None, None,
                                     act=ACT_NONE)
         elif kind == "conv4s2":
             dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV4S2, x, None, du), 4, 4)
             if need_x:
-                dx = ops.convT4x4s2(du, None, ops.pack_convT_weight(weight.detach()), None, None, act=ACT_NONE)
+                dx = ops.convT4x4s2(du, None, ops.pack_igemm_weight(weight.detach(), True), None, None, act=ACT_NONE)
         elif kind == "convT4s2":
             dW = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, skip, du), 4, 4)
             if need_x:
-                dx = ops.conv4x4s2(du, ops.pack_conv_weight(weight.detach()[:c1]), None, None, act=ACT_NONE)
+                dx = ops.conv4x4s2(du, ops.pack_igemm_weight(weight.detach()[:c1]), None, None, act=ACT_NONE)
             if need_skip:
-                dskip = ops.conv4x4s2(du, ops.pack_conv_weight(weight.detach()[c1:]), None, None, act=ACT_NONE)
+                dskip = ops.conv4x4s2(du, ops.pack_igemm_weight(weight.detach()[c1:]), None, None, act=ACT_NONE)
         elif kind in ("conv3_first", "conv4s2_first"):
             if need_x:
                 raise RuntimeError("gradients w.r.t. the input frames are not part of the DVG training path")

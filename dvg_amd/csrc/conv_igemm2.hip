@@ -1,0 +1,436 @@
+// v2 schedule of the fp32-MFMA implicit-GEMM convolutions (same math, same epilogue as conv_igemm.hip).
+//
+// What changed, and why (profiles/r01_pmc_conv3x3.md: matrix pipe 2/3 busy, the rest were
+// `ds_read -> s_waitcnt -> 8 MFMA` groups and one workgroup barrier per tap):
+//   * a stage = ALL taps of a 16-channel K chunk: the halo tile (<=14 KB) and the weights of every
+//     tap (9 x 64 x 16 floats) sit in LDS together, so there is ONE barrier pair per 72-144 MFMAs
+//     per wave instead of one barrier per 16-32;
+//   * the next stage's global loads are issued into registers before the stage's MFMAs and written
+//     to LDS after them (T14 async-stage split of the CDNA guide): their latency hides under ~9 k
+//     cycles of matrix work;
+//   * fragments are double-buffered in registers across taps, so the LDS reads of tap t+1 are in
+//     flight while the MFMAs of tap t issue;
+//   * weights are re-packed [Cin/16][tap][Cout][16]: a stage's weight tile is one contiguous 36 KB
+//     run (fully coalesced 16-B loads).
+// BN is fixed at 64 (2 waves along N) so that two workgroups share a CU (<= 67 KB LDS each) and
+// cover each other's stage hand-offs.
+#include "dvg_common.h"
+
+namespace dvg {
+
+enum { M2_CONV3 = 0, M2_CONV4S2 = 1, M2_CONVT4S2 = 2 };
+
+struct Igemm2Params {
+    const float* x;
+    const float* skip;
+    const float* w;      // packed [Cin/16][taps][Cout][16]
+    const float* scale;
+    const float* shift;
+    float* y;
+    float* y_pool;
+    float* stats;
+    int N, H, W, C1, C2, Cout, upsample, act;
+    float slope;
+    int tiles_y, tiles_x, tiles_n, nblk_n;
+    int ablate;  // debug only (dvg_debug_set_ablate): 1 = no global loads / LDS refills in the loop, 2 = also no barriers
+};
+
+static int g_ablate = 0;
+
+template <int MODE, int TI, int TH, int TW>
+struct Cfg2 {
+    static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;
+    static constexpr int SPAN = (MODE == M2_CONV4S2) ? 4 : 3;
+    static constexpr int HH = (TH - 1) * S + SPAN, HW = (TW - 1) * S + SPAN;
+    static constexpr int HP = TI * HH * HW;
+    static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64;
+    static constexpr int NTAPS = (MODE == M2_CONV3) ? 9 : 16;
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : 4);  // taps resident per stage
+    static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
+    static constexpr int KC = 16, LD = 20;  // 80-B LDS rows: b128 lane groups land on distinct 16-B slots
+    static constexpr int A_FLOATS = HP * LD, B_FLOATS = GT * BN * LD;
+    static constexpr int NLA = (HP * 4 + 255) / 256;
+    static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
+    static_assert(BM == 64 || BM == 128, "BM");
+};
+
+template <int MODE, int TI, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params p) {
+    using C = Cfg2<MODE, TI, TH, TW>;
+    constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
+                  BN = C::BN, NLA = C::NLA;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + C::A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    int par = 0;
+    if (MODE == M2_CONVT4S2) { par = lid & 3; lid >>= 2; }
+    const int nb = lid % p.nblk_n;
+    unsigned t = lid / p.nblk_n;
+    const int tx_i = t % p.tiles_x; t /= p.tiles_x;
+    const int ty_i = t % p.tiles_y; t /= p.tiles_y;
+    const int n0 = (int)t * TI, y0 = ty_i * TH, x0 = tx_i * TW;
+    const int yin0 = y0 * S - 1, xin0 = x0 * S - 1, nb0 = nb * BN;
+    const int py = par >> 1, px = par & 1;
+    const int Cin = p.C1 + p.C2;
+
+    int a_base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = wm * (C::BM / 2) + mt * 32 + l31;
+        const int ti = m / (TH * TW), r = m % (TH * TW);
+        a_base[mt] = ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * LD + hh * 8;
+    }
+    const int b_base = (wn * 32 + l31) * LD + hh * 8;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    // ---- loader geometry, computed once --------------------------------------------------------
+    long offx[NLA], offs[NLA];  // element offsets of this thread's halo float4s in x / skip (-1: zero fill)
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int idx = tid + i * 256;
+        const int hp = idx >> 2, q = idx & 3;
+        const int ti = hp / (HH * HW), r = hp % (HH * HW);
+        const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
+        const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const int sh = p.upsample;
+        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : -1;
+        offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : -1;
+    }
+    const int brow = tid >> 2, bq = tid & 3;  // weight tile: one float4 per thread per tap
+
+    auto tap_w = [&](int grp, int tt) -> int {
+        if (MODE == M2_CONVT4S2) return (2 + py - 2 * (tt >> 1)) * 4 + (2 + px - 2 * (tt & 1));
+        return grp * GT + tt;
+    };
+    auto tap_lds = [&](int grp, int tt) -> int {
+        int th, tw;
+        if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
+        else if (MODE == M2_CONV4S2) { th = grp * 2 + (tt >> 2); tw = tt & 3; }
+        else { th = 1 + py - (tt >> 1); tw = 1 + px - (tt & 1); }
+        return (th * HW + tw) * LD;
+    };
+    auto gload_a = [&](int c0, f32x4 (&ra)[NLA]) {
+        const bool from_x = c0 < p.C1;
+        const float* src = from_x ? p.x + c0 : p.skip + (c0 - p.C1);
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const long o = from_x ? offx[i] : offs[i];
+            ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + o);
+        }
+    };
+    auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[GT]) {
+#pragma unroll
+        for (int tt = 0; tt < GT; ++tt)
+            rb[tt] = *reinterpret_cast<const f32x4*>(
+                p.w + (((size_t)chunk * C::NTAPS + tap_w(grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4);
+    };
+    auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < HP * 4) *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = ra[i];
+        }
+    };
+    auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
+#pragma unroll
+        for (int tt = 0; tt < GT; ++tt) *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
+    };
+
+    const int nstages = (Cin / C::KC) * NG;
+    f32x4 ra[NLA], rb[GT];
+    if ((p.ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);  // experiment: break the lockstep of co-resident WGs
+    gload_a(0, ra);
+    gload_b(0, 0, rb);
+    lds_store_a(ra);
+    lds_store_b(rb);
+    __syncthreads();
+
+    for (int s = 0; s < nstages; ++s) {
+        const int grp = s % NG;
+        const bool has_next = s + 1 < nstages;
+        const int nchunk = (s + 1) / NG, ngrp = (s + 1) % NG;
+        const bool next_a = has_next && ngrp == 0;
+        if ((p.ablate & 3) == 0) {
+            if (next_a) gload_a(nchunk * C::KC, ra);
+            if (has_next) gload_b(nchunk, ngrp, rb);
+        }
+
+        // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
+        f32x4 fa[2][MT][2], fb[2][2];
+        {
+            const int ao = tap_lds(grp, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[0][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
+                fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + j * 4]);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < GT; ++tt) {
+            const int cur = tt & 1, nxt = cur ^ 1;
+            if (tt + 1 < GT) {
+                const int ao = tap_lds(grp, tt + 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
+                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LD + j * 4]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][j][e], acc[mt], 0, 0, 0);
+            // Pin the software pipeline: hipcc otherwise sinks the next tap's ds_reads down to their first use
+            // (ds_read x3 -> s_waitcnt -> mfma x8), exposing the LDS latency every 8 MFMAs.  One ds_read_b128 per two
+            // MFMAs, issued a full tap (16 / 8 MFMAs) ahead of its consumer.
+            constexpr int NREAD = 2 * MT + 2, NMFMA = 8 * MT;
+            if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // tap 0's own fragments
+            if (tt + 1 < GT) {
+#pragma unroll
+                for (int r = 0; r < NREAD; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                if (NMFMA > 2 * NREAD) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NREAD, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            }
+        }
+
+        if (has_next && (p.ablate & 3) < 2) {
+            __syncthreads();  // every wave has finished reading this stage's tiles
+            if ((p.ablate & 3) == 0) {
+                if (next_a) lds_store_a(ra);
+                lds_store_b(rb);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (identical math to v1) --------------------------------------------------------------
+    int Ho, Wo;
+    if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
+    else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
+    else { Ho = p.H * 2; Wo = p.W * 2; }
+    const int c = nb0 + wn * 32 + l31;
+    const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float v[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
+        const int mbase = wm * (C::BM / 2) + mt * 32;
+        const int ti0 = mbase / (TH * TW);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            const int m = mbase + row;
+            const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
+            const int r = m % (TH * TW);
+            const int ty = r / TW, tx = r % TW;
+            const int n = n0 + tii;
+            if (n < p.N) {
+                s1 += v[reg];
+                s2 += v[reg] * v[reg];
+                const float o = apply_act(v[reg], p.act, p.slope);
+                v[reg] = o;
+                int oy, ox;
+                if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+                else { oy = y0 + ty; ox = x0 + tx; }
+                p.y[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = o;
+            }
+        }
+        if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
+            if (p.y_pool != nullptr) {
+                constexpr int RY = (TW == 16) ? 8 : 4;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool ty_even = (TW == 16) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
+                    if ((reg & 1) == 0 && ty_even) {
+                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        const int r = (mbase + row) % (TH * TW);
+                        const int ty = r / TW, tx = r % TW;
+                        const float mx = fmaxf(fmaxf(v[reg], v[reg + 1]), fmaxf(v[reg + RY], v[reg + RY + 1]));
+                        const int n = n0 + ti0;
+                        if (n < p.N)
+                            p.y_pool[(((size_t)n * (Ho >> 1) + ((y0 + ty) >> 1)) * (Wo >> 1) + ((x0 + tx) >> 1)) * p.Cout +
+                                     c] = mx;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        float* red = smem;
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        __syncthreads();
+        if (wm == 1 && hh == 0) {
+            red[wn * 64 + l31] = s1;
+            red[wn * 64 + 32 + l31] = s2;
+        }
+        __syncthreads();
+        if (wm == 0 && hh == 0) {
+            const unsigned rowid = (MODE == M2_CONVT4S2 ? (lid / p.nblk_n) * 4 + par : lid / p.nblk_n);
+            float* dst = p.stats + (size_t)rowid * 2 * p.Cout;
+            dst[c] = s1 + red[wn * 64 + l31];
+            dst[p.Cout + c] = s2 + red[wn * 64 + 32 + l31];
+        }
+    }
+}
+
+template <int MODE, int TI, int TH, int TW>
+static int launch2(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
+    using C = Cfg2<MODE, TI, TH, TW>;
+    if (Hg % TH || Wg % TW || p.Cout % 64) return fail(DVG_ERR_SHAPE, "conv_igemm2: tile does not divide shape");
+    p.tiles_y = Hg / TH;
+    p.tiles_x = Wg / TW;
+    p.tiles_n = (p.N + TI - 1) / TI;
+    p.nblk_n = p.Cout / 64;
+    p.ablate = g_ablate;
+    const unsigned grid = (unsigned)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    return check_launch("conv_igemm2");
+}
+
+// spatial tile on the grid the tiles cover; 8x16 unless the map is 8 wide / that leaves < 2 workgroups per CU
+static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, int* tw) {
+    const int par = mode == M2_CONVT4S2 ? 4 : 1;
+    if (Hg == 4 && Wg == 4) { *ti = 4; *th = 4; *tw = 4; return 0; }
+    if (Hg % 8 || Wg % 8) return -1;
+    *ti = 1; *th = 8; *tw = 8;
+    if (mode != M2_CONV4S2 && Wg % 16 == 0) {
+        const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
+        if (wgs >= 512) *tw = 16;
+    }
+    return 0;
+}
+
+__global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
+                                int kw, int transposed) {
+    // dst[chunk][t][co][16]  <-  conv: w[co][ci][a][b]   convT: w[ci][co][KH-1-a][KW-1-b]
+    const long total = (long)cout * cin * kh * kw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i & 15;
+        long r = i >> 4;
+        const int co = r % cout; r /= cout;
+        const int t = r % (kh * kw);
+        const int chunk = r / (kh * kw);
+        const int ci = chunk * 16 + k, a = t / kw, b = t % kw;
+        const long j = transposed ? ((((long)ci * cout + co) * kh + (kh - 1 - a)) * kw + (kw - 1 - b))
+                                  : ((((long)co * cin + ci) * kh + a) * kw + b);
+        dst[i] = src[j];
+    }
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" void dvg_debug_set_ablate(int v) { g_ablate = v; }
+
+extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
+                                        int transposed, void* stream) {
+    DVG_REQUIRE(w && w_packed, DVG_ERR_NULL, "dvg_pack_conv_weight_k16: NULL pointer");
+    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0 && kh > 0 && kw > 0, DVG_ERR_SHAPE,
+                "dvg_pack_conv_weight_k16: Cin must be a multiple of 16");
+    const long total = (long)cout * cin * kh * kw;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_k16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, w_packed, cout, cin, kh,
+                       kw, transposed);
+    return check_launch("dvg_pack_conv_weight_k16");
+}
+
+extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cout) {
+    int Hg = H, Wg = W;
+    if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
+    int ti, th, tw;
+    if (tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
+    return ((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * (mode == M2_CONVT4S2 ? 4 : 1);
+}
+
+static int checks2(const Igemm2Params& p, const char* who) {
+    DVG_REQUIRE(p.x && p.w && p.y, DVG_ERR_NULL, "%s: x/w/y must not be NULL", who);
+    DVG_REQUIRE((p.skip != nullptr) == (p.C2 > 0), DVG_ERR_SHAPE, "%s: skip pointer / C2 mismatch", who);
+    DVG_REQUIRE(p.N > 0 && p.H > 0 && p.W > 0, DVG_ERR_SHAPE, "%s: empty shape", who);
+    DVG_REQUIRE(p.C1 > 0 && p.C1 % 16 == 0 && p.C2 % 16 == 0, DVG_ERR_SHAPE, "%s: C1=%d C2=%d must be multiples of 16",
+                who, p.C1, p.C2);
+    DVG_REQUIRE(p.Cout > 0 && p.Cout % 64 == 0, DVG_ERR_SHAPE, "%s: Cout=%d must be a multiple of 64", who, p.Cout);
+    DVG_REQUIRE(aligned16(p.x) && aligned16(p.w) && aligned16(p.y) && aligned16(p.skip), DVG_ERR_ALIGN,
+                "%s: pointers must be 16-byte aligned", who);
+    DVG_REQUIRE(p.act >= DVG_ACT_NONE && p.act <= DVG_ACT_SIGMOID, DVG_ERR_SHAPE, "%s: bad act", who);
+    return DVG_OK;
+}
+
+#define D2(MODE, TI_, TH_, TW_) \
+    if (ti == TI_ && th == TH_ && tw == TW_) return launch2<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
+
+extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
+                                     const float* shift, float* y, float* y_pool, float* stats, int N, int H, int W,
+                                     int C1, int C2, int Cout, int upsample_x, int act, float slope, void* stream) {
+    Igemm2Params p{x, skip, w_k16, scale, shift, y, y_pool, stats, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, act, slope,
+                   0, 0, 0, 0, 0};
+    if (int e = checks2(p, "dvg_conv3x3_bn_act_v2")) return e;
+    DVG_REQUIRE(H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: H=%d W=%d must be multiples of 8", H, W);
+    int Hg = H, Wg = W, ti, th, tw;
+    DVG_REQUIRE(tile2(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
+                "dvg_conv3x3_bn_act_v2: no tile for %dx%d", H, W);
+    D2(M2_CONV3, 1, 8, 16)
+    D2(M2_CONV3, 1, 8, 8)
+    return fail(DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: no kernel");
+}
+
+extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale, const float* shift,
+                                       float* y, float* stats, int N, int H, int W, int Cin, int Cout, int act,
+                                       float slope, void* stream) {
+    Igemm2Params p{x, nullptr, w_k16, scale, shift, y, nullptr, stats, N, H, W, Cin, 0, Cout, 0, act, slope, 0, 0, 0, 0, 0};
+    if (int e = checks2(p, "dvg_conv4x4s2_bn_act_v2")) return e;
+    DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_conv4x4s2_bn_act_v2: odd input");
+    int Hg = H / 2, Wg = W / 2, ti, th, tw;
+    DVG_REQUIRE(tile2(M2_CONV4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,
+                "dvg_conv4x4s2_bn_act_v2: unsupported map %dx%d", H, W);
+    D2(M2_CONV4S2, 1, 8, 8)
+    D2(M2_CONV4S2, 4, 4, 4)
+    return fail(DVG_ERR_SHAPE, "dvg_conv4x4s2_bn_act_v2: no kernel");
+}
+
+extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
+                                        const float* shift, float* y, float* stats, int N, int H, int W, int C1,
+                                        int C2, int Cout, int act, float slope, void* stream) {
+    Igemm2Params p{x, skip, w_k16, scale, shift, y, nullptr, stats, N, H, W, C1, C2, Cout, 0, act, slope, 0, 0, 0, 0, 0};
+    if (int e = checks2(p, "dvg_convT4x4s2_bn_act_v2")) return e;
+    int Hg = H, Wg = W, ti, th, tw;
+    DVG_REQUIRE(tile2(M2_CONVT4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,
+                "dvg_convT4x4s2_bn_act_v2: unsupported map %dx%d", H, W);
+    D2(M2_CONVT4S2, 1, 8, 16)
+    D2(M2_CONVT4S2, 1, 8, 8)
+    D2(M2_CONVT4S2, 4, 4, 4)
+    return fail(DVG_ERR_SHAPE, "dvg_convT4x4s2_bn_act_v2: no kernel");
+}

@@ -44,10 +44,7 @@ def packed_weight(conv: nn.Module) -> torch.Tensor:
     hit = slot.get("wp")
     if hit is not None and hit[0] == key:
         return hit[1]
-    if isinstance(conv, nn.ConvTranspose2d):
-        wp = ops.pack_convT_weight(conv.weight)
-    else:
-        wp = ops.pack_conv_weight(conv.weight)
+    wp = ops.pack_igemm_weight(conv.weight, transposed=isinstance(conv, nn.ConvTranspose2d))
     slot["wp"] = (key, wp)
     return wp
 

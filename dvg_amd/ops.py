@@ -6,9 +6,14 @@ arithmetic op of the hot path is a kernel of libdvg_hip.so.  Activations travel 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import check, lib
+
+# implicit-GEMM schedule: 2 = conv_igemm2.hip (chunk-staged, register-prefetched), 1 = conv_igemm.hip
+IGEMM_V = int(os.environ.get("DVG_IGEMM", "2"))
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2 = 0, 1, 2
@@ -127,6 +132,28 @@ def pack_convT_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_igemm_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """Weight in the layout the selected implicit-GEMM kernels read (v2: [Cin/16][taps][Cout][16])."""
+    if IGEMM_V == 1:
+        return pack_convT_weight(w) if transposed else pack_conv_weight(w)
+    _dev_f32(w, "pack_igemm_weight")
+    w = w.detach().contiguous()
+    if transposed:
+        ci, co, kh, kw = w.shape
+    else:
+        co, ci, kh, kw = w.shape
+    out = torch.empty((ci // 16, kh * kw, co, 16), device=w.device, dtype=torch.float32)
+    check(lib().dvg_pack_conv_weight_k16(_p(w), _p(out), co, ci, kh, kw, int(transposed), _stream()), "pack_k16")
+    return out
+
+
+def _wp_dims(wp: torch.Tensor):
+    """(taps, cout, cin) of a packed igemm weight in either layout."""
+    if wp.dim() == 4:
+        return wp.shape[1], wp.shape[2], wp.shape[0] * 16
+    return tuple(wp.shape)
+
+
 def unpack_conv_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
     t, co, ci = wp.shape
     out = torch.empty((co, ci, kh, kw), device=wp.device, dtype=torch.float32)
@@ -164,15 +191,16 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         c2 = skip.shape[1]
         if tuple(skip.shape) != (n, c2, h, w):
             raise RuntimeError(f"conv3x3: skip shape {tuple(skip.shape)} does not match {(n, c2, h, w)}")
-    taps, cout, cin = wp.shape
-    if taps != 9 or cin != c1 + c2:
+    taps, cout, cin = _wp_dims(wp)
+    if taps != 9 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV3, n, h, w, cout), cout, x.device) if stats else None
+    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
+    st = _stats_buf(rows_fn(MODE_CONV3, n, h, w, cout), cout, x.device) if stats else None
     _run("conv3x3_igemm", 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) +
                                                                    n * h * w * cout + wp.numel()),
-         lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
+         lib().dvg_conv3x3_bn_act_v2 if IGEMM_V == 2 else lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
          c2, cout, int(upsample), act, slope, _stream())
     out = (y, yp) if pool else y
     return (out, st) if stats else out
@@ -211,13 +239,15 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     _dev_f32(x, "conv4x4s2.x")
     assert is_nhwc(x)
     n, cin, h, w = x.shape
-    taps, cout, cin_w = wp.shape
-    if taps != 16 or cin_w != cin:
+    taps, cout, cin_w = _wp_dims(wp)
+    if taps != 16 or cin_w != cin or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
     y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
-    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONV4S2, n, h, w, cout), cout, x.device) if stats else None
+    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
+    st = _stats_buf(rows_fn(MODE_CONV4S2, n, h, w, cout), cout, x.device) if stats else None
     _run("conv4x4s2_igemm", 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin,
-         4.0 * (x.numel() + y.numel() + wp.numel()), lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift),
+         4.0 * (x.numel() + y.numel() + wp.numel()),
+         lib().dvg_conv4x4s2_bn_act_v2 if IGEMM_V == 2 else lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift),
          _p(y), _p(st), n, h, w, cin, cout, act, slope, _stream())
     return (y, st) if stats else y
 
@@ -248,13 +278,15 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
         c2 = skip.shape[1]
         if tuple(skip.shape) != (n, c2, h, w):
             raise RuntimeError("convT4x4s2: skip shape mismatch")
-    taps, cout, cin = wp.shape
-    if taps != 16 or cin != c1 + c2:
+    taps, cout, cin = _wp_dims(wp)
+    if taps != 16 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
-    st = _stats_buf(lib().dvg_conv_stats_rows(MODE_CONVT4S2, n, h, w, cout), cout, x.device) if stats else None
+    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
+    st = _stats_buf(rows_fn(MODE_CONVT4S2, n, h, w, cout), cout, x.device) if stats else None
     _run("convT4x4s2_igemm", 2.0 * n * h * w * cout * 16 * cin,
-         4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel()), lib().dvg_convT4x4s2_bn_act,
+         4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel()),
+         lib().dvg_convT4x4s2_bn_act_v2 if IGEMM_V == 2 else lib().dvg_convT4x4s2_bn_act,
          _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())
     return (y, st) if stats else y
 

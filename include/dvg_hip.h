@@ -109,6 +109,25 @@ int dvg_conv3x3_bn_act(const float* x, const float* skip, const float* w_packed,
                        int C2, int Cout, int upsample_x, int act, float slope,
                        void* stream);
 
+/* v2 schedule of the three implicit-GEMM convs (conv_igemm2.hip): identical semantics and
+ * arguments, but the weights are packed [Cin/16][tap][Cout][16] by dvg_pack_conv_weight_k16
+ * (transposed != 0: ConvTranspose2d weight (Cin,Cout,KH,KW), flipped) and `stats` has
+ * dvg_conv_stats_rows_v2(...) rows.  C1, C2 multiples of 16; Cout multiple of 64.      */
+int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
+                             int transposed, void* stream);
+int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cout);
+int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
+                          const float* scale, const float* shift, float* y, float* y_pool,
+                          float* stats, int N, int H, int W, int C1, int C2, int Cout,
+                          int upsample_x, int act, float slope, void* stream);
+int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
+                            const float* shift, float* y, float* stats, int N, int H, int W,
+                            int Cin, int Cout, int act, float slope, void* stream);
+int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16,
+                             const float* scale, const float* shift, float* y, float* stats,
+                             int N, int H, int W, int C1, int C2, int Cout, int act, float slope,
+                             void* stream);
+
 /* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
  * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.
  * x is NCHW (N,nc,H,W) exactly as the caller's frame tensor (utils.py:90-91);

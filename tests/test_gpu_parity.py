@@ -71,7 +71,7 @@ def test_conv3x3_igemm(N, H, W, C1, C2, Cout, up, pool):
     if sk is not None:
         xin = torch.cat([xin, sk], 1)
     ref = F.leaky_relu(F.conv2d(xin, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
-    wp = ops.pack_conv_weight(w.to(dev()))
+    wp = ops.pack_igemm_weight(w.to(dev()))
     out = ops.conv3x3(nhwc(x), None if sk is None else nhwc(sk), wp, sc.to(dev()), sh.to(dev()), upsample=up,
                       pool=pool)
     y, yp = out if pool else (out, None)
@@ -88,7 +88,7 @@ def test_conv3x3_stats_epilogue():
     w = params.normal(21, Cout, C, 3, 3, scale=0.1)
     b = params.normal(22, Cout, scale=0.2)
     u_ref = F.conv2d(x, w, b, 1, 1)
-    (u, st) = ops.conv3x3(nhwc(x), None, ops.pack_conv_weight(w.to(dev())), None, b.to(dev()), act=ops.ACT_NONE,
+    (u, st) = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(w.to(dev())), None, b.to(dev()), act=ops.ACT_NONE,
                           stats=True)
     assert rel_err(u, u_ref) < 2e-5
     tot = st.double().sum(0).cpu()
@@ -128,7 +128,7 @@ def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
     w = params.normal(41, Cout, Cin, 4, 4, scale=1.0 / np.sqrt(16 * Cin))
     sc, sh = 1 + 0.1 * params.normal(42, Cout), 0.1 * params.normal(43, Cout)
     ref = F.leaky_relu(F.conv2d(x, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
-    y, st = ops.conv4x4s2(nhwc(x), ops.pack_conv_weight(w.to(dev())), sc.to(dev()), sh.to(dev()), stats=True)
+    y, st = ops.conv4x4s2(nhwc(x), ops.pack_igemm_weight(w.to(dev())), sc.to(dev()), sh.to(dev()), stats=True)
     assert rel_err(y, ref) < 2e-5
     pre = F.conv2d(x, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
     np.testing.assert_allclose(st.double().sum(0)[1].cpu().numpy(), (pre.double() ** 2).sum((0, 2, 3)).numpy(),
@@ -145,7 +145,7 @@ def test_convT4x4s2_igemm(N, H, W, C1, C2, Cout):
     sc, sh = 1 + 0.1 * params.normal(53, Cout), 0.1 * params.normal(54, Cout)
     xin = x if sk is None else torch.cat([x, sk], 1)
     pre = F.conv_transpose2d(xin, w, None, 2, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
-    y, st = ops.convT4x4s2(nhwc(x), None if sk is None else nhwc(sk), ops.pack_convT_weight(w.to(dev())),
+    y, st = ops.convT4x4s2(nhwc(x), None if sk is None else nhwc(sk), ops.pack_igemm_weight(w.to(dev()), True),
                            sc.to(dev()), sh.to(dev()), stats=True)
     assert rel_err(y, F.leaky_relu(pre, 0.2)) < 2e-5
     np.testing.assert_allclose(st.double().sum(0)[0].cpu().numpy(), pre.double().sum((0, 2, 3)).numpy(), rtol=1e-4,

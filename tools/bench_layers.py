@@ -38,7 +38,12 @@ def time_fn(fn, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--ablate", type=int, default=0)
     args = ap.parse_args()
+    if args.ablate:
+        import ctypes
+        from dvg_amd._lib import LIB_PATH
+        ctypes.CDLL(LIB_PATH).dvg_debug_set_ablate(args.ablate)
     dev = torch.device("cuda:0")
     N = args.batch
     tot_us = tot_fl = 0.0
@@ -46,7 +51,7 @@ def main():
         hx = H // 2 if up else H
         x = ops.nhwc_empty(N, C1, hx, hx, dev).normal_()
         sk = ops.nhwc_empty(N, C2, H, H, dev).normal_() if C2 else None
-        wp = torch.randn(9, Cout, C1 + C2, device=dev) * 0.02
+        wp = ops.pack_igemm_weight(torch.randn(Cout, C1 + C2, 3, 3, device=dev) * 0.02)
         sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1
         us = time_fn(lambda: ops.conv3x3(x, sk, wp, sc, sh, upsample=bool(up), pool=bool(pool)))
         fl = 2.0 * N * H * H * Cout * 9 * (C1 + C2)
