@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--n_future", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,7 +142,7 @@ def main():
 
     from dvg_amd import ops, utils
     from dvg_amd.data import SyntheticMovingMNIST
-    from dvg_amd.rollout import sample_rollout
+    from dvg_amd.rollout import GraphedRollout, sample_rollout
 
     n_eval = args.n_past + args.n_future
     enc, dec, fp, gp, lik = build_models(args.model, args.batch, 1, dev, args.seed + rank)
@@ -150,8 +151,14 @@ def main():
     x = [t.to(dev) for t in x]
     calibrate_batchnorm(enc, dec, x[0])
 
-    def step():
+    def eager_step():
         return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
+
+    if args.no_graph:
+        step = eager_step
+    else:   # the whole rollout as ONE hipGraph replay
+        graphed = GraphedRollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
+        step = graphed
 
     for _ in range(args.warmup):
         step()
@@ -183,7 +190,8 @@ def main():
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "
                                f"{args.n_past}-in/{args.n_future}-out", "model_family": args.model,
                    "batch_per_gpu": args.batch, "n_past": args.n_past, "n_future": args.n_future,
-                   "parallelism": f"replicas x{world} (no data-path collective)"},
+                   "parallelism": f"replicas x{world} (no data-path collective)",
+                   "launch": "eager" if args.no_graph else "hipGraph replay"},
     }
 
     if rank == 0:
@@ -191,7 +199,7 @@ def main():
         timer = ops.KernelTimer()
         ops.set_timer(timer)
         for _ in range(3):
-            step()
+            eager_step()   # events need eager launches; same kernels, same shapes as the graphed step
         ops.set_timer(None)
         agg = timer.summary()
         total_ms = sum(a["ms"] for a in agg.values())

@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 
     const int nstages = (Cin / C::KC) * NG;
     f32x4 ra[NLA], rb[GT];
-    if ((p.ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);  // experiment: break the lockstep of co-resident WGs
+    // experiments: break the lockstep of co-resident workgroups (which pairs share a CU is not architected)
+    if ((p.ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);
+    if ((p.ablate & 8) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(127);
+    if ((p.ablate & 16) && ((blockIdx.x >> 4) & 1)) __builtin_amdgcn_s_sleep(127);
     gload_a(0, ra);
     gload_b(0, 0, rb);
     lds_store_a(ra);

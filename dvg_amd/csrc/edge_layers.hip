@@ -19,67 +19,138 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float* __restrict__ shift, float* __restrict__ y,
                                                          float* __restrict__ stats, int N, int H, int W, int nc,
                                                          int Cout, int act, float slope) {
-    constexpr int TH = 4, TW = 32;  // output tile per workgroup: 4 rows (one per wave) x 32 columns
+    // Output tile per workgroup: 4 rows (one per wave) x 32 columns x 64 channels.
+    // lane = (pixel sub-index 0..3) x (channel quad 0..15): a lane owns 4 consecutive output channels of one
+    // pixel, so the store is 16 B per lane and a wave writes 4 pixels = 1 KiB contiguous NHWC bytes; the
+    // KS*KS*nc input taps are LDS reads with 4 distinct addresses per wave (broadcast within a quad group).
+    // Workgroups are persistent over tiles (grid-stride): the next tile's few input floats are prefetched into
+    // registers while the current tile computes, so the global->LDS latency is paid once per workgroup.
+    constexpr int TH = 4, TW = 32;
     constexpr int HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
-    __shared__ float tile[4 * HH * HW];
+    constexpr int NT = KS * KS;
+    constexpr int NPRE = (4 * HH * HW + 255) / 256;
+    __shared__ float tiles[2][4 * HH * HW];
+    __shared__ __attribute__((aligned(16))) float wl[4 * NT * 64];  // weights [ci*NT+tap][64 channels of this group]
     __shared__ float red[2 * 4 * 64];
     const int Ho = (H + 2 - KS) / S + 1, Wo = (W + 2 - KS) / S + 1;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    const int cg = blockIdx.y;  // group of 64 output channels
-    int t = blockIdx.x;
-    const int tx_i = t % tiles_x; t /= tiles_x;
-    const int ty_i = t % tiles_y;
-    const int n = t / tiles_y;
-    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int ntiles = N * tiles_y * tiles_x;
+    const int cg = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, cq = lane & 15;
+    const int c0 = cg * 64 + cq * 4;
+    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sf = shift ? *reinterpret_cast<const f32x4*>(shift + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int i = threadIdx.x; i < nc * HH * HW; i += 256) {
-        const int ci = i / (HH * HW), r = i % (HH * HW);
-        const int yy = iy0 + r / HW, xx = ix0 + r % HW;
-        float v = 0.f;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((size_t)n * nc + ci) * H + yy) * W + xx];
-        tile[i] = v;
+    // the 64 x (nc*NT) weights of this channel group stay in LDS for the whole workgroup lifetime
+    for (int i = threadIdx.x; i < nc * NT * 64; i += 256) {
+        const int c = i & 63, q = i >> 6;
+        wl[q * 64 + c] = w[(size_t)(cg * 64 + c) * nc * NT + q];
     }
-    const int c = cg * 64 + lane;
-    float wr[4 * KS * KS];
-#pragma unroll
-    for (int i = 0; i < 4 * KS * KS; ++i) wr[i] = (i < nc * KS * KS) ? w[(size_t)c * nc * KS * KS + i] : 0.f;
-    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
-    __syncthreads();
 
-    float s1 = 0.f, s2 = 0.f;
-    const int oy = oy0 + wave;
-    if (oy < Ho) {
-        for (int px = 0; px < TW; ++px) {
-            const int ox = ox0 + px;
-            if (ox >= Wo) break;
-            float acc = 0.f;
+    float pre[NPRE];
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int tx_i = t % tiles_x; t /= tiles_x;
+        const int ty_i = t % tiles_y;
+        const int n = t / tiles_y;
+        const int iy0 = ty_i * TH * S - 1, ix0 = tx_i * TW * S - 1;
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {  // static register indexing of wr[] (nc <= 4, uniform predicate)
-                if (ci < nc) {
-                    const float* tp = tile + ci * HH * HW + (wave * S) * HW + px * S;
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int ci = i / (HH * HW), r = i % (HH * HW);
+            const int yy = iy0 + r / HW, xx = ix0 + r % HW;
+            pre[j] = 0.f;
+            if (i < nc * HH * HW && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                pre[j] = x[(((size_t)n * nc + ci) * H + yy) * W + xx];
+        }
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        float* tl = tiles[buf];
 #pragma unroll
-                    for (int a = 0; a < KS; ++a)
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < nc * HH * HW) tl[i] = pre[j];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+
+        int t = tile;
+        const int tx_i = t % tiles_x; t /= tiles_x;
+        const int ty_i = t % tiles_y;
+        const int n = t / tiles_y;
+        const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        const int oy = oy0 + wave;
+        if (oy < Ho) {
+            // two passes of 4 pixels per lane: 16 accumulators live at a time keeps the kernel at <= 64 VGPRs
+            // (8 waves/SIMD): this layer is HBM-write-bound and wants occupancy, not ILP
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                f32x4 acc[TW / 8];
 #pragma unroll
-                        for (int b = 0; b < KS; ++b) acc = fmaf(tp[a * HW + b], wr[ci * KS * KS + a * KS + b], acc);
+                for (int it = 0; it < TW / 8; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ci = 0; ci < nc; ++ci) {
+#pragma unroll 1
+                    for (int a = 0; a < KS; ++a) {
+                        const float* row = tl + ci * HH * HW + (wave * S + a) * HW + (half * 16 + sub) * S;
+                        const float* wrow = &wl[(ci * NT + a * KS) * 64 + cq * 4];
+#pragma unroll
+                        for (int b = 0; b < KS; ++b) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + b * 64);
+#pragma unroll
+                            for (int it = 0; it < TW / 8; ++it) {
+                                const float v = row[it * 4 * S + b];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[it][k] = fmaf(v, wv[k], acc[it][k]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < TW / 8; ++it) {
+                    const int ox = ox0 + half * 16 + it * 4 + sub;
+                    if (ox < Wo) {
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float u = acc[it][k] * sc[k] + sf[k];
+                            s1[k] += u;
+                            s2[k] += u * u;
+                            o[k] = apply_act(u, act, slope);
+                        }
+                        *reinterpret_cast<f32x4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0) = o;
+                    }
                 }
             }
-            const float u = acc * sc + sf;
-            s1 += u;
-            s2 += u * u;
-            y[(((size_t)n * Ho + oy) * Wo + ox) * Cout + c] = apply_act(u, act, slope);
         }
-    }
-    if (stats != nullptr) {
-        red[wave * 64 + lane] = s1;
-        red[256 + wave * 64 + lane] = s2;
-        __syncthreads();
-        if (wave == 0) {
-            float* dst = stats + (size_t)blockIdx.x * 2 * Cout;
-            dst[c] = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
-            dst[Cout + c] = red[256 + lane] + red[320 + lane] + red[384 + lane] + red[448 + lane];
+        if (stats != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // fold the 4 pixel sub-lanes that share a channel quad
+                s1[k] += __shfl_xor(s1[k], 16);
+                s1[k] += __shfl_xor(s1[k], 32);
+                s2[k] += __shfl_xor(s2[k], 16);
+                s2[k] += __shfl_xor(s2[k], 32);
+            }
+            __syncthreads();  // red[] of the previous tile has been consumed
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    red[wave * 64 + cq * 4 + k] = s1[k];
+                    red[256 + wave * 64 + cq * 4 + k] = s2[k];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int c = cg * 64 + lane;
+                float* dst = stats + (size_t)tile * 2 * Cout;
+                dst[c] = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+                dst[Cout + c] = red[256 + lane] + red[320 + lane] + red[384 + lane] + red[448 + lane];
+            }
         }
+        buf ^= 1;
     }
 }
 
@@ -214,7 +285,8 @@ extern "C" int dvg_conv3x3_first(const float* x, const float* w, const float* sc
                                  float* stats, int N, int H, int W, int nc, int Cout, int act, float slope,
                                  void* stream) {
     if (int e = first_checks("dvg_conv3x3_first", x, w, y, N, H, W, nc, Cout, act)) return e;
-    const unsigned gx = (unsigned)N * ((H + 3) / 4) * ((W + 31) / 32);
+    unsigned gx = (unsigned)N * ((H + 3) / 4) * ((W + 31) / 32);
+    if (gx > 1024) gx = 1024;  // persistent over tiles: 4 workgroups per CU
     hipLaunchKernelGGL((conv_first_kernel<3, 1>), dim3(gx, Cout / 64), dim3(256), 0, (hipStream_t)stream, x, w, scale,
                        shift, y, stats, N, H, W, nc, Cout, act, slope);
     return check_launch("dvg_conv3x3_first");
@@ -226,7 +298,8 @@ extern "C" int dvg_conv4x4s2_first(const float* x, const float* w, const float* 
     if (int e = first_checks("dvg_conv4x4s2_first", x, w, y, N, H, W, nc, Cout, act)) return e;
     DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_conv4x4s2_first: odd input");
     const int Ho = H / 2, Wo = W / 2;
-    const unsigned gx = (unsigned)N * ((Ho + 3) / 4) * ((Wo + 31) / 32);
+    unsigned gx = (unsigned)N * ((Ho + 3) / 4) * ((Wo + 31) / 32);
+    if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL((conv_first_kernel<4, 2>), dim3(gx, Cout / 64), dim3(256), 0, (hipStream_t)stream, x, w, scale,
                        shift, y, stats, N, H, W, nc, Cout, act, slope);
     return check_launch("dvg_conv4x4s2_first");

@@ -125,6 +125,10 @@ class GPRegressionLayer1(nn.Module):
         self.covar_module.base_kernel = _Holder()
         self.covar_module.base_kernel.raw_lengthscale = nn.Parameter(torch.zeros(D, 1, 1))  # RBFKernel(batch_size=D)
 
+    def load_state_dict(self, *a, **k):
+        self._init_checked = False
+        return super().load_state_dict(*a, **k)
+
     # -- hyper-parameters ---------------------------------------------------------------
     def hypers(self):
         s = F.softplus(self.covar_module.raw_outputscale).reshape(-1)
@@ -156,8 +160,10 @@ class GPRegressionLayer1(nn.Module):
     def forward(self, x):
         """x: (D,B,1) as produced by `h.transpose(0,1).view(D,B,1)` (train.py:225) — a strided view
         that shares storage with h — or directly h (B,D)."""
-        if not int(self.variational_strategy.variational_params_initialized.item()):
-            self.initialize_variational_dist()
+        if not getattr(self, "_init_checked", False):   # host-side flag: no device sync per call (graph-capturable)
+            if not int(self.variational_strategy.variational_params_initialized.item()):
+                self.initialize_variational_dist()
+            self._init_checked = True
         if x.dim() == 3:
             if x.shape[0] != self.num_dims or x.shape[2] != 1:
                 raise RuntimeError(f"GP input must be ({self.num_dims},B,1), got {tuple(x.shape)}")

