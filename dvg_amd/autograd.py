@@ -12,6 +12,8 @@ Gradient recipe per conv block  y = act(BN(conv(cat(up(x), skip)) + b)):
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -20,6 +22,27 @@ from .ops import ACT_NONE, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2
 
 def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# Packed-weight cache for the training path: a parameter is re-packed once per optimizer step (its `_version`
+# changes), not once per forward/backward call — train_model alone calls the encoder 2*S and the decoder 3*S times
+# between two optimizer steps (train.py:213-232).
+_pack_cache = {}
+
+
+def _packed(weight, transposed=False, lo=None, hi=None, dim=0):
+    key = (id(weight), transposed, lo, hi, dim)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    w = weight.detach()
+    if lo is not None:
+        w = _c(w[lo:hi] if dim == 0 else w[:, lo:hi])
+    wp = ops.pack_igemm_weight(w, transposed)
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), wp)
+    return wp
 
 
 def _bn_forward(bn, u, stats, count, act, slope, pool):
@@ -52,16 +75,16 @@ class _ConvBlock(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         need_stats = bn.training
         if kind == "conv3":
-            wp = ops.pack_igemm_weight(weight)
+            wp = _packed(weight)
             r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
         elif kind == "conv3_first":
             r = ops.conv3x3_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "conv4s2":
-            r = ops.conv4x4s2(x, ops.pack_igemm_weight(weight), None, b, act=ACT_NONE, stats=need_stats)
+            r = ops.conv4x4s2(x, _packed(weight), None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "conv4s2_first":
             r = ops.conv4x4s2_first(x, weight, None, b, act=ACT_NONE, stats=need_stats)
         elif kind == "convT4s2":
-            r = ops.convT4x4s2(x, skip, ops.pack_igemm_weight(weight, True), None, b, act=ACT_NONE, stats=need_stats)
+            r = ops.convT4x4s2(x, skip, _packed(weight, True), None, b, act=ACT_NONE, stats=need_stats)
         else:
             raise RuntimeError(kind)
         u, st = r if need_stats else (r, None)
@@ -89,22 +112,22 @@ class _ConvBlock(torch.autograd.Function):
         if kind == "conv3":
             dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, skip, du, upsample=up), 3, 3)
             if need_x:  # dgrad = the same igemm with the flipped / transposed weights
-                wd = ops.pack_igemm_weight(_c(weight.detach()[:, :c1]), True)
+                wd = _packed(weight, True, 0, c1, 1)
                 dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
                 dx = ops.upsample2x_bwd(dxu) if up else dxu
             if need_skip:
-                dskip = ops.conv3x3(du, None, ops.pack_igemm_weight(_c(weight.detach()[:, c1:]), True), None, None,
+                dskip = ops.conv3x3(du, None, _packed(weight, True, c1, weight.shape[1], 1), None, None,
                                     act=ACT_NONE)
         elif kind == "conv4s2":
             dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV4S2, x, None, du), 4, 4)
             if need_x:
-                dx = ops.convT4x4s2(du, None, ops.pack_igemm_weight(weight.detach(), True), None, None, act=ACT_NONE)
+                dx = ops.convT4x4s2(du, None, _packed(weight, True), None, None, act=ACT_NONE)
         elif kind == "convT4s2":
             dW = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, skip, du), 4, 4)
             if need_x:
-                dx = ops.conv4x4s2(du, ops.pack_igemm_weight(weight.detach()[:c1]), None, None, act=ACT_NONE)
+                dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
             if need_skip:
-                dskip = ops.conv4x4s2(du, ops.pack_igemm_weight(weight.detach()[c1:]), None, None, act=ACT_NONE)
+                dskip = ops.conv4x4s2(du, _packed(weight, False, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         elif kind in ("conv3_first", "conv4s2_first"):
             if need_x:
                 raise RuntimeError("gradients w.r.t. the input frames are not part of the DVG training path")

@@ -115,19 +115,35 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     }
 }
 
-// coefficients of du = A*dp + B*u + Cc, plus dgamma, dbeta, dbias
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
-                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       float* __restrict__ coefA, float* __restrict__ coefB,
-                                       float* __restrict__ coefC, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ dbias, int C, double count,
-                                       int train) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// coefficients of du = A*dp + B*u + Cc, plus dgamma, dbeta, dbias.  64 channels x 16 row lanes per workgroup
+// (see bn_finalize_kernel in misc_kernels.hip for why).
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrows,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               float* __restrict__ coefA, float* __restrict__ coefB,
+                                                               float* __restrict__ coefC, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                               int C, double count, int train) {
+    __shared__ double red[16 * 64 * 2];
+    const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lc;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        for (int r = rl; r < nrows; r += 16) {
+            a1 += (double)partial[(size_t)r * 2 * C + c];
+            a2 += (double)partial[(size_t)r * 2 * C + C + c];
+        }
+    }
+    red[(rl * 64 + lc) * 2] = a1;
+    red[(rl * 64 + lc) * 2 + 1] = a2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrows; ++r) {
-        s1 += (double)partial[(size_t)r * 2 * C + c];
-        s2 += (double)partial[(size_t)r * 2 * C + C + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s1 += red[(k * 64 + lc) * 2];
+        s2 += red[(k * 64 + lc) * 2 + 1];
     }
     const double mu = mean[c], is = invstd[c];
     const double g = gamma ? gamma[c] : 1.0;
@@ -233,16 +249,42 @@ __global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ o
     out[c] = s;
 }
 
-// out[i] = sum_s partial[s][i]
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, long n4) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 s = reinterpret_cast<const f32x4*>(partial)[i];
-        for (int k = 1; k < S; ++k) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)k * n4 + i];
+// out[i] = sum_s partial[s][i].  Workgroup = 64 float4 columns x 4 slab lanes; every lane walks its slabs with
+// 4 independent accumulators (loads in flight), lanes combine through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int S, long n4) {
+    __shared__ f32x4 red[4 * 64];
+    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lc;
+    f32x4 acc[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += v[e];
+    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = sl;
+        for (; s + 12 < S; s += 16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)(s + 4 * k) * n4 + i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[k][e] += v[e];
+            }
         }
-        reinterpret_cast<f32x4*>(out)[i] = s;
+        for (; s < S; s += 4) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)s * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
+        }
+    }
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    red[sl * 64 + lc] = t;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (red[lc][e] + red[64 + lc][e]) + (red[128 + lc][e] + red[192 + lc][e]);
+        reinterpret_cast<f32x4*>(out)[i] = o;
     }
 }
 
@@ -397,7 +439,7 @@ extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float*
                                    float* dbeta, float* dbias, int C, double count, int train, void* stream) {
     DVG_REQUIRE(partial && mean && invstd && coefA && coefB && coefC, DVG_ERR_NULL, "dvg_bn_bwd_finalize: NULL");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nrows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
                        gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train);
     return check_launch("dvg_bn_bwd_finalize");
 }
@@ -443,8 +485,8 @@ extern "C" int dvg_reduce_partials(const float* partial, float* out, int S, long
     DVG_REQUIRE(partial && out, DVG_ERR_NULL, "dvg_reduce_partials: NULL pointer");
     DVG_REQUIRE(S > 0 && n > 0 && n % 4 == 0, DVG_ERR_SHAPE, "dvg_reduce_partials: n %% 4 != 0");
     DVG_REQUIRE(aligned16(partial) && aligned16(out), DVG_ERR_ALIGN, "dvg_reduce_partials: alignment");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial, out,
-                       S, n / 4);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       partial, out, S, n / 4);
     return check_launch("dvg_reduce_partials");
 }
 

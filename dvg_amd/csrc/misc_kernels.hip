@@ -84,18 +84,46 @@ __global__ void channel_stats_kernel(const float* __restrict__ u, float* __restr
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd, int C, double count, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrows; ++r) {
-        s1 += (double)partial[(size_t)r * 2 * C + c];
-        s2 += (double)partial[(size_t)r * 2 * C + C + c];
+// Column sums of the partial rows in double: a workgroup = 64 channels x 16 row lanes (1024 threads), rows are
+// strided over the 16 lanes (coalesced 256-B reads per wave), combined through LDS.  (A single thread per channel
+// walking up to 2048 rows serially took 100-230 us per call and ~40 % of a training iteration.)
+__device__ __forceinline__ void partial_colsums(const float* __restrict__ partial, int nrows, int C, int c, int rl,
+                                                double* red, double& s1, double& s2) {
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        for (int r = rl; r < nrows; r += 16) {
+            a1 += (double)partial[(size_t)r * 2 * C + c];
+            a2 += (double)partial[(size_t)r * 2 * C + C + c];
+        }
     }
+    const int lc = threadIdx.x & 63;
+    red[(rl * 64 + lc) * 2] = a1;
+    red[(rl * 64 + lc) * 2 + 1] = a2;
+    __syncthreads();
+    s1 = 0.0;
+    s2 = 0.0;
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s1 += red[(k * 64 + lc) * 2];
+            s2 += red[(k * 64 + lc) * 2 + 1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nrows,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, int C, double count,
+                                                           float eps, float momentum) {
+    __shared__ double red[16 * 64 * 2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    double s1, s2;
+    partial_colsums(partial, nrows, C, c, rl, red, s1, s2);
+    if (rl != 0 || c >= C) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -240,7 +268,7 @@ extern "C" int dvg_bn_finalize(const float* stats_partial, int nrows, const floa
                                void* stream) {
     DVG_REQUIRE(stats_partial && scale && shift, DVG_ERR_NULL, "dvg_bn_finalize: NULL pointer");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats_partial, nrows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats_partial, nrows,
                        gamma, beta, scale, shift, running_mean, running_var, save_mean, save_invstd, C, count, eps,
                        momentum);
     return check_launch("dvg_bn_finalize");

@@ -201,7 +201,9 @@ extern "C" int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int
     const long tiles = (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw);
     const int groups = mode == W_CONV3 ? 1 : (mode == W_CONV4S2 ? 2 : 4);
     const long base = (long)(Cin / 64) * (Cout / 64) * groups;
-    long S = (768 + base - 1) / base;
+    // two workgroups fit a CU (78 KB of LDS each): aim at <= 512 workgroups in ONE residency round — a grid of
+    // e.g. 704 runs as 2 rounds for 1.4 rounds of work
+    long S = 512 / base;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;
     // every split must own at least one tile
