@@ -157,7 +157,7 @@ class _DenseBlock(torch.autograd.Function):
             n, c, h, wd = x.shape
             a = x.permute(0, 2, 3, 1).reshape(n, h * wd * c)
             gw = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()  # [dim][K]
-            u2 = ops.gemm_nt(a, gw, None, b, act=ACT_NONE, splitk=max(1, min(64, a.shape[1] // 256)))
+            u2 = ops.gemm_nt(a, gw, None, b, act=ACT_NONE, splitk=max(1, min(64, a.shape[1] // 128)))
             rows, ch = n, w.shape[0]
         else:
             dim, cout, kh, kw = w.shape

@@ -27,18 +27,21 @@ struct GemmParams {
     float* ws;
     int M, N, K, lda, ldo, period, splitk, kper, act;
     float slope;
-    int vec;
+    int vec;    // w rows are 16-B aligned and K % 4 == 0
+    int vec_a;  // a rows are 16-B aligned (lda % 4 == 0)
 };
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
-    constexpr int BK = 16, LD = 68;
+    // 64x64 output tile, BK = 32, 4x4 micro-tile per thread.  The next K tile is prefetched into registers
+    // while the current one is consumed from LDS (one barrier pair per 32-deep step).
+    constexpr int BK = 32, LD = 68;
     __shared__ __attribute__((aligned(16))) float As[BK * LD];
     __shared__ __attribute__((aligned(16))) float Ws[BK * LD];
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, z = blockIdx.z;
     const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
     const int tx = tid & 15, ty = tid >> 4;
-    const int lr = tid >> 2, lq = tid & 3;  // loader: row 0..63, k-quad 0..3
+    const int lr = tid >> 2, lq = tid & 3;  // loader: row 0..63, k-quad 0..3 (two quads per thread: lq and lq+4)
 
     float acc[4][4];
 #pragma unroll
@@ -46,32 +49,43 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+    auto gload = [&](int k0, f32x4 (&av)[2], f32x4 (&wv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = k0 + (lq + 4 * h) * 4;
+            av[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m0 + lr < p.M && kk < kend) {
+                const float* ap = p.a + (size_t)(m0 + lr) * p.lda + kk;
+                if (p.vec_a && kk + 3 < kend) av[h] = *reinterpret_cast<const f32x4*>(ap);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kk + e < kend) av[h][e] = ap[e];
+            }
+            if (n0 + lr < p.N && kk < kend) {
+                const float* wp = p.w + (size_t)(n0 + lr) * p.K + kk;
+                if (p.vec && kk + 3 < kend) wv[h] = *reinterpret_cast<const f32x4*>(wp);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kk + e < kend) wv[h][e] = wp[e];
+            }
+        }
+    };
+    f32x4 av[2], wv[2];
+    if (kbeg < kend) gload(kbeg, av, wv);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-        const int kk = k0 + lq * 4;
-        if (m0 + lr < p.M) {
-            const float* ap = p.a + (size_t)(m0 + lr) * p.lda + kk;
-            if (p.vec && kk + 3 < kend) av = *reinterpret_cast<const f32x4*>(ap);
-            else
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (kk + e < kend) av[e] = ap[e];
-        }
-        if (n0 + lr < p.N) {
-            const float* wp = p.w + (size_t)(n0 + lr) * p.K + kk;
-            if (p.vec && kk + 3 < kend) wv = *reinterpret_cast<const f32x4*>(wp);
-            else
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (kk + e < kend) wv[e] = wp[e];
-        }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            As[(lq * 4 + e) * LD + lr] = av[e];
-            Ws[(lq * 4 + e) * LD + lr] = wv[e];
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                As[((lq + 4 * h) * 4 + e) * LD + lr] = av[h][e];
+                Ws[((lq + 4 * h) * 4 + e) * LD + lr] = wv[h][e];
+            }
         __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK, av, wv);
 #pragma unroll
         for (int k = 0; k < BK; ++k) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[k * LD + ty * 4]);
@@ -213,12 +227,13 @@ extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float*
     DVG_REQUIRE(splitk >= 1 && splitk <= 256, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad splitk");
     DVG_REQUIRE(splitk == 1 || workspace != nullptr, DVG_ERR_NULL, "dvg_gemm_nt_bias_act: workspace needed");
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad act");
-    GemmParams p{a, w, scale, shift, out, workspace, M, N, K, lda, ldo, period, splitk, 0, act, slope, 0};
+    GemmParams p{a, w, scale, shift, out, workspace, M, N, K, lda, ldo, period, splitk, 0, act, slope, 0, 0};
     int kper = (K + splitk - 1) / splitk;
-    kper = ((kper + 15) / 16) * 16;
+    kper = ((kper + 31) / 32) * 32;
     p.kper = kper;
     p.splitk = (K + kper - 1) / kper;  // drop empty splits
-    p.vec = (K % 4 == 0 && lda % 4 == 0 && aligned16(a) && aligned16(w)) ? 1 : 0;
+    p.vec = (K % 4 == 0 && aligned16(w)) ? 1 : 0;
+    p.vec_a = (K % 4 == 0 && lda % 4 == 0 && aligned16(a)) ? 1 : 0;
     dim3 grid((N + 63) / 64, (M + 63) / 64, p.splitk);
     hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     if (int e = check_launch("dvg_gemm_nt_bias_act")) return e;

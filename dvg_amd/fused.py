@@ -200,7 +200,7 @@ def head_bn_tanh(conv, bn, x):
     gw = gemm_weight(conv, "head")
     a = x.permute(0, 2, 3, 1).reshape(n, h * w * c)  # NHWC buffer viewed as [N][K]; no copy
     k = a.shape[1]
-    splitk = max(1, min(64, k // 256))
+    splitk = max(1, min(64, k // 128))
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
         return ops.gemm_nt(a, gw, sc, sh, act=ACT_TANH, splitk=splitk)
