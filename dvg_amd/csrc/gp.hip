@@ -43,11 +43,31 @@ __device__ void wave_cholesky(float* A, int n, int ld, int lane) {
         const bool a0 = i0 >= j && i0 < n, a1 = i1 >= j && i1 < n;
         if (a0) s0 = A[i0 * ld + j];
         if (a1) s1 = A[i1 * ld + j];
-        for (int k = 0; k < j; ++k) {
-            const float ljk = A[j * ld + k];
-            if (a0) s0 = fmaf(-A[i0 * ld + k], ljk, s0);
-            if (a1) s1 = fmaf(-A[i1 * ld + k], ljk, s1);
+        // 4 columns per trip with independent partial sums: the 8-12 LDS reads of a trip are issued together, so the
+        // ~64-cycle LDS latency is paid once per 4 columns instead of once per column
+        float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= j; k += 4) {
+            float lj[4], v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lj[q] = A[j * ld + k + q];
+                v0[q] = a0 ? A[i0 * ld + k + q] : 0.f;
+                v1[q] = a1 ? A[i1 * ld + k + q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t0[q] = fmaf(v0[q], lj[q], t0[q]);
+                t1[q] = fmaf(v1[q], lj[q], t1[q]);
+            }
         }
+        for (; k < j; ++k) {
+            const float ljk = A[j * ld + k];
+            if (a0) t0[0] = fmaf(A[i0 * ld + k], ljk, t0[0]);
+            if (a1) t1[0] = fmaf(A[i1 * ld + k], ljk, t1[0]);
+        }
+        s0 -= (t0[0] + t0[1]) + (t0[2] + t0[3]);
+        s1 -= (t1[0] + t1[1]) + (t1[2] + t1[3]);
         // the diagonal element lives in lane j%64, slot j/64
         float d = __shfl((j < 64) ? s0 : s1, j & 63);
         d = sqrtf(fmaxf(d, 1e-12f));
@@ -132,6 +152,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     for (int col = tid; col < B + 1; col += 256) {
         for (int i = 0; i < M; ++i) {
             float acc = AK[i * LB + col];
+#pragma unroll 4
             for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], AK[j * LB + col], acc);
             AK[i * LB + col] = acc / L[i * LM + i];
         }
@@ -182,6 +203,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
         for (int i = tid; i < B * B; i += 256) {
             const int r = i / B, q = i % B;
             float acc = 0.f;
+#pragma unroll 4
             for (int k = 0; k < M; ++k) {
                 acc = fmaf(Wm[k * LB + r], Wm[k * LB + q], acc);
                 acc = fmaf(-AK[k * LB + r], AK[k * LB + q], acc);
@@ -198,6 +220,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
             __syncthreads();
             for (int b = tid; b < B; b += 256) {
                 float acc = mu[b];
+#pragma unroll 4
                 for (int j = 0; j <= b; ++j) acc = fmaf(Sg[b * LS + j], p.eps[(size_t)d * B + j], acc);
                 p.sample[(size_t)d * B + b] = acc;
             }
@@ -310,11 +333,13 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
         const int col = tid;
         for (int i = 0; i < M; ++i) {            // L y = b
             float acc = P[i * LB + col];
+#pragma unroll 4
             for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], P[j * LB + col], acc);
             P[i * LB + col] = acc / L[i * LM + i];
         }
         for (int i = M - 1; i >= 0; --i) {       // L^T x = y
             float acc = P[i * LB + col];
+#pragma unroll 4
             for (int k = i + 1; k < M; ++k) acc = fmaf(-L[k * LM + i], P[k * LB + col], acc);
             P[i * LB + col] = acc / L[i * LM + i];
         }
