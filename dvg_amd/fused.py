@@ -242,8 +242,8 @@ def convT3_last(conv, x, *, act=ACT_SIGMOID):
     if _needs_grad(x, conv.weight):
         from .autograd import last_layer_autograd
         return last_layer_autograd("convT3", conv, x, None, act=act)
-    return ops.convT3x3_last(x, conv.weight, conv.bias.detach() if conv.bias is not None else None,
-                             conv.weight.shape[1], act=act)
+    return ops.convT_last_two_step(x, None, conv.weight, conv.bias.detach() if conv.bias is not None else None,
+                                   conv.weight.shape[1], 3, act=act)
 
 
 def convT4s2_last(conv, x, skip, *, act=ACT_TANH):
@@ -251,5 +251,5 @@ def convT4s2_last(conv, x, skip, *, act=ACT_TANH):
     if _needs_grad(x, skip, conv.weight):
         from .autograd import last_layer_autograd
         return last_layer_autograd("convT4s2", conv, x, skip, act=act)
-    return ops.convT4x4s2_last(x, skip, conv.weight, conv.bias.detach() if conv.bias is not None else None,
-                               conv.weight.shape[1], act=act)
+    return ops.convT_last_two_step(x, skip, conv.weight, conv.bias.detach() if conv.bias is not None else None,
+                                   conv.weight.shape[1], 4, act=act)

@@ -546,3 +546,24 @@ def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3):
                                  _p(out["dm"]), _p(out["dls"]), _p(out["dc"]), _p(out["ds"]), _p(out["dell"]), b, d,
                                  mm, jitter, _stream()), "gp_train_bwd")
     return out
+
+
+def convT_last_two_step(x, skip, w, bias, nc, ks, *, act):
+    """Last layer as per-pixel projection (small GEMM, reads the activation once) + shifted sum (dvg_convT_gather).
+    x / skip NHWC-in-memory; w the original ConvTranspose2d weight (Cin,nc,ks,ks); returns NCHW frames."""
+    assert is_nhwc(x)
+    n, c1, h, wd = x.shape
+    wdet = w.detach()
+    t = ks * ks * nc
+
+    def proj(inp, wpart):
+        c = inp.shape[1]
+        wm = wpart.permute(2, 3, 1, 0).reshape(t, c).contiguous()          # [(kh,kw,co)][ci]
+        return gemm_nt(inp.permute(0, 2, 3, 1).reshape(n * h * wd, c), wm, None, None)
+    d1 = proj(x, wdet[:c1])
+    d2 = proj(skip, wdet[c1:]) if skip is not None else None
+    s = 2 if ks == 4 else 1
+    y = torch.empty((n, nc, s * h, s * wd), device=x.device, dtype=torch.float32)
+    _run("convT_gather", 0.0, 4.0 * (d1.numel() * (2 if skip is not None else 1) + y.numel()), lib().dvg_convT_gather,
+         _p(d1), _p(d2), _p(bias), _p(y), ks, n, h, wd, nc, act, _stream())
+    return y

@@ -176,6 +176,13 @@ int dvg_convT4x4s2_last(const float* x, const float* skip, const float* w_iohw,
                         const float* bias, float* y_nchw, int N, int H, int W,
                         int C1, int C2, int nc, int act, void* stream);
 
+/* Second step of the two-step last layers (inference path): y (N,nc,S*H,S*W) NCHW = act(bias + shifted sum of
+ * the per-pixel projections d = x . W computed with dvg_gemm_nt_bias_act, d1/d2 [N*H*W][ks*ks*nc] (one per
+ * concatenated input, d2 may be NULL), column order (kh, kw, co).  ks = 3: ConvTranspose2d(.,nc,3,1,1)
+ * (vgg_64.py:88-92); ks = 4: ConvTranspose2d(.,nc,4,2,1) (dcgan_64.py:75-79).                          */
+int dvg_convT_gather(const float* d1, const float* d2, const float* bias, float* y_nchw, int ks,
+                     int N, int H, int W, int nc, int act, void* stream);
+
 /* Per-channel sum / sum-of-squares of a [rows][C] (NHWC) tensor, written as
  * dvg_channel_stats_rows(rows) partial rows [2][C] (deterministic slab sums).
  * Used for the small BN inputs (encoder head, decoder stem).                  */
