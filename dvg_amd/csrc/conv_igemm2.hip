@@ -33,6 +33,9 @@ struct Igemm2Params {
     float slope;
     int tiles_y, tiles_x, tiles_n, nblk_n;
     int ablate;  // debug only (dvg_debug_set_ablate): 1 = no global loads / LDS refills in the loop, 2 = also no barriers
+    int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
+    int cps;     // K chunks (of 16 channels) per split
+    float* ws;   // [splitk][N*Ho*Wo][Cout]
 };
 
 static int g_ablate = 0;
@@ -70,6 +73,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
     int par = 0;
     if (MODE == M2_CONVT4S2) { par = lid & 3; lid >>= 2; }
+    const int split = lid % p.splitk;
+    lid /= p.splitk;
     const int nb = lid % p.nblk_n;
     unsigned t = lid / p.nblk_n;
     const int tx_i = t % p.tiles_x; t /= p.tiles_x;
@@ -148,19 +153,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         for (int tt = 0; tt < GT; ++tt) *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
     };
 
-    const int nstages = (Cin / C::KC) * NG;
+    const int chunk_begin = split * p.cps;
+    const int chunk_end = min(Cin / C::KC, chunk_begin + p.cps);
+    const int s_begin = chunk_begin * NG, nstages = chunk_end * NG;
     f32x4 ra[NLA], rb[GT];
     // experiments: break the lockstep of co-resident workgroups (which pairs share a CU is not architected)
     if ((p.ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);
     if ((p.ablate & 8) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(127);
     if ((p.ablate & 16) && ((blockIdx.x >> 4) & 1)) __builtin_amdgcn_s_sleep(127);
-    gload_a(0, ra);
-    gload_b(0, 0, rb);
+    gload_a(chunk_begin * C::KC, ra);
+    gload_b(chunk_begin, 0, rb);
     lds_store_a(ra);
     lds_store_b(rb);
     __syncthreads();
 
-    for (int s = 0; s < nstages; ++s) {
+    for (int s = s_begin; s < nstages; ++s) {
         const int grp = s % NG;
         const bool has_next = s + 1 < nstages;
         const int nchunk = (s + 1) / NG, ngrp = (s + 1) % NG;
@@ -235,6 +242,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
     else { Ho = p.H * 2; Wo = p.W * 2; }
     const int c = nb0 + wn * 32 + l31;
+    if (p.splitk > 1) {
+        // raw partial tile of this K split; scale / activation / pool / statistics happen in splitk_finish_kernel
+        float* wsp = p.ws + (size_t)split * ((size_t)p.N * Ho * Wo) * p.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mbase = wm * (C::BM / 2) + mt * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int tii = m / (TH * TW), r = m % (TH * TW);
+                const int ty = r / TW, tx = r % TW;
+                const int n = n0 + tii;
+                int oy, ox;
+                if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+                else { oy = y0 + ty; ox = x0 + tx; }
+                if (n < p.N) wsp[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = acc[mt][reg];
+            }
+        }
+        return;
+    }
     const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -583,8 +610,105 @@ __global__ __launch_bounds__(768, 3) void conv_igemm3_kernel(const Igemm2Params 
     }
 }
 
+
+// out = act((sum_s ws[s]) * scale + shift) (+ 2x2 max-pool, + per-channel sum / sum of squares of the pre-activation)
+// One thread = one pixel (or one 2x2 window when pooling) x 4 channels; blockDim = 256 = TC x TP as in the BN
+// backward reduction; one partial statistics row per workgroup.
+template <bool POOL>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            float* __restrict__ y_pool, float* __restrict__ stats, int N,
+                                                            int H, int W, int C, int act, float slope,
+                                                            int units_per_block) {
+    __shared__ float red[2 * 256 * 4];
+    const int C4 = C >> 2;
+    const int TC = C4 < 256 ? C4 : 256, TP = 256 / TC;
+    const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
+    const int Hu = POOL ? H >> 1 : H, Wu = POOL ? W >> 1 : W;
+    const long units = (long)N * Hu * Wu, slab4 = (long)N * H * W * C4;
+    const long u0 = (long)blockIdx.x * units_per_block, u1 = min(units, u0 + units_per_block);
+    const int c4 = tc;
+    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + c4 * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sf = shift ? *reinterpret_cast<const f32x4*>(shift + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (long w_ = u0 + tp; w_ < u1; w_ += TP) {
+        f32x4 mx;
+#pragma unroll
+        for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+            size_t off;
+            if (POOL) {
+                const int xp = w_ % Wu;
+                long r = w_ / Wu;
+                const int yp = r % Hu;
+                const int n = r / Hu;
+                off = (((size_t)n * H + 2 * yp + (q >> 1)) * W + 2 * xp + (q & 1)) * C4 + c4;
+            } else {
+                off = (size_t)w_ * C4 + c4;
+            }
+            f32x4 v = reinterpret_cast<const f32x4*>(ws)[off];
+            for (int s = 1; s < S; ++s) {
+                const f32x4 t = reinterpret_cast<const f32x4*>(ws)[(size_t)s * slab4 + off];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += t[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = v[k] * sc[k] + sf[k];
+                s1[k] += u;
+                s2[k] = fmaf(u, u, s2[k]);
+                v[k] = apply_act(u, act, slope);
+            }
+            reinterpret_cast<f32x4*>(y)[off] = v;
+            if (POOL) {
+                if (q == 0) mx = v;
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], v[k]);
+            }
+        }
+        if (POOL) reinterpret_cast<f32x4*>(y_pool)[w_ * C4 + c4] = mx;
+    }
+    if (stats != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[(tp * TC + tc) * 4 + k] = s1[k];
+            red[1024 + (tp * TC + tc) * 4 + k] = s2[k];
+        }
+        __syncthreads();
+        if (tp == 0) {
+            float* dst = stats + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = 0.f, b = 0.f;
+                for (int r = 0; r < TP; ++r) {
+                    a += red[(r * TC + tc) * 4 + k];
+                    b += red[1024 + (r * TC + tc) * 4 + k];
+                }
+                dst[c4 * 4 + k] = a;
+                dst[C + c4 * 4 + k] = b;
+            }
+        }
+    }
+}
+
+static int finish_units_per_block(long units) {
+    long upb = (units + 1023) / 1024;
+    if (upb < 8) upb = 8;
+    return (int)upb;
+}
+
+// number of K splits for a v2 launch: only when the grid would leave CUs idle and K is deep enough
+static int choose_splitk(long wgs, int nchunks) {
+    if (wgs >= 384 || nchunks < 8) return 1;
+    long s = 512 / wgs;
+    if (s > 8) s = 8;
+    if (s > nchunks / 4) s = nchunks / 4;   // at least 4 chunks (= 4 stages of 72-144 MFMAs) per split
+    return s < 2 ? 1 : (int)s;
+}
+
 template <int MODE, int TI, int TH, int TW>
-static int launch2(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
+static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hipStream_t stream) {
     using C = Cfg2<MODE, TI, TH, TW>;
     if (Hg % TH || Wg % TW || p.Cout % 64) return fail(DVG_ERR_SHAPE, "conv_igemm2: tile does not divide shape");
     p.tiles_y = Hg / TH;
@@ -592,7 +716,21 @@ static int launch2(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
     p.ablate = g_ablate;
-    const unsigned grid = (unsigned)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
+    const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
+    const int nchunks = (p.C1 + p.C2) / C::KC;
+    int Ho, Wo;
+    if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
+    else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
+    else { Ho = p.H * 2; Wo = p.W * 2; }
+    const long out_floats = (long)p.N * Ho * Wo * p.Cout;
+    int S = (ws != nullptr) ? choose_splitk(wgs, nchunks) : 1;
+    if (S > 1 && (long)S * out_floats > ws_floats) return fail(DVG_ERR_SHAPE, "conv_igemm2: split-K workspace too small");
+    p.splitk = S;
+    p.cps = (nchunks + S - 1) / S;
+    p.ws = ws;
+    float* y_pool = p.y_pool;
+    float* stats = p.stats;
+    const unsigned grid = (unsigned)(wgs * S);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW>),
@@ -601,7 +739,21 @@ static int launch2(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
-    return check_launch("conv_igemm2");
+    if (int e = check_launch("conv_igemm2")) return e;
+    if (S > 1) {
+        const bool pool = y_pool != nullptr;
+        const long units = pool ? (long)p.N * (Ho / 2) * (Wo / 2) : (long)p.N * Ho * Wo;
+        const int upb = finish_units_per_block(units);
+        const unsigned fgrid = (unsigned)((units + upb - 1) / upb);
+        if (pool)
+            hipLaunchKernelGGL((splitk_finish_kernel<true>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb);
+        else
+            hipLaunchKernelGGL((splitk_finish_kernel<false>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb);
+        return check_launch("splitk_finish");
+    }
+    return DVG_OK;
 }
 
 template <int MODE, int TI, int TH, int TW>
@@ -692,12 +844,35 @@ static int tile3(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
     return 0;
 }
 
-extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cout) {
+static long v2_wgs(int mode, int N, int Hg, int Wg, int Cout, int ti, int th, int tw) {
+    return (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * (Cout / 64) * (mode == M2_CONVT4S2 ? 4 : 1);
+}
+
+// K splits the v2 launch of this shape will use when a workspace is supplied (1 = no split)
+extern "C" int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout) {
+    if (g_schedule == 3 && mode == M2_CONV3) return 1;
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
-    if (!(g_schedule == 3 && mode == M2_CONV3 && tile3(mode, N, Hg, Wg, Cout, &ti, &th, &tw) == 0))
-        if (tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
+    if (Cin % 16 || Cout % 64 || tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
+    return choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16);
+}
+
+extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, int Cout, int pool, int with_workspace) {
+    int Hg = H, Wg = W;
+    if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
+    int ti, th, tw;
+    if (g_schedule == 3 && mode == M2_CONV3 && tile3(mode, N, Hg, Wg, Cout, &ti, &th, &tw) == 0)
+        return ((N + ti - 1) / ti) * (Hg / th) * (Wg / tw);
+    if (tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
+    if (with_workspace && choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16) > 1) {
+        int Ho = H, Wo = W;
+        if (mode == M2_CONV4S2) { Ho = H / 2; Wo = W / 2; }
+        if (mode == M2_CONVT4S2) { Ho = 2 * H; Wo = 2 * W; }
+        const long units = pool ? (long)N * (Ho / 2) * (Wo / 2) : (long)N * Ho * Wo;
+        const int upb = finish_units_per_block(units);
+        return (int)((units + upb - 1) / upb);
+    }
     return ((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * (mode == M2_CONVT4S2 ? 4 : 1);
 }
 
@@ -715,7 +890,8 @@ static int checks2(const Igemm2Params& p, const char* who) {
 }
 
 #define D2(MODE, TI_, TH_, TW_) \
-    if (ti == TI_ && th == TH_ && tw == TW_) return launch2<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
+    if (ti == TI_ && th == TH_ && tw == TW_)                                             \
+        return launch2<MODE, TI_, TH_, TW_>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
 #define D3(MODE, TI_, TH_, TW_) \
     if (ti == TI_ && th == TH_ && tw == TW_) return launch3<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
 
@@ -723,9 +899,10 @@ static int checks2(const Igemm2Params& p, const char* who) {
 
 extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                      const float* shift, float* y, float* y_pool, float* stats, int N, int H, int W,
-                                     int C1, int C2, int Cout, int upsample_x, int act, float slope, void* stream) {
+                                     int C1, int C2, int Cout, int upsample_x, int act, float slope,
+                                     float* workspace, long workspace_floats, void* stream) {
     Igemm2Params p{x, skip, w_k16, scale, shift, y, y_pool, stats, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, act, slope,
-                   0, 0, 0, 0, 0};
+                   0, 0, 0, 0, 0, 1, 0, nullptr};
     if (int e = checks2(p, "dvg_conv3x3_bn_act_v2")) return e;
     DVG_REQUIRE(H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: H=%d W=%d must be multiples of 8", H, W);
     int Hg = H, Wg = W, ti, th, tw;
@@ -743,8 +920,9 @@ extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const fl
 
 extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale, const float* shift,
                                        float* y, float* stats, int N, int H, int W, int Cin, int Cout, int act,
-                                       float slope, void* stream) {
-    Igemm2Params p{x, nullptr, w_k16, scale, shift, y, nullptr, stats, N, H, W, Cin, 0, Cout, 0, act, slope, 0, 0, 0, 0, 0};
+                                       float slope, float* workspace, long workspace_floats, void* stream) {
+    Igemm2Params p{x, nullptr, w_k16, scale, shift, y, nullptr, stats, N, H, W, Cin, 0, Cout, 0, act, slope, 0, 0, 0, 0, 0,
+                   1, 0, nullptr};
     if (int e = checks2(p, "dvg_conv4x4s2_bn_act_v2")) return e;
     DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_conv4x4s2_bn_act_v2: odd input");
     int Hg = H / 2, Wg = W / 2, ti, th, tw;
@@ -757,8 +935,10 @@ extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const
 
 extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                         const float* shift, float* y, float* stats, int N, int H, int W, int C1,
-                                        int C2, int Cout, int act, float slope, void* stream) {
-    Igemm2Params p{x, skip, w_k16, scale, shift, y, nullptr, stats, N, H, W, C1, C2, Cout, 0, act, slope, 0, 0, 0, 0, 0};
+                                        int C2, int Cout, int act, float slope, float* workspace, long workspace_floats,
+                                        void* stream) {
+    Igemm2Params p{x, skip, w_k16, scale, shift, y, nullptr, stats, N, H, W, C1, C2, Cout, 0, act, slope, 0, 0, 0, 0, 0,
+                   1, 0, nullptr};
     if (int e = checks2(p, "dvg_convT4x4s2_bn_act_v2")) return e;
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_CONVT4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,

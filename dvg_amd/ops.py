@@ -178,6 +178,16 @@ def unpack_convT_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
 # conv blocks.  All take / return NHWC-in-memory (N,C,H,W) tensors.
 # `stats=True` returns (y, stats_partial) with stats_partial [rows][2][Cout].
 # ----------------------------------------------------------------------------------
+def _splitk_ws(mode, n, h, w, cin, cout, out_numel, device):
+    """Workspace for the split-K path of the v2 implicit GEMM (None when the launch fills the chip on its own)."""
+    if IGEMM_V != 2:
+        return None
+    s = lib().dvg_conv_splitk_v2(mode, n, h, w, cin, cout)
+    if s <= 1:
+        return None
+    return torch.empty(s * out_numel, device=device, dtype=torch.float32)
+
+
 def _stats_buf(rows: int, cout: int, device):
     if rows <= 0:
         raise RuntimeError("unsupported shape for fused BN statistics")
@@ -201,12 +211,20 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
-    st = _stats_buf(rows_fn(MODE_CONV3, n, h, w, cout), cout, x.device) if stats else None
-    _run("conv3x3_igemm", 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) +
-                                                                   n * h * w * cout + wp.numel()),
-         lib().dvg_conv3x3_bn_act_v2 if IGEMM_V == 2 else lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(yp), _p(st), n, h, w, c1,
-         c2, cout, int(upsample), act, slope, _stream())
+    ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
+    if stats:
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None)) \
+            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONV3, n, h, w, cout)
+    st = _stats_buf(rows, cout, x.device) if stats else None
+    fl, by = 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) + n * h * w * cout +
+                                                      wp.numel())
+    if IGEMM_V == 2:
+        _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
+             _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _p(ws), 0 if ws is None else ws.numel(),
+             _stream())
+    else:
+        _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
+             _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _stream())
     out = (y, yp) if pool else y
     return (out, st) if stats else out
 
@@ -248,12 +266,18 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     if taps != 16 or cin_w != cin or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
     y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
-    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
-    st = _stats_buf(rows_fn(MODE_CONV4S2, n, h, w, cout), cout, x.device) if stats else None
-    _run("conv4x4s2_igemm", 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin,
-         4.0 * (x.numel() + y.numel() + wp.numel()),
-         lib().dvg_conv4x4s2_bn_act_v2 if IGEMM_V == 2 else lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift),
-         _p(y), _p(st), n, h, w, cin, cout, act, slope, _stream())
+    ws = _splitk_ws(MODE_CONV4S2, n, h, w, cin, cout, y.numel(), x.device)
+    if stats:
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV4S2, n, h, w, cin, cout, 0, int(ws is not None)) \
+            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONV4S2, n, h, w, cout)
+    st = _stats_buf(rows, cout, x.device) if stats else None
+    fl, by = 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin, 4.0 * (x.numel() + y.numel() + wp.numel())
+    if IGEMM_V == 2:
+        _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act_v2, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
+             n, h, w, cin, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
+    else:
+        _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
+             n, h, w, cin, cout, act, slope, _stream())
     return (y, st) if stats else y
 
 
@@ -287,12 +311,19 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     if taps != 16 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
-    rows_fn = lib().dvg_conv_stats_rows_v2 if IGEMM_V == 2 else lib().dvg_conv_stats_rows
-    st = _stats_buf(rows_fn(MODE_CONVT4S2, n, h, w, cout), cout, x.device) if stats else None
-    _run("convT4x4s2_igemm", 2.0 * n * h * w * cout * 16 * cin,
-         4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel()),
-         lib().dvg_convT4x4s2_bn_act_v2 if IGEMM_V == 2 else lib().dvg_convT4x4s2_bn_act,
-         _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())
+    ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
+    if stats:
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None)) \
+            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONVT4S2, n, h, w, cout)
+    st = _stats_buf(rows, cout, x.device) if stats else None
+    fl = 2.0 * n * h * w * cout * 16 * cin
+    by = 4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel())
+    if IGEMM_V == 2:
+        _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
+             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
+    else:
+        _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
+             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())
     return (y, st) if stats else y
 
 

@@ -50,6 +50,9 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     with pytest.raises(RuntimeError):
         _lib.check(rc, "gp")
     assert lib.dvg_conv_stats_rows(0, 64, 64, 64, 64) == 64 * 8 * 4
+    assert lib.dvg_conv_splitk_v2(0, 64, 64, 64, 64, 64) == 1          # 2048 workgroups: no split
+    assert lib.dvg_conv_splitk_v2(0, 64, 8, 8, 512, 256) == 2          # 256 workgroups, K = 32 chunks
+    assert lib.dvg_conv_splitk_v2(0, 16, 8, 8, 512, 512) == 4          # per-GPU batch 16
     assert lib.dvg_gp_lds_bytes(64, 40, 1) < 64 * 1024
 
 

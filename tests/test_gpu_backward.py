@@ -132,11 +132,15 @@ def _module_grads(tag, family):
             diff = p.grad.double().cpu() - g
             err = float(diff.abs().max()) / scale
             l2 = float(diff.norm() / g.norm().clamp_min(1e-12))
-            cpu = float((r32[k].grad.double() - g).abs().max()) / scale
-            # a single kink flip moves a few entries by O(1e-2) of the max but barely moves the L2 norm;
-            # a wrong kernel moves both by O(1)
-            if not (l2 < 5e-3 and err < max(5e-2, 3.0 * cpu)):
-                bad.append((name, k, err, l2, cpu))
+            cdiff = r32[k].grad.double() - g
+            cpu = float(cdiff.abs().max()) / scale
+            cpu_l2 = float(cdiff.norm() / g.norm().clamp_min(1e-12))
+            # a single kink flip moves a few entries by O(1e-2) of the max but barely moves the L2 norm; a wrong
+            # kernel moves both by O(1).  The fp32 CPU oracle's own distance from fp64 is the yardstick.
+            # (kernel-level gradient tests above hold 2e-3; this module-level check guards the WIRING, where a
+            #  mistake shows up as O(1) — a dropped skip gradient, a wrong channel slice, a missing upsample sum)
+            if not (l2 < max(2e-2, 3.0 * cpu_l2) and err < max(0.15, 3.0 * cpu)):
+                bad.append((name, k, err, l2, cpu, cpu_l2))
     assert not bad, bad[:8]
 
 

@@ -58,6 +58,8 @@ def test_weight_pack_roundtrip_is_bit_exact():
     (1, 8, 8, 64, 64, 128, True, False),
     (2, 32, 32, 32, 64, 64, False, False),    # cat without upsample
     (64, 8, 8, 64, 0, 128, False, False),     # enough tiles for BN=128
+    (8, 8, 8, 512, 0, 256, False, True),      # 32 workgroups, 32 K chunks: split-K x8 + finish kernel (pool)
+    (4, 16, 16, 128, 128, 64, True, False),   # split-K with fused up + cat
 ])
 def test_conv3x3_igemm(N, H, W, C1, C2, Cout, up, pool):
     from dvg_amd import ops
@@ -81,9 +83,9 @@ def test_conv3x3_igemm(N, H, W, C1, C2, Cout, up, pool):
         assert rel_err(yp, F.max_pool2d(ref, 2, 2)) < 2e-5
 
 
-def test_conv3x3_stats_epilogue():
+@pytest.mark.parametrize("N,H,W,C,Cout", [(4, 16, 16, 32, 64), (4, 8, 8, 128, 64)])   # second case: split-K finish path
+def test_conv3x3_stats_epilogue(N, H, W, C, Cout):
     from dvg_amd import ops
-    N, H, W, C, Cout = 4, 16, 16, 32, 64
     x = params.normal(20, N, C, H, W)
     w = params.normal(21, Cout, C, 3, 3, scale=0.1)
     b = params.normal(22, Cout, scale=0.2)
@@ -121,7 +123,7 @@ def test_first_layers(nc, res):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (2, 16, 16, 128, 256), (5, 8, 8, 256, 512),
-                                            (2, 64, 64, 64, 64)])
+                                            (2, 64, 64, 64, 64), (16, 8, 8, 256, 512)])
 def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
     from dvg_amd import ops
     x = params.normal(40, N, Cin, H, W)
@@ -136,7 +138,8 @@ def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("N,H,W,C1,C2,Cout", [(2, 4, 4, 512, 512, 256), (3, 8, 8, 256, 256, 128),
-                                              (2, 16, 16, 128, 128, 64), (2, 32, 32, 64, 0, 64)])
+                                              (2, 16, 16, 128, 128, 64), (2, 32, 32, 64, 0, 64),
+                                              (16, 4, 4, 512, 512, 256)])
 def test_convT4x4s2_igemm(N, H, W, C1, C2, Cout):
     from dvg_amd import ops
     x = params.normal(50, N, C1, H, W)
