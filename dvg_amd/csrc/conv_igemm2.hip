@@ -405,51 +405,68 @@ __global__ __launch_bounds__(768, 3) void conv_igemm3_kernel(const Igemm2Params 
                 offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : -1;
             }
         };
-        auto stage_in = [&](int step) {   // global -> registers -> LDS buffer (step & 1)
+        // Loads run a full stage ahead of their LDS write (two register sets), and the LDS writes are PACED over the
+        // stage: measured on this kernel, a burst of 48 ds_write_b128 per stage blocks the consumers' ds_reads for
+        // longer than their one-tap prefetch slack (-7 points), and loads issued only one barrier ahead make the
+        // consumers wait for L2/MALL latency at the stage barrier (-8 points).
+        auto gload = [&](int step, f32x4 (&ra)[NLA], f32x4 (&rb)[GT], bool& has_a) {
             const int s = step % nst;
             if (s == 0) geometry((int)first + (step / nst) * (int)gridDim.x);
             const int chunk = s / NG, grp = s % NG;
-            float* As = smem + (step & 1) * STAGE_FLOATS;
-            float* Bs = As + C::A_FLOATS;
-            f32x4 rb[GT];
 #pragma unroll
             for (int tt = 0; tt < GT; ++tt)
                 rb[tt] = *reinterpret_cast<const f32x4*>(
                     p.w + (((size_t)chunk * C::NTAPS + tap_w(par, grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4);
-            if (grp == 0) {   // a new K chunk: the halo tile changes
+            has_a = grp == 0;
+            if (has_a) {
                 const int c0 = chunk * C::KC;
                 const bool from_x = c0 < p.C1;
                 const float* src = from_x ? p.x + c0 : p.skip + (c0 - p.C1);
-                f32x4 ra[NLA];
 #pragma unroll
                 for (int i = 0; i < NLA; ++i) {
                     const long o = from_x ? offx[i] : offs[i];
                     ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (o >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + o);
                 }
+            }
+        };
+        const bool pace_long = (p.ablate & 512) != 0;
+        auto lstore = [&](int step, const f32x4 (&ra)[NLA], const f32x4 (&rb)[GT], bool has_a, bool paced) {
+            float* As = smem + (step & 1) * STAGE_FLOATS;
+            float* Bs = As + C::A_FLOATS;
+            const float* Ao = smem + ((step & 1) ^ 1) * STAGE_FLOATS;
 #pragma unroll
-                for (int i = 0; i < NLA; ++i) {
-                    const int idx = rt + i * 256;
-                    if (idx < HP * 4) *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = ra[i];
+            for (int i = 0; i < NLA; ++i) {
+                const int idx = rt + i * 256;
+                if (idx < HP * 4) {
+                    const int o = (idx >> 2) * LD + (idx & 3) * 4;
+                    *reinterpret_cast<f32x4*>(&As[o]) = has_a ? ra[i] : *reinterpret_cast<const f32x4*>(&Ao[o]);
                 }
-            } else {          // same chunk, next tap group: the halo tile is copied LDS -> LDS from the other buffer
-                const float* Ao = smem + ((step & 1) ^ 1) * STAGE_FLOATS;
-#pragma unroll
-                for (int i = 0; i < NLA; ++i) {
-                    const int idx = rt + i * 256;
-                    if (idx < HP * 4) {
-                        const int o = (idx >> 2) * LD + (idx & 3) * 4;
-                        *reinterpret_cast<f32x4*>(&As[o]) = *reinterpret_cast<const f32x4*>(&Ao[o]);
-                    }
-                }
+                if (paced) { if (pace_long) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(2); }
             }
 #pragma unroll
-            for (int tt = 0; tt < GT; ++tt) *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
+            for (int tt = 0; tt < GT; ++tt) {
+                *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
+                if (paced) { if (pace_long) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(2); }
+            }
         };
-        if (total_steps > 0) stage_in(0);
+        f32x4 ra0[NLA], rb0[GT], ra1[NLA], rb1[GT];
+        bool a0 = false, a1 = false;
+        const bool pace = !(p.ablate & 256);
+        const int T = total_steps;
+        if (T > 0) {
+            gload(0, ra0, rb0, a0);
+            lstore(0, ra0, rb0, a0, false);
+        }
+        if (T > 1) gload(1, ra1, rb1, a1);
         __syncthreads();
-        for (int step = 0; step < total_steps; ++step) {
-            if (step + 1 < total_steps) stage_in(step + 1);
+        for (int step = 0; step < T; step += 2) {
+            if (step + 1 < T) lstore(step + 1, ra1, rb1, a1, pace);   // stage step+1 was loaded a stage ago (set 1)
+            if (step + 2 < T) gload(step + 2, ra0, rb0, a0);
+            __syncthreads();
+            if (step + 1 >= T) break;
+            if (step + 2 < T) lstore(step + 2, ra0, rb0, a0, pace);
+            if (step + 3 < T) gload(step + 3, ra1, rb1, a1);
             __syncthreads();
         }
         return;
