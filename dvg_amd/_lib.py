@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdvg_hip.so")
+# DVG_HIP_LIB: an alternative BUILD of the same library (kernel A/B experiments, tools/ab_variants.sh); still no fallback
+LIB_PATH = os.environ.get("DVG_HIP_LIB") or os.path.join(_HERE, "csrc", "libdvg_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int

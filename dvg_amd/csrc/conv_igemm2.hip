@@ -14,7 +14,18 @@
 //     run (fully coalesced 16-B loads).
 // BN is fixed at 64 (2 waves along N) so that two workgroups share a CU (<= 67 KB LDS each) and
 // cover each other's stage hand-offs.
+#include <type_traits>
+
 #include "dvg_common.h"
+
+// Placement of the next stage's global loads inside a stage (same-box A/B with tools/ab_variants.sh): 0 = left to
+// hipcc (which sinks them behind the last taps), 1 = all at the stage top, 2 = two per tap from tap 0, 3 = three
+// per tap, 4 = two per tap from tap 2.  Measured over the 18 vgg_64 layers: 0 and 2 tie at 82.6-82.9 % of the fp32
+// MFMA peak (1: 81.0, 3: 81.4, 4: 82.3); 0 is the better one for 128-pixel tiles, 2 for 64-pixel tiles.
+// -1 (default) = per tile shape.
+#ifndef DVG_VMEM_POLICY
+#define DVG_VMEM_POLICY -1
+#endif
 
 namespace dvg {
 
@@ -36,9 +47,11 @@ struct Igemm2Params {
     int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
     int cps;     // K chunks (of 16 channels) per split
     float* ws;   // [splitk][N*Ho*Wo][Cout]
+    unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
 };
 
 static int g_ablate = 0;
+static unsigned long long* g_clk = nullptr;
 
 template <int MODE, int TI, int TH, int TW>
 struct Cfg2 {
@@ -100,7 +113,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     // ---- loader geometry, computed once --------------------------------------------------------
-    long offx[NLA], offs[NLA];  // element offsets of this thread's halo float4s in x / skip (-1: zero fill)
+    // element offsets of this thread's halo float4s in x / skip.  Halo / out-of-image slots read offset 0 (a
+    // valid address) and are zeroed at the LDS write (okmask): no divergent branch, and no per-path wait
+    // bookkeeping, around the loads.
+    long offx[NLA], offs[NLA];
+    unsigned okmask = 0;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
         const int idx = tid + i * 256;
@@ -109,8 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
         const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         const int sh = p.upsample;
-        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : -1;
-        offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : -1;
+        okmask |= ok ? (1u << i) : 0u;
+        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : 0;
+        offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
     }
     const int brow = tid >> 2, bq = tid & 3;  // weight tile: one float4 per thread per tap
 
@@ -129,11 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         const bool from_x = c0 < p.C1;
         const float* src = from_x ? p.x + c0 : p.skip + (c0 - p.C1);
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const long o = from_x ? offx[i] : offs[i];
-            ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (o >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + o);
-        }
+        for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(src + (from_x ? offx[i] : offs[i]));
     };
     auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[GT]) {
 #pragma unroll
@@ -145,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + i * 256;
-            if (idx < HP * 4) *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = ra[i];
+            const f32x4 v = ((okmask >> i) & 1u) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < HP * 4) *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = v;
         }
     };
     auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
@@ -155,27 +170,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 
     const int chunk_begin = split * p.cps;
     const int chunk_end = min(Cin / C::KC, chunk_begin + p.cps);
-    const int s_begin = chunk_begin * NG, nstages = chunk_end * NG;
     f32x4 ra[NLA], rb[GT];
-    // experiments: break the lockstep of co-resident workgroups (which pairs share a CU is not architected)
-    if ((p.ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);
-    if ((p.ablate & 8) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(127);
-    if ((p.ablate & 16) && ((blockIdx.x >> 4) & 1)) __builtin_amdgcn_s_sleep(127);
+    unsigned long long clk0 = 0, wclk0 = 0;
+    if (p.clk && threadIdx.x == 0) {
+        clk0 = clock64();
+        wclk0 = wall_clock64();
+    }
     gload_a(chunk_begin * C::KC, ra);
     gload_b(chunk_begin, 0, rb);
     lds_store_a(ra);
     lds_store_b(rb);
     __syncthreads();
+    unsigned long long clk1 = 0;
+    if (p.clk && threadIdx.x == 0) clk1 = clock64();
 
-    for (int s = s_begin; s < nstages; ++s) {
-        const int grp = s % NG;
-        const bool has_next = s + 1 < nstages;
-        const int nchunk = (s + 1) / NG, ngrp = (s + 1) % NG;
-        const bool next_a = has_next && ngrp == 0;
-        if ((p.ablate & 3) == 0) {
-            if (next_a) gload_a(nchunk * C::KC, ra);
-            if (has_next) gload_b(nchunk, ngrp, rb);
-        }
+    // One stage = all resident taps of one 16-channel chunk from LDS.  GRP (stage within the chunk) and HAS_NEXT
+    // are compile-time: the loop below is peeled so that inside it the next stage's global loads and their LDS
+    // stores are UNCONDITIONAL.  With the loads under one runtime `if` and the stores under another, hipcc's
+    // (path-insensitive) s_waitcnt insertion assumed the previous stage's loads could still be pending at the loop
+    // head and emitted vmcnt(0) right after the new A loads were issued - a full memory latency exposed per stage.
+    auto stage = [&](const int chunk, auto grp_c, auto has_next_c) {
+        constexpr int grp = decltype(grp_c)::value;
+        constexpr bool has_next = decltype(has_next_c)::value;
+        constexpr int ngrp = (grp + 1) % NG;
+        constexpr bool next_a = has_next && ngrp == 0;
+        const int nchunk = chunk + (ngrp == 0 ? 1 : 0);
+        if constexpr (next_a) gload_a(nchunk * C::KC, ra);
+        if constexpr (has_next) gload_b(nchunk, ngrp, rb);
 
         // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
         f32x4 fa[2][MT][2], fb[2][2];
@@ -213,7 +234,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
             // (ds_read x3 -> s_waitcnt -> mfma x8), exposing the LDS latency every 8 MFMAs.  One ds_read_b128 per two
             // MFMAs, issued a full tap (16 / 8 MFMAs) ahead of its consumer.
             constexpr int NREAD = 2 * MT + 2, NMFMA = 8 * MT;
-            if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // tap 0's own fragments
+            // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
+            // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
+            constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? GT : 0);
+            constexpr int POLICY = (DVG_VMEM_POLICY >= 0) ? DVG_VMEM_POLICY : (MT == 1 ? 2 : 0);
+            constexpr int VPT = (POLICY == 3) ? 3 : 2, VTAPS = (NVMEM + VPT - 1) / VPT;
+            constexpr int VT0 = (POLICY == 4) ? 2 : 0;
+            if (tt == 0) {
+                if (POLICY == 1 && NVMEM > 0) __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // tap 0's own fragments
+            }
             if (tt + 1 < GT) {
 #pragma unroll
                 for (int r = 0; r < NREAD; ++r) {
@@ -224,17 +254,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             }
+            if (POLICY >= 2 && tt >= VT0 && tt < VT0 + VTAPS && tt + 1 < GT) __builtin_amdgcn_sched_group_barrier(0x020, VPT, 0);
         }
 
-        if (has_next && (p.ablate & 3) < 2) {
+        if constexpr (has_next) {
             __syncthreads();  // every wave has finished reading this stage's tiles
-            if ((p.ablate & 3) == 0) {
-                if (next_a) lds_store_a(ra);
-                lds_store_b(rb);
-            }
+            if constexpr (next_a) lds_store_a(ra);
+            lds_store_b(rb);
             __syncthreads();
         }
+    };
+    using std::integral_constant;
+    int chunk = chunk_begin;
+    for (; chunk + 1 < chunk_end; ++chunk) {
+        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+        if constexpr (NG == 2) stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, true>{});
     }
+    if constexpr (NG == 2) {
+        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+        stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    } else {
+        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    }
+    unsigned long long clk_loop = 0;
+    if (p.clk && threadIdx.x == 0) clk_loop = clock64();
+    auto clk_exit = [&]() {
+        if (p.clk && threadIdx.x == 0) {
+            unsigned long long* d = p.clk + (size_t)blockIdx.x * 8;
+            d[0] = clk0; d[1] = clk1; d[2] = clk_loop; d[3] = clock64(); d[4] = wclk0; d[5] = wall_clock64();
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            d[6] = xcc; d[7] = hwid;
+        }
+    };
 
     // ---- epilogue (identical math to v1) --------------------------------------------------------------
     int Ho, Wo;
@@ -260,56 +314,67 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
                 if (n < p.N) wsp[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = acc[mt][reg];
             }
         }
+        clk_exit();
         return;
     }
     const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    // The activation is dispatched ONCE (it used to be a runtime switch per value, tanh/exp code inlined 32 times),
+    // and addresses are a per-workgroup 64-bit base plus 32-bit per-value offsets.
+    float* const yb = p.y + (size_t)n0 * Ho * Wo * p.Cout + c;
+    float* const pb = p.y_pool ? p.y_pool + (size_t)n0 * (Ho >> 1) * (Wo >> 1) * p.Cout + c : nullptr;
+    auto epilogue = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;  // -1: generic (runtime p.act)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float v[16];
+        for (int mt = 0; mt < MT; ++mt) {
+            float v[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
-        const int mbase = wm * (C::BM / 2) + mt * 32;
-        const int ti0 = mbase / (TH * TW);
+            for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
+            const int mbase = wm * (C::BM / 2) + mt * 32;
+            const int ti0 = mbase / (TH * TW);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            const int m = mbase + row;
-            const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
-            const int r = m % (TH * TW);
-            const int ty = r / TW, tx = r % TW;
-            const int n = n0 + tii;
-            if (n < p.N) {
-                s1 += v[reg];
-                s2 += v[reg] * v[reg];
-                const float o = apply_act(v[reg], p.act, p.slope);
-                v[reg] = o;
-                int oy, ox;
-                if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
-                else { oy = y0 + ty; ox = x0 + tx; }
-                p.y[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = o;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int m = mbase + row;
+                const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
+                const int r = m % (TH * TW);
+                const int ty = r / TW, tx = r % TW;
+                if (TI == 1 || n0 + tii < p.N) {
+                    s1 += v[reg];
+                    s2 += v[reg] * v[reg];
+                    float o;
+                    if constexpr (ACT == DVG_ACT_LRELU) o = v[reg] > 0.f ? v[reg] : v[reg] * p.slope;
+                    else if constexpr (ACT == DVG_ACT_NONE) o = v[reg];
+                    else o = apply_act(v[reg], p.act, p.slope);
+                    v[reg] = o;
+                    int oy, ox;
+                    if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+                    else { oy = y0 + ty; ox = x0 + tx; }
+                    yb[((tii * Ho + oy) * Wo + ox) * p.Cout] = o;
+                }
             }
-        }
-        if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
-            if (p.y_pool != nullptr) {
-                constexpr int RY = (TW == 16) ? 8 : 4;
+            if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
+                if (pb != nullptr) {
+                    constexpr int RY = (TW == 16) ? 8 : 4;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const bool ty_even = (TW == 16) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
-                    if ((reg & 1) == 0 && ty_even) {
-                        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                        const int r = (mbase + row) % (TH * TW);
-                        const int ty = r / TW, tx = r % TW;
-                        const float mx = fmaxf(fmaxf(v[reg], v[reg + 1]), fmaxf(v[reg + RY], v[reg + RY + 1]));
-                        const int n = n0 + ti0;
-                        if (n < p.N)
-                            p.y_pool[(((size_t)n * (Ho >> 1) + ((y0 + ty) >> 1)) * (Wo >> 1) + ((x0 + tx) >> 1)) * p.Cout +
-                                     c] = mx;
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const bool ty_even = (TW == 16) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
+                        if ((reg & 1) == 0 && ty_even) {
+                            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                            const int r = (mbase + row) % (TH * TW);
+                            const int ty = r / TW, tx = r % TW;
+                            const float mx = fmaxf(fmaxf(v[reg], v[reg + 1]), fmaxf(v[reg + RY], v[reg + RY + 1]));
+                            if (TI == 1 || n0 + ti0 < p.N)
+                                pb[((ti0 * (Ho >> 1) + ((y0 + ty) >> 1)) * (Wo >> 1) + ((x0 + tx) >> 1)) * p.Cout] = mx;
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (p.act == DVG_ACT_LRELU) epilogue(std::integral_constant<int, DVG_ACT_LRELU>{});
+    else if (p.act == DVG_ACT_NONE) epilogue(std::integral_constant<int, DVG_ACT_NONE>{});
+    else epilogue(std::integral_constant<int, -1>{});
     if (p.stats != nullptr) {
         float* red = smem;
         s1 += __shfl_xor(s1, 32);
@@ -327,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
             dst[p.Cout + c] = s2 + red[wn * 64 + 32 + l31];
         }
     }
+    clk_exit();
 }
 
 // =====================================================================================================
@@ -733,6 +799,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
     p.ablate = g_ablate;
+    p.clk = g_clk;
     const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
     const int nchunks = (p.C1 + p.C2) / C::KC;
     int Ho, Wo;
@@ -742,8 +809,9 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     const long out_floats = (long)p.N * Ho * Wo * p.Cout;
     int S = (ws != nullptr) ? choose_splitk(wgs, nchunks) : 1;
     if (S > 1 && (long)S * out_floats > ws_floats) return fail(DVG_ERR_SHAPE, "conv_igemm2: split-K workspace too small");
-    p.splitk = S;
     p.cps = (nchunks + S - 1) / S;
+    S = (nchunks + p.cps - 1) / p.cps;  // no empty split: the kernel's peeled stage loop needs >= 1 chunk per workgroup
+    p.splitk = S;
     p.ws = ws;
     float* y_pool = p.y_pool;
     float* stats = p.stats;
@@ -782,6 +850,7 @@ static int launch3(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
     p.ablate = g_ablate;
+    p.clk = g_clk;
     const int items = p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
     const int lds = (2 * (C::A_FLOATS + C::B_FLOATS) + 768) * 4;
     static bool attr_set = false;
@@ -834,6 +903,7 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
 using namespace dvg;
 
 extern "C" void dvg_debug_set_ablate(int v) { g_ablate = v; }
+extern "C" void dvg_debug_set_clockbuf(void* buf) { g_clk = (unsigned long long*)buf; }
 
 extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                                         int transposed, void* stream) {

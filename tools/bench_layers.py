@@ -4,6 +4,7 @@ Prints one line per layer: shape, tile config hint, µs, TFLOP/s, fraction of th
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -22,10 +23,13 @@ VGG64 = [  # (H, C1, C2, Cout, upsample, pool)
 ]
 
 
-def time_fn(fn, iters=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+def time_fn(fn, iters=50, warm_s=0.5):
+    # sustained warm-up: after idling the shader clock needs ~100s of ms of load to reach its steady ~2.36 GHz
+    t0 = time.time()
+    while time.time() - t0 < warm_s:
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
