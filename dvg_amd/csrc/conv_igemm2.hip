@@ -18,13 +18,17 @@
 
 #include "dvg_common.h"
 
-// Placement of the next stage's global loads inside a stage (same-box A/B with tools/ab_variants.sh): 0 = left to
-// hipcc (which sinks them behind the last taps), 1 = all at the stage top, 2 = two per tap from tap 0, 3 = three
-// per tap, 4 = two per tap from tap 2.  Measured over the 18 vgg_64 layers: 0 and 2 tie at 82.6-82.9 % of the fp32
-// MFMA peak (1: 81.0, 3: 81.4, 4: 82.3); 0 is the better one for 128-pixel tiles, 2 for 64-pixel tiles.
-// -1 (default) = per tile shape.
+// Stage schedule knobs, fixed by same-box A/B runs (tools/ab_variants.sh) over the 18 vgg_64 layers at B = 64:
+//  DVG_WRITE_OVERLAP 1: barrier BEFORE the last tap's MFMAs, next stage's ds_writes interleaved with them
+//                       (0: MFMA-less write pass between two barriers).                      84.7 % vs 80.8 % of peak
+//  DVG_VMEM_POLICY: where the next stage's global loads issue: 0 = left to hipcc (sinks them behind the last taps:
+//                       latency exposed at the ds_write), 1 = all at the stage top (delays the first MFMAs), 2 = two
+//                       per tap from tap 0, 3 = three per tap, 4 = two per tap from tap 2.   4: 84.7, 2: 84.4, 3: 84.3
 #ifndef DVG_VMEM_POLICY
-#define DVG_VMEM_POLICY -1
+#define DVG_VMEM_POLICY 4
+#endif
+#ifndef DVG_WRITE_OVERLAP
+#define DVG_WRITE_OVERLAP 1
 #endif
 
 namespace dvg {
@@ -64,8 +68,9 @@ struct Cfg2 {
     static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : 4);  // taps resident per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
     static constexpr int KC = 16, LD = 20;  // 80-B LDS rows: b128 lane groups land on distinct 16-B slots
-    static constexpr int A_FLOATS = HP * LD, B_FLOATS = GT * BN * LD;
     static constexpr int NLA = (HP * 4 + 255) / 256;
+    // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
+    static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LD;
     static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
     static constexpr int MT3 = BM / 128;  // v3: 8 consumer waves as 4(M) x 2(N)
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + i * 256;
             const f32x4 v = ((okmask >> i) & 1u) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < HP * 4) *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = v;
+            *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = v;  // rows >= HP: padding
         }
     };
     auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
@@ -223,6 +228,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
                     fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LD + j * 4]);
                 }
             }
+            constexpr bool overlap_writes = DVG_WRITE_OVERLAP && has_next;
+            if (overlap_writes && tt == GT - 1) {
+                // The last tap's fragments are in registers: every wave is done reading this stage's tiles after
+                // this barrier, and the next stage's ds_writes interleave with the last tap's MFMAs instead of
+                // forming an MFMA-less pass between two barriers.
+                __syncthreads();
+                if constexpr (next_a) lds_store_a(ra);
+                lds_store_b(rb);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
             // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
             constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? GT : 0);
-            constexpr int POLICY = (DVG_VMEM_POLICY >= 0) ? DVG_VMEM_POLICY : (MT == 1 ? 2 : 0);
+            constexpr int POLICY = DVG_VMEM_POLICY;
             constexpr int VPT = (POLICY == 3) ? 3 : 2, VTAPS = (NVMEM + VPT - 1) / VPT;
             constexpr int VT0 = (POLICY == 4) ? 2 : 0;
             if (tt == 0) {
@@ -251,6 +265,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 if (NMFMA > 2 * NREAD) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NREAD, 0);
+            } else if (overlap_writes) {
+                constexpr int NW = (next_a ? NLA : 0) + GT;
+#pragma unroll
+                for (int r = 0; r < NW; ++r) {
+                    if (r < NMFMA) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                if (NMFMA > NW) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NW, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             }
@@ -258,9 +280,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         }
 
         if constexpr (has_next) {
-            __syncthreads();  // every wave has finished reading this stage's tiles
-            if constexpr (next_a) lds_store_a(ra);
-            lds_store_b(rb);
+            if (!DVG_WRITE_OVERLAP) {
+                __syncthreads();  // every wave has finished reading this stage's tiles
+                if constexpr (next_a) lds_store_a(ra);
+                lds_store_b(rb);
+            }
             __syncthreads();
         }
     };

@@ -8,7 +8,7 @@ make -s -j6
 src=$1; macro=$2; shift 2
 mkdir -p ../../tools/_ab
 for v in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D${macro}=${v} -c $src -o /tmp/ab_${macro}_${v}.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D${macro}=${v} $EXTRA -c $src -o /tmp/ab_${macro}_${v}.o
   objs=$(ls *.o | grep -v "^${src%.hip}.o$")
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs /tmp/ab_${macro}_${v}.o -o ../../tools/_ab/lib_${macro}_${v}.so
   echo built tools/_ab/lib_${macro}_${v}.so
