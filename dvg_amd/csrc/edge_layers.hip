@@ -323,6 +323,74 @@ __global__ void convT_gather_kernel(const float* __restrict__ d1, const float* _
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// pixel_proj: d[px][t] = sum_c in[px][c] * w[t][c]   (first step of the two-step last layer)
+//
+// The per-pixel projection of the decoder's last ConvTranspose (vgg_64.py:90-93 / dcgan_64.py:75-79) onto its
+// T = ks*ks*nc tap outputs.  HBM-bound: the activation (B*H*W x C fp32, 67 MB for vgg_64 at B = 64) is read exactly
+// once, 16 pixels x 16 channels per wave-instruction straight into MFMA A fragments (no LDS); the T x C weight
+// lives in registers as B fragments.  v_mfma_f32_16x16x4_f32: lane l holds A[i = l%16][k = l/16]; a float4 load
+// of channels 16j + 4*(l/16) .. +3 feeds the four MFMAs of channel block j (the K order inside a block is
+// permuted identically for A and B).  D: lane l holds rows 4*(l/16) + r, column l%16.
+// ---------------------------------------------------------------------------
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CB, int NT>
+__global__ __launch_bounds__(256) void pixel_proj_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                         float* __restrict__ out, long P, int T) {
+    constexpr int C = CB * 16, U = 4;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    float bf[NT][CB][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int t = nt * 16 + i16;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < T) v = *reinterpret_cast<const f32x4_u*>(w + (size_t)t * C + 16 * j + 4 * kq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[nt][j][e] = v[e];
+        }
+    const long ntiles = P >> 4;
+    const long wave_id = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long t0 = wave_id * U; t0 < ntiles; t0 += nwaves * U) {
+        f32x4 a[U][CB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long tile = (t0 + u < ntiles) ? t0 + u : ntiles - 1;   // clamped: the duplicate is not stored
+            const float* src = in + ((tile << 4) + i16) * C + 4 * kq;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) a[u][j] = *reinterpret_cast<const f32x4*>(src + 16 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j][e], bf[nt][j][e], acc[nt], 0, 0, 0);
+            if (t0 + u < ntiles) {
+                const long px0 = ((t0 + u) << 4) + 4 * kq;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = nt * 16 + i16;
+                    if (col < T) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[(px0 + r) * T + col] = acc[nt][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -414,4 +482,27 @@ extern "C" int dvg_convT_gather(const float* d1, const float* d2, const float* b
         hipLaunchKernelGGL((convT_gather_kernel<4, 2>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d1, d2, bias,
                            y_nchw, N, H, W, nc, act);
     return check_launch("dvg_convT_gather");
+}
+
+extern "C" int dvg_pixel_proj(const float* in, const float* w, float* out, long P, int C, int T, void* stream) {
+    DVG_REQUIRE(in && w && out, DVG_ERR_NULL, "dvg_pixel_proj: NULL pointer");
+    DVG_REQUIRE(P > 0 && P % 16 == 0, DVG_ERR_SHAPE, "dvg_pixel_proj: P=%ld must be a positive multiple of 16", P);
+    DVG_REQUIRE(C == 64 || C == 128, DVG_ERR_SHAPE, "dvg_pixel_proj: C=%d must be 64 or 128", C);
+    DVG_REQUIRE(T >= 1 && T <= 48, DVG_ERR_SHAPE, "dvg_pixel_proj: T=%d must be in 1..48", T);
+    DVG_REQUIRE(aligned16(in), DVG_ERR_ALIGN, "dvg_pixel_proj: input must be 16-byte aligned");
+    const int nt = (T + 15) / 16;
+    const long tiles = P / 16;
+    long g = (tiles + 15) / 16;   // 4 waves x 4 tiles per workgroup pass
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    const dim3 grid((unsigned)g), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define DVG_PP(CB_, NT_) hipLaunchKernelGGL((pixel_proj_kernel<CB_, NT_>), grid, block, 0, s, in, w, out, P, T)
+    if (C == 64) {
+        if (nt == 1) DVG_PP(4, 1); else if (nt == 2) DVG_PP(4, 2); else DVG_PP(4, 3);
+    } else {
+        if (nt == 1) DVG_PP(8, 1); else if (nt == 2) DVG_PP(8, 2); else DVG_PP(8, 3);
+    }
+#undef DVG_PP
+    return check_launch("dvg_pixel_proj");
 }

@@ -20,6 +20,8 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from . import ops
+
 
 def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
     return [i for i in range(n_past, n_eval) if i % period == 0]
@@ -118,8 +120,10 @@ class GraphedRollout:
                 sample_rollout(*self._args, self.static_x, **self._kw)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        ops.clear_skip_proj_cache()   # nothing cached eagerly may be referenced by the graph ...
         with torch.cuda.graph(self.graph):
             self.frames = sample_rollout(*self._args, self.static_x, **self._kw)
+        ops.clear_skip_proj_cache()   # ... and nothing from the graph's pool by later eager calls
 
     def __call__(self, x: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
         if x is not None:

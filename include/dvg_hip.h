@@ -183,6 +183,12 @@ int dvg_convT4x4s2_last(const float* x, const float* skip, const float* w_iohw,
                         const float* bias, float* y_nchw, int N, int H, int W,
                         int C1, int C2, int nc, int act, void* stream);
 
+/* First step of the two-step last layer: d[px][t] = sum_c in[px][c] * w[t][c] for the P = N*H*W pixels of an
+ * NHWC activation (C = 64 or 128 channels) and the T = ks*ks*nc <= 48 tap outputs of the decoder's final
+ * ConvTranspose2d (vgg_64.py:90-93, dcgan_64.py:75-79; w is that weight as [(kh,kw,co)][ci]).  HBM-bound MFMA
+ * kernel; dvg_convT_gather (below) sums the shifted taps.  P must be a multiple of 16. */
+int dvg_pixel_proj(const float* in, const float* w, float* out, long P, int C, int T, void* stream);
+
 /* Second step of the two-step last layers (inference path): y (N,nc,S*H,S*W) NCHW = act(bias + shifted sum of
  * the per-pixel projections d = x . W computed with dvg_gemm_nt_bias_act, d1/d2 [N*H*W][ks*ks*nc] (one per
  * concatenated input, d2 may be NULL), column order (kh, kw, co).  ks = 3: ConvTranspose2d(.,nc,3,1,1)

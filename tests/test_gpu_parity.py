@@ -171,6 +171,45 @@ def test_last_layers(nc):
     assert rel_err(y, ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,T,P", [(64, 9, 64 * 48), (64, 16, 16), (64, 27, 4096 + 16), (128, 48, 2048), (128, 16, 80)])
+def test_pixel_proj(C, T, P):
+    """dvg_pixel_proj (MFMA 16x16x4, fragments straight from global memory) against a float64 matmul, including
+    tile counts that are not a multiple of the 4-tile unroll and T that is not a multiple of 16."""
+    from dvg_amd import ops
+    x = params.normal(66, 1, P, 1, C).permute(0, 3, 1, 2).contiguous()    # (1,C,P,1)
+    w = params.normal(67, T, C, scale=0.1)
+    d = ops.pixel_proj(nhwc(x), w.to(dev()))
+    ref = x[0, :, :, 0].t().double() @ w.double().t()
+    assert d.shape == (P, T) and rel_err(d, ref) < 2e-5
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_last_layers_two_step(nc):
+    """The product path of the last layer (projection + gather), with the skip projection cached across calls
+    while the skip tensor is unchanged and recomputed when it is modified in place."""
+    from dvg_amd import ops
+    b = params.normal(62, nc, scale=0.1)
+    x = params.normal(60, 2, 64, 40, 64)
+    w = params.normal(61, 64, nc, 3, 3, scale=0.05)
+    ref = torch.sigmoid(F.conv_transpose2d(x, w, b, 1, 1))
+    y = ops.convT_last_two_step(nhwc(x), None, w.to(dev()), b.to(dev()), nc, 3, act=ops.ACT_SIGMOID)
+    assert rel_err(y, ref) < 2e-5 and y.is_contiguous()
+    x2 = params.normal(64, 2, 64, 32, 32)
+    w4 = params.normal(65, 128, nc, 4, 4, scale=0.05).to(dev())
+    sk = nhwc(x2)
+    ops.clear_skip_proj_cache()
+    for seed in (63, 68, 69):
+        x1 = params.normal(seed, 2, 64, 32, 32)
+        ref = torch.tanh(F.conv_transpose2d(torch.cat([x1, x2], 1), w4.cpu(), b, 2, 1))
+        y = ops.convT_last_two_step(nhwc(x1), sk, w4, b.to(dev()), nc, 4, act=ops.ACT_TANH)
+        assert rel_err(y, ref) < 2e-5
+    assert len(ops._SKIP_PROJ_CACHE) == 1
+    sk.mul_(0.5)                                         # in-place change: the cached projection must not be reused
+    ref = torch.tanh(F.conv_transpose2d(torch.cat([x1, 0.5 * x2], 1), w4.cpu(), b, 2, 1))
+    y = ops.convT_last_two_step(nhwc(x1), sk, w4, b.to(dev()), nc, 4, act=ops.ACT_TANH)
+    assert rel_err(y, ref) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K,splitk,period", [(64, 90, 8192, 32, 90), (64, 8192, 90, 1, 512), (5, 256, 90, 1, 256),
                                                  (50, 90, 256, 1, 90), (7, 33, 1000, 4, 11)])
 def test_gemm_nt(M, N, K, splitk, period):

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-launch cost (kernel + inter-kernel gap) of the small kernels under hipGraph replay: a graph of 100 dependent
+launches of each, replayed at steady clocks (GPU only)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dvg_amd import ops  # noqa: E402
+
+
+def graph_time(fn, n=100, reps=50):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                fn()
+    t0 = time.time()
+    while time.time() - t0 < 0.3:
+        g.replay()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps / n * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B = 64
+    r = lambda *s: torch.randn(*s, device=dev)
+    x, h, c = r(B, 256), r(B, 256), r(B, 256)
+    wi, wh, bi, bh = r(1024, 256), r(1024, 256), r(1024), r(1024)
+    state = {"h": h, "c": c}
+
+    def cell():
+        state["h"], state["c"] = ops.lstm_cell(x, state["h"], state["c"], wi, wh, bi, bh)
+    print(f"lstm_cell (chain)            {graph_time(cell):7.2f} us/launch")
+    a90, w_e = r(B, 90), r(256, 90)
+    print(f"gemm embed (64,256,90)       {graph_time(lambda: ops.gemm_nt(a90, w_e, None, None)):7.2f} us/launch")
+    a256, w_o = r(B, 256), r(90, 256)
+    print(f"gemm output (64,90,256)      {graph_time(lambda: ops.gemm_nt(a256, w_o, None, None)):7.2f} us/launch")
+    a8k, w8k = r(B, 8192), r(90, 8192)
+    print(f"gemm c5 (64,90,8192) sk16    {graph_time(lambda: ops.gemm_nt(a8k, w8k, None, None, splitk=16)):7.2f} us/launch (2 kernels)")
+    w_up = r(8192, 90)
+    print(f"gemm upc1 (64,8192,90)       {graph_time(lambda: ops.gemm_nt(a90, w_up, None, None)):7.2f} us/launch")
+    big, w9 = r(B * 4096, 64), r(9, 64)
+    print(f"gemm last proj (262144,9,64) {graph_time(lambda: ops.gemm_nt(big, w9, None, None), n=20):7.2f} us/launch")
+    t = torch.zeros(64, device=dev)
+    print(f"torch fill (64 floats)       {graph_time(lambda: t.fill_(1.0)):7.2f} us/launch")
+
+
+if __name__ == "__main__":
+    main()
