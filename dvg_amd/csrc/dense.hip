@@ -162,30 +162,39 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 64; ++i) v[i] = 0.f;
 
+    // epilogue operands of this lane's (batch, unit, gate), fetched with the first K slice instead of after the
+    // butterfly (three more dependent round trips otherwise)
+    const int eb = min(b0 + (lane >> 3), B - 1), ej = j0 + ((lane >> 2) & 1), eg = lane & 3;
+    const float e_bias = b_ih[eg * H + ej] + b_hh[eg * H + ej];
+    const float e_c = c[(size_t)eb * H + ej];
+
+    // All 32 float4 loads of a 256-deep K slice are issued before the first FMA and none sits behind a branch
+    // (rows past B are clamped to B-1 and their results dropped at the end): with `if (b < B)` guards hipcc put
+    // each x/h pair in its own block behind a full vmcnt(0) - eight serialized memory round trips per slice.
     for (int k0 = lane * 4; k0 < H; k0 += 256) {
-        f32x4 xv[8], hv[8];
+        f32x4 xv[8], hv[8], wi[8], wh[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            if (b0 + b < B) {
-                xv[b] = *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + b) * H + k0);
-                hv[b] = *reinterpret_cast<const f32x4*>(h + (size_t)(b0 + b) * H + k0);
-            } else {
-                xv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                hv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const int bb = min(b0 + b, B - 1);
+            xv[b] = *reinterpret_cast<const f32x4*>(x + (size_t)bb * H + k0);
+            hv[b] = *reinterpret_cast<const f32x4*>(h + (size_t)bb * H + k0);
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = (r & 3) * H + j0 + (r >> 2);
-            const f32x4 wi = *reinterpret_cast<const f32x4*>(w_ih + (size_t)row * H + k0);
-            const f32x4 wh = *reinterpret_cast<const f32x4*>(w_hh + (size_t)row * H + k0);
+            wi[r] = *reinterpret_cast<const f32x4*>(w_ih + (size_t)row * H + k0);
+            wh[r] = *reinterpret_cast<const f32x4*>(w_hh + (size_t)row * H + k0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise re-interleaves load / vmcnt(0) / FMA one load at a time
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 float s = v[b * 8 + r];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = fmaf(xv[b][e], wi[e], s);
+                for (int e = 0; e < 4; ++e) s = fmaf(xv[b][e], wi[r][e], s);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = fmaf(hv[b][e], wh[e], s);
+                for (int e = 0; e < 4; ++e) s = fmaf(hv[b][e], wh[r][e], s);
                 v[b * 8 + r] = s;
             }
         }
@@ -200,16 +209,111 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 
     const int b = lane >> 3, jj = (lane >> 2) & 1, g = lane & 3;
     const int j = j0 + jj;
-    const float pre = v[0] + b_ih[g * H + j] + b_hh[g * H + j];
+    const float pre = v[0] + e_bias;
     const float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
     const int q = lane & ~3;
     const float gi = __shfl(a, q), gf = __shfl(a, q + 1), gg = __shfl(a, q + 2), go = __shfl(a, q + 3);
     if (b0 + b < B) {
         if (gates_out) gates_out[(size_t)(b0 + b) * 4 * H + g * H + j] = a;
         if (g == 0) {
-            const float cn = gf * c[(size_t)(b0 + b) * H + j] + gi * gg;
+            const float cn = gf * e_c + gi * gg;
             c_out[(size_t)(b0 + b) * H + j] = cn;
             h_out[(size_t)(b0 + b) * H + j] = go * tanhf(cn);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// gemm_dot: the same product for SMALL M (the B = 64 latent path: lstm.py:50,55 embed / output, the encoder head
+// and decoder stem of vgg_64.py:44-48,65-69 / dcgan_64.py:41-45,62-66).  A 64x64-tile GEMM leaves these shapes
+// with a handful of workgroups crawling through K in serial, latency-bound steps (10-30 us for < 3 MB of
+// operands).  Here a WAVE owns an 8 x 8 output block with K spread over its 64 lanes (the lstm_cell scheme):
+// every operand load of a K slice is issued before the first FMA, the 64 partial sums per lane are combined by
+// the 63-shuffle butterfly, and (M/8)(N/8)splitk waves cover the chip.  Rows / columns past M / N are clamped
+// and dropped.
+// ------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_dot_kernel(const GemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const long wid = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nblk_n = (p.N + 7) >> 3, nblk_m = (p.M + 7) >> 3;
+    const long per_split = (long)nblk_n * nblk_m;
+    if (wid >= per_split * p.splitk) return;  // wave-uniform
+    const int z = (int)(wid / per_split);
+    const int rem = (int)(wid % per_split);
+    const int m0 = (rem / nblk_n) * 8, n0 = (rem % nblk_n) * 8;
+    const int kbeg = z * p.kper, kend = min(p.K, kbeg + p.kper);
+
+    float v[64];  // v[b * 8 + r]
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = 0.f;
+    const float* arow[8];
+    const float* wrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        arow[i] = p.a + (size_t)min(m0 + i, p.M - 1) * p.lda;
+        wrow[i] = p.w + (size_t)min(n0 + i, p.N - 1) * p.K;
+    }
+    if (VEC) {
+        for (int kk = kbeg; kk < kend; kk += 256) {
+            const int k0 = kk + lane * 4;
+            const bool valid = k0 < kend;              // K % 4 == 0 and kper % 4 == 0: whole float4s
+            const int kc = valid ? k0 : kbeg;
+            f32x4 av[8], wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kc);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const f32x4 wz = valid ? wv[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    float s = v[b * 8 + r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(av[b][e], wz[e], s);
+                    v[b * 8 + r] = s;
+                }
+            }
+        }
+    } else {
+        for (int kk = kbeg; kk < kend; kk += 128) {
+            float av[2][8], wv[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k0 = kk + h * 64 + lane;
+                const bool valid = k0 < kend;
+                const int kc = valid ? k0 : kbeg;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) av[h][i] = arow[i][kc];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wv[h][i] = valid ? wrow[i][kc] : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) v[b * 8 + r] = fmaf(av[h][b], wv[h][r], v[b * 8 + r]);
+        }
+    }
+    butterfly_step<32>(v, lane);
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+    const int m = m0 + (lane >> 3), n = n0 + (lane & 7);
+    if (m < p.M && n < p.N) {
+        if (p.splitk > 1) {
+            p.ws[((size_t)z * p.M + m) * p.N + n] = v[0];
+        } else {
+            const int c = n % p.period;
+            const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
+            p.out[(size_t)m * p.ldo + n] = apply_act(v[0] * sc + sf, p.act, p.slope);
         }
     }
 }
@@ -234,8 +338,22 @@ extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float*
     p.splitk = (K + kper - 1) / kper;  // drop empty splits
     p.vec = (K % 4 == 0 && aligned16(w)) ? 1 : 0;
     p.vec_a = (K % 4 == 0 && lda % 4 == 0 && aligned16(a)) ? 1 : 0;
-    dim3 grid((N + 63) / 64, (M + 63) / 64, p.splitk);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (M <= 1024 && N <= 2048) {
+        // small-M (latent path) shapes: wave-level dot products instead of the 64x64-tile kernel (the N = 8192
+        // decoder stem re-reads each weight row from 8 waves here and stays on the tile kernel: 10.1 vs 11.3 us)
+        if (p.vec && p.vec_a) {
+            kper = (((K + splitk - 1) / splitk + 255) / 256) * 256;   // whole 256-wide lane slices per split
+            p.kper = kper;
+            p.splitk = (K + kper - 1) / kper;
+        }
+        const long waves = (long)((M + 7) / 8) * ((N + 7) / 8) * p.splitk;
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (p.vec && p.vec_a) hipLaunchKernelGGL(gemm_dot_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_dot_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, p.splitk);
+        hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     if (int e = check_launch("dvg_gemm_nt_bias_act")) return e;
     if (p.splitk > 1) {
         const long total = (long)M * N;
