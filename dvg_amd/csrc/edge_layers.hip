@@ -7,6 +7,16 @@
 //   last layers:  lane = pixel, channels staged through LDS in chunks of 16.
 #include "dvg_common.h"
 
+// Output stores of the first layer are nontemporal (the 67 MB activation is read back once, by a kernel that is not
+// memory-bound): 4.14 vs 3.93 TB/s at B = 64 (same-box A/B, tools/ab_variants.sh); grid cap 512 / 1024 / 2048:
+// 3.57 / 4.14 / 4.14 TB/s.
+#ifndef DVG_FIRST_NT
+#define DVG_FIRST_NT 1
+#endif
+#ifndef DVG_FIRST_GRID
+#define DVG_FIRST_GRID 1024
+#endif
+
 namespace dvg {
 
 // ---------------------------------------------------------------------------
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     };
     int buf = 0;
     if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+    const bool lrelu = act == DVG_ACT_LRELU;  // the common case, kept off the generic (tanh / exp) switch
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float* tl = tiles[buf];
 #pragma unroll
@@ -119,9 +130,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                             const float u = acc[it][k] * sc[k] + sf[k];
                             s1[k] += u;
                             s2[k] += u * u;
-                            o[k] = apply_act(u, act, slope);
+                            o[k] = lrelu ? (u > 0.f ? u : u * slope) : apply_act(u, act, slope);
                         }
-                        *reinterpret_cast<f32x4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0) = o;
+                        f32x4* dst = reinterpret_cast<f32x4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0);
+#if DVG_FIRST_NT
+                        __builtin_nontemporal_store(o, dst);
+#else
+                        *dst = o;
+#endif
                     }
                 }
             }
@@ -416,7 +432,7 @@ extern "C" int dvg_conv3x3_first(const float* x, const float* w, const float* sc
                                  void* stream) {
     if (int e = first_checks("dvg_conv3x3_first", x, w, y, N, H, W, nc, Cout, act)) return e;
     unsigned gx = (unsigned)N * ((H + 3) / 4) * ((W + 31) / 32);
-    if (gx > 1024) gx = 1024;  // persistent over tiles: 4 workgroups per CU
+    if (gx > DVG_FIRST_GRID) gx = DVG_FIRST_GRID;  // persistent over tiles: 4 workgroups per CU
     hipLaunchKernelGGL((conv_first_kernel<3, 1>), dim3(gx, Cout / 64), dim3(256), 0, (hipStream_t)stream, x, w, scale,
                        shift, y, stats, N, H, W, nc, Cout, act, slope);
     return check_launch("dvg_conv3x3_first");

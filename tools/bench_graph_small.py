@@ -55,6 +55,14 @@ def main():
     print(f"gemm upc1 (64,8192,90)       {graph_time(lambda: ops.gemm_nt(a90, w_up, None, None)):7.2f} us/launch")
     big, w9 = r(B * 4096, 64), r(9, 64)
     print(f"gemm last proj (262144,9,64) {graph_time(lambda: ops.gemm_nt(big, w9, None, None), n=20):7.2f} us/launch")
+    xf, wf = torch.rand(B, 1, 64, 64, device=dev), r(64, 1, 3, 3) * 0.1
+    sc, sh = torch.rand(64, device=dev) + 0.5, r(64) * 0.1
+    us = graph_time(lambda: ops.conv3x3_first(xf, wf, sc, sh), n=20)
+    print(f"conv3x3_first (64,1,64,64)->64 {us:7.2f} us/launch  {(xf.numel() + B * 4096 * 64) * 4 / us / 1e3:7.1f} GB/s")
+    xp = ops.nhwc_empty(B, 64, 64, 64, dev).normal_()
+    w9 = r(9, 64)
+    us = graph_time(lambda: ops.pixel_proj(xp, w9), n=20)
+    print(f"pixel_proj (262144,9,64)     {us:7.2f} us/launch  {(xp.numel() + B * 4096 * 9) * 4 / us / 1e3:7.1f} GB/s")
     t = torch.zeros(64, device=dev)
     print(f"torch fill (64 floats)       {graph_time(lambda: t.fill_(1.0)):7.2f} us/launch")
 
