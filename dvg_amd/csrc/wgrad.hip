@@ -81,6 +81,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
 
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.tiles_total, t_begin + p.tiles_per_split);
+    constexpr int NLD = (P * 16 + 255) / 256, NLH = (HP * 16 + 255) / 256;
+    static_assert(P * 16 % 256 == 0, "dOut tile is a whole number of 256-thread passes");
+    const int q4 = (tid & 15) * 4;
+    const float* Ap = Ad + wr * 32 + l31;
+    const float* Xp = Xh + wc * 32 + l31;
+    auto tap_off = [&](int t2) -> int {
+        int th, tw;
+        if (MODE == W_CONV3) { th = t2 / 3; tw = t2 % 3; }
+        else if (MODE == W_CONV4S2) { const int tap = grp * GT + t2; th = tap >> 2; tw = tap & 3; }
+        else { th = 1 + py - (t2 >> 1); tw = 1 + px - (t2 & 1); }
+        return (th * HW + tw) * 64;
+    };
+    auto frag_base = [&](int pp) -> int {
+        const int ti = pp / (TH * TW), r = pp % (TH * TW);
+        return ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * 64;
+    };
     for (int tile = t_begin; tile < t_end; ++tile) {
         int t = tile;
         const int tx_i = t % p.tiles_x; t /= p.tiles_x;
@@ -88,52 +104,85 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
         const int n0 = t * TI;
         const int y0 = ty_i * TH, x0 = tx_i * TW;  // iteration grid: output grid (CONV3/CONV4S2), input grid (CONVT)
         const int yin0 = y0 * S - 1, xin0 = x0 * S - 1;
-        __syncthreads();
-        // dOut tile
-        for (int idx = tid; idx < P * 16; idx += 256) {
-            const int pp = idx >> 4, q = idx & 15;
-            const int ti = pp / (TH * TW), r = pp % (TH * TW);
-            const int ty = r / TW, tx = r % TW;
-            const int n = n0 + ti;
-            int oy, ox;
-            if (MODE == W_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
-            else { oy = y0 + ty; ox = x0 + tx; }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N)
-                v = *reinterpret_cast<const f32x4*>(p.dout + (((size_t)n * Ho + oy) * Wo + ox) * p.Cout + co0 + q * 4);
-            *reinterpret_cast<f32x4*>(&Ad[pp * 64 + q * 4]) = v;
+        // The tile's global loads are issued back to back, branch-free (out-of-range slots read a clamped, valid
+        // address and are zeroed at the LDS write), the first batch BEFORE the barrier that waits for the
+        // previous tile's MFMAs.  (As `for` loops with a guarded load each, hipcc emitted load -> vmcnt(0) ->
+        // ds_write per iteration: twenty serialized memory round trips per tile.)  Two batches, so that at most
+        // NB1 float4s are live next to the 16*GT accumulator registers.
+        constexpr int NB1 = (NLD + NLH + 1) / 2;   // slots 0..NB1-1: dOut tile then the first halo slots
+        auto load_slot = [&](int i, bool& ok) -> f32x4 {   // i: compile-time after unrolling
+            if (i < NLD) {
+                const int pp = (tid + i * 256) >> 4;
+                const int d_ti = pp / (TH * TW), d_ty = (pp % (TH * TW)) / TW, d_tx = pp % TW;
+                const int n = n0 + d_ti;
+                ok = n < p.N;
+                int oy, ox;
+                if (MODE == W_CONVT4S2) { oy = 2 * (y0 + d_ty) + py; ox = 2 * (x0 + d_tx) + px; }
+                else { oy = y0 + d_ty; ox = x0 + d_tx; }
+                return *reinterpret_cast<const f32x4*>(p.dout + (((size_t)min(n, p.N - 1) * Ho + oy) * Wo + ox) * p.Cout + co0 + q4);
+            }
+            const int hp = min((tid + (i - NLD) * 256) >> 4, HP - 1);
+            const int n = n0 + hp / (HH * HW), yy = yin0 + (hp % (HH * HW)) / HW, xx = xin0 + hp % HW;
+            ok = n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const int yc = min(max(yy, 0), p.H - 1) >> sh, xc = min(max(xx, 0), p.W - 1) >> sh;
+            return *reinterpret_cast<const f32x4*>(src + (((size_t)min(n, p.N - 1) * Hs + yc) * Ws + xc) * Cs + cc + q4);
+        };
+        auto store_slot = [&](int i, const f32x4& v, bool ok) {
+            const f32x4 z = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < NLD) {
+                *reinterpret_cast<f32x4*>(&Ad[((tid + i * 256) >> 4) * 64 + q4]) = z;
+            } else {
+                const int hp = (tid + (i - NLD) * 256) >> 4;
+                if (NLH * 256 == HP * 16 || hp < HP) *reinterpret_cast<f32x4*>(&Xh[hp * 64 + q4]) = z;
+            }
+        };
+        {
+            f32x4 r1[NB1];
+            bool ok1[NB1];
+#pragma unroll
+            for (int i = 0; i < NB1; ++i) r1[i] = load_slot(i, ok1[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();   // every wave is done with the previous tile's LDS image
+#pragma unroll
+            for (int i = 0; i < NB1; ++i) store_slot(i, r1[i], ok1[i]);
         }
-        // input halo tile
-        for (int idx = tid; idx < HP * 16; idx += 256) {
-            const int hp = idx >> 4, q = idx & 15;
-            const int ti = hp / (HH * HW), r = hp % (HH * HW);
-            const int hy = r / HW, hx = r % HW;
-            const int n = n0 + ti, yy = yin0 + hy, xx = xin0 + hx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * Hs + (yy >> sh)) * Ws + (xx >> sh)) * Cs + cc +
-                                                    q * 4);
-            *reinterpret_cast<f32x4*>(&Xh[hp * 64 + q * 4]) = v;
+        {
+            constexpr int NB2 = NLD + NLH - NB1;
+            f32x4 r2[NB2];
+            bool ok2[NB2];
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) r2[i] = load_slot(NB1 + i, ok2[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) store_slot(NB1 + i, r2[i], ok2[i]);
         }
         __syncthreads();
-        const float* Ap = Ad + wr * 32 + l31;
-        const float* Xp = Xh + wc * 32 + l31;
+        // k loop over the tile's pixels, two per MFMA; fragments of step k+1 are read while step k's MFMAs run
+        float a_cur = Ap[kk * 64], b_cur[GT];
+        {
+            const int hb = frag_base(kk);
+#pragma unroll
+            for (int t2 = 0; t2 < GT; ++t2) b_cur[t2] = Xp[hb + tap_off(t2)];
+        }
 #pragma unroll 2
         for (int k0 = 0; k0 < P; k0 += 2) {
-            const int pp = k0 + kk;
-            const int ti = pp / (TH * TW), r = pp % (TH * TW);
-            const int ty = r / TW, tx = r % TW;
-            const float a = Ap[pp * 64];
-            const int hb = ((ti * HH + ty * S) * HW + tx * S) * 64;
+            const int pn = min(k0 + 2, P - 2) + kk;   // last step re-reads its own fragments (unused)
+            const float a_nxt = Ap[pn * 64];
+            float b_nxt[GT];
+            const int hb = frag_base(pn);
 #pragma unroll
-            for (int t2 = 0; t2 < GT; ++t2) {
-                int th, tw;
-                if (MODE == W_CONV3) { th = t2 / 3; tw = t2 % 3; }
-                else if (MODE == W_CONV4S2) { const int tap = grp * GT + t2; th = tap >> 2; tw = tap & 3; }
-                else { th = 1 + py - (t2 >> 1); tw = 1 + px - (t2 & 1); }
-                const float bv = Xp[hb + (th * HW + tw) * 64];
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t2], 0, 0, 0);
+            for (int t2 = 0; t2 < GT; ++t2) b_nxt[t2] = Xp[hb + tap_off(t2)];
+#pragma unroll
+            for (int t2 = 0; t2 < GT; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t2], acc[t2], 0, 0, 0);
+#pragma unroll
+            for (int t2 = 0; t2 < GT; ++t2) {   // one ds_read per MFMA, a full step ahead of its consumer
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t2 = 0; t2 < GT; ++t2) b_cur[t2] = b_nxt[t2];
         }
     }
     // write partial[split][tapw][co][ci]
