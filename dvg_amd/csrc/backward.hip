@@ -125,25 +125,40 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ coefC, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ dbias,
                                                                int C, double count, int train) {
-    __shared__ double red[16 * 64 * 2];
-    const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lc;
-    double a1 = 0.0, a2 = 0.0;
+    __shared__ double red[64 * 16 * 2];
+    // 16 channels x 64 row lanes per workgroup, C/16 workgroups (misc_kernels.hip partial_colsums has the history)
+    const int lc = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lc;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
-        for (int r = rl; r < nrows; r += 16) {
-            a1 += (double)partial[(size_t)r * 2 * C + c];
-            a2 += (double)partial[(size_t)r * 2 * C + C + c];
+        int r = rl;
+        for (; r + 192 < nrows; r += 256) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v1[k] = partial[(size_t)(r + 64 * k) * 2 * C + c];
+                v2[k] = partial[(size_t)(r + 64 * k) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a1[k] += (double)v1[k];
+                a2[k] += (double)v2[k];
+            }
+        }
+        for (; r < nrows; r += 64) {
+            a1[0] += (double)partial[(size_t)r * 2 * C + c];
+            a2[0] += (double)partial[(size_t)r * 2 * C + C + c];
         }
     }
-    red[(rl * 64 + lc) * 2] = a1;
-    red[(rl * 64 + lc) * 2 + 1] = a2;
+    red[(rl * 16 + lc) * 2] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    red[(rl * 16 + lc) * 2 + 1] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     __syncthreads();
     if (rl != 0 || c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        s1 += red[(k * 64 + lc) * 2];
-        s2 += red[(k * 64 + lc) * 2 + 1];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+        s1 += red[(k * 16 + lc) * 2];
+        s2 += red[(k * 16 + lc) * 2 + 1];
     }
     const double mu = mean[c], is = invstd[c];
     const double g = gamma ? gamma[c] : 1.0;
@@ -253,23 +268,26 @@ __global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ o
 // 4 independent accumulators (loads in flight), lanes combine through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                               int S, long n4) {
-    __shared__ f32x4 red[4 * 64];
-    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + lc;
+    // 16 float4 columns x 16 split lanes per workgroup (n4/16 workgroups: a 64x64x9 weight gradient used to get only
+    // 144 workgroups of serial loads); every lane keeps four independent partial sums; fixed combination order.
+    __shared__ f32x4 red[16 * 16];
+    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + lc;
     f32x4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         int s = sl;
-        for (; s + 12 < S; s += 16) {
+        for (; s + 48 < S; s += 64) {
+            f32x4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)(s + 4 * k) * n4 + i];
+            for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const f32x4*>(partial)[(size_t)(s + 16 * k) * n4 + i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[k][e] += v[e];
-            }
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[k][e] += v[k][e];
         }
-        for (; s < S; s += 4) {
+        for (; s < S; s += 16) {
             const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)s * n4 + i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
@@ -278,12 +296,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     f32x4 t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
-    red[sl * 64 + lc] = t;
+    red[sl * 16 + lc] = t;
     __syncthreads();
     if (sl == 0 && i < n4) {
-        f32x4 o;
+        f32x4 o = red[lc];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (red[lc][e] + red[64 + lc][e]) + (red[128 + lc][e] + red[192 + lc][e]);
+        for (int k = 1; k < 16; ++k) {
+            const f32x4 v = red[k * 16 + lc];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += v[e];
+        }
         reinterpret_cast<f32x4*>(out)[i] = o;
     }
 }
@@ -439,7 +461,7 @@ extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float*
                                    float* dbeta, float* dbias, int C, double count, int train, void* stream) {
     DVG_REQUIRE(partial && mean && invstd && coefA && coefB && coefC, DVG_ERR_NULL, "dvg_bn_bwd_finalize: NULL");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
                        gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train);
     return check_launch("dvg_bn_bwd_finalize");
 }
@@ -485,7 +507,7 @@ extern "C" int dvg_reduce_partials(const float* partial, float* out, int S, long
     DVG_REQUIRE(partial && out, DVG_ERR_NULL, "dvg_reduce_partials: NULL pointer");
     DVG_REQUIRE(S > 0 && n > 0 && n % 4 == 0, DVG_ERR_SHAPE, "dvg_reduce_partials: n %% 4 != 0");
     DVG_REQUIRE(aligned16(partial) && aligned16(out), DVG_ERR_ALIGN, "dvg_reduce_partials: alignment");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        partial, out, S, n / 4);
     return check_launch("dvg_reduce_partials");
 }

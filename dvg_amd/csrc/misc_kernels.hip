@@ -84,29 +84,46 @@ __global__ void channel_stats_kernel(const float* __restrict__ u, float* __restr
     }
 }
 
-// Column sums of the partial rows in double: a workgroup = 64 channels x 16 row lanes (1024 threads), rows are
-// strided over the 16 lanes (coalesced 256-B reads per wave), combined through LDS.  (A single thread per channel
-// walking up to 2048 rows serially took 100-230 us per call and ~40 % of a training iteration.)
+// Column sums of the partial rows in double: a workgroup = 16 channels x 64 row lanes (1024 threads) and the grid
+// is C/16 workgroups; each lane walks its rows four at a time (eight independent loads in flight), lanes are
+// combined through LDS in a fixed order (deterministic).  History: one thread per channel walking up to 2048
+// rows serially took 100-230 us per call; 64 channels x 16 lanes in C/64 workgroups (ONE workgroup for a 64-channel
+// layer) still 13-21 us.
+#define DVG_COLSUM_CT 16
 __device__ __forceinline__ void partial_colsums(const float* __restrict__ partial, int nrows, int C, int c, int rl,
                                                 double* red, double& s1, double& s2) {
-    double a1 = 0.0, a2 = 0.0;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
-        for (int r = rl; r < nrows; r += 16) {
-            a1 += (double)partial[(size_t)r * 2 * C + c];
-            a2 += (double)partial[(size_t)r * 2 * C + C + c];
+        int r = rl;
+        for (; r + 192 < nrows; r += 256) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v1[k] = partial[(size_t)(r + 64 * k) * 2 * C + c];
+                v2[k] = partial[(size_t)(r + 64 * k) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a1[k] += (double)v1[k];
+                a2[k] += (double)v2[k];
+            }
+        }
+        for (; r < nrows; r += 64) {
+            a1[0] += (double)partial[(size_t)r * 2 * C + c];
+            a2[0] += (double)partial[(size_t)r * 2 * C + C + c];
         }
     }
-    const int lc = threadIdx.x & 63;
-    red[(rl * 64 + lc) * 2] = a1;
-    red[(rl * 64 + lc) * 2 + 1] = a2;
+    const int lc = threadIdx.x & (DVG_COLSUM_CT - 1);
+    red[(rl * DVG_COLSUM_CT + lc) * 2] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    red[(rl * DVG_COLSUM_CT + lc) * 2 + 1] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     __syncthreads();
     s1 = 0.0;
     s2 = 0.0;
     if (rl == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            s1 += red[(k * 64 + lc) * 2];
-            s2 += red[(k * 64 + lc) * 2 + 1];
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) {
+            s1 += red[(k * DVG_COLSUM_CT + lc) * 2];
+            s2 += red[(k * DVG_COLSUM_CT + lc) * 2 + 1];
         }
     }
 }
@@ -119,8 +136,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, int C, double count,
                                                            float eps, float momentum) {
-    __shared__ double red[16 * 64 * 2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ double red[64 * DVG_COLSUM_CT * 2];
+    const int c = blockIdx.x * DVG_COLSUM_CT + (threadIdx.x & (DVG_COLSUM_CT - 1)), rl = threadIdx.x >> 4;
     double s1, s2;
     partial_colsums(partial, nrows, C, c, rl, red, s1, s2);
     if (rl != 0 || c >= C) return;
@@ -268,7 +285,7 @@ extern "C" int dvg_bn_finalize(const float* stats_partial, int nrows, const floa
                                void* stream) {
     DVG_REQUIRE(stats_partial && scale && shift, DVG_ERR_NULL, "dvg_bn_finalize: NULL pointer");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats_partial, nrows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + DVG_COLSUM_CT - 1) / DVG_COLSUM_CT), dim3(1024), 0, (hipStream_t)stream, stats_partial, nrows,
                        gamma, beta, scale, shift, running_mean, running_var, save_mean, save_invstd, C, count, eps,
                        momentum);
     return check_launch("dvg_bn_finalize");
