@@ -86,6 +86,30 @@ def test_train_model_loss_matches_oracle(model):
         assert torch.equal(p, enc_before[k]), "train_frame_predictor / train_GP step only their own optimizers"
 
 
+def test_finetune_closures_without_encoder_autograd_match_reference_structure():
+    """train.py runs the encoder of the two fine-tuning closures without autograd (the reference's encoder gradients
+    there are discarded).  Both structures must give the same LSTM / GP parameter updates and BatchNorm buffers."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    res = []
+    for with_grad in (False, True):
+        torch.manual_seed(3)
+        opt = _opt("dcgan")
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        tr.train_mode()
+        tr.finetune_encoder_grad = with_grad
+        seq = SyntheticMovingMNIST(seq_len=4, seed=5).batch(4)
+        x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
+        v = tr.finetune_temporal_encoders(x)
+        res.append((v, copy.deepcopy(tr.frame_predictor.state_dict()), copy.deepcopy(tr.gp_layer.state_dict()),
+                    copy.deepcopy(tr.encoder.state_dict())))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * max(1.0, abs(res[1][0]))
+    for a, b in zip(res[0][1:], res[1][1:]):
+        for k in a:
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-6), k
+
+
 def test_train_script_runs_and_checkpoint_drives_generate(tmp_path):
     import generate_frames
     import train

@@ -93,6 +93,9 @@ class Trainer:
         for m in self.modules:
             m.to(device)
         parallel.broadcast_parameters(self.modules)
+        # True = back-propagate into the encoder in the two fine-tuning closures like the reference does (and then
+        # discards); kept only so that tests can show both ways give the same updates
+        self.finetune_encoder_grad = False
         self.frame_predictor_optimizer = torch.optim.Adam(self.frame_predictor.parameters(), lr=0.002)
         self.encoder_optimizer = torch.optim.Adam(self.encoder.parameters(), lr=0.002)
         self.decoder_optimizer = torch.optim.Adam(self.decoder.parameters(), lr=0.002)
@@ -130,8 +133,13 @@ class Trainer:
         max_ll = 0
         skip = None
         for i in range(1, opt.n_past + opt.n_future):
-            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
-            h_target = self.encoder(x[i])[0].detach()
+            # Only the GP optimiser steps after this closure (train.py:170-171): the reference back-propagates into
+            # the encoder and then discards those gradients (encoder.zero_grad() opens the next train_model).  The
+            # encoder therefore runs without autograd here - same outputs, same BatchNorm running-stat updates, same
+            # parameter updates, none of the wasted encoder backward.
+            with torch.set_grad_enabled(self.finetune_encoder_grad):
+                h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
+                h_target = self.encoder(x[i])[0].detach()
             h_pred = self.gp_layer(self._gp_in(h))
             max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
@@ -147,8 +155,9 @@ class Trainer:
         mse_latent = 0
         skip = None
         for i in range(1, opt.n_past + opt.n_future):
-            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
-            h_target = self.encoder(x[i])[0]
+            with torch.set_grad_enabled(self.finetune_encoder_grad):   # only frame_predictor_optimizer steps (train.py:195-196)
+                h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
+                h_target = self.encoder(x[i])[0]
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
