@@ -408,6 +408,41 @@ static inline unsigned grid_for(long n, int block = 256, int cap = 4096) {
     return (unsigned)g;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Fused Adam over a flat parameter group (train.py:95-106: torch.optim.Adam(lr=0.002), default betas / eps):
+//   g' = g + wd p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)        bc1 = 1 - b1^t, bc2 = 1 - b2^t
+// (torch.optim.Adam's arithmetic, non-amsgrad).  One launch per group instead of the foreach chain.
+// ------------------------------------------------------------------------------------
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, float lr_over_bc1, float b1, float b2, float eps,
+                                 float wd, float inv_sqrt_bc2) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] + wd * pv[e];
+            mv[e] = b1 * mv[e] + (1.f - b1) * gg;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
+            pv[e] -= lr_over_bc1 * mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] + wd * p[i];
+        const float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] -= lr_over_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -542,4 +577,17 @@ extern "C" int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, flo
         hipLaunchKernelGGL((wgrad_thin_kernel<4, 2>), dim3(gx, C / 64), dim3(256), 0, (hipStream_t)stream, inp_nchw,
                            dout_nhwc, partial, N, Hi, Wi, nc, C);
     return check_launch("dvg_wgrad_thin");
+}
+
+extern "C" int dvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    DVG_REQUIRE(param && grad && exp_avg && exp_avg_sq, DVG_ERR_NULL, "dvg_adam_step: NULL pointer");
+    DVG_REQUIRE(n > 0 && step >= 1, DVG_ERR_SHAPE, "dvg_adam_step: n=%ld step=%d", n, step);
+    DVG_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), DVG_ERR_ALIGN,
+                "dvg_adam_step: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, (float)((double)lr / bc1), beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / sqrt(bc2)));
+    return check_launch("dvg_adam_step");
 }

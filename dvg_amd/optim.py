@@ -1,0 +1,108 @@
+"""Fused multi-tensor Adam for the four optimisers of train.py:95-106.
+
+`FusedAdam(params, lr=...)` is a `torch.optim.Optimizer` with torch.optim.Adam's arithmetic (non-amsgrad) and
+state layout (`step`, `exp_avg`, `exp_avg_sq` per parameter, so `state_dict()` is interchangeable with
+torch.optim.Adam's and `MultiStepLR` drives `param_groups[...]['lr']` as in train.py:105-106), but every
+parameter group lives in ONE flat fp32 buffer: parameters are re-pointed at views of it, the moments are views of
+two more, and a step is one gradient gather (`torch._foreach_copy_`) + ONE `dvg_adam_step` launch per group
+instead of the per-tensor foreach chain.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = {}   # group index -> dict(p, g, m, v, params, offsets, gviews)
+
+    # ---- flat storage -------------------------------------------------------------------------------
+    def _build(self, gi: int, group) -> dict:
+        params: List[torch.nn.Parameter] = [p for p in group["params"] if p.requires_grad]
+        if not params:
+            return {}
+        dev = params[0].device
+        for p in params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("FusedAdam: parameters of a group must be fp32 on one device")
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4          # every view 16-byte aligned
+        flat_p = torch.zeros(n, device=dev)
+        flat_m, flat_v, flat_g = torch.zeros_like(flat_p), torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+        steps = {}
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p)
+                st = self.state.get(p, {})
+                if "exp_avg" in st:                 # state restored by load_state_dict
+                    flat_m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                    flat_v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps[p] = float(st["step"])
+                p.data = view                       # the module keeps the same Parameter object
+        f = dict(p=flat_p, g=flat_g, m=flat_m, v=flat_v, params=params, offsets=offs,
+                 gviews=[flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)])
+        for p, o in zip(params, offs):
+            self.state[p] = {"step": torch.tensor(steps.get(p, 0.0)), "exp_avg": flat_m[o:o + p.numel()].view(p.shape),
+                             "exp_avg_sq": flat_v[o:o + p.numel()].view(p.shape)}
+        self._flat[gi] = f
+        return f
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # torch aliases (does not copy) the tensors of `state_dict`: copy them into our flat buffers right away
+        self._flat.clear()
+        for gi, group in enumerate(self.param_groups):
+            self._build(gi, group)
+
+    # ---- step ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            f = self._flat.get(gi)
+            if f is None or [id(p) for p in f.get("params", [])] != [id(p) for p in group["params"] if p.requires_grad]:
+                f = self._build(gi, group)
+            if not f:
+                continue
+            have = [p.grad is not None for p in f["params"]]
+            if not any(have):
+                continue
+            b1, b2 = group["betas"]
+            hyper = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            steps = {int(self.state[p]["step"]) for p in f["params"]}
+            if all(have) and len(steps) == 1:
+                # the whole group in one launch
+                torch._foreach_copy_(f["gviews"], [p.grad for p in f["params"]])
+                t = steps.pop() + 1
+                check(lib().dvg_adam_step(ops._p(f["p"]), ops._p(f["g"]), ops._p(f["m"]), ops._p(f["v"]),
+                                          f["p"].numel(), *hyper, t, ops._stream()), "dvg_adam_step")
+                touched = f["params"]
+            else:
+                # torch.optim.Adam semantics for a partially used group: parameters without a gradient are skipped
+                # (no moment decay, no step count) - one launch per parameter that has one
+                touched = [p for p in f["params"] if p.grad is not None]
+                for p, gv in zip(f["params"], f["gviews"]):
+                    if p.grad is None:
+                        continue
+                    st = self.state[p]
+                    gv.copy_(p.grad)
+                    check(lib().dvg_adam_step(ops._p(p), ops._p(gv), ops._p(st["exp_avg"]), ops._p(st["exp_avg_sq"]),
+                                              p.numel(), *hyper, int(st["step"]) + 1, ops._stream()), "dvg_adam_step")
+            for p in touched:
+                torch.autograd.graph.increment_version(p)   # the kernel wrote through raw pointers
+                self.state[p]["step"] += 1
+        return loss

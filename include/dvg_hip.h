@@ -336,6 +336,12 @@ int dvg_wgrad_thin_rows(int ks, int N, int Hi, int Wi);
 int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, float* partial, int ks, int N,
                    int Hi, int Wi, int nc, int C, void* stream);
 
+/* Fused Adam step over one flat parameter group (train.py:95-106: torch.optim.Adam(lr=0.002) with default
+ * betas (0.9, 0.999) and eps 1e-8; torch.optim.Adam arithmetic, non-amsgrad): param / exp_avg / exp_avg_sq are
+ * updated in place, `step` is the 1-based step count used for the bias corrections. */
+int dvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* nn.LSTMCell backward, elementwise part: gate pre-activation gradients dG [B][4H] and
  * dc_prev [B][H] from dh', dc' (either may be NULL), the saved activated gates, c, c'.
  * The GEMM parts (dx = dG W_ih, dW_ih = dG^T x, ...) go through dvg_gemm_nt_bias_act. */

@@ -155,3 +155,48 @@ def test_rollout_matches_oracle_rollout():
     for t in range(n_eval):
         tol = 1e-4 if t < 15 else 5e-3   # after the GP sample the fp32 Cholesky noise is chained through the rollout
         assert rel_err(ours[t], ref[t]) < tol, (t, rel_err(ours[t], ref[t]))
+
+
+def test_fused_adam_matches_torch_adam():
+    """dvg_adam_step over flat groups against torch.optim.Adam: 4 steps on two groups (one with weight decay and an
+    lr change from MultiStepLR), a step where one parameter has no gradient, state_dict interchange."""
+    from dvg_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 3), (64,), (17, 5), (1,), (90, 40, 40)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    mk = lambda cls, ps: cls([{"params": ps[:3]}, {"params": ps[3:], "weight_decay": 0.01}], lr=2e-3)  # noqa: E731
+    o_ref, o_mine = mk(torch.optim.Adam, ref), mk(FusedAdam, mine)
+    s_ref = torch.optim.lr_scheduler.MultiStepLR(o_ref, milestones=[2], gamma=0.1)
+    s_mine = torch.optim.lr_scheduler.MultiStepLR(o_mine, milestones=[2], gamma=0.1)
+    for it in range(5):
+        grads = [torch.randn_like(p) for p in ref]
+        for p, q, g in zip(ref, mine, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        if it == 3:                       # partially used group: torch skips the parameter without a gradient
+            ref[1].grad = None
+            mine[1].grad = None
+        v0 = mine[0]._version
+        o_ref.step()
+        o_mine.step()
+        s_ref.step()
+        s_mine.step()
+        assert mine[0]._version > v0, "weight caches key on the version counter"
+        for p, q in zip(ref, mine):
+            assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), it
+    sd = o_mine.state_dict()
+    o_new = mk(torch.optim.Adam, [torch.nn.Parameter(p.detach().clone()) for p in mine])
+    o_new.load_state_dict(sd)             # interchangeable state layout
+    k0 = o_ref.state_dict()["state"][0]
+    assert torch.allclose(sd["state"][0]["exp_avg"], k0["exp_avg"], rtol=1e-5, atol=1e-7)
+    assert float(sd["state"][0]["step"]) == float(k0["step"]) == 5.0
+    assert float(sd["state"][1]["step"]) == 4.0
+    o_back = mk(FusedAdam, mine)
+    o_back.load_state_dict(o_ref.state_dict())
+    for p, q in zip(ref, mine):
+        g = torch.randn_like(p)
+        p.grad, q.grad = g.clone(), g.clone()
+    o_ref.step()
+    o_back.step()
+    for p, q in zip(ref, mine):
+        assert torch.allclose(p, q, rtol=2e-6, atol=2e-7)
