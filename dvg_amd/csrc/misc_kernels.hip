@@ -223,6 +223,81 @@ static inline unsigned grid_for(long n, int block = 256, int cap = 2048) {
     return (unsigned)g;
 }
 
+
+// ------------------------------------------------------------------------------------
+// eval_frames: SSIM and PSNR of one predicted channel image against its ground truth, as utils.eval_seq
+// (utils.py:220-234) computes them through skimage.measure.compare_ssim / compare_psnr (utils.py:13-14; skimage
+// <= 0.15 defaults): 7x7 uniform window, sample covariance (x 49/48), K1 = 0.01, K2 = 0.03, data range 2 for float
+// images, mean over the (H-6)x(W-6) window positions that lie inside the image; PSNR with data range 1 when the
+// ground truth is non-negative (else 2).  One workgroup per (sample, channel) image, both images in LDS, window
+// sums in double.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eval_frames_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                          float* __restrict__ ssim, float* __restrict__ psnr, int H,
+                                                          int W) {
+    extern __shared__ __attribute__((aligned(16))) float img[];   // [2][H*W]
+    float* X = img;
+    float* Y = img + H * W;
+    __shared__ double red[3 * 4];
+    __shared__ float redmin[4];
+    const size_t base = (size_t)blockIdx.x * H * W;
+    double se = 0.0;
+    float mn = 3.4e38f;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const float a = gt[base + i], b = pred[base + i];
+        X[i] = a;
+        Y[i] = b;
+        const double d = (double)a - (double)b;
+        se += d * d;
+        mn = fminf(mn, a);
+    }
+    __syncthreads();
+    constexpr int WIN = 7;
+    const int Ho = H - WIN + 1, Wo = W - WIN + 1;
+    const double NP = WIN * WIN, cov_norm = NP / (NP - 1.0);
+    const double C1 = (0.01 * 2.0) * (0.01 * 2.0), C2 = (0.03 * 2.0) * (0.03 * 2.0);
+    double ssum = 0.0;
+    for (int o = threadIdx.x; o < Ho * Wo; o += 256) {
+        const int oy = o / Wo, ox = o % Wo;
+        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dy = 0; dy < WIN; ++dy) {
+            const float* xr = X + (oy + dy) * W + ox;
+            const float* yr = Y + (oy + dy) * W + ox;
+#pragma unroll
+            for (int dx = 0; dx < WIN; ++dx) {
+                const double a = xr[dx], b = yr[dx];
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        }
+        const double ux = sx / NP, uy = sy / NP;
+        const double vx = cov_norm * (sxx / NP - ux * ux), vy = cov_norm * (syy / NP - uy * uy);
+        const double vxy = cov_norm * (sxy / NP - ux * uy);
+        ssum += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+    // workgroup reduction (fixed order)
+    for (int off = 32; off > 0; off >>= 1) {
+        ssum += __shfl_xor(ssum, off);
+        se += __shfl_xor(se, off);
+        mn = fminf(mn, __shfl_xor(mn, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave] = ssum;
+        red[4 + wave] = se;
+        redmin[wave] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = (red[0] + red[1]) + (red[2] + red[3]);
+        const double e = (red[4] + red[5]) + (red[6] + red[7]);
+        const float m = fminf(fminf(redmin[0], redmin[1]), fminf(redmin[2], redmin[3]));
+        ssim[blockIdx.x] = (float)(s / ((double)Ho * Wo));
+        const double range = m >= 0.f ? 1.0 : 2.0;
+        const double mse = e / ((double)H * W);
+        psnr[blockIdx.x] = (float)(10.0 * log10(range * range / mse));   // +inf for identical images, like skimage
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -315,4 +390,22 @@ extern "C" int dvg_bn_act_apply(const float* u, const float* scale, const float*
                            shift, y, n4, C / 4, act, slope);
     }
     return check_launch("dvg_bn_act_apply");
+}
+
+extern "C" int dvg_eval_frames(const float* gt, const float* pred, float* ssim, float* psnr, int n_images, int H, int W,
+                               void* stream) {
+    DVG_REQUIRE(gt && pred && ssim && psnr, DVG_ERR_NULL, "dvg_eval_frames: NULL pointer");
+    DVG_REQUIRE(n_images > 0 && H >= 7 && W >= 7, DVG_ERR_SHAPE, "dvg_eval_frames: images must be at least 7x7");
+    const size_t lds = (size_t)2 * H * W * sizeof(float);
+    DVG_REQUIRE(lds <= 150 * 1024, DVG_ERR_SHAPE, "dvg_eval_frames: %dx%d does not fit the LDS tile", H, W);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_frames_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(eval_frames_kernel, dim3(n_images), dim3(256), lds, (hipStream_t)stream, gt, pred, ssim, psnr, H,
+                       W);
+    return check_launch("dvg_eval_frames");
 }

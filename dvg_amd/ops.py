@@ -635,3 +635,19 @@ def convT_last_two_step(x, skip, w, bias, nc, ks, *, act):
     _run("convT_gather", 0.0, 4.0 * (d1.numel() * (2 if skip is not None else 1) + y.numel()), lib().dvg_convT_gather,
          _p(d1), _p(d2), _p(bias), _p(y), ks, n, h, wd, nc, act, _stream())
     return y
+
+
+def eval_frames(gt, pred):
+    """(ssim, psnr), each (B,), of a predicted NCHW frame batch against the ground truth: per-channel skimage-style
+    metrics (dvg_eval_frames) averaged over channels as utils.eval_seq does (utils.py:227-232)."""
+    _dev_f32(gt, "eval_frames.gt")
+    _dev_f32(pred, "eval_frames.pred")
+    if gt.shape != pred.shape or gt.dim() != 4:
+        raise RuntimeError(f"eval_frames: shapes {tuple(gt.shape)} vs {tuple(pred.shape)}")
+    gt = gt if gt.is_contiguous() else gt.contiguous()
+    pred = pred if pred.is_contiguous() else pred.contiguous()
+    b, c, h, w = gt.shape
+    out = torch.empty((2, b, c), device=gt.device, dtype=torch.float32)
+    _run("eval_frames", 0.0, 8.0 * gt.numel(), lib().dvg_eval_frames, _p(gt), _p(pred), _p(out[0]), _p(out[1]), b * c, h,
+         w, _stream())
+    return out[0].mean(1), out[1].mean(1)

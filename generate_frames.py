@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import utils  # noqa: E402
+from dvg_amd import ops  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
 from dvg_amd.rollout import posterior_rollout, sample_rollout  # noqa: E402
 from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
@@ -62,12 +63,6 @@ def build_parser():
     return p
 
 
-def psnr(gt: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
-    """Per-sample PSNR (data range 1) over (C,H,W): the on-device stand-in for utils.eval_seq's psnr_metric."""
-    mse = ((gt - pred) ** 2).flatten(1).mean(1).clamp_min(1e-12)
-    return 10.0 * torch.log10(1.0 / mse)
-
-
 class Generator:
     def __init__(self, opt, ckpt, device):
         self.opt, self.dev = opt, device
@@ -90,16 +85,18 @@ class Generator:
         post = posterior_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood, x,
                                  opt.n_past, opt.n_eval, opt.last_frame_skip)
         B, T = x[0].shape[0], opt.n_eval - opt.n_past
-        score = torch.zeros(B, nsample, T, device=self.dev)
+        ssim = torch.zeros(B, nsample, T, device=self.dev)
+        psnr = torch.zeros(B, nsample, T, device=self.dev)
         all_gen = []
         for s in range(nsample):
             frames = sample_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood,
                                     x, opt.n_past, opt.n_eval, opt.last_frame_skip)
-            for t in range(T):
-                score[:, s, t] = psnr(x[opt.n_past + t], frames[opt.n_past + t])
+            for t in range(T):   # utils.eval_seq (generate_frames.py:178) on device: dvg_eval_frames
+                ssim[:, s, t], psnr[:, s, t] = ops.eval_frames(x[opt.n_past + t], frames[opt.n_past + t])
             all_gen.append(torch.stack(frames))
-        best = score.mean(2).argsort(1)[:, -1]   # generate_frames.py:188-189,207: np.argsort(mean)[-1]
-        return {'posterior': torch.stack(post), 'samples': torch.stack(all_gen), 'psnr': score, 'best': best}
+        best = ssim.mean(2).argsort(1)[:, -1]   # generate_frames.py:188-189,207: np.argsort(mean_ssim)[-1]
+        return {'posterior': torch.stack(post), 'samples': torch.stack(all_gen), 'ssim': ssim, 'psnr': psnr,
+                'best': best}
 
     @torch.no_grad()
     def _generation(self, x_in, skip):
@@ -192,10 +189,12 @@ def main(argv=None):
         else:
             res = gen.make_gifs(test_x, args.nsample)
             torch.save({'posterior': res['posterior'][:, 0].cpu(), 'best': res['best'].cpu(), 'psnr': res['psnr'].cpu(),
+                        'ssim': res['ssim'].cpu(),
                         'best_sample_0': res['samples'][int(res['best'][0]), :, 0].cpu()},
                        '%s/gen/sample_lstm_%d.pt' % (opt.log_dir, i))
-            print('batch %d: mean PSNR of best-of-%d %.3f dB' % (
-                i, args.nsample, float(res['psnr'].mean(2).max(1).values.mean())))
+            sel = res['best'].view(-1, 1, 1).expand(-1, 1, res['ssim'].shape[2])
+            print('batch %d: best-of-%d by mean SSIM: SSIM %.4f, PSNR %.3f dB' % (
+                i, args.nsample, float(res['ssim'].gather(1, sel).mean()), float(res['psnr'].gather(1, sel).mean())))
 
 
 if __name__ == '__main__':

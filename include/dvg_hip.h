@@ -336,6 +336,13 @@ int dvg_wgrad_thin_rows(int ks, int N, int Hi, int Wi);
 int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, float* partial, int ks, int N,
                    int Hi, int Wi, int nc, int C, void* stream);
 
+/* Evaluation metrics of utils.eval_seq (utils.py:220-234): per (sample, channel) image, SSIM as
+ * skimage.measure.compare_ssim computes it with its defaults (7x7 uniform window, sample covariance, data range 2
+ * for float images, mean over the valid window positions) and PSNR as compare_psnr (data range 1 for non-negative
+ * ground truth).  gt / pred: n_images contiguous HxW fp32 images (an NCHW frame batch is B*C of them). */
+int dvg_eval_frames(const float* gt, const float* pred, float* ssim, float* psnr, int n_images, int H, int W,
+                    void* stream);
+
 /* Fused Adam step over one flat parameter group (train.py:95-106: torch.optim.Adam(lr=0.002) with default
  * betas (0.9, 0.999) and eps 1e-8; torch.optim.Adam arithmetic, non-amsgrad): param / exp_avg / exp_avg_sq are
  * updated in place, `step` is the 1-based step count used for the bias corrections. */

@@ -328,3 +328,57 @@ def rollout(x: Sequence[torch.Tensor], enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd:
                 x_in = dec(h_pred, skip)
         frames.append(x_in)
     return frames
+
+
+# --------------------------------------------------------------------------------------
+# Evaluation metrics of utils.eval_seq (utils.py:220-234)
+#
+# The reference calls skimage.measure.compare_ssim / compare_psnr (utils.py:13-14).  scikit-image is a third-party
+# dependency that is neither vendored in /root/reference nor pinned by any manifest (the `compare_*` names exist up
+# to skimage 0.15) and is not installed in this image, so this is a restatement of its PUBLISHED algorithm with the
+# defaults the reference relies on - **parity unpinned** for these two functions (no reference golden vectors):
+#   compare_ssim(X, Y): float64; win_size 7; uniform_filter means; sample covariance (cov_norm = NP/(NP-1));
+#     K1 = 0.01, K2 = 0.03; data_range = dtype range of float images = 2; mean of S over the image cropped by
+#     (win_size-1)//2 on every side.
+#   compare_psnr(true, test): data_range = 1 if true.min() >= 0 else 2 (float images); 10 log10(R^2 / mse).
+# --------------------------------------------------------------------------------------
+def ssim_skimage(x, y) -> float:
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    win, k1, k2, rng = 7, 0.01, 0.03, 2.0
+    npix = win * win
+    cov_norm = npix / (npix - 1.0)
+    ux, uy = uniform_filter(x, size=win), uniform_filter(y, size=win)
+    uxx, uyy, uxy = uniform_filter(x * x, size=win), uniform_filter(y * y, size=win), uniform_filter(x * y, size=win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    pad = (win - 1) // 2
+    return float(s[pad:-pad, pad:-pad].mean())
+
+
+def psnr_skimage(true, test) -> float:
+    import numpy as np
+    true = np.asarray(true, dtype=np.float64)
+    test = np.asarray(test, dtype=np.float64)
+    rng = 1.0 if true.min() >= 0 else 2.0
+    mse = np.mean((true - test) ** 2)
+    return float(10.0 * np.log10(rng * rng / mse))
+
+
+def eval_seq(gt: Sequence[torch.Tensor], pred: Sequence[torch.Tensor]):
+    """utils.eval_seq (utils.py:220-234): (ssim, psnr) arrays (B, T), channel-averaged."""
+    import numpy as np
+    T, bs = len(gt), gt[0].shape[0]
+    ssim, psnr = np.zeros((bs, T)), np.zeros((bs, T))
+    for i in range(bs):
+        for t in range(T):
+            nc = gt[t][i].shape[0]
+            for c in range(nc):
+                ssim[i, t] += ssim_skimage(gt[t][i][c].numpy(), pred[t][i][c].numpy())
+                psnr[i, t] += psnr_skimage(gt[t][i][c].numpy(), pred[t][i][c].numpy())
+            ssim[i, t] /= nc
+            psnr[i, t] /= nc
+    return ssim, psnr

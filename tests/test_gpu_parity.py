@@ -355,3 +355,20 @@ def test_skip_tensors_are_not_recycled():
         for _ in range(3):
             enc(torch.rand_like(x).to(dev()))
     assert all(torch.equal(a, b) for a, b in zip(s1, keep))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 1, 64, 64), (2, 3, 128, 128), (2, 2, 9, 23)])
+def test_eval_frames(B, C, H, W):
+    """dvg_eval_frames (SSIM + PSNR of utils.eval_seq) against the oracle's float64 restatement of skimage."""
+    from dvg_amd import ops
+    gt = [(0.5 + 0.25 * params.normal(80 + t, B, C, H, W)).clamp(0, 1) for t in range(2)]
+    pred = [(g + 0.1 * params.normal(90 + t, B, C, H, W)).clamp(0, 1) for t, g in enumerate(gt)]
+    pred[1][0] = gt[1][0] * 0.5            # a structured error too
+    s_ref, p_ref = orc.eval_seq(gt, pred)
+    for t in range(2):
+        s, p = ops.eval_frames(gt[t].to(dev()), pred[t].to(dev()))
+        np.testing.assert_allclose(s.cpu().numpy(), s_ref[:, t], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref[:, t], rtol=2e-5, atol=2e-5)
+    neg = (gt[0] - 0.5).to(dev())          # negative ground truth -> data range 2 (dcgan Tanh frames)
+    s, p = ops.eval_frames(neg, neg + 0.01)
+    assert abs(float(p[0]) - 10 * np.log10(4 / 1e-4)) < 1e-2
