@@ -31,8 +31,10 @@ def _dp_worker(rank, world, port, q):
     local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
     red = parallel.FlatGradReducer(net.parameters())
     red.reduce()
-    out = {"rank": r, "world": w, "params": [p.detach().clone() for p in net.parameters()],
-           "local": local, "reduced": [None if p.grad is None else p.grad.clone() for p in net.parameters()],
+    # plain numpy through the queue: torch tensors travel by file descriptor, which races with this process exiting
+    npy = lambda t: None if t is None else t.detach().numpy().copy()  # noqa: E731
+    out = {"rank": r, "world": w, "params": [npy(p) for p in net.parameters()],
+           "local": [npy(g) for g in local], "reduced": [npy(p.grad) for p in net.parameters()],
            "shard": parallel.shard_batch(128, w)}
     q.put(out)
     dist.barrier()
@@ -51,6 +53,9 @@ def test_flat_grad_allreduce_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     a, b = res
+    for d in (a, b):
+        for k in ("params", "local", "reduced"):
+            d[k] = [None if v is None else torch.from_numpy(v) for v in d[k]]
     assert a["world"] == 2 and a["shard"] == 64
     for pa, pb in zip(a["params"], b["params"]):
         assert torch.equal(pa, pb), "broadcast_parameters must make the replicas identical"
