@@ -298,6 +298,34 @@ __global__ __launch_bounds__(256) void eval_frames_kernel(const float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// moving_mnist_compose: the compositing step of data/moving_mnist.py:86-90 (x[t, sy:sy+32, sx:sx+32, 0] += digit
+// per digit in order, then x[x > 1] = 1) written straight into the (T,B,1,S,S) layout utils.normalize_data
+// produces (utils.py:86-95).  The integer trajectories (bounce rules, RNG order) stay on the host; this is the
+// byte-moving part.  One thread per output pixel, digits summed in index order (bit-exact with the host loop).
+// ------------------------------------------------------------------------------------
+__global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, const int* __restrict__ ids,
+                                            const int* __restrict__ pos, float* __restrict__ out, int T, int B,
+                                            int ND, int S, int D) {
+    const long total = (long)T * B * S * S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S);
+        long r = i / S;
+        const int y = (int)(r % S); r /= S;
+        const int b = (int)(r % B);
+        const int t = (int)(r / B);
+        float v = 0.f;
+        for (int d = 0; d < ND; ++d) {
+            const int* pp = pos + (((size_t)b * ND + d) * T + t) * 2;
+            const int yy = y - pp[0], xx = x - pp[1];
+            if ((unsigned)yy < (unsigned)D && (unsigned)xx < (unsigned)D)
+                v += sprites[((size_t)ids[b * ND + d] * D + yy) * D + xx];
+        }
+        out[i] = v > 1.f ? 1.f : v;
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -408,4 +436,16 @@ extern "C" int dvg_eval_frames(const float* gt, const float* pred, float* ssim, 
     hipLaunchKernelGGL(eval_frames_kernel, dim3(n_images), dim3(256), lds, (hipStream_t)stream, gt, pred, ssim, psnr, H,
                        W);
     return check_launch("dvg_eval_frames");
+}
+
+extern "C" int dvg_moving_mnist_compose(const float* sprites, const int* ids, const int* pos, float* out, int n_sprites,
+                                        int T, int B, int num_digits, int image_size, int digit_size, void* stream) {
+    DVG_REQUIRE(sprites && ids && pos && out, DVG_ERR_NULL, "dvg_moving_mnist_compose: NULL pointer");
+    DVG_REQUIRE(n_sprites > 0 && T > 0 && B > 0 && num_digits > 0 && digit_size > 0 && image_size >= digit_size,
+                DVG_ERR_SHAPE, "dvg_moving_mnist_compose: bad shape");
+    // ids / pos are validated on the host by the caller (dvg_amd/data.py: 0 <= id < n_sprites, 0 <= pos <= S - D)
+    const long total = (long)T * B * image_size * image_size;
+    hipLaunchKernelGGL(moving_mnist_compose_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       sprites, ids, pos, out, T, B, num_digits, image_size, digit_size);
+    return check_launch("dvg_moving_mnist_compose");
 }

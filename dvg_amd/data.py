@@ -40,11 +40,14 @@ class SyntheticMovingMNIST:
     def __len__(self):
         return 10000
 
-    def __getitem__(self, index):
+    def _trajectory(self):
+        """One sample's RNG draws in the order of moving_mnist.py:43-85: per digit the sprite index, the start and
+        the velocity, then the per-frame bounce rules.  Returns (ids (num_digits,), pos (num_digits, T, 2) = (sy, sx))."""
         rng, S, D = self.rng, self.image_size, self.digit_size
-        x = np.zeros((self.seq_len, S, S, 1), np.float32)
-        for _ in range(self.num_digits):
-            digit = self.data[rng.integers(self.N)]
+        ids = np.zeros(self.num_digits, np.int32)
+        pos = np.zeros((self.num_digits, self.seq_len, 2), np.int32)
+        for n in range(self.num_digits):
+            ids[n] = rng.integers(self.N)
             sx, sy = int(rng.integers(S - D)), int(rng.integers(S - D))
             dx, dy = int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
             for t in range(self.seq_len):
@@ -72,11 +75,39 @@ class SyntheticMovingMNIST:
                         dx = -dx
                     else:
                         dx, dy = int(rng.integers(-4, 0)), int(rng.integers(-4, 5))
-                x[t, sy:sy + D, sx:sx + D, 0] += digit
+                pos[n, t] = (sy, sx)
                 sy += dy
                 sx += dx
+        return ids, pos
+
+    def __getitem__(self, index):
+        S, D = self.image_size, self.digit_size
+        ids, pos = self._trajectory()
+        x = np.zeros((self.seq_len, S, S, 1), np.float32)
+        for n in range(self.num_digits):
+            digit = self.data[ids[n]]
+            for t in range(self.seq_len):
+                sy, sx = pos[n, t]
+                x[t, sy:sy + D, sx:sx + D, 0] += digit
         x[x > 1] = 1.0
         return x
+
+    def batch_device(self, batch_size: int, device) -> list:
+        """The same batch as `utils.normalize_data(opt, dtype, self.batch(batch_size))` - bit for bit, given the same
+        generator state - composited on the GPU (dvg_moving_mnist_compose) straight into the T x (B,1,S,S) layout:
+        only the integer trajectories (a few KB) cross PCIe."""
+        from . import ops
+        trajs = [self._trajectory() for _ in range(batch_size)]
+        ids = np.stack([t[0] for t in trajs])
+        pos = np.stack([t[1] for t in trajs])
+        lim = self.image_size - self.digit_size
+        if ids.min() < 0 or ids.max() >= self.N or pos.min() < 0 or pos.max() > lim:
+            raise RuntimeError("SyntheticMovingMNIST: trajectory outside the canvas")
+        if getattr(self, "_dev_sprites", None) is None or self._dev_sprites.device != torch.device(device):
+            self._dev_sprites = torch.from_numpy(self.data).to(device)
+        out = ops.moving_mnist_compose(self._dev_sprites, torch.from_numpy(ids).to(device),
+                                       torch.from_numpy(pos).to(device), self.seq_len, self.image_size)
+        return [out[t] for t in range(self.seq_len)]
 
     def batch(self, batch_size: int) -> torch.Tensor:
         return torch.from_numpy(np.stack([self[i] for i in range(batch_size)]))  # (B,T,H,W,1)

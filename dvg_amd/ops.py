@@ -651,3 +651,18 @@ def eval_frames(gt, pred):
     _run("eval_frames", 0.0, 8.0 * gt.numel(), lib().dvg_eval_frames, _p(gt), _p(pred), _p(out[0]), _p(out[1]), b * c, h,
          w, _stream())
     return out[0].mean(1), out[1].mean(1)
+
+
+def moving_mnist_compose(sprites, ids, pos, seq_len, image_size):
+    """(T,B,1,S,S) frames from sprites (N,D,D), ids (B,ND) int32 and pos (B,ND,T,2) int32 (dvg_moving_mnist_compose)."""
+    _dev_f32(sprites, "moving_mnist_compose.sprites")
+    if ids.dtype != torch.int32 or pos.dtype != torch.int32 or not ids.is_cuda or not pos.is_cuda:
+        raise RuntimeError("moving_mnist_compose: ids / pos must be int32 device tensors")
+    ids, pos, sprites = ids.contiguous(), pos.contiguous(), sprites.contiguous()
+    b, nd = ids.shape
+    if tuple(pos.shape) != (b, nd, seq_len, 2):
+        raise RuntimeError(f"moving_mnist_compose: pos shape {tuple(pos.shape)}")
+    out = torch.empty((seq_len, b, 1, image_size, image_size), device=sprites.device, dtype=torch.float32)
+    check(lib().dvg_moving_mnist_compose(_p(sprites), _p(ids), _p(pos), _p(out), sprites.shape[0], seq_len, b, nd,
+                                         image_size, sprites.shape[1], _stream()), "dvg_moving_mnist_compose")
+    return out

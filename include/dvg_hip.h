@@ -336,6 +336,13 @@ int dvg_wgrad_thin_rows(int ks, int N, int Hi, int Wi);
 int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, float* partial, int ks, int N,
                    int Hi, int Wi, int nc, int C, void* stream);
 
+/* Compositing step of the Moving-MNIST generator (data/moving_mnist.py:86-90) fused with the layout change of
+ * utils.normalize_data (utils.py:86-95): out (T,B,1,S,S) = min(1, sum_d sprite[ids[b,d]] placed at pos[b,d,t] =
+ * (sy,sx)), digits added in index order.  sprites (n_sprites,D,D) fp32; ids (B,num_digits) int32; pos
+ * (B,num_digits,T,2) int32 with 0 <= sy,sx <= S-D (the host computes the trajectories, moving_mnist.py:49-85). */
+int dvg_moving_mnist_compose(const float* sprites, const int* ids, const int* pos, float* out, int n_sprites, int T,
+                             int B, int num_digits, int image_size, int digit_size, void* stream);
+
 /* Evaluation metrics of utils.eval_seq (utils.py:220-234): per (sample, channel) image, SSIM as
  * skimage.measure.compare_ssim computes it with its defaults (7x7 uniform window, sample covariance, data range 2
  * for float images, mean over the valid window positions) and PSNR as compare_psnr (data range 1 for non-negative
