@@ -145,6 +145,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from dvg_amd import fused as fused_mod
     from dvg_amd import ops, utils
     from dvg_amd.data import SyntheticMovingMNIST
     from dvg_amd.rollout import GraphedRollout, sample_rollout
@@ -196,7 +197,10 @@ def main():
                                f"{args.n_past}-in/{args.n_future}-out", "model_family": args.model,
                    "batch_per_gpu": args.batch, "n_past": args.n_past, "n_future": args.n_future,
                    "parallelism": f"replicas x{world} (no data-path collective)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+                   "launch": "eager" if args.no_graph else "hipGraph replay",
+                   # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's
+                   # first conv is computed once per rollout and added in the epilogue (DVG_SKIP_HOIST=0: recompute)
+                   "loop_invariant_skip_halves": "hoisted" if fused_mod.SKIP_HOIST else "recomputed every step"},
     }
 
     if rank == 0:

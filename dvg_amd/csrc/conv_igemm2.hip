@@ -51,6 +51,7 @@ struct Igemm2Params {
     int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
     int cps;     // K chunks (of 16 channels) per split
     float* ws;   // [splitk][N*Ho*Wo][Cout]
+    const float* addend;  // optional raw (pre-scale) partial sums, NHWC like y: y = act((acc + addend) * scale + shift)
     unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
 };
 
@@ -347,15 +348,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     // and addresses are a per-workgroup 64-bit base plus 32-bit per-value offsets.
     float* const yb = p.y + (size_t)n0 * Ho * Wo * p.Cout + c;
     float* const pb = p.y_pool ? p.y_pool + (size_t)n0 * (Ho >> 1) * (Wo >> 1) * p.Cout + c : nullptr;
+    const float* const ab = p.addend ? p.addend + (size_t)n0 * Ho * Wo * p.Cout + c : nullptr;
     auto epilogue = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;  // -1: generic (runtime p.act)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
             const int mbase = wm * (C::BM / 2) + mt * 32;
             const int ti0 = mbase / (TH * TW);
+            if (ab != nullptr) {
+                // hoisted skip half of a decoder conv (fused.py): raw partial sums of the loop-invariant input
+                float av[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
+                    const int r = m % (TH * TW);
+                    const int ty = r / TW, tx = r % TW;
+                    int oy, ox;
+                    if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+                    else { oy = y0 + ty; ox = x0 + tx; }
+                    av[reg] = (TI == 1 || n0 + tii < p.N) ? ab[((tii * Ho + oy) * Wo + ox) * p.Cout] : 0.f;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] = (acc[mt][reg] + av[reg]) * sc + sf;
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
@@ -727,7 +747,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             const float* __restrict__ shift, float* __restrict__ y,
                                                             float* __restrict__ y_pool, float* __restrict__ stats, int N,
                                                             int H, int W, int C, int act, float slope,
-                                                            int units_per_block) {
+                                                            int units_per_block, const float* __restrict__ addend) {
     __shared__ float red[2 * 256 * 4];
     const int C4 = C >> 2;
     const int TC = C4 < 256 ? C4 : 256, TP = 256 / TC;
@@ -756,6 +776,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             f32x4 v = reinterpret_cast<const f32x4*>(ws)[off];
             for (int s = 1; s < S; ++s) {
                 const f32x4 t = reinterpret_cast<const f32x4*>(ws)[(size_t)s * slab4 + off];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += t[k];
+            }
+            if (addend != nullptr) {   // hoisted skip half: one more (loop-invariant) partial slab
+                const f32x4 t = reinterpret_cast<const f32x4*>(addend)[off];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] += t[k];
             }
@@ -856,10 +881,10 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
         const unsigned fgrid = (unsigned)((units + upb - 1) / upb);
         if (pool)
             hipLaunchKernelGGL((splitk_finish_kernel<true>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
-                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb);
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend);
         else
             hipLaunchKernelGGL((splitk_finish_kernel<false>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
-                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb);
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend);
         return check_launch("splitk_finish");
     }
     return DVG_OK;
@@ -1011,13 +1036,16 @@ static int checks2(const Igemm2Params& p, const char* who) {
 extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                      const float* shift, float* y, float* y_pool, float* stats, int N, int H, int W,
                                      int C1, int C2, int Cout, int upsample_x, int act, float slope,
-                                     float* workspace, long workspace_floats, void* stream) {
+                                     float* workspace, long workspace_floats, const float* addend, void* stream) {
     Igemm2Params p{x, skip, w_k16, scale, shift, y, y_pool, stats, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, act, slope,
                    0, 0, 0, 0, 0, 1, 0, nullptr};
+    p.addend = addend;
     if (int e = checks2(p, "dvg_conv3x3_bn_act_v2")) return e;
+    DVG_REQUIRE(aligned16(addend) && (addend == nullptr || (y_pool == nullptr && stats == nullptr)), DVG_ERR_SHAPE,
+                "dvg_conv3x3_bn_act_v2: addend must be 16-byte aligned and excludes pool / statistics outputs");
     DVG_REQUIRE(H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: H=%d W=%d must be multiples of 8", H, W);
     int Hg = H, Wg = W, ti, th, tw;
-    if (g_schedule == 3 && tile3(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0) {
+    if (g_schedule == 3 && addend == nullptr && tile3(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0) {
         D3(M2_CONV3, 1, 16, 16)
         D3(M2_CONV3, 1, 8, 16)
         D3(M2_CONV3, 2, 8, 8)
@@ -1047,10 +1075,13 @@ extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const
 extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                         const float* shift, float* y, float* stats, int N, int H, int W, int C1,
                                         int C2, int Cout, int act, float slope, float* workspace, long workspace_floats,
-                                        void* stream) {
+                                        const float* addend, void* stream) {
     Igemm2Params p{x, skip, w_k16, scale, shift, y, nullptr, stats, N, H, W, C1, C2, Cout, 0, act, slope, 0, 0, 0, 0, 0,
                    1, 0, nullptr};
+    p.addend = addend;
     if (int e = checks2(p, "dvg_convT4x4s2_bn_act_v2")) return e;
+    DVG_REQUIRE(aligned16(addend) && (addend == nullptr || stats == nullptr), DVG_ERR_SHAPE,
+                "dvg_convT4x4s2_bn_act_v2: addend must be 16-byte aligned and excludes the statistics output");
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_CONVT4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,
                 "dvg_convT4x4s2_bn_act_v2: unsupported map %dx%d", H, W);

@@ -14,6 +14,7 @@ BN + activation (+ 2x2 max-pool) in one elementwise pass.
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -110,16 +111,91 @@ def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
 # --------------------------------------------------------------------------------------
 # blocks (forward).  x / skip are NHWC-in-memory; outputs likewise.
 # --------------------------------------------------------------------------------------
+
+# ---- loop-invariant skip halves -----------------------------------------------------------------------
+# In a rollout the skip tensors are frozen after the conditioning frames (generate_frames.py:154-157), so in the first
+# conv of every decoder block, conv(cat([up(d), skip])) = conv(up(d), W[:, :C1]) + conv(skip, W[:, C1:]), the second
+# term is the same at every prediction step.  When a block sees the SAME skip tensor object (same version) for the
+# second time it computes S = conv(skip, W_skip) once (raw accumulators) and from then on runs only the x half with S
+# as `addend` - identical maths up to fp32 summation order, half the K loop.  A skip that changes on every call
+# (training, last_frame_skip) never gets there and pays nothing.  DVG_SKIP_HOIST=0 disables it.
+SKIP_HOIST = os.environ.get("DVG_SKIP_HOIST", "1") != "0"
+_skip_seen = {}      # (id(conv), id(skip)) -> [weakref(skip), skip._version, weight key, sightings, S or None]
+
+
+_frozen = {}         # id(skip) -> (weakref(skip), version): declared loop-invariant by the caller
+
+
+def clear_skip_hoist_cache():
+    _skip_seen.clear()
+    _frozen.clear()
+
+
+def declare_frozen_skips(skips) -> None:
+    """A rollout tells the decoder blocks that these skip tensors will not change for the remaining steps
+    (generate_frames.py:154-157: the skip is only refreshed while i < n_past): the first decoder call then already
+    computes and uses the hoisted skip halves instead of waiting for a second sighting."""
+    if not SKIP_HOIST:
+        return
+    for dead in [k for k, e in _frozen.items() if e[0]() is None]:
+        del _frozen[dead]
+    for s in skips:
+        _frozen[id(s)] = (weakref.ref(s), s._version)
+
+
+def _split_packed(conv, c1: int):
+    """Packed weights of the x half and the skip half of a concat conv, cached per parameter version."""
+    slot = _slot(conv)
+    key = (_ver(conv.weight), c1)
+    hit = slot.get("wp_split")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    w = conv.weight.detach()
+    tr = isinstance(conv, nn.ConvTranspose2d)
+    wx, wsk = (w[:c1], w[c1:]) if tr else (w[:, :c1], w[:, c1:])
+    px, ps = ops.pack_igemm_weight(wx.contiguous(), transposed=tr), ops.pack_igemm_weight(wsk.contiguous(), transposed=tr)
+    slot["wp_split"] = (key, px, ps)
+    return px, ps
+
+
+def _hoisted_skip(conv, x, skip, partial_fn):
+    """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
+    if not SKIP_HOIST or skip is None or ops.IGEMM_V != 2:
+        return None
+    k = (id(conv), id(skip))
+    wkey = _ver(conv.weight)
+    ent = _skip_seen.get(k)
+    if ent is None or ent[0]() is not skip or ent[1] != skip._version or ent[2] != wkey:
+        for dead in [kk for kk, e in _skip_seen.items() if e[0]() is None]:   # their S buffers can go
+            del _skip_seen[dead]
+        if len(_skip_seen) > 64:
+            _skip_seen.clear()
+        _skip_seen[k] = ent = [weakref.ref(skip), skip._version, wkey, 1, None]
+        fz = _frozen.get(id(skip))
+        if fz is None or fz[0]() is not skip or fz[1] != skip._version:
+            return None                    # first sighting of an undeclared skip: the ordinary fused concat conv
+    else:
+        ent[3] += 1
+    px, ps = _split_packed(conv, x.shape[1])
+    if ent[4] is None:
+        ent[4] = partial_fn(ps)            # second sighting: S = conv(skip, W_skip), raw accumulators
+    return px, ent[4]
+
+
 def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2):
     """vgg_layer (vgg_64.py:5-15) with optional fused cat/upsample on the input and
     fused 2x2 max-pool on the output."""
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("conv3", conv, bn, x, skip, upsample=upsample, pool=pool, act=act, slope=slope)
-    wp = packed_weight(conv)
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
-        return ops.conv3x3(x, skip, wp, sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
+        if not pool:
+            hs = _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE))
+            if hs is not None:
+                return ops.conv3x3(x, None, hs[0], sc, sh, upsample=upsample, act=act, slope=slope, addend=hs[1])
+        return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
+    wp = packed_weight(conv)
     u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,
                         act=ACT_NONE, stats=True)
     n, _, h, w = u.shape
@@ -178,10 +254,13 @@ def convT4s2_bn_act(conv, bn, x, skip=None, *, act=ACT_LRELU, slope=0.2):
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("convT4s2", conv, bn, x, skip, act=act, slope=slope)
-    wp = packed_weight(conv)
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
-        return ops.convT4x4s2(x, skip, wp, sc, sh, act=act, slope=slope)
+        hs = _hoisted_skip(conv, x, skip, lambda ps: ops.convT4x4s2(skip, None, ps, None, None, act=ACT_NONE))
+        if hs is not None:
+            return ops.convT4x4s2(x, None, hs[0], sc, sh, act=act, slope=slope, addend=hs[1])
+        return ops.convT4x4s2(x, skip, packed_weight(conv), sc, sh, act=act, slope=slope)
+    wp = packed_weight(conv)
     u, st = ops.convT4x4s2(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE,
                            stats=True)
     n, _, h, w = u.shape

@@ -194,7 +194,21 @@ def _stats_buf(rows: int, cout: int, device):
     return torch.empty((rows, 2, cout), device=device, dtype=torch.float32)
 
 
-def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0.2, pool=False, stats=False):
+def _check_addend(addend, y, excluded):
+    if addend is None:
+        return
+    if IGEMM_V != 2:
+        raise RuntimeError("addend needs the v2 igemm schedule")
+    if excluded:
+        raise RuntimeError("addend excludes pool / statistics outputs")
+    _dev_f32(addend, "addend")
+    if tuple(addend.shape) != tuple(y.shape) or addend.stride() != y.stride():
+        raise RuntimeError(f"addend {tuple(addend.shape)} must match the output {tuple(y.shape)} (NHWC in memory)")
+
+
+def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0.2, pool=False, stats=False,
+            addend=None):
+    """`addend`: raw partial sums in the output's NHWC shape, y = act((conv + addend) * scale + shift) (v2 only)."""
     _dev_f32(x, "conv3x3.x")
     assert is_nhwc(x), "conv3x3: x must be NHWC in memory"
     n, c1, hx, wx = x.shape
@@ -211,6 +225,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
+    _check_addend(addend, y, pool or stats)
     ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None)) \
@@ -221,7 +236,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
     if IGEMM_V == 2:
         _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
              _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _p(ws), 0 if ws is None else ws.numel(),
-             _stream())
+             _p(addend), _stream())
     else:
         _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
              _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _stream())
@@ -297,7 +312,7 @@ def conv4x4s2_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=
     return (y, st) if stats else y
 
 
-def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
+def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False, addend=None):
     _dev_f32(x, "convT4x4s2.x")
     assert is_nhwc(x)
     n, c1, h, w = x.shape
@@ -311,6 +326,7 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     if taps != 16 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
+    _check_addend(addend, y, stats)
     ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None)) \
@@ -320,7 +336,8 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     by = 4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel())
     if IGEMM_V == 2:
         _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
-             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
+             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _p(addend),
+             _stream())
     else:
         _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
              _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import fused, ops
 
 
 def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
@@ -63,6 +63,8 @@ def sample_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x: S
         h, sk = encoder(x_in)
         if last_frame_skip or i < n_past:
             skip = sk
+        if i == n_past and not last_frame_skip and not decoder.training:
+            fused.declare_frozen_skips(skip)    # frozen from here on: decoder blocks hoist their skip halves now
         if i < n_past:
             frame_predictor(h)
             x_in = x[i]
@@ -121,9 +123,11 @@ class GraphedRollout:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         ops.clear_skip_proj_cache()   # nothing cached eagerly may be referenced by the graph ...
+        fused.clear_skip_hoist_cache()
         with torch.cuda.graph(self.graph):
             self.frames = sample_rollout(*self._args, self.static_x, **self._kw)
         ops.clear_skip_proj_cache()   # ... and nothing from the graph's pool by later eager calls
+        fused.clear_skip_hoist_cache()
 
     def __call__(self, x: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
         if x is not None:

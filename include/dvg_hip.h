@@ -118,14 +118,19 @@ int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin,
 /* Split-K: when a layer would launch < 384 workgroups (deep, narrow layers; small per-GPU batches) and the caller
  * supplies `workspace` (>= dvg_conv_splitk_v2(...) * N*Ho*Wo*Cout floats), K is split over workgroups, raw partial
  * tiles go to the workspace and a finish kernel applies scale/shift/act (+pool, +statistics).  workspace may be
- * NULL (no split).  `stats` then has dvg_conv_stats_rows_v2(..., pool, with_workspace) rows.               */
+ * NULL (no split).  `stats` then has dvg_conv_stats_rows_v2(..., pool, with_workspace) rows.
+ * `addend` (may be NULL): raw pre-scale partial sums in y's NHWC shape, y = act((conv + addend) * scale + shift).
+ * It carries the skip half of a decoder block's first conv, cat([up(d), skip]) (vgg_64.py:98-105, dcgan_64.py:84-86),
+ * when the skip tensor is loop-invariant over the steps of a rollout (generate_frames.py:154-157): the caller
+ * computes conv(skip, W[:, C1:]) once with scale = shift = NULL, act = NONE and then runs only the x half per step.
+ * Excludes the pool / statistics outputs.                                                                    */
 int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout);
 int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, int Cout, int pool, int with_workspace);
 int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                           const float* scale, const float* shift, float* y, float* y_pool,
                           float* stats, int N, int H, int W, int C1, int C2, int Cout,
                           int upsample_x, int act, float slope, float* workspace,
-                          long workspace_floats, void* stream);
+                          long workspace_floats, const float* addend, void* stream);
 int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
                             const float* shift, float* y, float* stats, int N, int H, int W,
                             int Cin, int Cout, int act, float slope, float* workspace,
@@ -133,7 +138,7 @@ int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* sca
 int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                              const float* scale, const float* shift, float* y, float* stats,
                              int N, int H, int W, int C1, int C2, int Cout, int act, float slope,
-                             float* workspace, long workspace_floats, void* stream);
+                             float* workspace, long workspace_floats, const float* addend, void* stream);
 
 /* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
  * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.

@@ -390,3 +390,57 @@ def test_moving_mnist_device_compositing_is_bit_exact():
         # the generator state advanced identically: the next batches agree as well
         ref2, _ = utils.normalize_data(None, torch.cuda.FloatTensor, host.batch(2))
         assert all(torch.equal(a, b) for a, b in zip(ref2, devg.batch_device(2, dev())))
+
+
+@pytest.mark.parametrize("H,C1,C2,Cout,up", [(16, 64, 64, 64, True), (8, 32, 48, 128, False), (8, 512, 512, 256, True)])
+def test_conv3x3_addend_equals_concat_conv(H, C1, C2, Cout, up):
+    """conv(cat([up(x), skip])) == conv(up(x), W[:, :C1]) + conv(skip, W[:, C1:]) with the second term passed as the
+    raw `addend` of dvg_conv3x3_bn_act_v2 (incl. a split-K shape where the finish kernel adds it)."""
+    from dvg_amd import ops
+    N = 4
+    hx = H // 2 if up else H
+    x, sk = params.normal(100, N, C1, hx, hx), params.normal(101, N, C2, H, H)
+    w = params.normal(102, Cout, C1 + C2, 3, 3, scale=0.05)
+    sc, sh = 1 + 0.1 * params.normal(103, Cout), 0.1 * params.normal(104, Cout)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.leaky_relu(F.conv2d(torch.cat([xin, sk], 1).double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1) +
+                       sh.double().view(1, -1, 1, 1), 0.2)
+    wd = w.to(dev())
+    S = ops.conv3x3(nhwc(sk), None, ops.pack_igemm_weight(wd[:, C1:].contiguous()), None, None, act=ops.ACT_NONE)
+    y = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(wd[:, :C1].contiguous()), sc.to(dev()), sh.to(dev()),
+                    upsample=up, addend=S)
+    assert rel_err(y, ref) < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(wd[:, :C1].contiguous()), None, None, upsample=up,
+                    addend=S[:, :, :-1])
+
+
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_decoder_skip_hoisting_is_transparent(family):
+    """Calling the eval-mode decoder repeatedly with the SAME skip tensors (a rollout) engages the hoisted skip
+    halves from the second call on; every call still matches the oracle, a modified skip is recomputed, and
+    DVG_SKIP_HOIST semantics (fused.SKIP_HOIST = False) give the same frames."""
+    import importlib
+    from dvg_amd import fused
+    mod = importlib.import_module(f"dvg_amd.models.{family}_64")
+    torch.manual_seed(0)
+    enc, dec = mod.encoder(90, 1).to(dev()).eval(), mod.decoder(90, 1).to(dev()).eval()
+    x = params.frames(110, 4, 1, 64).to(dev())
+    with torch.no_grad():
+        h, skip = enc(x)
+        fused.clear_skip_hoist_cache()
+        fused.SKIP_HOIST = False
+        ref = [dec([h * s, skip]).clone() for s in (1.0, 0.5, -0.25, 0.75)]
+        fused.SKIP_HOIST = True
+        got = [dec([h * s, skip]).clone() for s in (1.0, 0.5, -0.25, 0.75)]
+        engaged = [e for e in fused._skip_seen.values() if e[4] is not None]
+        nblocks = 4 if family == "vgg" else 3   # dcgan's 4th concat layer is the last one (projection cache, ops.py)
+        assert len(engaged) == nblocks and all(e[3] == 4 for e in engaged), "concat blocks hoist from the 2nd call"
+        for a, b in zip(ref, got):
+            assert rel_err(b, a) < 1e-5
+        skip[0].mul_(0.5)                                    # in-place change of one skip tensor
+        fused.SKIP_HOIST = False
+        ref2 = dec([h, skip]).clone()
+        fused.SKIP_HOIST = True
+        assert rel_err(dec([h, skip]), ref2) < 1e-5          # first sighting of the new version: ordinary path
+        assert rel_err(dec([h, skip]), ref2) < 1e-5          # second: recomputed S
