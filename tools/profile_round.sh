@@ -1,15 +1,23 @@
 #!/bin/bash
 # Collect the round's rocprof evidence on the GPU box (run through gpurun from the repo root):
-#   kernel-trace stats of the default bench, then three separate PMC passes (no trace domains mixed in).
-# Outputs under gpurun_out/prof_round/; tools/pmc_summary.py turns them into profiles/*.
+#   kernel-trace stats of the default bench (vgg_64) and of dcgan_64 and one training iteration, then three separate
+#   PMC passes (no trace domains mixed in).  Outputs under gpurun_out/prof_round/; tools/pmc_summary.py + the
+#   snippet in DESIGN.md section 5 turn them into profiles/*.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_round
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o vgg -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dcgan -o dcgan -- python3 bench.py --model dcgan --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_dcgan_under_rocprof.log 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o train -- python3 tools/bench_train.py --model vgg --iters 2 > $out/train_vgg_under_rocprof.log 2>&1 < /dev/null
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$tag -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $out/pmc_$tag.log 2>&1 < /dev/null
 done
-find $out -name "*.csv" | head -20
-tail -1 $out/bench_under_rocprof.log | cut -c1-300
+timeout 300 python3 bench.py > $out/bench_vgg.json 2> $out/bench_vgg.err < /dev/null
+timeout 200 python3 bench.py --model dcgan > $out/bench_dcgan.json 2> $out/bench_dcgan.err < /dev/null
+timeout 300 python3 tools/bench_train.py --model vgg --iters 3 2>/dev/null | grep ms_per_iter > $out/train_vgg.json < /dev/null
+timeout 300 python3 tools/bench_train.py --model dcgan --iters 3 2>/dev/null | grep ms_per_iter > $out/train_dcgan.json < /dev/null
+rm -f $out/*/*kernel_trace.csv   # large; the stats / counter files are what gets kept
+ls -la $out $out/stats | head -40
+tail -c 300 $out/bench_vgg.json
