@@ -98,7 +98,7 @@ class Trainer:
         # discards); kept only so that tests can show both ways give the same updates
         self.finetune_encoder_grad = False
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group
-        Adam = FusedAdam if device.type == 'cuda' else torch.optim.Adam
+        Adam = FusedAdam   # HIP only, like the models themselves: no CPU fallback on the product path
         self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002)
         self.encoder_optimizer = Adam(self.encoder.parameters(), lr=0.002)
         self.decoder_optimizer = Adam(self.decoder.parameters(), lr=0.002)
