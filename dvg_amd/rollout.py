@@ -92,6 +92,8 @@ def posterior_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x
         h, sk = encoder(x_in)
         if last_frame_skip or i < n_past:
             skip = sk
+        if i == n_past and not last_frame_skip and not decoder.training:
+            fused.declare_frozen_skips(skip)
         if i < n_past:
             frame_predictor(h)
             x_in = x[i]
