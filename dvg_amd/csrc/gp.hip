@@ -14,6 +14,8 @@
 
 namespace dvg {
 
+static unsigned long long* g_gp_clk = nullptr;  // debug only (dvg_debug_set_gp_clockbuf): phase stamps per workgroup
+
 struct GpParams {
     const float* h;         // [B][D]
     const float* z;         // [D][M]
@@ -31,6 +33,7 @@ struct GpParams {
     float* kl;           // [D]
     int B, D, M, train_mode;
     float jitter;
+    unsigned long long* clk;  // debug only
 };
 
 // In-place lower Cholesky of the n x n matrix A (row stride ld) by ONE wave:
@@ -79,6 +82,92 @@ __device__ void wave_cholesky(float* A, int n, int ld, int lane) {
     }
 }
 
+// In-place lower Cholesky of the n x n matrix A (row stride ld, n <= 128) by the WHOLE 256-thread workgroup:
+// right-looking in panels of 8 columns.  The panel (8 columns, all rows below) is factored by wave 0 with dot
+// products of at most 7 terms; the trailing matrix gets its rank-8 update from all 256 threads (thread = one row x
+// a strided set of columns, the row's panel entries in registers, the column's broadcast from LDS; the panel
+// itself is factored in registers with uniform-lane shuffles).  The
+// wave-serial left-looking version (wave_cholesky, kept for the backward kernel's concurrent phases) spent 242 K
+// cycles on the 64x64 predictive covariance and 96 K on K_ZZ - 72 % of gp_predict.
+// Every thread of the workgroup must call it (it contains __syncthreads).  Only the lower triangle is written.
+// value of `v` in lane `src` (compile-time constant after unrolling): v_readlane_b32, not a ds_bpermute round trip
+__device__ __forceinline__ float read_lane(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+__device__ void block_cholesky(float* A, int n, int ld, int tid) {
+    constexpr int NB = 8;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = min(NB, n - k0);
+        if (wave == 0) {
+            // The panel lives in registers: lane owns rows k0+lane and k0+lane+64, a0[q] / a1[q] = A[row][k0+q].
+            // Column jj: pivot = lane jj's a0[jj]; the entries L[k0+q][jj] the remaining panel columns need are
+            // lane q's freshly scaled value - uniform-lane shuffles (v_readlane), no LDS round trip per column.
+            const int i0 = k0 + lane, i1 = k0 + lane + 64;
+            const bool v0 = i0 < n, v1 = i1 < n;
+            float a0[NB], a1[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                a0[q] = (v0 && q < kb) ? A[i0 * ld + k0 + q] : 0.f;
+                a1[q] = (v1 && q < kb) ? A[i1 * ld + k0 + q] : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) {
+                if (jj < kb) {
+                    const float dg = sqrtf(fmaxf(read_lane(a0[jj], jj), 1e-12f));
+                    const float inv = 1.f / dg;
+                    const float l0 = (lane == jj) ? dg : a0[jj] * inv;   // lanes < jj: upper triangle, never read
+                    const float l1 = a1[jj] * inv;
+                    a0[jj] = l0;
+                    a1[jj] = l1;
+#pragma unroll
+                    for (int q = jj + 1; q < NB; ++q) {
+                        const float lq = read_lane(l0, q);               // L[k0+q][k0+jj]
+                        a0[q] = fmaf(-l0, lq, a0[q]);
+                        a1[q] = fmaf(-l1, lq, a1[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                if (v0 && q < kb && lane >= q) A[i0 * ld + k0 + q] = a0[q];
+                if (v1 && q < kb) A[i1 * ld + k0 + q] = a1[q];
+            }
+        }
+        __syncthreads();
+        const int t0 = k0 + kb;
+        if (t0 < n) {
+            const int RL = (n - t0 <= 64) ? 64 : 128, G = 256 / RL;
+            const int i = t0 + tid % RL, g = tid / RL;
+            if (i < n) {
+                float ai[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) ai[q] = q < kb ? A[i * ld + k0 + q] : 0.f;
+                int j = t0 + g;
+                for (; j + 3 * G <= i; j += 4 * G) {     // four columns per trip: their LDS reads issue together
+                    float dot[4] = {0.f, 0.f, 0.f, 0.f}, cur[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cur[u] = A[i * ld + j + u * G];
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) dot[u] = fmaf(ai[q], q < kb ? A[(j + u * G) * ld + k0 + q] : 0.f, dot[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) A[i * ld + j + u * G] = cur[u] - dot[u];
+                }
+                for (; j <= i; j += G) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) dot = fmaf(ai[q], q < kb ? A[j * ld + k0 + q] : 0.f, dot);
+                    A[i * ld + j] -= dot;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
     // 256 threads; scratch >= 4 floats
 #pragma unroll
@@ -91,7 +180,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
 
 __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B;
     const int LM = M + 1;   // row stride of the MxM matrices
     const int LB = B + 2;   // row stride of the M x (B+1) matrices
@@ -113,6 +202,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     const float noise = p.noise ? p.noise[d] : 0.f;
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
+    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 0] = clock64();
     for (int i = tid; i < M; i += 256) zs[i] = p.z[(size_t)d * M + i];
     for (int b = tid; b < B; b += 256) xs[b] = p.h[(size_t)b * p.D + d];
     __syncthreads();
@@ -135,29 +225,54 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     }
     __syncthreads();
 
-    // wave 0: chol(K_ZZ).  waves 1-3: W = L_S^T K_Zx (needs the un-solved K_Zx).
-    if (wave == 0) {
-        wave_cholesky(L, M, LM, lane);
-    } else {
-        for (int i = tid - 64; i < M * B; i += 192) {
-            const int r = i / B, b = i % B;
-            float acc = 0.f;
-            for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], AK[j * LB + b], acc);
-            Wm[r * LB + b] = acc;
-        }
+    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 1] = clock64();
+    // W = L_S^T K_Zx (needs the un-solved K_Zx), then chol(K_ZZ) by the whole workgroup
+    for (int i = tid; i < M * B; i += 256) {
+        const int r = i / B, b = i % B;
+        float acc = 0.f;
+        for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], AK[j * LB + b], acc);
+        Wm[r * LB + b] = acc;
     }
-    __syncthreads();
+    block_cholesky(L, M, LM, tid);   // ends with __syncthreads
+    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 2] = clock64();
 
-    // forward substitution, one thread per column of [K_Zx | m-c]
-    for (int col = tid; col < B + 1; col += 256) {
-        for (int i = 0; i < M; ++i) {
-            float acc = AK[i * LB + col];
-#pragma unroll 4
-            for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], AK[j * LB + col], acc);
-            AK[i * LB + col] = acc / L[i * LM + i];
+    // Blocked forward substitution L X = [K_Zx | m-c]: per block of 8 rows, one thread per column solves the 8x8
+    // triangle, then all threads subtract the block's contribution from the rows below (one thread per column
+    // walking all M rows serially took 49 K cycles).
+    {
+        constexpr int RB = 8;
+        const int ncol = B + 1;
+        for (int r0 = 0; r0 < M; r0 += RB) {
+            const int rb = min(RB, M - r0);
+            for (int col = tid; col < ncol; col += 256) {
+                float xv[RB];
+#pragma unroll
+                for (int a = 0; a < RB; ++a) {
+                    xv[a] = 0.f;
+                    if (a < rb) {
+                        float acc = AK[(r0 + a) * LB + col];
+#pragma unroll
+                        for (int q = 0; q < RB; ++q)
+                            if (q < a) acc = fmaf(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
+                        xv[a] = acc / L[(r0 + a) * LM + r0 + a];
+                        AK[(r0 + a) * LB + col] = xv[a];
+                    }
+                }
+            }
+            __syncthreads();
+            const int below = M - (r0 + rb);
+            for (int e = tid; e < below * ncol; e += 256) {
+                const int i = r0 + rb + e / ncol, col = e % ncol;
+                float acc = AK[i * LB + col];
+#pragma unroll
+                for (int q = 0; q < RB; ++q)
+                    if (q < rb) acc = fmaf(-L[i * LM + r0 + q], AK[(r0 + q) * LB + col], acc);
+                AK[i * LB + col] = acc;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
+    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 3] = clock64();
 
     // predictive mean and marginal variance
     for (int b = tid; b < B; b += 256) {
@@ -200,24 +315,63 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
 
     if (need_cov) {
         __syncthreads();
-        for (int i = tid; i < B * B; i += 256) {
-            const int r = i / B, q = i % B;
-            float acc = 0.f;
-#pragma unroll 4
-            for (int k = 0; k < M; ++k) {
-                acc = fmaf(Wm[k * LB + r], Wm[k * LB + q], acc);
-                acc = fmaf(-AK[k * LB + r], AK[k * LB + q], acc);
+        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 4] = clock64();
+        // Sigma = W^T W - A^T A + k(x,x) (+ noise I): 4x4 register tiles (16 LDS reads per 32 FMAs instead of 4 per 2),
+        // lower-triangular tiles only, mirrored on store
+        {
+            const int nt = (B + 3) / 4;
+            for (int t = tid; t < nt * nt; t += 256) {
+                const int tr = t / nt, tq = t % nt;
+                if (tq > tr) continue;
+                float acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = 0.f;
+                int rr[4], qq[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    rr[a] = min(tr * 4 + a, B - 1);
+                    qq[a] = min(tq * 4 + a, B - 1);
+                }
+                for (int k = 0; k < M; ++k) {
+                    float wr[4], wq[4], ar[4], aq[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        wr[a] = Wm[k * LB + rr[a]];
+                        wq[a] = Wm[k * LB + qq[a]];
+                        ar[a] = AK[k * LB + rr[a]];
+                        aq[a] = AK[k * LB + qq[a]];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = fmaf(wr[a], wq[b2], fmaf(-ar[a], aq[b2], acc[a][b2]));
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const int r = tr * 4 + a, q = tq * 4 + b2;
+                        if (r < B && q < B) {
+                            const float dx = xs[r] - xs[q];
+                            float v = acc[a][b2] + s * expf(dx * dx * ninv);
+                            if (r == q) v += noise;
+                            Sg[r * LS + q] = v;
+                            Sg[q * LS + r] = v;
+                            if (p.cov) {
+                                p.cov[((size_t)d * B + r) * B + q] = v;
+                                p.cov[((size_t)d * B + q) * B + r] = v;
+                            }
+                        }
+                    }
             }
-            const float dx = xs[r] - xs[q];
-            acc += s * expf(dx * dx * ninv);
-            if (r == q) acc += noise;
-            Sg[r * LS + q] = acc;
-            if (p.cov) p.cov[((size_t)d * B + r) * B + q] = acc;
         }
         __syncthreads();
+        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 5] = clock64();
         if (p.sample != nullptr) {
-            if (wave == 0) wave_cholesky(Sg, B, LS, lane);
-            __syncthreads();
+            block_cholesky(Sg, B, LS, tid);   // ends with __syncthreads
+        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 6] = clock64();
             for (int b = tid; b < B; b += 256) {
                 float acc = mu[b];
 #pragma unroll 4
@@ -226,6 +380,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
             }
         }
     }
+    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 7] = clock64();
 }
 
 
@@ -486,7 +641,7 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
         attr_lds = lds;
     }
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
-               B, D, M, train_mode, jitter};
+               B, D, M, train_mode, jitter, g_gp_clk};
     hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("dvg_gp_predict");
 }
@@ -519,3 +674,5 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
     hipLaunchKernelGGL(gp_train_bwd_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("dvg_gp_train_bwd");
 }
+
+extern "C" void dvg_debug_set_gp_clockbuf(void* buf) { g_gp_clk = (unsigned long long*)buf; }
