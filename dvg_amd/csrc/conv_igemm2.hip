@@ -774,10 +774,22 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                 off = (size_t)w_ * C4 + c4;
             }
             f32x4 v = reinterpret_cast<const f32x4*>(ws)[off];
-            for (int s = 1; s < S; ++s) {
-                const f32x4 t = reinterpret_cast<const f32x4*>(ws)[(size_t)s * slab4 + off];
+            {
+                int s = 1;
+                for (; s + 3 <= S; s += 3) {   // three slabs per trip: their loads issue together, fixed-order sum
+                    f32x4 t[3];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += t[k];
+                    for (int u = 0; u < 3; ++u) t[u] = reinterpret_cast<const f32x4*>(ws)[(size_t)(s + u) * slab4 + off];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += t[u][k];
+                }
+                for (; s < S; ++s) {
+                    const f32x4 t = reinterpret_cast<const f32x4*>(ws)[(size_t)s * slab4 + off];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += t[k];
+                }
             }
             if (addend != nullptr) {   // hoisted skip half: one more (loop-invariant) partial slab
                 const f32x4 t = reinterpret_cast<const f32x4*>(addend)[off];

@@ -119,8 +119,18 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p) {
     const long total = (long)p.M * p.N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = i / p.N, n = i % p.N;
+        // eight independent loads per trip (one per split slab), then a fixed-order sum: a `s += ws[z]` loop is one
+        // dependent memory round trip per split (9.8 us for the 16-way, 5760-element sum of the encoder head)
         float s = 0.f;
-        for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * total + i];
+        int z = 0;
+        for (; z + 8 <= p.splitk; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p.ws[(size_t)(z + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < p.splitk; ++z) s += p.ws[(size_t)z * total + i];
         const int c = n % p.period;
         const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
         p.out[(size_t)m * p.ldo + n] = apply_act(s * sc + sf, p.act, p.slope);
@@ -357,8 +367,8 @@ extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float*
     if (int e = check_launch("dvg_gemm_nt_bias_act")) return e;
     if (p.splitk > 1) {
         const long total = (long)M * N;
-        const unsigned g = (unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+        const unsigned g = (unsigned)((total + 63) / 64 > 4096 ? 4096 : (total + 63) / 64);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(64), 0, (hipStream_t)stream, p);
         return check_launch("dvg_gemm_nt_bias_act(reduce)");
     }
     return DVG_OK;
