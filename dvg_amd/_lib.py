@@ -46,7 +46,7 @@ SIGNATURES = {
     "dvg_convT4x4s2_last": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_moving_mnist_compose": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_eval_frames": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
-    "dvg_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p]),
+    "dvg_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p]),
     "dvg_pixel_proj": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "dvg_convT_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_channel_stats_rows": (_i, [_l]),

@@ -223,10 +223,9 @@ class _LastLayer(torch.autograd.Function):
     def forward(ctx, x, skip, weight, bias, cfg):
         nc = weight.shape[1]
         b = bias.detach() if bias is not None else None
-        if cfg["kind"] == "convT3":
-            y = ops.convT3x3_last(x, weight, b, nc, act=cfg["act"])
-        else:
-            y = ops.convT4x4s2_last(x, skip, weight, b, nc, act=cfg["act"])
+        # the product path of the last layer (HBM-bound projection + gather), not the direct kernel (288 us at 16x3x64x64)
+        ks = 3 if cfg["kind"] == "convT3" else 4
+        y = ops.convT_last_two_step(x, skip if ks == 4 else None, weight, b, nc, ks, act=cfg["act"])
         ctx.save_for_backward(x, skip, weight, y)
         ctx.cfg = dict(cfg, has_bias=bias is not None)
         return y

@@ -416,8 +416,12 @@ static inline unsigned grid_for(long n, int block = 256, int cap = 4096) {
 // (torch.optim.Adam's arithmetic, non-amsgrad).  One launch per group instead of the foreach chain.
 // ------------------------------------------------------------------------------------
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                 float* __restrict__ v, long n, float lr_over_bc1, float b1, float b2, float eps,
-                                 float wd, float inv_sqrt_bc2) {
+                                 float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                 const int* __restrict__ step_dev, int step_host) {
+    // the step count may live in device memory (a captured hipGraph replays with a fresh count every iteration)
+    const int t = step_dev ? *step_dev : step_host;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float lr_over_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const long n4 = n >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
@@ -580,14 +584,13 @@ extern "C" int dvg_wgrad_thin(const float* inp_nchw, const float* dout_nhwc, flo
 }
 
 extern "C" int dvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+                             float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                             void* stream) {
     DVG_REQUIRE(param && grad && exp_avg && exp_avg_sq, DVG_ERR_NULL, "dvg_adam_step: NULL pointer");
-    DVG_REQUIRE(n > 0 && step >= 1, DVG_ERR_SHAPE, "dvg_adam_step: n=%ld step=%d", n, step);
+    DVG_REQUIRE(n > 0 && (step >= 1 || step_dev != nullptr), DVG_ERR_SHAPE, "dvg_adam_step: n=%ld step=%d", n, step);
     DVG_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), DVG_ERR_ALIGN,
                 "dvg_adam_step: buffers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, (float)((double)lr / bc1), beta1, beta2, eps, weight_decay,
-                       (float)(1.0 / sqrt(bc2)));
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, step);
     return check_launch("dvg_adam_step");
 }

@@ -22,7 +22,8 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._flat = {}   # group index -> dict(p, g, m, v, params, offsets, gviews)
+        self._flat = {}   # group index -> dict(p, g, m, v, params, offsets, gviews, tdev)
+        self._captured_groups = []   # groups stepped while a hipGraph was being captured (see after_graph_replay)
 
     # ---- flat storage -------------------------------------------------------------------------------
     def _build(self, gi: int, group) -> dict:
@@ -51,6 +52,7 @@ class FusedAdam(torch.optim.Optimizer):
                     steps[p] = float(st["step"])
                 p.data = view                       # the module keeps the same Parameter object
         f = dict(p=flat_p, g=flat_g, m=flat_m, v=flat_v, params=params, offsets=offs,
+                 tdev=torch.zeros(1, dtype=torch.int32, device=dev),     # device-side step count of the group
                  gviews=[flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)])
         for p, o in zip(params, offs):
             self.state[p] = {"step": torch.tensor(steps.get(p, 0.0)), "exp_avg": flat_m[o:o + p.numel()].view(p.shape),
@@ -64,6 +66,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat.clear()
         for gi, group in enumerate(self.param_groups):
             self._build(gi, group)
+
+    # ---- hipGraph support -------------------------------------------------------------------------------
+    def begin_capture(self) -> None:
+        """Call right before capturing a graph that contains step(): the device step counts are synchronised with the
+        host ones (the captured kernels then increment and read them on the device)."""
+        self._captured_groups = []
+        for gi, f in self._flat.items():
+            if f:
+                f["tdev"].fill_(int(self.state[f["params"][0]]["step"]))
+
+    def after_graph_replay(self) -> None:
+        """The replayed kernels stepped the parameters through raw pointers: advance the host-side step counts (state_dict,
+        torch.optim compatibility) and the version counters the packed-weight caches key on."""
+        for gi in self._captured_groups:
+            for p in self._flat[gi]["params"]:
+                torch.autograd.graph.increment_version(p)
+                self.state[p]["step"] += 1
 
     # ---- step ---------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -84,16 +103,25 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             hyper = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
             steps = {int(self.state[p]["step"]) for p in f["params"]}
+            capturing = torch.cuda.is_current_stream_capturing()
             if all(have) and len(steps) == 1:
-                # the whole group in one launch
+                # the whole group in one launch; the step count lives on the device so that a captured hipGraph
+                # (train.GraphedIteration) applies fresh bias corrections at every replay
                 torch._foreach_copy_(f["gviews"], [p.grad for p in f["params"]])
                 t = steps.pop() + 1
+                if not capturing:
+                    f["tdev"].fill_(t - 1)           # host and device counts agree outside a capture
+                f["tdev"].add_(1)
                 check(lib().dvg_adam_step(ops._p(f["p"]), ops._p(f["g"]), ops._p(f["m"]), ops._p(f["v"]),
-                                          f["p"].numel(), *hyper, t, ops._stream()), "dvg_adam_step")
+                                          f["p"].numel(), *hyper, t, ops._p(f["tdev"]), ops._stream()), "dvg_adam_step")
                 touched = f["params"]
+                if capturing:
+                    self._captured_groups.append(gi)
             else:
                 # torch.optim.Adam semantics for a partially used group: parameters without a gradient are skipped
                 # (no moment decay, no step count) - one launch per parameter that has one
+                if capturing:
+                    raise RuntimeError("FusedAdam: a partially used parameter group cannot be captured in a hipGraph")
                 touched = [p for p in f["params"] if p.grad is not None]
                 for p, gv in zip(f["params"], f["gviews"]):
                     if p.grad is None:
@@ -101,8 +129,12 @@ class FusedAdam(torch.optim.Optimizer):
                     st = self.state[p]
                     gv.copy_(p.grad)
                     check(lib().dvg_adam_step(ops._p(p), ops._p(gv), ops._p(st["exp_avg"]), ops._p(st["exp_avg_sq"]),
-                                              p.numel(), *hyper, int(st["step"]) + 1, ops._stream()), "dvg_adam_step")
+                                              p.numel(), *hyper, int(st["step"]) + 1, None, ops._stream()),
+                          "dvg_adam_step")
             for p in touched:
-                torch.autograd.graph.increment_version(p)   # the kernel wrote through raw pointers
-                self.state[p]["step"] += 1
+                # the kernel wrote through raw pointers; also while capturing, so that code captured AFTER this step
+                # re-packs its weights instead of reusing the packs from before the step
+                torch.autograd.graph.increment_version(p)
+                if not capturing:                # a capture executes nothing: after_graph_replay() counts the replays
+                    self.state[p]["step"] += 1
         return loss

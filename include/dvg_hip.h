@@ -357,9 +357,10 @@ int dvg_eval_frames(const float* gt, const float* pred, float* ssim, float* psnr
 
 /* Fused Adam step over one flat parameter group (train.py:95-106: torch.optim.Adam(lr=0.002) with default
  * betas (0.9, 0.999) and eps 1e-8; torch.optim.Adam arithmetic, non-amsgrad): param / exp_avg / exp_avg_sq are
- * updated in place, `step` is the 1-based step count used for the bias corrections. */
+ * updated in place, `step` is the 1-based step count used for the bias corrections; when `step_dev` is not NULL the
+ * count is read from that device int instead (a captured hipGraph replays with a new count every iteration). */
 int dvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, void* stream);
+                  float beta2, float eps, float weight_decay, int step, const int* step_dev, void* stream);
 
 /* nn.LSTMCell backward, elementwise part: gate pre-activation gradients dG [B][4H] and
  * dc_prev [B][H] from dh', dc' (either may be NULL), the saved activated gates, c, c'.

@@ -200,3 +200,43 @@ def test_fused_adam_matches_torch_adam():
     o_back.step()
     for p, q in zip(ref, mine):
         assert torch.allclose(p, q, rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_graphed_iteration_matches_eager(model):
+    """train.GraphedIteration (whole iteration = one hipGraph: 3 backward passes + 4 fused Adam steps) against the
+    eager loop from the same seed and batches: losses, parameters, BatchNorm buffers and optimiser state agree, and
+    eval-mode code after the replays sees the updated weights (version counters are bumped)."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    res = []
+    for graphed in (False, True):
+        torch.manual_seed(11)
+        opt = _opt(model)
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        tr.train_mode()
+        gen = SyntheticMovingMNIST(seq_len=4, seed=9)
+        step = train.GraphedIteration(tr, warmup=2) if graphed else tr.iteration
+        losses = []
+        for it in range(5):
+            x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(4))
+            if it == 4:                         # an lr change (MultiStepLR milestone) must trigger a re-capture
+                for g in tr.optimizer.param_groups:
+                    g['lr'] *= 0.1
+            losses.append(step(x) + (tr.last_loss,))
+        tr.encoder.eval()
+        with torch.no_grad():
+            h_eval = tr.encoder(x[0])[0].clone()
+        res.append((losses, copy.deepcopy(tr.encoder.state_dict()), copy.deepcopy(tr.decoder.state_dict()),
+                    copy.deepcopy(tr.frame_predictor.state_dict()), copy.deepcopy(tr.gp_layer.state_dict()), h_eval,
+                    float(tr.encoder_optimizer.state_dict()["state"][0]["step"])))
+    (la, *sa, ha, stepa), (lb, *sb, hb, stepb) = res
+    assert stepa == stepb == 5.0
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            assert abs(u - v) <= 2e-4 * max(1.0, abs(u)), (la, lb)
+    for a, b in zip(sa, sb):
+        for k in a:
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=2e-3, atol=2e-5), k
+    assert torch.allclose(ha, hb, rtol=2e-3, atol=2e-5)
