@@ -16,7 +16,7 @@ import weakref
 
 import torch
 
-from . import ops
+from . import fused, ops
 from .ops import ACT_NONE, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2
 
 
@@ -51,9 +51,8 @@ def _bn_forward(bn, u, stats, count, act, slope, pool):
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, bn.weight.detach(), bn.bias.detach(), bn.running_mean if bn.track_running_stats else None,
             bn.running_var if bn.track_running_stats else None, count, bn.eps,
-            bn.momentum if bn.momentum is not None else 0.1, save=True)
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            fused.bn_momentum(bn), save=True)
+        fused.bn_count_passes(bn)
     else:
         with torch.no_grad():
             mean = bn.running_mean.clone()

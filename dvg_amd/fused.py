@@ -97,14 +97,43 @@ def _needs_grad(*ts) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
+# A train-mode forward pass that stands for k identical reference passes (train.py encodes every middle frame of a
+# sequence twice per closure: as step i's target and as step i+1's input - same weights, same batch, same outputs):
+# k momentum updates with the same batch statistics equal ONE update with momentum 1 - (1 - m)^k, and
+# num_batches_tracked advances by k.  Set by train.Trainer through `bn_passes(k)`.
+_BN_PASSES = 1
+
+
+class bn_passes:
+    def __init__(self, k: int):
+        self.k = int(k)
+
+    def __enter__(self):
+        global _BN_PASSES
+        self.prev, _BN_PASSES = _BN_PASSES, self.k
+
+    def __exit__(self, *exc):
+        global _BN_PASSES
+        _BN_PASSES = self.prev
+
+
+def bn_momentum(bn) -> float:
+    m = bn.momentum if bn.momentum is not None else 0.1
+    return 1.0 - (1.0 - m) ** _BN_PASSES
+
+
+def bn_count_passes(bn) -> None:
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += _BN_PASSES
+
+
 def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
     res = ops.bn_finalize(stats, bn.weight.detach() if bn.weight is not None else None,
                           bn.bias.detach() if bn.bias is not None else None,
                           bn.running_mean if bn.track_running_stats else None,
                           bn.running_var if bn.track_running_stats else None, count, bn.eps,
-                          bn.momentum if bn.momentum is not None else 0.1, save=save)
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+                          bn_momentum(bn), save=save)
+    bn_count_passes(bn)
     return res
 
 

@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import utils  # noqa: E402
-from dvg_amd import parallel  # noqa: E402
+from dvg_amd import fused, parallel  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
 from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1, VariationalELBO  # noqa: E402
 from dvg_amd.optim import FusedAdam  # noqa: E402
@@ -99,6 +99,8 @@ class Trainer:
         # True = back-propagate into the encoder in the two fine-tuning closures like the reference does (and then
         # discards); kept only so that tests can show both ways give the same updates
         self.finetune_encoder_grad = False
+        # False = encode every middle frame twice per closure like the reference does (tests compare both ways)
+        self.share_encoder_passes = True
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group
         Adam = FusedAdam   # HIP only, like the models themselves: no CPU fallback on the product path
         self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002)
@@ -131,6 +133,27 @@ class Trainer:
         return enc_out[0], skip
 
     # ---- the three closures -------------------------------------------------------------------
+    def _encode_sequence(self, x, grad: bool):
+        """encoder(x[t]) for every frame of the sequence, ONCE per frame.  The reference encodes every middle frame twice
+        per closure (train.py:158-162,184-188,217-221: as step i's target and again as step i+1's input) with the same
+        weights and the same batch, i.e. with identical outputs; one pass whose output is used twice gives the same
+        losses and - autograd sums the two uses - the same gradients, and `fused.bn_passes(2)` reproduces the BatchNorm
+        side effect of the second pass (two momentum updates, num_batches_tracked += 2) in the reference's order.
+        (6S encoder passes per iteration become 3(S+1).)"""
+        T = self.opt.n_past + self.opt.n_future
+        outs = []
+        with torch.set_grad_enabled(grad):
+            for t in range(T):
+                with fused.bn_passes(1 if (t == 0 or t == T - 1) else 2):
+                    outs.append(self.encoder(x[t]))
+        return outs
+
+    def _enc(self, enc_all, x, t, grad=True):
+        if enc_all is not None:
+            return enc_all[t]
+        with torch.set_grad_enabled(grad):
+            return self.encoder(x[t])
+
     # Each closure has a `_dev` form that returns device tensors and never synchronises with the host, so that a whole
     # iteration can be captured into one hipGraph (GraphedIteration below); the public forms add the float()s.
     def train_GP_Frame_predictor(self, x):
@@ -151,14 +174,15 @@ class Trainer:
         self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         max_ll = 0
         skip = None
+        g = self.finetune_encoder_grad
+        enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
         for i in range(1, opt.n_past + opt.n_future):
             # Only the GP optimiser steps after this closure (train.py:170-171): the reference back-propagates into
             # the encoder and then discards those gradients (encoder.zero_grad() opens the next train_model).  The
             # encoder therefore runs without autograd here - same outputs, same BatchNorm running-stat updates, same
             # parameter updates, none of the wasted encoder backward.
-            with torch.set_grad_enabled(self.finetune_encoder_grad):
-                h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
-                h_target = self.encoder(x[i])[0].detach()
+            h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
+            h_target = self._enc(enc_all, x, i, g)[0].detach()
             h_pred = self.gp_layer(self._gp_in(h))
             max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
@@ -173,10 +197,11 @@ class Trainer:
         self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         mse_latent = 0
         skip = None
+        g = self.finetune_encoder_grad   # only frame_predictor_optimizer steps (train.py:195-196)
+        enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
         for i in range(1, opt.n_past + opt.n_future):
-            with torch.set_grad_enabled(self.finetune_encoder_grad):   # only frame_predictor_optimizer steps (train.py:195-196)
-                h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
-                h_target = self.encoder(x[i])[0]
+            h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
+            h_target = self._enc(enc_all, x, i, g)[0]
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
@@ -194,9 +219,10 @@ class Trainer:
         mse = mse_latent = mse_gp = ae_mse = 0
         max_ll = 0
         skip = None
+        enc_all = self._encode_sequence(x, True) if self.share_encoder_passes else None
         for i in range(1, opt.n_past + opt.n_future):
-            h, skip = self._skip_rule(i, self.encoder(x[i - 1]), skip)
-            h_target = self.encoder(x[i])[0]
+            h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1), skip)
+            h_target = self._enc(enc_all, x, i)[0]
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
             gp_pred = self.gp_layer(self._gp_in(h))
