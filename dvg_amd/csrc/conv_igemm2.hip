@@ -47,7 +47,8 @@ struct Igemm2Params {
     int N, H, W, C1, C2, Cout, upsample, act;
     float slope;
     int tiles_y, tiles_x, tiles_n, nblk_n;
-    int ablate;  // debug only (dvg_debug_set_ablate): 1 = no global loads / LDS refills in the loop, 2 = also no barriers
+    int ablate;  // debug only (dvg_debug_set_ablate): v3 producer pacing experiments (bits 256 / 512); the v2 loop ablations
+                 // that located the staging cost were removed with the loop restructure
     int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
     int cps;     // K chunks (of 16 channels) per split
     float* ws;   // [splitk][N*Ho*Wo][Cout]

@@ -16,8 +16,9 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_
 done
 timeout 300 python3 bench.py > $out/bench_vgg.json 2> $out/bench_vgg.err < /dev/null
 timeout 200 python3 bench.py --model dcgan > $out/bench_dcgan.json 2> $out/bench_dcgan.err < /dev/null
-timeout 300 python3 tools/bench_train.py --model vgg --iters 3 2>/dev/null | grep ms_per_iter > $out/train_vgg.json < /dev/null
-timeout 300 python3 tools/bench_train.py --model dcgan --iters 3 2>/dev/null | grep ms_per_iter > $out/train_dcgan.json < /dev/null
+for cfg in "--model vgg" "--model dcgan" "--model vgg --channels 3 --batch 16 --n_past 2 --n_future 10" "--model dcgan --channels 3 --batch 16 --n_past 2 --n_future 10" "--model vgg --channels 3 --image_width 128 --batch 4 --n_past 4 --n_future 12" "--model dcgan --channels 3 --image_width 128 --batch 4 --n_past 4 --n_future 12"; do
+  timeout 400 python3 tools/bench_train.py $cfg --iters 5 --graph 2>> $out/train.err < /dev/null | grep ms_per_iter >> $out/train_graph.jsonl
+done
 rm -f $out/*/*kernel_trace.csv   # large; the stats / counter files are what gets kept
 ls -la $out $out/stats | head -40
 tail -c 300 $out/bench_vgg.json
