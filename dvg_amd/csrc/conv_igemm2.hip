@@ -54,6 +54,7 @@ struct Igemm2Params {
     float* ws;   // [splitk][N*Ho*Wo][Cout]
     const float* addend;  // optional raw (pre-scale) partial sums, NHWC like y: y = act((acc + addend) * scale + shift)
     unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
+    int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
 };
 
 static int g_ablate = 0;
@@ -95,8 +96,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     if (MODE == M2_CONVT4S2) { par = lid & 3; lid >>= 2; }
     const int split = lid % p.splitk;
     lid /= p.splitk;
-    const int nb = lid % p.nblk_n;
-    unsigned t = lid / p.nblk_n;
+    // Order: Cout-block-within-group fastest, then pixel tile, then group.  xcd_remap hands each XCD a contiguous lid
+    // range, i.e. nb_group Cout blocks x (range / nb_group) pixel tiles: the host picks nb_group so that the weight
+    // slabs plus the input tiles an XCD's L2 has to fetch are smallest (with all Cout blocks per XCD every L2 pulled
+    // the full 9.4 MB of an 8x8 512->512 layer's weights).
+    const int tiles_total = p.tiles_x * p.tiles_y * p.tiles_n;
+    const unsigned lr = lid / p.nb_group;
+    const int nb = (int)(lr / tiles_total) * p.nb_group + (int)(lid % p.nb_group);
+    const unsigned tile_id = lr % tiles_total;
+    unsigned t = tile_id;
     const int tx_i = t % p.tiles_x; t /= p.tiles_x;
     const int ty_i = t % p.tiles_y; t /= p.tiles_y;
     const int n0 = (int)t * TI, y0 = ty_i * TH, x0 = tx_i * TW;
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         }
         __syncthreads();
         if (wm == 0 && hh == 0) {
-            const unsigned rowid = (MODE == M2_CONVT4S2 ? (lid / p.nblk_n) * 4 + par : lid / p.nblk_n);
+            const unsigned rowid = (MODE == M2_CONVT4S2 ? tile_id * 4 + par : tile_id);
             float* dst = p.stats + (size_t)rowid * 2 * p.Cout;
             dst[c] = s1 + red[wn * 64 + l31];
             dst[p.Cout + c] = s2 + red[wn * 64 + 32 + l31];
@@ -863,6 +871,23 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.ablate = g_ablate;
     p.clk = g_clk;
     const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
+    {
+        // Cout blocks per XCD group: minimise (weight slabs + input tiles) one XCD's L2 fetches for its share of the
+        // launch; a must divide nblk_n, and a group must hold at least one XCD's share of pixel tiles
+        const long tiles = (long)p.tiles_y * p.tiles_x * p.tiles_n;
+        const double per_xcd = (double)tiles * p.nblk_n / 8.0;
+        const double wb = (double)C::NTAPS * (p.C1 + p.C2) * 64 * 4, ib = (double)C::BM * (p.C1 + p.C2) * 4;
+        int best = p.nblk_n;
+        double cost = 1e300;
+        for (int a = 1; a <= p.nblk_n; ++a) {
+            if (p.nblk_n % a) continue;
+            const double share_tiles = per_xcd / a;
+            if (share_tiles > (double)tiles) continue;   // more tiles than exist: the range would span several groups
+            const double c = a * wb + (share_tiles < 1.0 ? 1.0 : share_tiles) * ib;
+            if (c < cost) { cost = c; best = a; }
+        }
+        p.nb_group = best;
+    }
     const int nchunks = (p.C1 + p.C2) / C::KC;
     int Ho, Wo;
     if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
@@ -911,6 +936,7 @@ static int launch3(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
+    p.nb_group = p.nblk_n;
     p.ablate = g_ablate;
     p.clk = g_clk;
     const int items = p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
