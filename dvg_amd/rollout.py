@@ -42,42 +42,61 @@ def _encode_conditioning(encoder, x, n_past, last_frame_skip):
 
 
 @torch.no_grad()
-def sample_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x: Sequence[torch.Tensor], n_past: int,
-                   n_eval: int, last_frame_skip: bool = False, period: int = 15,
-                   eps_by_step: Optional[Dict[int, torch.Tensor]] = None,
-                   batch_conditioning: bool = True) -> List[torch.Tensor]:
-    """Returns the n_eval frames [x0, ..] of one sample (conditioning frames are the inputs themselves)."""
+def condition(encoder, frame_predictor, x: Sequence[torch.Tensor], n_past: int, last_frame_skip: bool = False,
+              batch_conditioning: bool = True) -> dict:
+    """The part of a sample rollout that does not depend on the sample (generate_frames.py:147-162 for i < n_past):
+    the LSTM is reset and stepped on the encodings of the conditioning frames x[0..n_past-2] (outputs discarded), the
+    skip tensors are those of x[n_past-2].  Deterministic in eval mode, so `make_gifs` (nsample rollouts of the SAME
+    batch) computes it once per batch and draws every sample with `sample_from`."""
     frame_predictor.hidden = frame_predictor.init_hidden()
-    frames = [x[0]]
-    x_in = x[0]
     skip = None
-    start = 1
     if batch_conditioning and n_past >= 3 and not encoder.training:
         hs, skip = _encode_conditioning(encoder, x, n_past, last_frame_skip)
         for i in range(1, n_past):
             frame_predictor(hs[i - 1])          # LSTM stepped on conditioning frames, output discarded (:162)
-            frames.append(x[i])
-        x_in = x[n_past - 1]
-        start = n_past
-    for i in range(start, n_eval):
+    else:
+        for i in range(1, n_past):
+            h, skip = encoder(x[i - 1])
+            frame_predictor(h)
+    return {"hidden": list(frame_predictor.hidden), "skip": skip, "frames": [x[i] for i in range(n_past)]}
+
+
+@torch.no_grad()
+def sample_from(state: dict, encoder, decoder, frame_predictor, gp_layer, likelihood, n_past: int, n_eval: int,
+                last_frame_skip: bool = False, period: int = 15,
+                eps_by_step: Optional[Dict[int, torch.Tensor]] = None) -> List[torch.Tensor]:
+    """The prediction phase of one sample (generate_frames.py:163-176), starting from a `condition()` state."""
+    frame_predictor.hidden = list(state["hidden"])   # lstm_cell returns new tensors: the saved state is never mutated
+    frames = list(state["frames"])
+    skip = state["skip"]
+    x_in = frames[n_past - 1]
+    for i in range(n_past, n_eval):
         h, sk = encoder(x_in)
-        if last_frame_skip or i < n_past:
+        if last_frame_skip or skip is None:
             skip = sk
         if i == n_past and not last_frame_skip and not decoder.training:
             fused.declare_frozen_skips(skip)    # frozen from here on: decoder blocks hoist their skip halves now
-        if i < n_past:
-            frame_predictor(h)
-            x_in = x[i]
+        h_pred = frame_predictor(h)
+        if period and i % period == 0:
+            pred = likelihood(gp_layer(h.transpose(0, 1).view(gp_layer.num_dims, h.shape[0], 1)))
+            z = pred.rsample(None if eps_by_step is None else eps_by_step[i])
+            x_in = decoder([z.transpose(0, 1), skip])
         else:
-            h_pred = frame_predictor(h)
-            if period and i % period == 0:
-                pred = likelihood(gp_layer(h.transpose(0, 1).view(gp_layer.num_dims, h.shape[0], 1)))
-                z = pred.rsample(None if eps_by_step is None else eps_by_step[i])
-                x_in = decoder([z.transpose(0, 1), skip])
-            else:
-                x_in = decoder([h_pred, skip])
+            x_in = decoder([h_pred, skip])
         frames.append(x_in)
     return frames
+
+
+@torch.no_grad()
+def sample_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x: Sequence[torch.Tensor], n_past: int,
+                   n_eval: int, last_frame_skip: bool = False, period: int = 15,
+                   eps_by_step: Optional[Dict[int, torch.Tensor]] = None,
+                   batch_conditioning: bool = True) -> List[torch.Tensor]:
+    """Returns the n_eval frames [x0, ..] of one sample (conditioning frames are the inputs themselves): one complete
+    rollout = condition() + sample_from()."""
+    state = condition(encoder, frame_predictor, x, n_past, last_frame_skip, batch_conditioning)
+    return sample_from(state, encoder, decoder, frame_predictor, gp_layer, likelihood, n_past, n_eval, last_frame_skip,
+                       period, eps_by_step)
 
 
 @torch.no_grad()

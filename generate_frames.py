@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import utils  # noqa: E402
 from dvg_amd import ops  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
-from dvg_amd.rollout import posterior_rollout, sample_rollout  # noqa: E402
+from dvg_amd.rollout import condition, posterior_rollout, sample_from, sample_rollout  # noqa: E402
 from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
 
 
@@ -88,9 +88,11 @@ class Generator:
         ssim = torch.zeros(B, nsample, T, device=self.dev)
         psnr = torch.zeros(B, nsample, T, device=self.dev)
         all_gen = []
+        # everything before the first predicted frame is the same for all nsample rollouts of this batch: once per batch
+        state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip)
         for s in range(nsample):
-            frames = sample_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood,
-                                    x, opt.n_past, opt.n_eval, opt.last_frame_skip)
+            frames = sample_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
+                                 self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip)
             for t in range(T):   # utils.eval_seq (generate_frames.py:178) on device: dvg_eval_frames
                 ssim[:, s, t], psnr[:, s, t] = ops.eval_frames(x[opt.n_past + t], frames[opt.n_past + t])
             all_gen.append(torch.stack(frames))

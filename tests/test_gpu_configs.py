@@ -157,3 +157,25 @@ def test_full_size_rollout_properties(family):
     for t in range(n_past, 15):          # before the trigger step the replay is deterministic and equals eager
         assert rel_err(a[t], eager[t]) < 2e-5 and torch.equal(a[t], b[t]), t
     assert not torch.equal(a[15], b[15]), "fresh GP noise per replay (captured Philox stream)"
+
+
+def test_condition_once_sample_many_equals_complete_rollouts():
+    """generate_frames.make_gifs conditions once per batch and draws every sample with sample_from: each sample must be
+    exactly the complete rollout (same eps), and drawing one sample must not disturb the shared conditioning state."""
+    from dvg_amd.rollout import condition, sample_from, sample_rollout
+    B, n_past, n_eval = 8, 5, 17
+    mods, _ = _build("dcgan", 64, 1, B, 950)
+    for m in mods:
+        m.to(DEV).eval()
+    enc, dec, fp, gp, like = mods
+    xs = [params.frames(960 + t, B, 1, 64).to(DEV) for t in range(n_eval)]
+    eps = [{15: params.normal(970 + s, 90, B).to(DEV)} for s in range(3)]
+    with torch.no_grad():
+        ref = [sample_rollout(enc, dec, fp, gp, like, xs, n_past, n_eval, eps_by_step=e) for e in eps]
+        state = condition(enc, fp, xs, n_past)
+        got = [sample_from(state, enc, dec, fp, gp, like, n_past, n_eval, eps_by_step=e) for e in eps]
+    for a, b in zip(ref, got):
+        assert len(a) == len(b) == n_eval
+        for t in range(n_eval):
+            assert torch.equal(a[t], b[t]), t
+    assert not torch.equal(got[0][16], got[1][16])
