@@ -68,12 +68,23 @@ class _ConvBlock(torch.autograd.Function):
     conv4s2_first, convT4s2."""
 
     @staticmethod
-    def forward(ctx, x, skip, weight, bias, gamma, beta, cfg):
+    def forward(ctx, x, skip, weight, bias, gamma, beta, addend, cfg):
         kind, bn = cfg["kind"], cfg["bn"]
         act, slope, pool, up = cfg["act"], cfg["slope"], cfg.get("pool", False), cfg.get("upsample", False)
         b = bias.detach() if bias is not None else None
         need_stats = bn.training
-        if kind == "conv3":
+        c1 = x.shape[1]
+        if addend is not None:
+            # x half of a concat conv; `addend` = conv(skip, W_skip) shared by the decoder calls of a step (_SkipHalf)
+            if kind == "conv3":
+                r = ops.conv3x3(x, None, _packed(weight, False, 0, c1, 1), None, b, upsample=up, act=ACT_NONE,
+                                stats=need_stats, addend=addend)
+            elif kind == "convT4s2":
+                r = ops.convT4x4s2(x, None, _packed(weight, True, 0, c1, 0), None, b, act=ACT_NONE, stats=need_stats,
+                                   addend=addend)
+            else:
+                raise RuntimeError(kind)
+        elif kind == "conv3":
             wp = _packed(weight)
             r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
         elif kind == "conv3_first":
@@ -91,7 +102,7 @@ class _ConvBlock(torch.autograd.Function):
         out, mean, invstd = _bn_forward(bn, u, st, n * h * w, act, slope, pool)
         y = out[0] if pool else out
         ctx.save_for_backward(x, skip, weight, gamma, u, y, mean, invstd)
-        ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None)
+        ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None, x_half=addend is not None)
         return out if pool else y
 
     @staticmethod
@@ -102,12 +113,27 @@ class _ConvBlock(torch.autograd.Function):
         dy = None if dy is None else ops.to_nhwc(dy)
         dyp = None if dyp is None else ops.to_nhwc(dyp)
         if dy is None and dyp is None:
-            return (None,) * 7
+            return (None,) * 8
         du, dgamma, dbeta, dbias = ops.bn_act_bwd(dy, dyp, y, u, gamma.detach(), mean, invstd, cfg["count"], act=act,
                                                   slope=slope, train=cfg["train"])
         need_x, need_skip = ctx.needs_input_grad[0], skip is not None and ctx.needs_input_grad[1]
         dx = dskip = None
         c1 = x.shape[1]
+        if cfg["x_half"]:
+            # gradient of the x half only; the skip half's dgrad / wgrad happen once per step in _SkipHalf.backward,
+            # which receives du (d addend = du) summed over the decoder calls that shared it
+            dW = torch.zeros_like(weight)
+            if kind == "conv3":
+                dW[:, :c1] = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, None, du, upsample=up), 3, 3)
+                if need_x:
+                    dxu = ops.conv3x3(du, None, _packed(weight, True, 0, c1, 1), None, None, act=ACT_NONE)
+                    dx = ops.upsample2x_bwd(dxu) if up else dxu
+            else:
+                dW[:c1] = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, None, du), 4, 4)
+                if need_x:
+                    dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
+            return (dx, None, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta,
+                    du if ctx.needs_input_grad[6] else None, None)
         if kind == "conv3":
             dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, skip, du, upsample=up), 3, 3)
             if need_x:  # dgrad = the same igemm with the flipped / transposed weights
@@ -133,14 +159,57 @@ class _ConvBlock(torch.autograd.Function):
             dW = ops.wgrad_thin(x, du, 3 if kind == "conv3_first" else 4)
         else:
             raise RuntimeError(kind)
-        return dx, dskip, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta, None
+        return dx, dskip, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta, None, None
+
+
+class _SkipHalf(torch.autograd.Function):
+    """S = conv(skip, W[:, C1:]) (raw accumulators): the skip half of a decoder block's concat conv
+    (vgg_64.py:98-105 / dcgan_64.py:84-86).  train_model calls the decoder three times per time step with the same skip
+    tensors (train.py:227-231); with fused.share_skip_halves() the three calls share one S, so this forward and its
+    dgrad / wgrad run once per step (autograd sums the three d addend = du into dS)."""
+
+    @staticmethod
+    def forward(ctx, skip, weight, cfg):
+        kind, c1 = cfg["kind"], cfg["c1"]
+        if kind == "conv3":
+            s = ops.conv3x3(skip, None, _packed(weight, False, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
+        else:
+            s = ops.convT4x4s2(skip, None, _packed(weight, True, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
+        ctx.save_for_backward(skip, weight)
+        ctx.cfg = cfg
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        skip, weight = ctx.saved_tensors
+        kind, c1 = ctx.cfg["kind"], ctx.cfg["c1"]
+        ds = ops.to_nhwc(ds)
+        dW = torch.zeros_like(weight)
+        dskip = None
+        if kind == "conv3":
+            dW[:, c1:] = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, skip, None, ds), 3, 3)
+            if ctx.needs_input_grad[0]:
+                dskip = ops.conv3x3(ds, None, _packed(weight, True, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
+        else:
+            dW[c1:] = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, skip, None, ds), 4, 4)
+            if ctx.needs_input_grad[0]:
+                dskip = ops.conv4x4s2(ds, _packed(weight, False, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
+        return dskip, dW, None
 
 
 def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, act, slope=0.2):
     cfg = {"kind": kind, "bn": bn, "upsample": upsample, "pool": pool, "act": act, "slope": slope}
     if kind in ("conv3", "conv4s2", "convT4s2"):
         x = ops.to_nhwc(x)
-    return _ConvBlock.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, cfg)
+    share = fused.skip_share_scope()
+    if share is not None and skip is not None and kind in ("conv3", "convT4s2") and not pool and ops.IGEMM_V == 2:
+        key = (id(conv), id(skip), skip._version)
+        ent = share.get(key)
+        if ent is None or ent[0] is not skip:
+            s = _SkipHalf.apply(ops.to_nhwc(skip), conv.weight, {"kind": kind, "c1": x.shape[1]})
+            share[key] = ent = (skip, s)        # holds the skip alive while the scope lives: ids cannot be recycled
+        return _ConvBlock.apply(x, None, conv.weight, conv.bias, bn.weight, bn.bias, ent[1], cfg)
+    return _ConvBlock.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, None, cfg)
 
 
 class _DenseBlock(torch.autograd.Function):

@@ -1080,8 +1080,8 @@ extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const fl
                    0, 0, 0, 0, 0, 1, 0, nullptr};
     p.addend = addend;
     if (int e = checks2(p, "dvg_conv3x3_bn_act_v2")) return e;
-    DVG_REQUIRE(aligned16(addend) && (addend == nullptr || (y_pool == nullptr && stats == nullptr)), DVG_ERR_SHAPE,
-                "dvg_conv3x3_bn_act_v2: addend must be 16-byte aligned and excludes pool / statistics outputs");
+    DVG_REQUIRE(aligned16(addend) && (addend == nullptr || y_pool == nullptr), DVG_ERR_SHAPE,
+                "dvg_conv3x3_bn_act_v2: addend must be 16-byte aligned and excludes the pooled output");
     DVG_REQUIRE(H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: H=%d W=%d must be multiples of 8", H, W);
     int Hg = H, Wg = W, ti, th, tw;
     if (g_schedule == 3 && addend == nullptr && tile3(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0) {
@@ -1119,8 +1119,7 @@ extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const
                    1, 0, nullptr};
     p.addend = addend;
     if (int e = checks2(p, "dvg_convT4x4s2_bn_act_v2")) return e;
-    DVG_REQUIRE(aligned16(addend) && (addend == nullptr || stats == nullptr), DVG_ERR_SHAPE,
-                "dvg_convT4x4s2_bn_act_v2: addend must be 16-byte aligned and excludes the statistics output");
+    DVG_REQUIRE(aligned16(addend), DVG_ERR_ALIGN, "dvg_convT4x4s2_bn_act_v2: addend must be 16-byte aligned");
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_CONVT4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,
                 "dvg_convT4x4s2_bn_act_v2: unsupported map %dx%d", H, W);

@@ -187,6 +187,28 @@ def _split_packed(conv, c1: int):
     return px, ps
 
 
+_SHARE_SCOPE = None   # dict while inside share_skip_halves(), else None
+
+
+class share_skip_halves:
+    """Training-side twin of the rollout hoisting: inside this scope the decoder calls that receive the SAME skip
+    tensors share one skip half per concat block, forward and backward (autograd._SkipHalf).  train.Trainer opens one
+    scope per time step around the three decoder calls of train.py:227-231."""
+
+    def __enter__(self):
+        global _SHARE_SCOPE
+        self.prev, _SHARE_SCOPE = _SHARE_SCOPE, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _SHARE_SCOPE
+        _SHARE_SCOPE = self.prev
+
+
+def skip_share_scope():
+    return _SHARE_SCOPE
+
+
 def _hoisted_skip(conv, x, skip, partial_fn):
     """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
     if not SKIP_HOIST or skip is None or ops.IGEMM_V != 2:

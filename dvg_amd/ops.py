@@ -200,7 +200,7 @@ def _check_addend(addend, y, excluded):
     if IGEMM_V != 2:
         raise RuntimeError("addend needs the v2 igemm schedule")
     if excluded:
-        raise RuntimeError("addend excludes pool / statistics outputs")
+        raise RuntimeError("addend excludes the pooled output")
     _dev_f32(addend, "addend")
     if tuple(addend.shape) != tuple(y.shape) or addend.stride() != y.stride():
         raise RuntimeError(f"addend {tuple(addend.shape)} must match the output {tuple(y.shape)} (NHWC in memory)")
@@ -225,7 +225,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    _check_addend(addend, y, pool or stats)
+    _check_addend(addend, y, pool)
     ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None)) \
@@ -326,7 +326,7 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     if taps != 16 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
-    _check_addend(addend, y, stats)
+    _check_addend(addend, y, False)
     ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None)) \

@@ -123,7 +123,7 @@ int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin,
  * It carries the skip half of a decoder block's first conv, cat([up(d), skip]) (vgg_64.py:98-105, dcgan_64.py:84-86),
  * when the skip tensor is loop-invariant over the steps of a rollout (generate_frames.py:154-157): the caller
  * computes conv(skip, W[:, C1:]) once with scale = shift = NULL, act = NONE and then runs only the x half per step.
- * Excludes the pool / statistics outputs.                                                                    */
+ * Statistics (train-mode BatchNorm) are taken over conv + addend; excludes the pooled output.                 */
 int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout);
 int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, int Cout, int pool, int with_workspace);
 int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,

@@ -283,3 +283,46 @@ def test_shared_encoder_passes_match_reference_structure(model):
                 assert cos > 0.98 and agree > 0.97, (k, cos, agree)
             else:   # BatchNorm running statistics and other buffers
                 assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_shared_skip_halves_match_reference_structure(model):
+    """Trainer.share_skip_halves (the three decoder calls of a time step share the skip half of every concat conv,
+    forward and backward: autograd._SkipHalf) against three full concat convs: same losses, same BatchNorm running
+    statistics and batch counts, same parameter updates.  (The first Adam step is lr * sign(g) per
+    element, so an element whose gradient is ~0 may flip under a change of summation order: updates are compared by
+    direction and by the fraction of elements that agree, not element by element.)"""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    res = []
+    for share in (False, True):
+        torch.manual_seed(5)
+        opt = _opt(model, ["--n_past", "2", "--n_future", "3"])
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        tr.train_mode()
+        tr.share_skip_halves = share
+        x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, SyntheticMovingMNIST(seq_len=5, seed=4).batch(4))
+        before = [copy.deepcopy(m.state_dict()) for m in tr.modules]
+        out = tr.train_model(x)
+        after = [copy.deepcopy(m.state_dict()) for m in tr.modules]
+        ft = tr.finetune_temporal_encoders(x)   # runs on the updated weights: compared loosely (see the docstring)
+        res.append((out + (tr.last_loss,), before, after, [{n for n, _ in m.named_parameters()} for m in tr.modules], ft,
+                    int(tr.encoder.state_dict()[[k for k in tr.encoder.state_dict() if k.endswith("num_batches_tracked")][0]])))
+    (la, ba, sa, pa, fa, na), (lb, bb, sb, _, fb, nb) = res
+    for u, v in zip(la, lb):
+        assert abs(u - v) <= 1e-4 * max(1.0, abs(u)), (la, lb)
+    assert abs(fa - fb) <= 2e-2 * max(1.0, abs(fa)) and na == nb == 3 * 2 * 4   # 3 closures x 2(T-1) passes, T = 5
+    for b0, a, b, pnames in zip(ba, sa, sb, pa):
+        for k in a:
+            if k.endswith("num_batches_tracked"):
+                assert int(a[k]) == int(b[k]), k
+            elif k in pnames:
+                da, db = (a[k] - b0[k]).flatten().double(), (b[k] - b0[k]).flatten().double()
+                if float(da.norm()) == 0.0 and float(db.norm()) == 0.0:
+                    continue
+                cos = float((da @ db) / (da.norm() * db.norm()))
+                agree = float(((da - db).abs() <= 1e-4).double().mean())
+                assert cos > 0.98 and agree > 0.97, (k, cos, agree)
+            else:   # BatchNorm running statistics and other buffers
+                assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))

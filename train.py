@@ -101,6 +101,8 @@ class Trainer:
         self.finetune_encoder_grad = False
         # False = encode every middle frame twice per closure like the reference does (tests compare both ways)
         self.share_encoder_passes = True
+        # True = the three decoder calls of a time step compute the skip half of each concat conv once (forward + backward)
+        self.share_skip_halves = True
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group
         Adam = FusedAdam   # HIP only, like the models themselves: no CPU fallback on the product path
         self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002)
@@ -147,6 +149,10 @@ class Trainer:
                 with fused.bn_passes(1 if (t == 0 or t == T - 1) else 2):
                     outs.append(self.encoder(x[t]))
         return outs
+
+    def _share_scope(self):
+        import contextlib
+        return fused.share_skip_halves() if self.share_skip_halves else contextlib.nullcontext()
 
     def _enc(self, enc_all, x, t, grad=True):
         if enc_all is not None:
@@ -227,10 +233,11 @@ class Trainer:
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
             gp_pred = self.gp_layer(self._gp_in(h))
             max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
-            x_pred = self.decoder([h_pred, skip])
-            x_target_pred = self.decoder([h_target, skip])
+            with self._share_scope():   # the three decoder calls of a step share the skip halves of their concat convs
+                x_pred = self.decoder([h_pred, skip])
+                x_target_pred = self.decoder([h_target, skip])
+                x_pred_gp = self.decoder([gp_pred.mean.transpose(0, 1), skip])
             ae_mse = ae_mse + self.mse_latent_criterion(x_target_pred, x[i])
-            x_pred_gp = self.decoder([gp_pred.mean.transpose(0, 1), skip])
             mse = mse + self.mse_criterion(x_pred, x[i])
             mse_gp = mse_gp + self.mse_latent_criterion(x_pred_gp, x[i])
         loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
