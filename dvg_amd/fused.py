@@ -127,7 +127,40 @@ def bn_count_passes(bn) -> None:
         bn.num_batches_tracked += _BN_PASSES
 
 
+# Recording / replaying the BatchNorm side effects of a no-grad train-mode forward: the GP fine-tuning closure encodes
+# exactly what the LSTM fine-tuning closure just encoded (same frames, same encoder weights - only LSTM parameters stepped
+# in between, train.py:175-198 then :146-172), so train.Trainer reuses those encodings and REPLAYS the running-statistic
+# updates of the second set of passes from the recorded per-call statistics: the same dvg_bn_finalize launches on the
+# same inputs in the same order - bit-identical buffers, none of the convolutions.
+_BN_TRACE = None
+
+
+class bn_trace:
+    def __enter__(self):
+        global _BN_TRACE
+        self.prev, self.entries = _BN_TRACE, []
+        _BN_TRACE = self.entries
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_TRACE
+        _BN_TRACE = self.prev
+
+
+def replay_bn_trace(entries) -> None:
+    global _BN_TRACE
+    prev, _BN_TRACE = _BN_TRACE, None
+    try:
+        for bn, stats, count, passes in entries:
+            with bn_passes(passes):
+                _train_bn(bn, stats, count)
+    finally:
+        _BN_TRACE = prev
+
+
 def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
+    if _BN_TRACE is not None:
+        _BN_TRACE.append((bn, stats, count, _BN_PASSES))
     res = ops.bn_finalize(stats, bn.weight.detach() if bn.weight is not None else None,
                           bn.bias.detach() if bn.bias is not None else None,
                           bn.running_mean if bn.track_running_stats else None,

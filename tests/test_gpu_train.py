@@ -326,3 +326,28 @@ def test_shared_skip_halves_match_reference_structure(model):
                 assert cos > 0.98 and agree > 0.97, (k, cos, agree)
             else:   # BatchNorm running statistics and other buffers
                 assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_gp_closure_reuses_lstm_closure_encodings_exactly(model):
+    """Trainer.share_closure_encodings: the GP fine-tuning closure reuses the encodings of the LSTM fine-tuning closure and
+    replays its BatchNorm updates.  Same kernels on the same inputs in the same order: losses, parameters and BatchNorm
+    buffers must be IDENTICAL to re-encoding, bit for bit."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    res = []
+    for share in (False, True):
+        torch.manual_seed(6)
+        opt = _opt(model, ["--n_past", "2", "--n_future", "3"])
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        tr.train_mode()
+        tr.share_closure_encodings = share
+        x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, SyntheticMovingMNIST(seq_len=5, seed=4).batch(4))
+        out = [tr.iteration(x) for _ in range(2)]
+        res.append((out, [copy.deepcopy(m.state_dict()) for m in tr.modules]))
+    (la, sa), (lb, sb) = res
+    assert la == lb
+    for a, b in zip(sa, sb):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

@@ -103,6 +103,8 @@ class Trainer:
         self.share_encoder_passes = True
         # True = the three decoder calls of a time step compute the skip half of each concat conv once (forward + backward)
         self.share_skip_halves = True
+        # True = the GP fine-tuning closure reuses the encodings of the LSTM fine-tuning closure that precedes it
+        self.share_closure_encodings = True
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group
         Adam = FusedAdam   # HIP only, like the models themselves: no CPU fallback on the product path
         self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002)
@@ -181,7 +183,13 @@ class Trainer:
         max_ll = 0
         skip = None
         g = self.finetune_encoder_grad
-        enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
+        cache, self._ft_cache = getattr(self, '_ft_cache', None), None
+        if (cache is not None and cache[0] is x and not g and self.encoder.training and
+                cache[3] == tuple(p._version for p in self.encoder.parameters())):
+            enc_all = cache[1]                       # same frames, same encoder weights: identical encodings ...
+            fused.replay_bn_trace(cache[2])          # ... and the BatchNorm side effects of re-encoding them, replayed
+        else:
+            enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
         for i in range(1, opt.n_past + opt.n_future):
             # Only the GP optimiser steps after this closure (train.py:170-171): the reference back-propagates into
             # the encoder and then discards those gradients (encoder.zero_grad() opens the next train_model).  The
@@ -204,7 +212,15 @@ class Trainer:
         mse_latent = 0
         skip = None
         g = self.finetune_encoder_grad   # only frame_predictor_optimizer steps (train.py:195-196)
-        enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
+        self._ft_cache = None
+        if self.share_encoder_passes and self.share_closure_encodings and not g:
+            # the GP closure that follows encodes the same frames with the same encoder weights: keep the encodings and
+            # the BatchNorm statistics of these passes for it (fused.bn_trace / replay_bn_trace)
+            with fused.bn_trace() as trace:
+                enc_all = self._encode_sequence(x, False)
+            self._ft_cache = (x, enc_all, trace.entries, tuple(p._version for p in self.encoder.parameters()))
+        else:
+            enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
         for i in range(1, opt.n_past + opt.n_future):
             h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
             h_target = self._enc(enc_all, x, i, g)[0]
