@@ -25,7 +25,10 @@ struct WgradParams {
     int N, H, W;        // forward INPUT grid
     int C1, C2, Cout, upsample;
     int tiles_y, tiles_x, tiles_n, tiles_total, tiles_per_split, S, n_co, n_ci;
+    unsigned long long* clk;  // debug only (dvg_debug_set_wgrad_clockbuf): per-workgroup phase cycle sums
 };
+
+static unsigned long long* g_wclk = nullptr;
 
 template <int MODE, int TI, int TH, int TW>
 struct WCfg {
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
         const int ti = pp / (TH * TW), r = pp % (TH * TW);
         return ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * 64;
     };
+    unsigned long long c_stage = 0, c_mfma = 0, c_t0 = p.clk ? clock64() : 0, c_mark = c_t0;
     for (int tile = t_begin; tile < t_end; ++tile) {
         int t = tile;
         const int tx_i = t % p.tiles_x; t /= p.tiles_x;
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
             for (int i = 0; i < NB2; ++i) store_slot(NB1 + i, r2[i], ok2[i]);
         }
         __syncthreads();
+        if (p.clk && tid == 0) { const unsigned long long now = clock64(); c_stage += now - c_mark; c_mark = now; }
         // k loop over the tile's pixels, two per MFMA; fragments of step k+1 are read while step k's MFMAs run
         float a_cur = Ap[kk * 64], b_cur[GT];
         {
@@ -184,7 +189,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
 #pragma unroll
             for (int t2 = 0; t2 < GT; ++t2) b_cur[t2] = b_nxt[t2];
         }
+        if (p.clk && tid == 0) { const unsigned long long now = clock64(); c_mfma += now - c_mark; c_mark = now; }
     }
+    const unsigned long long c_loop_end = p.clk ? clock64() : 0;
     // write partial[split][tapw][co][ci]
 #pragma unroll
     for (int t2 = 0; t2 < GT; ++t2) {
@@ -198,6 +205,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kk;
             dst[(size_t)row * Cin] = acc[t2][reg];
         }
+    }
+    if (p.clk && tid == 0) {
+        unsigned long long* d = p.clk + (size_t)blockIdx.x * 4;
+        d[0] = c_stage; d[1] = c_mfma; d[2] = clock64() - c_loop_end; d[3] = (unsigned long long)(t_end - t_begin);
     }
 }
 
@@ -230,7 +241,8 @@ static int wgrad_tile(int mode, int Hg, int Wg, int* ti, int* th, int* tw) {
         return -1;
     }
     if (Hg % 8 == 0 && Wg % 16 == 0) { *ti = 1; *th = 8; *tw = 16; return 0; }
-    if (Hg == 8 && Wg == 8) { *ti = 2; *th = 8; *tw = 8; return 0; }
+    // 8x8 maps: one image per tile.  The two-image tile (2,8,8) needs 84 KB of LDS, i.e. ONE workgroup per CU and no
+    // interleaving of staging and MFMA phases (94 TF against 112 TF for the other layers).
     if (Hg % 8 == 0 && Wg % 8 == 0) { *ti = 1; *th = 8; *tw = 8; return 0; }
     if (Hg == 4 && Wg == 4) { *ti = 4; *th = 4; *tw = 4; return 0; }
     return -1;
@@ -280,7 +292,7 @@ extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const
     int ti, th, tw;
     DVG_REQUIRE(wgrad_tile(mode, Hg, Wg, &ti, &th, &tw) == 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: unsupported map %dx%d",
                 H, W);
-    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0, g_wclk};
     p.S = dvg_conv_wgrad_splits(mode, N, H, W, C1 + C2, Cout);
     DVG_REQUIRE(p.S > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad split");
     p.n_co = Cout / 64;
@@ -300,3 +312,5 @@ extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const
     }
     return fail(DVG_ERR_SHAPE, "dvg_conv_wgrad: no kernel for tile (%d,%d,%d)", ti, th, tw);
 }
+
+extern "C" void dvg_debug_set_wgrad_clockbuf(void* buf) { g_wclk = (unsigned long long*)buf; }
