@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -217,8 +218,9 @@ def main():
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside bench.py)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv3x3_traffic.json")
-        if dom == "conv3x3_igemm" and args.batch == 64 and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", {"conv3x3_igemm": "r01_conv3x3_traffic.json",
+                                                "conv4x4s2_igemm": "r01_conv4x4s2_traffic.json"}.get(dom, "-"))
+        if args.batch == 64 and os.path.exists(tpath):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -230,7 +232,11 @@ def main():
         result["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
                                  "avg_us": round(1000 * v["ms"] / v["launches"], 2),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in agg.items()}
+                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                 # fraction of the 8 TB/s HBM peak on the kernel's ALGORITHMIC bytes (meaningful for the
+                                 # HBM-bound first / last layers; the MFMA-bound kernels sit far below by design)
+                                 "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                             for k, v in agg.items()}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)
         print(json.dumps(result), flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 outputs of tools/profile_round.sh: per-kernel-family averages of the PMC counters (one CSV
-row per dispatch x counter) and the kernel-trace stats.  Usage: pmc_summary.py gpurun_out/prof_round [family-substr]"""
+row per dispatch x counter) and the kernel-trace stats.  Usage: pmc_summary.py gpurun_out/prof_round [dir-glob, default pmc_*]"""
 import csv
 import glob
 import json
@@ -18,7 +18,8 @@ def family(name):
 def main():
     root = sys.argv[1]
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    pat = sys.argv[2] if len(sys.argv) > 2 else "pmc_*"
+    for f in glob.glob(os.path.join(root, pat, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             a = acc[family(row["Kernel_Name"])][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"])

@@ -14,6 +14,9 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_
   tag=$(echo $c | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$tag -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $out/pmc_$tag.log 2>&1 < /dev/null
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmcd_$c -o pmc -- python3 bench.py --model dcgan --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $out/pmcd_$c.log 2>&1 < /dev/null
+done
 timeout 300 python3 bench.py > $out/bench_vgg.json 2> $out/bench_vgg.err < /dev/null
 timeout 200 python3 bench.py --model dcgan > $out/bench_dcgan.json 2> $out/bench_dcgan.err < /dev/null
 for cfg in "--model vgg" "--model dcgan" "--model vgg --channels 3 --batch 16 --n_past 2 --n_future 10" "--model dcgan --channels 3 --batch 16 --n_past 2 --n_future 10" "--model vgg --channels 3 --image_width 128 --batch 4 --n_past 4 --n_future 12" "--model dcgan --channels 3 --image_width 128 --batch 4 --n_past 4 --n_future 12"; do
