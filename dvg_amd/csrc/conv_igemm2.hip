@@ -47,8 +47,6 @@ struct Igemm2Params {
     int N, H, W, C1, C2, Cout, upsample, act;
     float slope;
     int tiles_y, tiles_x, tiles_n, nblk_n;
-    int ablate;  // debug only (dvg_debug_set_ablate): v3 producer pacing experiments (bits 256 / 512); the v2 loop ablations
-                 // that located the staging cost were removed with the loop restructure
     int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
     int cps;     // K chunks (of 16 channels) per split
     float* ws;   // [splitk][N*Ho*Wo][Cout]
@@ -57,7 +55,6 @@ struct Igemm2Params {
     int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
 };
 
-static int g_ablate = 0;
 static unsigned long long* g_clk = nullptr;
 
 template <int MODE, int TI, int TH, int TW>
@@ -75,7 +72,6 @@ struct Cfg2 {
     // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
     static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LD;
     static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
-    static constexpr int MT3 = BM / 128;  // v3: 8 consumer waves as 4(M) x 2(N)
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
 };
 
@@ -448,305 +444,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     clk_exit();
 }
 
-// =====================================================================================================
-// v3: wave-specialised persistent schedule.
-//   * 512-thread workgroup, ONE per CU (2 x 60 KB LDS stage buffers): waves 0-3 are CONSUMERS (ds_read + MFMA
-//     + epilogue only), waves 4-7 are PRODUCERS (global -> registers -> LDS of the NEXT stage).  Each SIMD hosts
-//     one consumer and one producer wave, so staging instructions never sit in the MFMA wave's stream and the
-//     matrix pipe only waits at the one workgroup barrier per stage.
-//   * workgroups are persistent over work items (tile x Cout-block [x parity]); the (item, stage) sequence is
-//     flattened, so the producers prefetch the first stage of the next item during the last stage of the current
-//     one: no exposed prologue, and a layer only needs >= 256 items to fill the chip.
-// Same stage layout, fragments, epilogue and numerics as v2.
-// =====================================================================================================
-template <int MODE, int TI, int TH, int TW>
-__global__ __launch_bounds__(768, 3) void conv_igemm3_kernel(const Igemm2Params p, const int total_items) {
-    using C = Cfg2<MODE, TI, TH, TW>;
-    constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT3, GT = C::GT, NG = C::NG,
-                  BN = C::BN, NLA = C::NLA;
-    static_assert(MT >= 1, "v3 needs BM >= 128");
-    constexpr int STAGE_FLOATS = C::A_FLOATS + C::B_FLOATS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* red = smem + 2 * STAGE_FLOATS;  // 2 x 384 floats for the statistics epilogue
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 8;       // waves 0-7: consumers (2 per SIMD), waves 8-11: producers (1 per SIMD)
-    const int rt = tid - 512;              // producer thread index 0..255
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;   // consumers: 4(M) x 2(N)
-    const int Cin = p.C1 + p.C2;
-    const int nst = (Cin / C::KC) * NG;    // stages per item
-
-    const unsigned first = xcd_remap(blockIdx.x, gridDim.x);
-    int my_items = 0;
-    if ((int)first < total_items) my_items = (total_items - 1 - (int)first) / (int)gridDim.x + 1;
-    const int total_steps = my_items * nst;
-
-    auto decode = [&](int item, int& par, int& nb0, int& n0, int& y0, int& x0) {
-        unsigned lid = (unsigned)item;
-        par = 0;
-        if (MODE == M2_CONVT4S2) { par = lid & 3; lid >>= 2; }
-        nb0 = (lid % p.nblk_n) * BN;
-        unsigned t = lid / p.nblk_n;
-        x0 = (t % p.tiles_x) * TW; t /= p.tiles_x;
-        y0 = (t % p.tiles_y) * TH; t /= p.tiles_y;
-        n0 = (int)t * TI;
-    };
-    auto tap_w = [&](int par, int grp, int tt) -> int {
-        if (MODE == M2_CONVT4S2) return (2 + (par >> 1) - 2 * (tt >> 1)) * 4 + (2 + (par & 1) - 2 * (tt & 1));
-        return grp * GT + tt;
-    };
-    auto tap_lds = [&](int par, int grp, int tt) -> int {
-        int th, tw;
-        if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
-        else if (MODE == M2_CONV4S2) { th = grp * 2 + (tt >> 2); tw = tt & 3; }
-        else { th = 1 + (par >> 1) - (tt >> 1); tw = 1 + (par & 1) - (tt & 1); }
-        return (th * HW + tw) * LD;
-    };
-
-    if (producer) {
-        // ------------------------------------------------------------------ producers ----------
-        long offx[NLA], offs[NLA];
-        int par = 0, nb0 = 0;
-        const int brow = rt >> 2, bq = rt & 3;
-        auto geometry = [&](int item) {
-            int n0, y0, x0;
-            decode(item, par, nb0, n0, y0, x0);
-            const int yin0 = y0 * S - 1, xin0 = x0 * S - 1;
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                const int idx = rt + i * 256;
-                const int hp = idx >> 2, q = idx & 3;
-                const int ti = hp / (HH * HW), r = hp % (HH * HW);
-                const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
-                const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                const int sh = p.upsample;
-                offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : -1;
-                offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : -1;
-            }
-        };
-        // Loads run a full stage ahead of their LDS write (two register sets), and the LDS writes are PACED over the
-        // stage: measured on this kernel, a burst of 48 ds_write_b128 per stage blocks the consumers' ds_reads for
-        // longer than their one-tap prefetch slack (-7 points), and loads issued only one barrier ahead make the
-        // consumers wait for L2/MALL latency at the stage barrier (-8 points).
-        auto gload = [&](int step, f32x4 (&ra)[NLA], f32x4 (&rb)[GT], bool& has_a) {
-            const int s = step % nst;
-            if (s == 0) geometry((int)first + (step / nst) * (int)gridDim.x);
-            const int chunk = s / NG, grp = s % NG;
-#pragma unroll
-            for (int tt = 0; tt < GT; ++tt)
-                rb[tt] = *reinterpret_cast<const f32x4*>(
-                    p.w + (((size_t)chunk * C::NTAPS + tap_w(par, grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4);
-            has_a = grp == 0;
-            if (has_a) {
-                const int c0 = chunk * C::KC;
-                const bool from_x = c0 < p.C1;
-                const float* src = from_x ? p.x + c0 : p.skip + (c0 - p.C1);
-#pragma unroll
-                for (int i = 0; i < NLA; ++i) {
-                    const long o = from_x ? offx[i] : offs[i];
-                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (o >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + o);
-                }
-            }
-        };
-        const bool pace_long = (p.ablate & 512) != 0;
-        auto lstore = [&](int step, const f32x4 (&ra)[NLA], const f32x4 (&rb)[GT], bool has_a, bool paced) {
-            float* As = smem + (step & 1) * STAGE_FLOATS;
-            float* Bs = As + C::A_FLOATS;
-            const float* Ao = smem + ((step & 1) ^ 1) * STAGE_FLOATS;
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                const int idx = rt + i * 256;
-                if (idx < HP * 4) {
-                    const int o = (idx >> 2) * LD + (idx & 3) * 4;
-                    *reinterpret_cast<f32x4*>(&As[o]) = has_a ? ra[i] : *reinterpret_cast<const f32x4*>(&Ao[o]);
-                }
-                if (paced) { if (pace_long) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(2); }
-            }
-#pragma unroll
-            for (int tt = 0; tt < GT; ++tt) {
-                *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
-                if (paced) { if (pace_long) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(2); }
-            }
-        };
-        f32x4 ra0[NLA], rb0[GT], ra1[NLA], rb1[GT];
-        bool a0 = false, a1 = false;
-        const bool pace = !(p.ablate & 256);
-        const int T = total_steps;
-        if (T > 0) {
-            gload(0, ra0, rb0, a0);
-            lstore(0, ra0, rb0, a0, false);
-        }
-        if (T > 1) gload(1, ra1, rb1, a1);
-        __syncthreads();
-        for (int step = 0; step < T; step += 2) {
-            if (step + 1 < T) lstore(step + 1, ra1, rb1, a1, pace);   // stage step+1 was loaded a stage ago (set 1)
-            if (step + 2 < T) gload(step + 2, ra0, rb0, a0);
-            __syncthreads();
-            if (step + 1 >= T) break;
-            if (step + 2 < T) lstore(step + 2, ra0, rb0, a0, pace);
-            if (step + 3 < T) gload(step + 3, ra1, rb1, a1);
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers ----------
-    int a_base[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = wm * (C::BM / 4) + mt * 32 + l31;
-        const int ti = m / (TH * TW), r = m % (TH * TW);
-        a_base[mt] = ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * LD + hh * 8;
-    }
-    const int b_base = (wn * 32 + l31) * LD + hh * 8;
-    int Ho, Wo;
-    if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
-    else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
-    else { Ho = p.H * 2; Wo = p.W * 2; }
-
-    f32x16 acc[MT];
-    int par = 0, nb0 = 0, n0 = 0, y0 = 0, x0 = 0, item = 0;
-    __syncthreads();   // stage 0 is in LDS
-    for (int step = 0; step < total_steps; ++step) {
-        const int s = step % nst;
-        if (s == 0) {
-            item = (int)first + (step / nst) * (int)gridDim.x;
-            decode(item, par, nb0, n0, y0, x0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-        }
-        const int grp = s % NG;
-        const float* As = smem + (step & 1) * STAGE_FLOATS;
-        const float* Bs = As + C::A_FLOATS;
-        float s1 = 0.f, s2 = 0.f;   // per-channel statistics of this item (live across the stage barrier)
-        f32x4 fa[2][MT][2], fb[2][2];
-        {
-            const int ao = tap_lds(par, grp, 0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    fa[0][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
-                fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + j * 4]);
-            }
-        }
-#pragma unroll
-        for (int tt = 0; tt < GT; ++tt) {
-            const int cur = tt & 1, nxt = cur ^ 1;
-            if (tt + 1 < GT) {
-                const int ao = tap_lds(par, grp, tt + 1);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
-                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LD + j * 4]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][j][e], acc[mt], 0, 0, 0);
-            constexpr int NREAD = 2 * MT + 2, NMFMA = 8 * MT;
-            if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
-            if (tt + 1 < GT) {
-#pragma unroll
-                for (int r = 0; r < NREAD; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-                if (NMFMA > 2 * NREAD) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NREAD, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
-            }
-        }
-
-        if (s == nst - 1) {
-            // ---- epilogue of this item (the producers are already staging the next item) ----
-            const int py = par >> 1, px = par & 1;
-            const int c = nb0 + wn * 32 + l31;
-            const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float v[16];
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) v[reg] = acc[mt][reg] * sc + sf;
-                const int mbase = wm * (C::BM / 4) + mt * 32;
-                const int ti0 = mbase / (TH * TW);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    const int m = mbase + row;
-                    const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
-                    const int r = m % (TH * TW);
-                    const int ty = r / TW, tx = r % TW;
-                    const int n = n0 + tii;
-                    if (n < p.N) {
-                        s1 += v[reg];
-                        s2 += v[reg] * v[reg];
-                        const float o = apply_act(v[reg], p.act, p.slope);
-                        v[reg] = o;
-                        int oy, ox;
-                        if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
-                        else { oy = y0 + ty; ox = x0 + tx; }
-                        p.y[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = o;
-                    }
-                }
-                if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
-                    if (p.y_pool != nullptr) {
-                        constexpr int RY = (TW == 16) ? 8 : 4;
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const bool ty_even = (TW == 16) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
-                            if ((reg & 1) == 0 && ty_even) {
-                                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                                const int r = (mbase + row) % (TH * TW);
-                                const int ty = r / TW, tx = r % TW;
-                                const float mx = fmaxf(fmaxf(v[reg], v[reg + 1]), fmaxf(v[reg + RY], v[reg + RY + 1]));
-                                const int n = n0 + ti0;
-                                if (n < p.N)
-                                    p.y_pool[(((size_t)n * (Ho >> 1) + ((y0 + ty) >> 1)) * (Wo >> 1) + ((x0 + tx) >> 1)) *
-                                                 p.Cout + c] = mx;
-                            }
-                        }
-                    }
-                }
-            }
-            if (p.stats != nullptr) {
-                // fold the lane halves; the wm = 1 wave hands its sums to the wm = 0 wave of the same wn through LDS,
-                // ordered by the stage barrier below.  red[] alternates between two halves per item so that the next
-                // item's hand-off can never overtake this one's read.
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (wm >= 1 && hh == 0) {
-                    float* rr = red + ((step / nst) & 1) * 384 + (wm - 1) * 128;
-                    rr[wn * 64 + l31] = s1;
-                    rr[wn * 64 + 32 + l31] = s2;
-                }
-            }
-        }
-        __syncthreads();
-        if (s == nst - 1 && p.stats != nullptr && wm == 0 && hh == 0) {
-            const float* rr = red + ((step / nst) & 1) * 384;
-            unsigned lid = (unsigned)item;
-            unsigned rowid;
-            if (MODE == M2_CONVT4S2) rowid = ((lid >> 2) / p.nblk_n) * 4 + (lid & 3);
-            else rowid = lid / p.nblk_n;
-            const int c = nb0 + wn * 32 + l31;
-            float* dst = p.stats + (size_t)rowid * 2 * p.Cout;
-            dst[c] = s1 + (rr[wn * 64 + l31] + rr[128 + wn * 64 + l31] + rr[256 + wn * 64 + l31]);
-            dst[p.Cout + c] = s2 + (rr[wn * 64 + 32 + l31] + rr[128 + wn * 64 + 32 + l31] + rr[256 + wn * 64 + 32 + l31]);
-        }
-    }
-}
-
-
 // out = act((sum_s ws[s]) * scale + shift) (+ 2x2 max-pool, + per-channel sum / sum of squares of the pre-activation)
 // One thread = one pixel (or one 2x2 window when pooling) x 4 channels; blockDim = 256 = TC x TP as in the BN
 // backward reduction; one partial statistics row per workgroup.
@@ -868,7 +565,6 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
-    p.ablate = g_ablate;
     p.clk = g_clk;
     const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
     {
@@ -928,33 +624,6 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     return DVG_OK;
 }
 
-template <int MODE, int TI, int TH, int TW>
-static int launch3(Igemm2Params p, int Hg, int Wg, hipStream_t stream) {
-    using C = Cfg2<MODE, TI, TH, TW>;
-    if (Hg % TH || Wg % TW || p.Cout % 64) return fail(DVG_ERR_SHAPE, "conv_igemm3: tile does not divide shape");
-    p.tiles_y = Hg / TH;
-    p.tiles_x = Wg / TW;
-    p.tiles_n = (p.N + TI - 1) / TI;
-    p.nblk_n = p.Cout / 64;
-    p.nb_group = p.nblk_n;
-    p.ablate = g_ablate;
-    p.clk = g_clk;
-    const int items = p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
-    const int lds = (2 * (C::A_FLOATS + C::B_FLOATS) + 768) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm3_kernel<MODE, TI, TH, TW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const unsigned grid = items < 256 ? items : 256;   // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv_igemm3_kernel<MODE, TI, TH, TW>), dim3(grid), dim3(768), lds, stream, p, items);
-    return check_launch("conv_igemm3");
-}
-
-static int g_schedule = 2;   // 2 = v2 (two workgroups per CU), 3 = wave-specialised persistent
-extern "C" void dvg_set_igemm_schedule(int v) { g_schedule = v; }
 
 // spatial tile on the grid the tiles cover; 8x16 unless the map is 8 wide / that leaves < 2 workgroups per CU
 static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, int* tw) {
@@ -990,7 +659,6 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
 
 using namespace dvg;
 
-extern "C" void dvg_debug_set_ablate(int v) { g_ablate = v; }
 extern "C" void dvg_debug_set_clockbuf(void* buf) { g_clk = (unsigned long long*)buf; }
 
 extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
@@ -1006,26 +674,12 @@ extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cou
     return check_launch("dvg_pack_conv_weight_k16");
 }
 
-// v3 tiles: 16x16 (256 px) when that still leaves >= 256 work items, else 8x16, 8x8 maps as two images
-static int tile3(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, int* tw) {
-    const int par = mode == M2_CONVT4S2 ? 4 : 1;
-    if (mode == M2_CONV4S2) return -1;   // stride-2 halo of a 128-px tile does not fit two LDS stage buffers
-    if (Hg % 8 || Wg % 8) return -1;
-    if (Hg % 16 == 0 && Wg % 16 == 0 && (long)N * (Hg / 16) * (Wg / 16) * (Cout / 64) * par >= 256) {
-        *ti = 1; *th = 16; *tw = 16; return 0;
-    }
-    if (Wg % 16 == 0) { *ti = 1; *th = 8; *tw = 16; return 0; }
-    *ti = 2; *th = 8; *tw = 8;
-    return 0;
-}
-
 static long v2_wgs(int mode, int N, int Hg, int Wg, int Cout, int ti, int th, int tw) {
     return (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * (Cout / 64) * (mode == M2_CONVT4S2 ? 4 : 1);
 }
 
 // K splits the v2 launch of this shape will use when a workspace is supplied (1 = no split)
 extern "C" int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout) {
-    if (g_schedule == 3 && mode == M2_CONV3) return 1;
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
@@ -1037,8 +691,6 @@ extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, in
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
-    if (g_schedule == 3 && mode == M2_CONV3 && tile3(mode, N, Hg, Wg, Cout, &ti, &th, &tw) == 0)
-        return ((N + ti - 1) / ti) * (Hg / th) * (Wg / tw);
     if (tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
     if (with_workspace && choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16) > 1) {
         int Ho = H, Wo = W;
@@ -1067,8 +719,6 @@ static int checks2(const Igemm2Params& p, const char* who) {
 #define D2(MODE, TI_, TH_, TW_) \
     if (ti == TI_ && th == TH_ && tw == TW_)                                             \
         return launch2<MODE, TI_, TH_, TW_>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
-#define D3(MODE, TI_, TH_, TW_) \
-    if (ti == TI_ && th == TH_ && tw == TW_) return launch3<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
 
 
 
@@ -1084,11 +734,6 @@ extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const fl
                 "dvg_conv3x3_bn_act_v2: addend must be 16-byte aligned and excludes the pooled output");
     DVG_REQUIRE(H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: H=%d W=%d must be multiples of 8", H, W);
     int Hg = H, Wg = W, ti, th, tw;
-    if (g_schedule == 3 && addend == nullptr && tile3(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0) {
-        D3(M2_CONV3, 1, 16, 16)
-        D3(M2_CONV3, 1, 8, 16)
-        D3(M2_CONV3, 2, 8, 8)
-    }
     DVG_REQUIRE(tile2(M2_CONV3, N, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
                 "dvg_conv3x3_bn_act_v2: no tile for %dx%d", H, W);
     D2(M2_CONV3, 1, 8, 16)

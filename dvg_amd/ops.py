@@ -14,11 +14,8 @@ from ._lib import check, lib
 
 # implicit-GEMM schedule: 2 = conv_igemm2.hip (chunk-staged, register-prefetched), 1 = conv_igemm.hip
 IGEMM_V = int(os.environ.get("DVG_IGEMM", "2"))
-if IGEMM_V == 3:   # same entry points and weight layout as v2, different schedule inside the library
-    import ctypes as _ct
-    from ._lib import LIB_PATH as _LP
-    _ct.CDLL(_LP).dvg_set_igemm_schedule(3)
-    IGEMM_V = 2
+if IGEMM_V not in (1, 2):
+    raise RuntimeError("DVG_IGEMM must be 1 (first schedule, conv_igemm.hip) or 2 (default, conv_igemm2.hip)")
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2 = 0, 1, 2

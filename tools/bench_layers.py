@@ -42,12 +42,7 @@ def time_fn(fn, iters=50, warm_s=0.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--ablate", type=int, default=0)
     args = ap.parse_args()
-    if args.ablate:
-        import ctypes
-        from dvg_amd._lib import LIB_PATH
-        ctypes.CDLL(LIB_PATH).dvg_debug_set_ablate(args.ablate)
     dev = torch.device("cuda:0")
     N = args.batch
     tot_us = tot_fl = 0.0

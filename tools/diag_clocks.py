@@ -23,8 +23,6 @@ WARM_S = float(os.environ.get('DIAG_WARM_S', '2.0'))
 def main():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dvg_debug_set_clockbuf.argtypes = [ctypes.c_void_p]
-    if len(sys.argv) > 1:
-        lib.dvg_debug_set_ablate(int(sys.argv[1]))
     dev = torch.device("cuda:0")
     N = 64
     buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
