@@ -52,10 +52,12 @@ struct Igemm2Params {
     float* ws;   // [splitk][N*Ho*Wo][Cout]
     const float* addend;  // optional raw (pre-scale) partial sums, NHWC like y: y = act((acc + addend) * scale + shift)
     unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
+    unsigned clk_cap;         // records the buffer holds (workgroups beyond it do not stamp)
     int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
 };
 
 static unsigned long long* g_clk = nullptr;
+static unsigned g_clk_cap = 0;
 
 template <int MODE, int TI, int TH, int TW>
 struct Cfg2 {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     unsigned long long clk_loop = 0;
     if (p.clk && threadIdx.x == 0) clk_loop = clock64();
     auto clk_exit = [&]() {
-        if (p.clk && threadIdx.x == 0) {
+        if (p.clk && threadIdx.x == 0 && blockIdx.x < p.clk_cap) {
             unsigned long long* d = p.clk + (size_t)blockIdx.x * 8;
             d[0] = clk0; d[1] = clk1; d[2] = clk_loop; d[3] = clock64(); d[4] = wclk0; d[5] = wall_clock64();
             unsigned xcc;
@@ -566,6 +568,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.tiles_n = (p.N + TI - 1) / TI;
     p.nblk_n = p.Cout / 64;
     p.clk = g_clk;
+    p.clk_cap = g_clk_cap;
     const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
     {
         // Cout blocks per XCD group: minimise (weight slabs + input tiles) one XCD's L2 fetches for its share of the
@@ -659,7 +662,10 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
 
 using namespace dvg;
 
-extern "C" void dvg_debug_set_clockbuf(void* buf) { g_clk = (unsigned long long*)buf; }
+extern "C" void dvg_debug_set_clockbuf(void* buf, unsigned records) {   // records of 8 x u64, one per workgroup
+    g_clk = (unsigned long long*)buf;
+    g_clk_cap = buf ? records : 0;
+}
 
 extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                                         int transposed, void* stream) {

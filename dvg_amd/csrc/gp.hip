@@ -14,7 +14,8 @@
 
 namespace dvg {
 
-static unsigned long long* g_gp_clk = nullptr;  // debug only (dvg_debug_set_gp_clockbuf): phase stamps per workgroup
+static unsigned long long* g_gp_clk = nullptr;
+static unsigned g_gp_clk_cap = 0;  // debug only (dvg_debug_set_gp_clockbuf): phase stamps per workgroup
 
 struct GpParams {
     const float* h;         // [B][D]
@@ -33,7 +34,8 @@ struct GpParams {
     float* kl;           // [D]
     int B, D, M, train_mode;
     float jitter;
-    unsigned long long* clk;  // debug only
+    unsigned long long* clk;  // debug only: 12 x u64 per workgroup (latent dim), for the first clk_cap workgroups
+    unsigned clk_cap;
 };
 
 // In-place lower Cholesky of the n x n matrix A (row stride ld) by ONE wave:
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     const float noise = p.noise ? p.noise[d] : 0.f;
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
-    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 0] = clock64();
+    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
     for (int i = tid; i < M; i += 256) zs[i] = p.z[(size_t)d * M + i];
     for (int b = tid; b < B; b += 256) xs[b] = p.h[(size_t)b * p.D + d];
     __syncthreads();
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     }
     __syncthreads();
 
-    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 1] = clock64();
+    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 1] = clock64();
     // W = L_S^T K_Zx (needs the un-solved K_Zx), then chol(K_ZZ) by the whole workgroup
     for (int i = tid; i < M * B; i += 256) {
         const int r = i / B, b = i % B;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
         Wm[r * LB + b] = acc;
     }
     block_cholesky(L, M, LM, tid);   // ends with __syncthreads
-    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 2] = clock64();
+    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 2] = clock64();
 
     // Blocked forward substitution L X = [K_Zx | m-c]: per block of 8 rows, one thread per column solves the 8x8
     // triangle, then all threads subtract the block's contribution from the rows below (one thread per column
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
             __syncthreads();
         }
     }
-    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 3] = clock64();
+    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 3] = clock64();
 
     // predictive mean and marginal variance
     for (int b = tid; b < B; b += 256) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
 
     if (need_cov) {
         __syncthreads();
-        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 4] = clock64();
+        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 4] = clock64();
         // Sigma = W^T W - A^T A + k(x,x) (+ noise I): 4x4 register tiles (16 LDS reads per 32 FMAs instead of 4 per 2),
         // lower-triangular tiles only, mirrored on store
         {
@@ -368,10 +370,10 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
             }
         }
         __syncthreads();
-        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 5] = clock64();
+        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 5] = clock64();
         if (p.sample != nullptr) {
             block_cholesky(Sg, B, LS, tid);   // ends with __syncthreads
-        if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 6] = clock64();
+        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 6] = clock64();
             for (int b = tid; b < B; b += 256) {
                 float acc = mu[b];
 #pragma unroll 4
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
             }
         }
     }
-    if (p.clk && tid == 0) p.clk[(size_t)d * 12 + 7] = clock64();
+    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 7] = clock64();
 }
 
 
@@ -641,7 +643,7 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
         attr_lds = lds;
     }
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
-               B, D, M, train_mode, jitter, g_gp_clk};
+               B, D, M, train_mode, jitter, g_gp_clk, g_gp_clk_cap};
     hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("dvg_gp_predict");
 }
@@ -675,4 +677,7 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
     return check_launch("dvg_gp_train_bwd");
 }
 
-extern "C" void dvg_debug_set_gp_clockbuf(void* buf) { g_gp_clk = (unsigned long long*)buf; }
+extern "C" void dvg_debug_set_gp_clockbuf(void* buf, unsigned records) {
+    g_gp_clk = (unsigned long long*)buf;
+    g_gp_clk_cap = buf ? records : 0;
+}

@@ -25,10 +25,12 @@ struct WgradParams {
     int N, H, W;        // forward INPUT grid
     int C1, C2, Cout, upsample;
     int tiles_y, tiles_x, tiles_n, tiles_total, tiles_per_split, S, n_co, n_ci;
-    unsigned long long* clk;  // debug only (dvg_debug_set_wgrad_clockbuf): per-workgroup phase cycle sums
+    unsigned long long* clk;  // debug only (dvg_debug_set_wgrad_clockbuf): per-workgroup phase cycle sums (4 x u64)
+    unsigned clk_cap;
 };
 
 static unsigned long long* g_wclk = nullptr;
+static unsigned g_wclk_cap = 0;
 
 template <int MODE, int TI, int TH, int TW>
 struct WCfg {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
             dst[(size_t)row * Cin] = acc[t2][reg];
         }
     }
-    if (p.clk && tid == 0) {
+    if (p.clk && tid == 0 && blockIdx.x < p.clk_cap) {
         unsigned long long* d = p.clk + (size_t)blockIdx.x * 4;
         d[0] = c_stage; d[1] = c_mfma; d[2] = clock64() - c_loop_end; d[3] = (unsigned long long)(t_end - t_begin);
     }
@@ -292,7 +294,7 @@ extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const
     int ti, th, tw;
     DVG_REQUIRE(wgrad_tile(mode, Hg, Wg, &ti, &th, &tw) == 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: unsupported map %dx%d",
                 H, W);
-    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0, g_wclk};
+    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0, g_wclk, g_wclk_cap};
     p.S = dvg_conv_wgrad_splits(mode, N, H, W, C1 + C2, Cout);
     DVG_REQUIRE(p.S > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad split");
     p.n_co = Cout / 64;
@@ -313,4 +315,7 @@ extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const
     return fail(DVG_ERR_SHAPE, "dvg_conv_wgrad: no kernel for tile (%d,%d,%d)", ti, th, tw);
 }
 
-extern "C" void dvg_debug_set_wgrad_clockbuf(void* buf) { g_wclk = (unsigned long long*)buf; }
+extern "C" void dvg_debug_set_wgrad_clockbuf(void* buf, unsigned records) {
+    g_wclk = (unsigned long long*)buf;
+    g_wclk_cap = buf ? records : 0;
+}

@@ -22,7 +22,7 @@ WARM_S = float(os.environ.get('DIAG_WARM_S', '2.0'))
 
 def main():
     lib = ctypes.CDLL(LIB_PATH)
-    lib.dvg_debug_set_clockbuf.argtypes = [ctypes.c_void_p]
+    lib.dvg_debug_set_clockbuf.argtypes = [ctypes.c_void_p, ctypes.c_uint]
     dev = torch.device("cuda:0")
     N = 64
     buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
@@ -40,13 +40,13 @@ def main():
                 fn()
             torch.cuda.synchronize()
         buf.zero_()
-        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(buf.data_ptr()))
+        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(buf.data_ptr()), buf.numel() // 8)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         torch.cuda.synchronize()
-        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(0))
+        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(0), 0)
         d = buf.cpu().numpy().reshape(-1, 8)
         d = d[d[:, 3] != 0]
         nwg = len(d)

@@ -19,7 +19,7 @@ WARM_S = float(os.environ.get("DIAG_WARM_S", "0.3"))
 
 def main():
     lib = ctypes.CDLL(LIB_PATH)
-    lib.dvg_debug_set_clockbuf.argtypes = [ctypes.c_void_p]
+    lib.dvg_debug_set_clockbuf.argtypes = [ctypes.c_void_p, ctypes.c_uint]
     dev = torch.device("cuda:0")
     N = int(os.environ.get("DIAG_BATCH", "64"))
     buf = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
@@ -50,10 +50,10 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
         buf.zero_()
-        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(buf.data_ptr()))
+        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(buf.data_ptr()), buf.numel() // 8)
         fn()
         torch.cuda.synchronize()
-        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(0))
+        lib.dvg_debug_set_clockbuf(ctypes.c_void_p(0), 0)
         d = buf.cpu().numpy().reshape(-1, 8)
         d = d[d[:, 3] != 0]
         c0, c1, c2, c3, w0, w1 = [d[:, i].astype(np.float64) for i in range(6)]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvg_amd import ops
 from dvg_amd._lib import LIB_PATH
 from oracle import params
-lib = ctypes.CDLL(LIB_PATH); lib.dvg_debug_set_gp_clockbuf.argtypes = [ctypes.c_void_p]
+lib = ctypes.CDLL(LIB_PATH); lib.dvg_debug_set_gp_clockbuf.argtypes = [ctypes.c_void_p, ctypes.c_uint]
 dev = torch.device("cuda:0"); B, D, M = 64, 90, 40
 gsd, lsd = params.gp_state(3, D, M)
 g = {k: v.to(dev) for k, v in gsd.items()}
@@ -19,7 +19,7 @@ run = lambda: ops.gp_predict(h, g["variational_strategy.inducing_points"], g["va
 for _ in range(20): run()
 torch.cuda.synchronize()
 buf = torch.zeros(D * 12, dtype=torch.int64, device=dev)
-lib.dvg_debug_set_gp_clockbuf(ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); lib.dvg_debug_set_gp_clockbuf(ctypes.c_void_p(0))
+lib.dvg_debug_set_gp_clockbuf(ctypes.c_void_p(buf.data_ptr()), buf.numel() // 12); run(); torch.cuda.synchronize(); lib.dvg_debug_set_gp_clockbuf(ctypes.c_void_p(0), 0)
 d = buf.cpu().numpy().reshape(D, 12).astype(np.float64)
 names = ["assemble", "chol(Kzz) || W", "fwd subst", "mean/var(+kl)", "covariance", "chol(Sigma)", "sample"]
 for i, n in enumerate(names):

@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvg_amd import ops
 from dvg_amd._lib import LIB_PATH
-lib = ctypes.CDLL(LIB_PATH); lib.dvg_debug_set_wgrad_clockbuf.argtypes = [ctypes.c_void_p]
+lib = ctypes.CDLL(LIB_PATH); lib.dvg_debug_set_wgrad_clockbuf.argtypes = [ctypes.c_void_p, ctypes.c_uint]
 dev = torch.device("cuda:0"); N = 64
 for (H, Cin, Cout) in [(64, 64, 64), (32, 128, 128), (16, 256, 256), (8, 512, 512)]:
     x = ops.nhwc_empty(N, Cin, H, H, dev).normal_(); du = ops.nhwc_empty(N, Cout, H, H, dev).normal_()
@@ -21,7 +21,7 @@ for (H, Cin, Cout) in [(64, 64, 64), (32, 128, 128), (16, 256, 256), (8, 512, 51
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     buf = torch.zeros(4096 * 4, dtype=torch.int64, device=dev)
-    lib.dvg_debug_set_wgrad_clockbuf(ctypes.c_void_p(buf.data_ptr())); fn(); torch.cuda.synchronize(); lib.dvg_debug_set_wgrad_clockbuf(ctypes.c_void_p(0))
+    lib.dvg_debug_set_wgrad_clockbuf(ctypes.c_void_p(buf.data_ptr()), buf.numel() // 4); fn(); torch.cuda.synchronize(); lib.dvg_debug_set_wgrad_clockbuf(ctypes.c_void_p(0), 0)
     d = buf.cpu().numpy().reshape(-1, 4).astype(np.float64); d = d[d[:, 3] > 0]
     fl = 2.0 * N * H * H * Cout * 9 * Cin
     tiles = d[:, 3].mean()
