@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void eval_frames_kernel(const float* __restric
 // ------------------------------------------------------------------------------------
 __global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, const int* __restrict__ ids,
                                             const int* __restrict__ pos, float* __restrict__ out, int T, int B,
-                                            int ND, int S, int D) {
+                                            int ND, int S, int D, int n_sprites) {
     const long total = (long)T * B * S * S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int x = (int)(i % S);
@@ -320,7 +320,7 @@ __global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, c
             const int* pp = pos + (((size_t)b * ND + d) * T + t) * 2;
             const int yy = y - pp[0], xx = x - pp[1];
             if ((unsigned)yy < (unsigned)D && (unsigned)xx < (unsigned)D)
-                v += sprites[((size_t)ids[b * ND + d] * D + yy) * D + xx];
+                v += sprites[((size_t)min(max(ids[b * ND + d], 0), n_sprites - 1) * D + yy) * D + xx];   // ids clamped: device data
         }
         out[i] = v > 1.f ? 1.f : v;
     }
@@ -443,9 +443,9 @@ extern "C" int dvg_moving_mnist_compose(const float* sprites, const int* ids, co
     DVG_REQUIRE(sprites && ids && pos && out, DVG_ERR_NULL, "dvg_moving_mnist_compose: NULL pointer");
     DVG_REQUIRE(n_sprites > 0 && T > 0 && B > 0 && num_digits > 0 && digit_size > 0 && image_size >= digit_size,
                 DVG_ERR_SHAPE, "dvg_moving_mnist_compose: bad shape");
-    // ids / pos are validated on the host by the caller (dvg_amd/data.py: 0 <= id < n_sprites, 0 <= pos <= S - D)
+    // ids / pos live in device memory: the kernel clamps ids and bounds-checks every sprite access against pos
     const long total = (long)T * B * image_size * image_size;
     hipLaunchKernelGGL(moving_mnist_compose_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       sprites, ids, pos, out, T, B, num_digits, image_size, digit_size);
+                       sprites, ids, pos, out, T, B, num_digits, image_size, digit_size, n_sprites);
     return check_launch("dvg_moving_mnist_compose");
 }
