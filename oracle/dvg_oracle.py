@@ -18,6 +18,10 @@ Pinning:
     GaussianLikelihood / VariationalELBO arithmetic as documented in DESIGN.md
     ("GP: equations of record") and are self-checked in fp64 against closed-form
     identities (tests/test_oracle_gp.py).
+  * evaluation metrics (utils.eval_seq -> skimage compare_ssim / compare_psnr): **parity unpinned** as well -
+    scikit-image is neither vendored, pinned nor installed; `ssim_skimage` / `psnr_skimage` restate its published
+    algorithm with the defaults the reference relies on, pinned by closed forms and a brute-force window evaluation
+    (tests/test_oracle_golden.py::test_eval_metrics_oracle_identities).
 """
 from __future__ import annotations
 
