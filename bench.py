@@ -201,7 +201,11 @@ def main():
                    "launch": "eager" if args.no_graph else "hipGraph replay",
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's
                    # first conv is computed once per rollout and added in the epilogue (DVG_SKIP_HOIST=0: recompute)
-                   "loop_invariant_skip_halves": "hoisted" if fused_mod.SKIP_HOIST else "recomputed every step"},
+                   "loop_invariant_skip_halves": "hoisted" if fused_mod.SKIP_HOIST else "recomputed every step",
+                   # nearest-x2 upsample + conv3x3 == 4x4 stride-2 transposed conv with K4 = W (*) ones(2x2): the x half of
+                   # the decoder blocks' first convs runs with 4/9 of the MACs (DVG_UPCONV_AS_CONVT=0: 9-tap form)
+                   "upsample_conv3x3": "as transposed 4x4/s2 conv" if (fused_mod.SKIP_HOIST and fused_mod.UPCONV_AS_CONVT)
+                   else "9-tap conv on the upsampled grid"},
     }
 
     if rank == 0:

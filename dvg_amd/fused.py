@@ -182,6 +182,8 @@ def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
 # as `addend` - identical maths up to fp32 summation order, half the K loop.  A skip that changes on every call
 # (training, last_frame_skip) never gets there and pays nothing.  DVG_SKIP_HOIST=0 disables it.
 SKIP_HOIST = os.environ.get("DVG_SKIP_HOIST", "1") != "0"
+# x half of an upsample + 3x3 conv as the equivalent 4x4 stride-2 transposed conv (see _upconv_packed); 0 disables
+UPCONV_AS_CONVT = os.environ.get("DVG_UPCONV_AS_CONVT", "1") != "0"
 _skip_seen = {}      # (id(conv), id(skip)) -> [weakref(skip), skip._version, weight key, sightings, S or None]
 
 
@@ -242,6 +244,27 @@ def skip_share_scope():
     return _SHARE_SCOPE
 
 
+def _upconv_packed(conv, c1: int):
+    """nearest-x2 upsampling followed by a 3x3 conv (pad 1) IS a stride-2 transposed conv with the 4x4 kernel
+    K4 = W (*) ones(2x2): of the 9 taps of an output pixel only 4 distinct low-resolution inputs contribute.  Returns
+    the packed K4 of the x half W[:, :c1] (ConvTranspose2d layout (Cin, Cout, 4, 4)), cached per parameter version:
+    the x half of every decoder block's first conv (vgg_64.py:98-105) then runs on the CONVT4S2 igemm mode with 4/9 of
+    the MACs.  Tap t (0..2) of the 3x3 kernel lands on k = 2 - t and k = 3 - t of the 4-tap kernel, per axis."""
+    slot = _slot(conv)
+    key = (_ver(conv.weight), c1)
+    hit = slot.get("k4")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = conv.weight.detach()[:, :c1]                      # (Cout, C1, 3, 3)
+    k4 = torch.zeros((w.shape[0], c1, 4, 4), device=w.device, dtype=torch.float32)
+    for ty in range(3):
+        for tx in range(3):
+            k4[:, :, 2 - ty:4 - ty, 2 - tx:4 - tx] += w[:, :, ty:ty + 1, tx:tx + 1]
+    kp = ops.pack_igemm_weight(k4.permute(1, 0, 2, 3).contiguous(), transposed=True)
+    slot["k4"] = (key, kp)
+    return kp
+
+
 def _hoisted_skip(conv, x, skip, partial_fn):
     """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
     if not SKIP_HOIST or skip is None or ops.IGEMM_V != 2:
@@ -277,6 +300,9 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         if not pool:
             hs = _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE))
             if hs is not None:
+                if upsample and UPCONV_AS_CONVT:
+                    return ops.convT4x4s2(x, None, _upconv_packed(conv, x.shape[1]), sc, sh, act=act, slope=slope,
+                                          addend=hs[1])
                 return ops.conv3x3(x, None, hs[0], sc, sh, upsample=upsample, act=act, slope=slope, addend=hs[1])
         return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
     wp = packed_weight(conv)

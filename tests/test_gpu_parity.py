@@ -448,3 +448,28 @@ def test_decoder_skip_hoisting_is_transparent(family):
         fused.SKIP_HOIST = True
         assert rel_err(dec([h, skip]), ref2) < 1e-5          # first sighting of the new version: ordinary path
         assert rel_err(dec([h, skip]), ref2) < 1e-5          # second: recomputed S
+
+
+@pytest.mark.parametrize("H,C1,Cout,N", [(4, 512, 512, 4), (8, 256, 256, 3), (16, 128, 128, 2), (32, 64, 64, 2)])
+def test_upsample_conv3x3_as_transposed_conv(H, C1, Cout, N):
+    """conv3x3(nearest_up2(x), W, pad 1) == convT4x4s2(x, K4) with K4 = W (*) ones(2x2) (fused._upconv_packed): the
+    x half of the decoder blocks' first convs runs with 4/9 of the MACs.  Checked against the fp64 reference,
+    including the raw `addend` and the folded scale / shift, at the four decoder shapes."""
+    if __import__("dvg_amd.ops", fromlist=["x"]).IGEMM_V != 2:
+        pytest.skip("v2 igemm only")
+    import torch.nn as nn
+    from dvg_amd import fused, ops
+    x = params.normal(140, N, C1, H, H)
+    w = params.normal(141, Cout, C1 + 64, 3, 3, scale=0.05)          # a concat conv: only W[:, :C1] is the x half
+    sc, sh = 1 + 0.1 * params.normal(142, Cout), 0.1 * params.normal(143, Cout)
+    S = params.normal(144, N, Cout, 2 * H, 2 * H)
+    conv = nn.Conv2d(C1 + 64, Cout, 3, 1, 1).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    ref = F.leaky_relu((F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest").double(), w[:, :C1].double(), padding=1) +
+                        S.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2)
+    y = ops.convT4x4s2(nhwc(x), None, fused._upconv_packed(conv, C1), sc.to(dev()), sh.to(dev()), addend=nhwc(S))
+    assert rel_err(y, ref) < 2e-5
+    y2 = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(conv.weight.detach()[:, :C1].contiguous()), sc.to(dev()),
+                     sh.to(dev()), upsample=True, addend=nhwc(S))
+    assert rel_err(y2, ref) < 2e-5
