@@ -24,6 +24,7 @@
 //  DVG_VMEM_POLICY: where the next stage's global loads issue: 0 = left to hipcc (sinks them behind the last taps:
 //                       latency exposed at the ds_write), 1 = all at the stage top (delays the first MFMAs), 2 = two
 //                       per tap from tap 0, 3 = three per tap, 4 = two per tap from tap 2.   4: 84.7, 2: 84.4, 3: 84.3
+//                       (4 generalises to the 4- / 8-tap modes: from tap 0, enough per tap to place every load)
 #ifndef DVG_VMEM_POLICY
 #define DVG_VMEM_POLICY 4
 #endif
@@ -260,8 +261,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
             constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? GT : 0);
             constexpr int POLICY = DVG_VMEM_POLICY;
-            constexpr int VPT = (POLICY == 3) ? 3 : 2, VTAPS = (NVMEM + VPT - 1) / VPT;
-            constexpr int VT0 = (POLICY == 4) ? 2 : 0;
+            // policy 4 (default): spread over the taps that are followed by another tap, starting at tap 2 in the 9-tap
+            // mode and at tap 0 in the 4- / 8-tap modes, as many per tap as it takes to place ALL of them (with the
+            // 9-tap constants, the 4-tap transposed mode pinned 2 of its 6-7 loads and the rest sank to the stage's end)
+            constexpr int VT0 = (POLICY == 4) ? (GT >= 9 ? 2 : 0) : 0;
+            constexpr int SLOTS = (GT - 1 - VT0) > 0 ? (GT - 1 - VT0) : 1;
+            constexpr int VNEED = (NVMEM + SLOTS - 1) / SLOTS;
+            constexpr int VPT = (POLICY == 3) ? 3 : (POLICY == 4 ? (VNEED > 2 ? VNEED : 2) : 2);
+            constexpr int VTAPS = (NVMEM + VPT - 1) / VPT;
             if (tt == 0) {
                 if (POLICY == 1 && NVMEM > 0) __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // tap 0's own fragments

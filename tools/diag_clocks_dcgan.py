@@ -13,7 +13,9 @@ from dvg_amd import ops  # noqa: E402
 from dvg_amd._lib import LIB_PATH  # noqa: E402
 
 LAYERS = [("c4s2", 32, 64, 0, 128), ("c4s2", 16, 128, 0, 256), ("c4s2", 8, 256, 0, 512),
-          ("cT", 4, 512, 512, 256), ("cT", 8, 256, 256, 128), ("cT", 16, 128, 128, 64)]
+          ("cT", 4, 512, 512, 256), ("cT", 8, 256, 256, 128), ("cT", 16, 128, 128, 64),
+          # x halves of the vgg_64 decoder's upsample convs (as transposed convs, fused._upconv_packed)
+          ("cT", 4, 512, 0, 512), ("cT", 8, 256, 0, 256), ("cT", 16, 128, 0, 128), ("cT", 32, 64, 0, 64)]
 WARM_S = float(os.environ.get("DIAG_WARM_S", "0.3"))
 
 
@@ -32,7 +34,7 @@ def main():
             fl = 2.0 * N * (H // 2) ** 2 * Cout * 16 * C1
             stages = (C1 // 16) * 2
         else:
-            sk = ops.nhwc_empty(N, C2, H, H, dev).normal_()
+            sk = ops.nhwc_empty(N, C2, H, H, dev).normal_() if C2 else None
             wp = ops.pack_igemm_weight(torch.randn(C1 + C2, Cout, 4, 4, device=dev) * 0.02, transposed=True)
             fn = lambda: ops.convT4x4s2(x, sk, wp, sc, sh)
             fl = 2.0 * N * H * H * Cout * 16 * (C1 + C2)
