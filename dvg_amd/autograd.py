@@ -63,6 +63,25 @@ def _bn_forward(bn, u, stats, count, act, slope, pool):
     return out, mean, invstd
 
 
+def _upconv_weights(weight, c1):
+    """K4 = W[:, :c1] (*) ones(2x2) as a ConvTranspose2d weight (C1, Cout, 4, 4) (see fused._upconv_packed: nearest-x2
+    upsampling + 3x3 conv == 4x4 stride-2 transposed conv), packed for the forward (transposed mode) and for the data
+    gradient (the adjoint: a plain 4x4 stride-2 conv with the same weight).  Cached per parameter version."""
+    key = (id(weight), "k4", c1)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    w = weight.detach()[:, :c1]
+    k4 = torch.zeros((w.shape[0], c1, 4, 4), device=w.device, dtype=torch.float32)
+    for ty in range(3):
+        for tx in range(3):
+            k4[:, :, 2 - ty:4 - ty, 2 - tx:4 - tx] += w[:, :, ty:ty + 1, tx:tx + 1]
+    k4 = k4.permute(1, 0, 2, 3).contiguous()                       # (C1, Cout, 4, 4)
+    res = (ops.pack_igemm_weight(k4, transposed=True), ops.pack_igemm_weight(k4, transposed=False))
+    _pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), res)
+    return res
+
+
 class _ConvBlock(torch.autograd.Function):
     """conv (+fused up/cat) + BatchNorm + activation (+ max-pool).  kinds: conv3, conv3_first, conv4s2,
     conv4s2_first, convT4s2."""
@@ -76,7 +95,11 @@ class _ConvBlock(torch.autograd.Function):
         c1 = x.shape[1]
         if addend is not None:
             # x half of a concat conv; `addend` = conv(skip, W_skip) shared by the decoder calls of a step (_SkipHalf)
-            if kind == "conv3":
+            if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
+                # upsample + conv3x3 as the equivalent transposed conv: 4/9 of the MACs, forward and backward
+                r = ops.convT4x4s2(x, None, _upconv_weights(weight, c1)[0], None, b, act=ACT_NONE, stats=need_stats,
+                                   addend=addend)
+            elif kind == "conv3":
                 r = ops.conv3x3(x, None, _packed(weight, False, 0, c1, 1), None, b, upsample=up, act=ACT_NONE,
                                 stats=need_stats, addend=addend)
             elif kind == "convT4s2":
@@ -123,7 +146,13 @@ class _ConvBlock(torch.autograd.Function):
             # gradient of the x half only; the skip half's dgrad / wgrad happen once per step in _SkipHalf.backward,
             # which receives du (d addend = du) summed over the decoder calls that shared it
             dW = torch.zeros_like(weight)
-            if kind == "conv3":
+            if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
+                dk4 = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, None, du), 4, 4)   # (C1, Cout, 4, 4)
+                # K4[.., 2-t+a, ..] += W[.., t, ..] (a = 0,1)  =>  dW[t] = sum of the 2x2 window of dK4 at (2-t), per axis
+                dW[:, :c1] = torch.flip(torch.nn.functional.avg_pool2d(dk4.permute(1, 0, 2, 3), 2, stride=1) * 4.0, (2, 3))
+                if need_x:
+                    dx = ops.conv4x4s2(du, _upconv_weights(weight, c1)[1], None, None, act=ACT_NONE)
+            elif kind == "conv3":
                 dW[:, :c1] = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, None, du, upsample=up), 3, 3)
                 if need_x:
                     dxu = ops.conv3x3(du, None, _packed(weight, True, 0, c1, 1), None, None, act=ACT_NONE)
