@@ -29,9 +29,7 @@ SIGNATURES = {
     "dvg_pack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_unpack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_unpack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "dvg_conv_stats_rows": (_i, [_i, _i, _i, _i, _i]),
     "dvg_conv_first_stats_rows": (_i, [_i, _i, _i, _i]),
-    "dvg_conv3x3_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_pack_conv_weight_k16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dvg_conv_splitk_v2": (_i, [_i, _i, _i, _i, _i, _i]),
     "dvg_conv_stats_rows_v2": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
@@ -40,9 +38,7 @@ SIGNATURES = {
     "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p]),
     "dvg_conv3x3_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_convT3x3_last": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "dvg_conv4x4s2_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_conv4x4s2_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "dvg_convT4x4s2_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_convT4x4s2_last": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_moving_mnist_compose": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_eval_frames": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
@@ -74,6 +70,10 @@ SIGNATURES = {
     "dvg_lstm_gates_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    # debug hooks (tools/diag_*.py)
+    "dvg_debug_set_clockbuf": (None, [_p, C.c_uint]),
+    "dvg_debug_set_gp_clockbuf": (None, [_p, C.c_uint]),
+    "dvg_debug_set_wgrad_clockbuf": (None, [_p, C.c_uint]),
 }
 
 _lock = threading.Lock()

@@ -7,7 +7,7 @@ Gradient recipe per conv block  y = act(BN(conv(cat(up(x), skip)) + b)):
   1. dp  = (dy + maxpool-scatter(dy_pool)) * act'(y), per-channel sums       dvg_bn_act_bwd_reduce
   2. du  = A*dp + B*u + C  (batch-statistics BN backward), dgamma, dbeta     dvg_bn_bwd_finalize / dvg_affine3_apply
   3. dW  = MFMA GEMM over pixels (K split + deterministic reduce)             dvg_conv_wgrad / dvg_reduce_partials
-  4. dx  = the forward implicit-GEMM kernel with re-packed weights           dvg_conv3x3_bn_act / conv4x4s2 / convT4x4s2
+  4. dx  = the forward implicit-GEMM kernel with re-packed weights           dvg_conv3x3_bn_act_v2 / conv4x4s2 / convT4x4s2
            (+ dvg_upsample2x_bwd when x entered through the fused nearest-x2)
 """
 from __future__ import annotations
@@ -231,7 +231,7 @@ def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, 
     if kind in ("conv3", "conv4s2", "convT4s2"):
         x = ops.to_nhwc(x)
     share = fused.skip_share_scope()
-    if share is not None and skip is not None and kind in ("conv3", "convT4s2") and not pool and ops.IGEMM_V == 2:
+    if share is not None and skip is not None and kind in ("conv3", "convT4s2") and not pool:
         key = (id(conv), id(skip), skip._version)
         ent = share.get(key)
         if ent is None or ent[0] is not skip:

@@ -1,7 +1,7 @@
 // Backward (training) kernels that are HBM-bound: BatchNorm + activation + max-pool backward,
 // nearest-upsample backward, LSTM gate backward, column sums, and the weight gradient of the
 // thin first / last layers.  The MFMA weight-gradient kernel lives in wgrad.hip; data gradients
-// of the dense convs reuse conv_igemm.hip with re-packed weights.
+// of the dense convs reuse conv_igemm2.hip with re-packed weights.
 //
 // Reference: these implement what `loss.backward()` (train.py:170,194,240) asks autograd to do for
 // the modules of vgg_64.py:5-15,49,93, dcgan_64.py:4-26 and lstm.py:51,65-72.

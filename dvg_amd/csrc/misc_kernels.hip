@@ -330,7 +330,7 @@ __global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, c
 
 using namespace dvg;
 
-extern "C" int dvg_abi_version(void) { return 2; }  // 2: `addend` parameter of the v2 conv3x3 / convT4x4s2 entries
+extern "C" int dvg_abi_version(void) { return 3; }  // 3: first igemm schedule (un-suffixed conv entry points) retired
 extern "C" const char* dvg_last_error(void) { return err_buf(); }
 
 #define PACK_ENTRY(NAME, TR, UN, A0, A1)                                                                        \

@@ -267,7 +267,7 @@ def _upconv_packed(conv, c1: int):
 
 def _hoisted_skip(conv, x, skip, partial_fn):
     """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
-    if not SKIP_HOIST or skip is None or ops.IGEMM_V != 2:
+    if not SKIP_HOIST or skip is None:
         return None
     k = (id(conv), id(skip))
     wkey = _ver(conv.weight)

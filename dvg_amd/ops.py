@@ -6,16 +6,9 @@ arithmetic op of the hot path is a kernel of libdvg_hip.so.  Activations travel 
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from ._lib import check, lib
-
-# implicit-GEMM schedule: 2 = conv_igemm2.hip (chunk-staged, register-prefetched), 1 = conv_igemm.hip
-IGEMM_V = int(os.environ.get("DVG_IGEMM", "2"))
-if IGEMM_V not in (1, 2):
-    raise RuntimeError("DVG_IGEMM must be 1 (first schedule, conv_igemm.hip) or 2 (default, conv_igemm2.hip)")
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2 = 0, 1, 2
@@ -135,9 +128,7 @@ def pack_convT_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_igemm_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-    """Weight in the layout the selected implicit-GEMM kernels read (v2: [Cin/16][taps][Cout][16])."""
-    if IGEMM_V == 1:
-        return pack_convT_weight(w) if transposed else pack_conv_weight(w)
+    """Weight in the layout the implicit-GEMM kernels read: [Cin/16][taps][Cout][16]."""
     _dev_f32(w, "pack_igemm_weight")
     w = w.detach().contiguous()
     if transposed:
@@ -150,10 +141,10 @@ def pack_igemm_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor
 
 
 def _wp_dims(wp: torch.Tensor):
-    """(taps, cout, cin) of a packed igemm weight in either layout."""
-    if wp.dim() == 4:
-        return wp.shape[1], wp.shape[2], wp.shape[0] * 16
-    return tuple(wp.shape)
+    """(taps, cout, cin) of a packed igemm weight [Cin/16][taps][Cout][16]."""
+    if wp.dim() != 4 or wp.shape[3] != 16:
+        raise RuntimeError(f"packed igemm weight must be [Cin/16][taps][Cout][16], got {tuple(wp.shape)}")
+    return wp.shape[1], wp.shape[2], wp.shape[0] * 16
 
 
 def unpack_conv_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
@@ -176,9 +167,7 @@ def unpack_convT_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
 # `stats=True` returns (y, stats_partial) with stats_partial [rows][2][Cout].
 # ----------------------------------------------------------------------------------
 def _splitk_ws(mode, n, h, w, cin, cout, out_numel, device):
-    """Workspace for the split-K path of the v2 implicit GEMM (None when the launch fills the chip on its own)."""
-    if IGEMM_V != 2:
-        return None
+    """Workspace for the split-K path of the implicit GEMM (None when the launch fills the chip on its own)."""
     s = lib().dvg_conv_splitk_v2(mode, n, h, w, cin, cout)
     if s <= 1:
         return None
@@ -194,8 +183,6 @@ def _stats_buf(rows: int, cout: int, device):
 def _check_addend(addend, y, excluded):
     if addend is None:
         return
-    if IGEMM_V != 2:
-        raise RuntimeError("addend needs the v2 igemm schedule")
     if excluded:
         raise RuntimeError("addend excludes the pooled output")
     _dev_f32(addend, "addend")
@@ -218,25 +205,20 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         if tuple(skip.shape) != (n, c2, h, w):
             raise RuntimeError(f"conv3x3: skip shape {tuple(skip.shape)} does not match {(n, c2, h, w)}")
     taps, cout, cin = _wp_dims(wp)
-    if taps != 9 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
+    if taps != 9 or cin != c1 + c2:
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
     _check_addend(addend, y, pool)
     ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
-        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None)) \
-            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONV3, n, h, w, cout)
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None))
     st = _stats_buf(rows, cout, x.device) if stats else None
     fl, by = 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) + n * h * w * cout +
                                                       wp.numel())
-    if IGEMM_V == 2:
-        _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
-             _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _p(ws), 0 if ws is None else ws.numel(),
-             _p(addend), _stream())
-    else:
-        _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
-             _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _stream())
+    _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
+         _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _p(ws), 0 if ws is None else ws.numel(),
+         _p(addend), _stream())
     out = (y, yp) if pool else y
     return (out, st) if stats else out
 
@@ -275,21 +257,16 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     assert is_nhwc(x)
     n, cin, h, w = x.shape
     taps, cout, cin_w = _wp_dims(wp)
-    if taps != 16 or cin_w != cin or (wp.dim() == 4) != (IGEMM_V == 2):
+    if taps != 16 or cin_w != cin:
         raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
     y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
     ws = _splitk_ws(MODE_CONV4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
-        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV4S2, n, h, w, cin, cout, 0, int(ws is not None)) \
-            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONV4S2, n, h, w, cout)
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONV4S2, n, h, w, cin, cout, 0, int(ws is not None))
     st = _stats_buf(rows, cout, x.device) if stats else None
     fl, by = 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin, 4.0 * (x.numel() + y.numel() + wp.numel())
-    if IGEMM_V == 2:
-        _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act_v2, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
-             n, h, w, cin, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
-    else:
-        _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
-             n, h, w, cin, cout, act, slope, _stream())
+    _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act_v2, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
+         n, h, w, cin, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
     return (y, st) if stats else y
 
 
@@ -320,24 +297,19 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
         if tuple(skip.shape) != (n, c2, h, w):
             raise RuntimeError("convT4x4s2: skip shape mismatch")
     taps, cout, cin = _wp_dims(wp)
-    if taps != 16 or cin != c1 + c2 or (wp.dim() == 4) != (IGEMM_V == 2):
+    if taps != 16 or cin != c1 + c2:
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
     _check_addend(addend, y, False)
     ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
-        rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None)) \
-            if IGEMM_V == 2 else lib().dvg_conv_stats_rows(MODE_CONVT4S2, n, h, w, cout)
+        rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None))
     st = _stats_buf(rows, cout, x.device) if stats else None
     fl = 2.0 * n * h * w * cout * 16 * cin
     by = 4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel())
-    if IGEMM_V == 2:
-        _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
-             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _p(addend),
-             _stream())
-    else:
-        _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
-             _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _stream())
+    _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
+         _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _p(addend),
+         _stream())
     return (y, st) if stats else y
 
 

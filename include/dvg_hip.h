@@ -16,7 +16,12 @@
  *     throws; dvg_last_error() gives a thread-local message;
  *   - all shape checks happen on the host BEFORE a kernel is launched: a call
  *     that fails a check launches nothing.
- *   - no function allocates, frees or synchronises: graph-capture safe.
+ *   - no function allocates, frees or synchronises: graph-capture safe;
+ *   - threading: ONE host thread per process drives the library (the reference's own
+ *     contract, SURVEY.md 8(b) "Threading"; data parallelism is one process per GPU).  The
+ *     first launch of each conv kernel instantiation raises its dynamic-LDS limit through an
+ *     unsynchronised function-local flag (conv_igemm2.hip `attr_set`), and the debug hooks
+ *     at the end of this file are plain globals.
  */
 #ifndef DVG_HIP_H
 #define DVG_HIP_H
@@ -86,7 +91,7 @@ int dvg_unpack_convT_weight(const float* w_packed, float* w_iohw, int cin, int c
  * NULL (=1 / =0).
  *
  * stats (optional, train-mode BN): float[rows][2][Cout] with
- * rows = dvg_conv_stats_rows(mode, N, H, W, Cout); every workgroup writes the
+ * rows = dvg_conv_stats_rows_v2(...); every workgroup writes the
  * per-channel sum(u') and sum(u'^2) of its own pixel tile, where
  * u' = u*scale+shift BEFORE the activation (callers pass scale=NULL,
  * shift=bias, act=NONE to obtain the raw conv output and its statistics).
@@ -97,22 +102,15 @@ int dvg_unpack_convT_weight(const float* w_packed, float* w_iohw, int cin, int c
 #define DVG_MODE_CONV3 0
 #define DVG_MODE_CONV4S2 1
 #define DVG_MODE_CONVT4S2 2
-/* rows of the `stats` partial buffer for the implicit-GEMM convs (H,W = the
- * H,W passed to the conv entry point); -1 if the shape is unsupported.        */
-int dvg_conv_stats_rows(int mode, int N, int H, int W, int Cout);
-/* same for the first-layer kernels (ks = 3 or 4)                              */
+/* rows of the `stats` partial buffer of the first-layer kernels (ks = 3 or 4); -1 if the
+ * shape is unsupported.  (The implicit-GEMM convs: dvg_conv_stats_rows_v2 below.)          */
 int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
 
-int dvg_conv3x3_bn_act(const float* x, const float* skip, const float* w_packed,
-                       const float* scale, const float* shift, float* y,
-                       float* y_pool, float* stats, int N, int H, int W, int C1,
-                       int C2, int Cout, int upsample_x, int act, float slope,
-                       void* stream);
-
-/* v2 schedule of the three implicit-GEMM convs (conv_igemm2.hip): identical semantics and
- * arguments, but the weights are packed [Cin/16][tap][Cout][16] by dvg_pack_conv_weight_k16
- * (transposed != 0: ConvTranspose2d weight (Cin,Cout,KH,KW), flipped) and `stats` has
- * dvg_conv_stats_rows_v2(...) rows.  C1, C2 multiples of 16; Cout multiple of 64.      */
+/* The three implicit-GEMM convs (conv_igemm2.hip; the "_v2" suffix is historical: the first
+ * schedule and its un-suffixed entry points were retired in ABI 3).  Weights are packed
+ * [Cin/16][tap][Cout][16] by dvg_pack_conv_weight_k16 (transposed != 0: ConvTranspose2d weight
+ * (Cin,Cout,KH,KW), flipped) and `stats` has dvg_conv_stats_rows_v2(...) rows.
+ * C1, C2 multiples of 16; Cout multiple of 64.                                          */
 int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                              int transposed, void* stream);
 /* Split-K: when a layer would launch < 384 workgroups (deep, narrow layers; small per-GPU batches) and the caller
@@ -131,10 +129,15 @@ int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                           float* stats, int N, int H, int W, int C1, int C2, int Cout,
                           int upsample_x, int act, float slope, float* workspace,
                           long workspace_floats, const float* addend, void* stream);
+/* dcgan_conv = Conv2d(nin,nout,4,2,1)+BN+LReLU (dcgan_64.py:4-14): K = 16*Cin,
+ * x NHWC (N,H,W,Cin) -> y NHWC (N,H/2,W/2,Cout).                                          */
 int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
                             const float* shift, float* y, float* stats, int N, int H, int W,
                             int Cin, int Cout, int act, float slope, float* workspace,
                             long workspace_floats, void* stream);
+/* dcgan_upconv = ConvTranspose2d(nin,nout,4,2,1)+BN+LReLU on cat([x, skip])
+ * (dcgan_64.py:16-26,84-87) as four parity-class implicit GEMMs (K = 4*Cin).
+ * x NHWC (N,H,W,C1), skip NHWC (N,H,W,C2) or NULL; y NHWC (N,2H,2W,Cout).                 */
 int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                              const float* scale, const float* shift, float* y, float* stats,
                              int N, int H, int W, int C1, int C2, int Cout, int act, float slope,
@@ -156,30 +159,11 @@ int dvg_convT3x3_last(const float* x, const float* w_iohw, const float* bias,
                       float* y_nchw, int N, int H, int W, int Cin, int nc, int act,
                       void* stream);
 
-/* dcgan_conv = Conv2d(nin,nout,4,2,1)+BN+LReLU (dcgan_64.py:4-14) as implicit
- * GEMM, K = 16*Cin.  x NHWC (N,H,W,Cin) -> y NHWC (N,H/2,W/2,Cout).
- * w_packed [16][Cout][Cin].  Cin % 32 == 0, Cout % 64 == 0, H,W % 16 == 0 or
- * H == W == 8.  stats as for dvg_conv3x3_bn_act.                              */
-int dvg_conv4x4s2_bn_act(const float* x, const float* w_packed, const float* scale,
-                         const float* shift, float* y, float* stats, int N, int H,
-                         int W, int Cin, int Cout, int act, float slope,
-                         void* stream);
-
 /* First dcgan layer Conv2d(nc,Cout,4,2,1)+BN+LReLU, nc in {1..4}
  * (dcgan_64.py:34).  x NCHW, w ORIGINAL (Cout,nc,4,4), y NHWC (N,H/2,W/2,Cout). */
 int dvg_conv4x4s2_first(const float* x_nchw, const float* w_oihw, const float* scale,
                         const float* shift, float* y, float* stats, int N, int H,
                         int W, int nc, int Cout, int act, float slope, void* stream);
-
-/* dcgan_upconv = ConvTranspose2d(nin,nout,4,2,1)+BN+LReLU on cat([x, skip])
- * (dcgan_64.py:16-26,84-87) as four parity-class implicit GEMMs (K = 4*Cin).
- * x NHWC (N,H,W,C1), skip NHWC (N,H,W,C2) or NULL; w_packed = the
- * dvg_pack_convT_weight layout [16][Cout][C1+C2]; y NHWC (N,2H,2W,Cout).
- * C1,C2 % 32 == 0, Cout % 64 == 0, H,W % 8 == 0 (or H == W == 4).             */
-int dvg_convT4x4s2_bn_act(const float* x, const float* skip, const float* w_packed,
-                          const float* scale, const float* shift, float* y,
-                          float* stats, int N, int H, int W, int C1, int C2,
-                          int Cout, int act, float slope, void* stream);
 
 /* Last dcgan layer ConvTranspose2d(C1+C2,nc,4,2,1)+Tanh|Sigmoid on cat([x,skip])
  * (dcgan_64.py:75-79; dcgan_128.py:80-84).  w ORIGINAL (C1+C2,nc,4,4),
@@ -288,9 +272,9 @@ int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
  * Backward (training) entry points: what `loss.backward()` (train.py:170,194,240)
  * runs for the modules above.  Data gradients of the dense convs reuse the
  * forward implicit-GEMM kernels with re-packed weights:
- *   dgrad(Conv2d 3x3)        = dvg_conv3x3_bn_act   with dvg_pack_convT_weight(W)
- *   dgrad(Conv2d 4x4 s2)     = dvg_convT4x4s2_bn_act with dvg_pack_convT_weight(W)
- *   dgrad(ConvTranspose 4x4) = dvg_conv4x4s2_bn_act with dvg_pack_conv_weight(W)
+ *   dgrad(Conv2d 3x3)        = dvg_conv3x3_bn_act_v2    with the transposed/flipped k16 pack of W
+ *   dgrad(Conv2d 4x4 s2)     = dvg_convT4x4s2_bn_act_v2 with the transposed k16 pack of W
+ *   dgrad(ConvTranspose 4x4) = dvg_conv4x4s2_bn_act_v2  with the plain k16 pack of W
  * ------------------------------------------------------------------ */
 
 /* BatchNorm + activation (+ 2x2 max-pool) backward, pass 1:
@@ -387,6 +371,16 @@ int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, cons
  * callers that insist on contiguous NCHW).                                    */
 int dvg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int dvg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Debug hooks (tools/diag_*.py).  Not part of the product path: they hand the next launches of
+ * one kernel family a device buffer that every workgroup fills with clock64()/wall_clock64()
+ * phase stamps.  buf == NULL (the default) disables stamping; the kernels then pay one
+ * uniform branch.  Not thread-safe: set, launch, synchronise, reset from ONE host thread.
+ * ------------------------------------------------------------------ */
+void dvg_debug_set_clockbuf(void* buf, unsigned records);        /* conv_igemm2 kernels: 8 x u64 per workgroup */
+void dvg_debug_set_gp_clockbuf(void* buf, unsigned records);     /* gp_predict_kernel: 12 x u64 per workgroup  */
+void dvg_debug_set_wgrad_clockbuf(void* buf, unsigned records);  /* wgrad_igemm_kernel: 4 x u64 per workgroup  */
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ def header_symbols():
 def test_header_declares_entry_points():
     syms = header_symbols()
     assert len(syms) >= 25
-    for must in ("dvg_conv3x3_bn_act", "dvg_lstm_cell", "dvg_gp_predict", "dvg_gemm_nt_bias_act"):
+    for must in ("dvg_conv3x3_bn_act_v2", "dvg_lstm_cell", "dvg_gp_predict", "dvg_gemm_nt_bias_act"):
         assert must in syms
 
 
@@ -33,7 +33,7 @@ def test_binding_table_covers_header():
     from dvg_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dvg_abi_version() == 2
+    assert lib.dvg_abi_version() == 3
 
 
 def test_host_side_checks_reject_bad_shapes_without_gpu():
@@ -41,15 +41,16 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     from dvg_amd import _lib
     lib = _lib.lib()
     one = ctypes.c_void_p(16)  # fake, never dereferenced: the call must fail in the checks
-    rc = lib.dvg_conv3x3_bn_act(one, None, one, None, None, one, None, None, 1, 8, 8, 48, 0, 64, 0, 1, 0.2, None)
-    assert rc == 1 and b"multiples of 32" in lib.dvg_last_error()
+    rc = lib.dvg_conv3x3_bn_act_v2(one, None, one, None, None, one, None, None, 1, 8, 8, 40, 0, 64, 0, 1, 0.2, None, 0,
+                                   None, None)
+    assert rc == 1 and b"16" in lib.dvg_last_error(), lib.dvg_last_error()
     rc = lib.dvg_lstm_cell(one, one, one, one, one, one, one, one, one, None, 4, 100, None)
     assert rc == 1
     rc = lib.dvg_gp_predict(*([one] * 7), None, None, one, None, None, None, None, 200, 90, 40, 0, 1e-3, None)
     assert rc == 1
     with pytest.raises(RuntimeError):
         _lib.check(rc, "gp")
-    assert lib.dvg_conv_stats_rows(0, 64, 64, 64, 64) == 64 * 8 * 4
+    assert lib.dvg_conv_stats_rows_v2(0, 64, 64, 64, 64, 64, 0, 0) > 0
     assert lib.dvg_conv_splitk_v2(0, 64, 64, 64, 64, 64) == 1          # 2048 workgroups: no split
     assert lib.dvg_conv_splitk_v2(0, 64, 8, 8, 512, 256) == 2          # 256 workgroups, K = 32 chunks
     assert lib.dvg_conv_splitk_v2(0, 16, 8, 8, 512, 512) == 4          # per-GPU batch 16

@@ -394,8 +394,6 @@ def test_moving_mnist_device_compositing_is_bit_exact():
 
 @pytest.mark.parametrize("H,C1,C2,Cout,up", [(16, 64, 64, 64, True), (8, 32, 48, 128, False), (8, 512, 512, 256, True)])
 def test_conv3x3_addend_equals_concat_conv(H, C1, C2, Cout, up):
-    if __import__("dvg_amd.ops", fromlist=["x"]).IGEMM_V != 2:
-        pytest.skip("addend is a feature of the default (v2) igemm schedule")
     """conv(cat([up(x), skip])) == conv(up(x), W[:, :C1]) + conv(skip, W[:, C1:]) with the second term passed as the
     raw `addend` of dvg_conv3x3_bn_act_v2 (incl. a split-K shape where the finish kernel adds it)."""
     from dvg_amd import ops
@@ -419,8 +417,6 @@ def test_conv3x3_addend_equals_concat_conv(H, C1, C2, Cout, up):
 
 @pytest.mark.parametrize("family", ["vgg", "dcgan"])
 def test_decoder_skip_hoisting_is_transparent(family):
-    if __import__("dvg_amd.ops", fromlist=["x"]).IGEMM_V != 2:
-        pytest.skip("skip-half hoisting needs the default (v2) igemm schedule")
     """Calling the eval-mode decoder repeatedly with the SAME skip tensors (a rollout) engages the hoisted skip
     halves from the second call on; every call still matches the oracle, a modified skip is recomputed, and
     DVG_SKIP_HOIST semantics (fused.SKIP_HOIST = False) give the same frames."""
@@ -455,8 +451,6 @@ def test_upsample_conv3x3_as_transposed_conv(H, C1, Cout, N):
     """conv3x3(nearest_up2(x), W, pad 1) == convT4x4s2(x, K4) with K4 = W (*) ones(2x2) (fused._upconv_packed): the
     x half of the decoder blocks' first convs runs with 4/9 of the MACs.  Checked against the fp64 reference,
     including the raw `addend` and the folded scale / shift, at the four decoder shapes."""
-    if __import__("dvg_amd.ops", fromlist=["x"]).IGEMM_V != 2:
-        pytest.skip("v2 igemm only")
     import torch.nn as nn
     from dvg_amd import fused, ops
     x = params.normal(140, N, C1, H, H)
