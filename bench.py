@@ -4,32 +4,90 @@
 A "step" is ONE rollout sample (one pass of the make_gifs sample loop, generate_frames.py:143-177)
 over one batch of synthetic Moving-MNIST: B=64, 64x64, 10 conditioning + 10 predicted frames
 (19 encoder calls, 10 decoder calls, 19 LSTM steps, 1 GP trigger sample at i=15), i.e.
-BASELINE.json configs[1].  value = B * n_future * steps * n_gpus / time.
+BASELINE.json configs[1].  value = B * n_future * steps * n_gpus / time  (vgg_64; the dcgan_64 family of
+the same metric is measured in the same process and reported under "families").
 
-  python bench.py --gpus N --steps K --warmup W [--model vgg|dcgan]
+  python bench.py --gpus N --steps K --warmup W
 
-For N>1 the driver launches one rank per GPU with torch.distributed.run; the rollout shards by
-replicas (every GPU rolls out its own batch: no data-path collective), scaling = "weak".
+N > 1: one rank per GPU over RCCL.  When the driver launches the ranks itself (torch.distributed.run sets
+WORLD_SIZE) each rank runs main(); from a bare shell `python bench.py --gpus N` spawns that launcher as a
+CHILD process before anything touches a GPU and relays rank 0's JSON line and the exit code.
+The rollout shards by replicas (every GPU rolls out its own batch: no data-path collective), scaling = "weak".
+The path that does have an exchange step - data-parallel training with a gradient all-reduce over xGMI
+(train.py:200-248 per step) - is timed as a second leg and reported under "train"
+(BASELINE.json configs[3] shape: dcgan_64, nc=3, 16 clips per GPU, 2-in/10-out).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command, committed under
+# profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
+TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r02_conv3x3_traffic.json",
+                 ("dcgan", "conv4x4s2_igemm"): "r02_conv4x4s2_traffic.json",
+                 ("dcgan", "convT4x4s2_igemm"): "r02_convT4x4s2_traffic.json"}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="vgg", choices=["vgg", "dcgan"], help="family reported as `value`")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--n_past", type=int, default=10)
+    ap.add_argument("--n_future", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-families", action="store_true", help="skip the other model family")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training leg")
+    ap.add_argument("--train-iters", type=int, default=6)
+    ap.add_argument("--train-graph-timeout", type=float, default=240.0,
+                    help="seconds the graphed data-parallel leg may take before it is reported as timed out")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` from a bare shell: start `torch.distributed.run` with N ranks as a child process
+    (never exec: this process has not touched a GPU and will not) and relay its output and exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    last_json = None
+    for line in proc.stdout:
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            last_json = line.strip()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    return rc if (rc != 0 or last_json is not None) else 1
+
+
+# ------------------------------------------------------------------------------------------------------------
 def build_models(model: str, batch: int, nc: int, dev, seed: int):
     import importlib
+    import torch
     from dvg_amd import utils
     from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1
     from dvg_amd.models.lstm import lstm
@@ -47,20 +105,21 @@ def build_models(model: str, batch: int, nc: int, dev, seed: int):
     return mods
 
 
-@torch.no_grad()
 def calibrate_batchnorm(enc, dec, frame):
     """Give the BatchNorm layers the running statistics a trained model would have (batch statistics
     of the synthetic data, momentum 1) so that eval-mode activations stay O(1) through all layers
     instead of collapsing / exploding with the N(0,0.02) init (degenerate operands flatter DVFS)."""
-    bns = [m for m in list(enc.modules()) + list(dec.modules()) if isinstance(m, torch.nn.BatchNorm2d)]
-    for m in bns:
-        m.momentum = 1.0
-    enc.train(), dec.train()
-    h, skips = enc(frame)
-    dec([h, skips])
-    for m in bns:
-        m.momentum = 0.1
-    enc.eval(), dec.eval()
+    import torch
+    with torch.no_grad():
+        bns = [m for m in list(enc.modules()) + list(dec.modules()) if isinstance(m, torch.nn.BatchNorm2d)]
+        for m in bns:
+            m.momentum = 1.0
+        enc.train(), dec.train()
+        h, skips = enc(frame)
+        dec([h, skips])
+        for m in bns:
+            m.momentum = 0.1
+        enc.eval(), dec.eval()
 
 
 def usable_cores() -> int:
@@ -76,10 +135,11 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int):
+def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int, budget_s: float = 10.0):
     """The oracle (CPU restatement, parity-checked against the reference's modules) timed on the host
-    cores of this box: ONE full rollout of the same workload (bounded: ~10-30 s of CPU work)."""
+    cores of this box: whole rollouts of the same workload until `budget_s` of CPU work have been timed."""
     import importlib
+    import torch
     from oracle import dvg_oracle as orc
     from oracle import params
     from dvg_amd.data import SyntheticMovingMNIST
@@ -104,11 +164,11 @@ def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int):
     with torch.no_grad():
         enc(x[0])  # warm the thread pool / allocator
         n, t0 = 0, time.perf_counter()
-        while True:   # bounded sample: whole rollouts until ~10 s of CPU work have been timed
+        while True:   # bounded sample: whole rollouts until ~budget_s of CPU work have been timed
             orc.rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps)
             n += 1
             dt = time.perf_counter() - t0
-            if dt >= 10.0 or n >= 40:
+            if dt >= budget_s or n >= 40:
                 break
     return {"value": round(n * batch * (n_eval - n_past) / dt, 2), "unit": "frames/s", "cores": cores,
             "kind": "port", "sample": f"{n} rollout(s) of the same workload ({model}_64, B={batch}, "
@@ -116,88 +176,218 @@ def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int):
                                       f"{cores} threads"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="vgg", choices=["vgg", "dcgan"])
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--n_past", type=int, default=10)
-    ap.add_argument("--n_future", type=int, default=10)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    args = ap.parse_args()
+class Ctx:
+    """rank / world / device / torch.distributed handle of this process."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    def __init__(self, args):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        self.dist = None
+        if self.world > 1 or os.environ.get("DVG_BENCH_FORCE_PG") == "1":
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            self.dist = dist
 
-    from dvg_amd import fused as fused_mod
-    from dvg_amd import ops, utils
+    def barrier(self):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt: float) -> float:
+        import torch
+        if self.dist is None:
+            return dt
+        t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict:
+    """W untimed + K timed rollouts of one family; barrier + synchronize on both sides, max over ranks.
+    Rank 0 adds the per-kernel HIP-event leg (roofline of the dominant kernel)."""
+    import torch
+    from dvg_amd import ops
     from dvg_amd.data import SyntheticMovingMNIST
     from dvg_amd.rollout import GraphedRollout, sample_rollout
-
     n_eval = args.n_past + args.n_future
-    enc, dec, fp, gp, lik = build_models(args.model, args.batch, 1, dev, args.seed + rank)
+    enc, dec, fp, gp, lik = build_models(model, args.batch, 1, ctx.dev, args.seed + ctx.rank)
     # inputs resident in HBM before the timed region; composited on the GPU (identical to normalize_data(host batch))
-    x = SyntheticMovingMNIST(seq_len=n_eval, seed=args.seed + rank).batch_device(args.batch, dev)
-    x = [t.to(dev) for t in x]
+    x = SyntheticMovingMNIST(seq_len=n_eval, seed=args.seed + ctx.rank).batch_device(args.batch, ctx.dev)
     calibrate_batchnorm(enc, dec, x[0])
 
     def eager_step():
         return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
 
-    if args.no_graph:
-        step = eager_step
-    else:   # the whole rollout as ONE hipGraph replay
-        graphed = GraphedRollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
-        step = graphed
-
-    for _ in range(args.warmup):
+    step = eager_step if args.no_graph else GraphedRollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
+    for _ in range(warmup):
         step()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
+    ctx.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ctx.barrier()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(out[-1]).all())
+    frames = args.batch * args.n_future * steps * ctx.world
+    res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3)}
+    if ctx.rank != 0:
+        return res
+    # roofline leg: the same rollout with every launch bracketed by HIP events on the launch stream
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    for _ in range(3):
+        eager_step()   # events need eager launches; same kernels, same shapes as the graphed step
+    ops.set_timer(None)
+    agg = timer.summary()
+    total_ms = sum(a["ms"] for a in agg.values())
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    a = agg[dom]
+    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    traffic, tsrc = None, None
+    tfile = TRAFFIC_FILES.get((model, dom))
+    if tfile and args.batch == 64 and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
+        traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["traffic_bytes_per_launch"]
+        tsrc = f"profiles/{tfile}: committed rocprofv3 PMC passes of this command (constant, NOT measured by this run)"
+    res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                       "traffic_source": tsrc,
+                       "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
+                       "algorithmic_flops_per_launch": round(a["flops"] / a["launches"]),
+                       "launches_per_step": a["launches"] // 3,
+                       "avg_launch_us": round(1000 * a["ms"] / a["launches"], 2),
+                       "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
+    res["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
+                          "avg_us": round(1000 * v["ms"] / v["launches"], 2),
+                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                          "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                          # fraction of the 8 TB/s HBM peak on the kernel's ALGORITHMIC bytes (meaningful for the
+                          # HBM-bound first / last layers; the MFMA-bound kernels sit far below by design)
+                          "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                      for k, v in agg.items()}
+    return res
 
-    frames = args.batch * args.n_future * args.steps * world
+
+def measure_train(ctx: Ctx, args, graphed: bool, allreduce: bool = True) -> dict:
+    """Data-parallel training at BASELINE.json configs[3]'s shape (BAIR-like: dcgan_64, nc=3, 16 clips per GPU,
+    2-in/10-out): train_model + both fine-tuning closures per iteration (train.py:354-361), gradients averaged over
+    RCCL (dvg_amd/parallel.py).  Weak scaling: the global batch is 16 x ranks."""
+    import torch
+    import train
+    import utils
+    from dvg_amd.data import synthetic_video
+    per_gpu, n_past, n_future = 16, 2, 10
+    T = n_past + n_future
+    opt = train.build_parser().parse_args(["--model", "dcgan", "--channels", "3", "--image_width", "64", "--dataset", "bair",
+                                           "--batch_size", str(per_gpu * ctx.world), "--n_past", str(n_past),
+                                           "--n_future", str(n_future), "--no_save", "--synthetic_data"])
+    opt.ft, opt.rank, opt.world, opt.local_batch = True, ctx.rank, ctx.world, per_gpu
+    torch.manual_seed(args.seed)
+    tr = train.Trainer(opt, ctx.dev)
+    tr.train_mode()
+    tr.set_allreduce(allreduce)
+    x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor,
+                                synthetic_video(per_gpu, T, 3, 64, seed=args.seed + 31 * ctx.rank))
+    step = train.GraphedIteration(tr, warmup=2) if graphed else tr.iteration
+    for _ in range(4 if graphed else 2):   # graphed: 2 eager warm-up iterations, the capture, one replay
+        step(x)
+    tr.reset_allreduce_stats()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_iters):
+        step(x)
+    ctx.barrier()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0) / args.train_iters
+    assert all(bool(torch.isfinite(p).all()) for p in tr.encoder.parameters())
+    res = {"ms_per_iter": round(1e3 * dt, 2),
+           "train_frames_per_s": round(per_gpu * ctx.world * (T - 1) / dt, 1)}
+    st = tr.allreduce_stats()
+    if st is not None and not graphed:
+        res.update(st)
+    return res
+
+
+def train_leg(ctx: Ctx, args) -> dict:
+    import torch
+    out = {"config": "BAIR-shaped synthetic clips 64x64 nc=3, dcgan_64 + lstm + GP, 16 clips per GPU (global batch "
+                     f"{16 * ctx.world}), 2-in/10-out, train_model + both fine-tuning closures per iteration",
+           "parallelism": f"dp{ctx.world}: gradient all-reduce over RCCL, per-replica BatchNorm statistics",
+           "scaling": "weak"}
+    if ctx.dist is not None:   # proof that RCCL connected the ranks: an actual all-reduce of ones
+        t = torch.ones(1, device=ctx.dev)
+        ctx.dist.all_reduce(t)
+        out["rccl_ranks"] = int(t.item())
+        assert out["rccl_ranks"] == ctx.dist.get_world_size()
+    else:
+        out["rccl_ranks"] = 1
+    out["eager"] = measure_train(ctx, args, graphed=False)
+    if ctx.world > 1:
+        out["eager_no_allreduce"] = measure_train(ctx, args, graphed=False, allreduce=False)
+        out["allreduce_exposed_ms_per_iter"] = round(out["eager"]["ms_per_iter"] -
+                                                     out["eager_no_allreduce"]["ms_per_iter"], 2)
+    out["train_frames_per_s"] = out["eager"]["train_frames_per_s"]
+    out["allreduce_ms_per_iter"] = out["eager"].get("allreduce_ms_per_iter")
+    return out
+
+
+def graphed_train_leg(ctx: Ctx, args, result: dict, emit) -> None:
+    """The same iteration replayed as ONE hipGraph (train.GraphedIteration); with ranks > 1 the graph contains the RCCL
+    all-reduces.  Guarded: a watchdog emits the JSON line without this leg and ends the process if a captured
+    collective hangs, and an exception is reported instead of raised."""
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.train_graph_timeout):
+            result["train"]["hipgraph"] = {"error": f"no completion within {args.train_graph_timeout:.0f} s"}
+            emit()
+            os._exit(0)
+    if ctx.world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        g = measure_train(ctx, args, graphed=True)
+        result["train"]["hipgraph"] = g
+        if g["train_frames_per_s"] > result["train"]["train_frames_per_s"]:
+            result["train"]["train_frames_per_s"] = g["train_frames_per_s"]
+            result["train"]["launch"] = "hipGraph replay"
+    except Exception as e:   # noqa: BLE001 - reported, not fatal: the headline metric has been measured
+        result["train"]["hipgraph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    done.set()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    import torch
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}", file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
+        print(f"bench.py: rank needs GPU {os.environ.get('LOCAL_RANK', '0')}, only {torch.cuda.device_count()} visible",
+              file=sys.stderr)
+        sys.exit(2)
+    ctx = Ctx(args)
+
+    from dvg_amd import fused as fused_mod
+    main_res = measure_rollout(ctx, args, args.model, args.steps, args.warmup)
     result = {
         "metric": "predicted frames/sec at 64x64, batch 64, 10-in/10-out",
-        "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
+        "value": main_res["value"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Moving-MNIST 64x64 rollout (generate_frames.py make_gifs sample loop), "
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "
                                f"{args.n_past}-in/{args.n_future}-out", "model_family": args.model,
                    "batch_per_gpu": args.batch, "n_past": args.n_past, "n_future": args.n_future,
-                   "parallelism": f"replicas x{world} (no data-path collective)",
+                   "parallelism": f"replicas x{ctx.world} (no data-path collective)",
                    "launch": "eager" if args.no_graph else "hipGraph replay",
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's
                    # first conv is computed once per rollout and added in the epilogue (DVG_SKIP_HOIST=0: recompute)
@@ -207,46 +397,33 @@ def main():
                    "upsample_conv3x3": "as transposed 4x4/s2 conv" if (fused_mod.SKIP_HOIST and fused_mod.UPCONV_AS_CONVT)
                    else "9-tap conv on the upsampled grid"},
     }
+    for k in ("roofline", "kernels"):
+        if k in main_res:
+            result[k] = main_res[k]
 
-    if rank == 0:
-        # roofline leg: the same rollout with every launch bracketed by HIP events on the launch stream
-        timer = ops.KernelTimer()
-        ops.set_timer(timer)
-        for _ in range(3):
-            eager_step()   # events need eager launches; same kernels, same shapes as the graphed step
-        ops.set_timer(None)
-        agg = timer.summary()
-        total_ms = sum(a["ms"] for a in agg.values())
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        a = agg[dom]
-        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside bench.py)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", {"conv3x3_igemm": "r01_conv3x3_traffic.json",
-                                                "conv4x4s2_igemm": "r01_conv4x4s2_traffic.json"}.get(dom, "-"))
-        if args.batch == 64 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-        result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
-                              "algorithmic_flops_per_launch": round(a["flops"] / a["launches"]),
-                              "launches_per_step": a["launches"] // 3,
-                              "avg_launch_us": round(1000 * a["ms"] / a["launches"], 2),
-                              "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
-        result["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
-                                 "avg_us": round(1000 * v["ms"] / v["launches"], 2),
-                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                 # fraction of the 8 TB/s HBM peak on the kernel's ALGORITHMIC bytes (meaningful for the
-                                 # HBM-bound first / last layers; the MFMA-bound kernels sit far below by design)
-                                 "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-                             for k, v in agg.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    def emit():
+        if ctx.rank == 0:
+            print(json.dumps(result), flush=True)
+
+    if not args.no_families:
+        other = "dcgan" if args.model == "vgg" else "vgg"
+        fam = measure_rollout(ctx, args, other, args.steps, args.warmup)
+        fam["workload"] = result["config"]["workload"].replace(f"{args.model}_64", f"{other}_64")
+        result["families"] = {other: fam}
+    n_eval = args.n_past + args.n_future
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)
+        if "families" in result:
+            for other, fam in result["families"].items():
+                fam["cpu_baseline"] = cpu_baseline(other, args.batch, args.n_past, n_eval, args.seed, budget_s=4.0)
+    if not args.no_train_leg:
+        ctx.barrier()
+        result["train"] = train_leg(ctx, args)
+        graphed_train_leg(ctx, args, result, emit)
+    emit()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

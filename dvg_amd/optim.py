@@ -4,12 +4,17 @@
 state layout (`step`, `exp_avg`, `exp_avg_sq` per parameter, so `state_dict()` is interchangeable with
 torch.optim.Adam's and `MultiStepLR` drives `param_groups[...]['lr']` as in train.py:105-106), but every
 parameter group lives in ONE flat fp32 buffer: parameters are re-pointed at views of it, the moments are views of
-two more, and a step is one gradient gather (`torch._foreach_copy_`) + ONE `dvg_adam_step` launch per group
-instead of the per-tensor foreach chain.
+two more, the GRADIENTS are views of a fourth (`p.grad` is set to its view, so backward accumulates straight into
+the flat buffer) and a step is ONE `dvg_adam_step` launch per group.
+
+`FlatArena`: several optimisers can carve their groups out of one shared arena (train.Trainer does: GP, likelihood,
+LSTM, decoder, encoder in that order), so that the data-parallel gradient all-reduce (dvg_amd/parallel.py) runs on
+contiguous ranges of ONE buffer - no gather into a communication buffer, no scatter back, no copy into the
+optimiser's buffer.
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional
 
 import torch
 
@@ -17,13 +22,42 @@ from . import ops
 from ._lib import check, lib
 
 
+class FlatArena:
+    """Four flat fp32 buffers (param, grad, exp_avg, exp_avg_sq) of `numel` floats; `alloc` hands out ranges."""
+
+    def __init__(self, numel: int, device):
+        self.p = torch.zeros(numel, device=device)
+        self.g = torch.zeros(numel, device=device)
+        self.m = torch.zeros(numel, device=device)
+        self.v = torch.zeros(numel, device=device)
+        self.used = 0
+
+    @staticmethod
+    def padded(n: int) -> int:
+        return (n + 3) // 4 * 4          # every view 16-byte aligned
+
+    @classmethod
+    def size_for(cls, params) -> int:
+        return sum(cls.padded(p.numel()) for p in params if p.requires_grad)
+
+    def alloc(self, n: int) -> int:
+        if self.used + n > self.p.numel():
+            raise RuntimeError("FlatArena: out of space")
+        off, self.used = self.used, self.used + n
+        return off
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, arena: Optional[FlatArena] = None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._flat = {}   # group index -> dict(p, g, m, v, params, offsets, gviews, tdev)
+        self.arena = arena
+        self._flat = {}   # group index -> dict(p, g, m, v, params, offsets, gviews, tdev, lo, hi)
         self._captured_groups = []   # groups stepped while a hipGraph was being captured (see after_graph_replay)
+        if all(p.is_cuda for g in self.param_groups for p in g["params"]):
+            for gi, group in enumerate(self.param_groups):   # flat storage right away: p.grad are views from the start
+                self._build(gi, group)
 
     # ---- flat storage -------------------------------------------------------------------------------
     def _build(self, gi: int, group) -> dict:
@@ -37,9 +71,15 @@ class FusedAdam(torch.optim.Optimizer):
         offs, n = [], 0
         for p in params:
             offs.append(n)
-            n += (p.numel() + 3) // 4 * 4          # every view 16-byte aligned
-        flat_p = torch.zeros(n, device=dev)
-        flat_m, flat_v, flat_g = torch.zeros_like(flat_p), torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+            n += FlatArena.padded(p.numel())
+        if self.arena is not None:
+            lo = self.arena.alloc(n)
+            a = self.arena
+            flat_p, flat_g, flat_m, flat_v = (t[lo:lo + n] for t in (a.p, a.g, a.m, a.v))
+        else:
+            lo = 0
+            flat_p = torch.zeros(n, device=dev)
+            flat_m, flat_v, flat_g = torch.zeros_like(flat_p), torch.zeros_like(flat_p), torch.zeros_like(flat_p)
         steps = {}
         with torch.no_grad():
             for p, o in zip(params, offs):
@@ -51,21 +91,59 @@ class FusedAdam(torch.optim.Optimizer):
                     flat_v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
                     steps[p] = float(st["step"])
                 p.data = view                       # the module keeps the same Parameter object
-        f = dict(p=flat_p, g=flat_g, m=flat_m, v=flat_v, params=params, offsets=offs,
+        f = dict(p=flat_p, g=flat_g, m=flat_m, v=flat_v, params=params, offsets=offs, lo=lo, hi=lo + n,
                  tdev=torch.zeros(1, dtype=torch.int32, device=dev),     # device-side step count of the group
                  gviews=[flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)])
-        for p, o in zip(params, offs):
+        for p, o, gv in zip(params, offs, f["gviews"]):
             self.state[p] = {"step": torch.tensor(steps.get(p, 0.0)), "exp_avg": flat_m[o:o + p.numel()].view(p.shape),
                              "exp_avg_sq": flat_v[o:o + p.numel()].view(p.shape)}
+            if p.grad is not None:
+                gv.copy_(p.grad)
+            p.grad = gv                             # backward accumulates into the flat gradient buffer
         self._flat[gi] = f
         return f
+
+    def flat_range(self, gi: int = 0):
+        """(lo, hi) of group `gi` in the arena (or in its own flat buffer)."""
+        f = self._flat[gi]
+        return f["lo"], f["hi"]
+
+    def flat_grad(self, gi: int = 0) -> torch.Tensor:
+        return self._flat[gi]["g"]
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # torch aliases (does not copy) the tensors of `state_dict`: copy them into our flat buffers right away
+        if self.arena is not None and self._flat:
+            for gi, f in self._flat.items():     # arena ranges are already ours: refresh moments / steps in place
+                for p, o in zip(f["params"], f["offsets"]):
+                    st = self.state[p]
+                    f["m"][o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                    f["v"][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.state[p] = {"step": torch.tensor(float(st["step"])),
+                                     "exp_avg": f["m"][o:o + p.numel()].view(p.shape),
+                                     "exp_avg_sq": f["v"][o:o + p.numel()].view(p.shape)}
+            return
         self._flat.clear()
         for gi, group in enumerate(self.param_groups):
             self._build(gi, group)
+
+    @torch.no_grad()
+    def zero_grad(self, set_to_none: bool = False):
+        """One fill per group; `p.grad` stays (or becomes again) the view of the flat gradient buffer.  Unlike
+        torch.optim the default is set_to_none=False: a None gradient makes autograd allocate a fresh tensor per parameter
+        and step() copy it back into the flat buffer (still correct - and it keeps torch.optim.Adam's "a parameter without
+        a gradient is skipped" semantics, which is why set_to_none=True is honoured when asked for)."""
+        for gi, group in enumerate(self.param_groups):
+            f = self._flat.get(gi)
+            if not f or set_to_none:
+                for p in group["params"]:
+                    p.grad = None
+                continue
+            f["g"].zero_()
+            for p, gv in zip(f["params"], f["gviews"]):
+                if p.grad is not gv:
+                    p.grad = gv
 
     # ---- hipGraph support -------------------------------------------------------------------------------
     def begin_capture(self) -> None:
@@ -94,6 +172,8 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             f = self._flat.get(gi)
             if f is None or [id(p) for p in f.get("params", [])] != [id(p) for p in group["params"] if p.requires_grad]:
+                if self.arena is not None and f is not None:
+                    raise RuntimeError("FusedAdam: the parameters of an arena-backed group cannot change")
                 f = self._build(gi, group)
             if not f:
                 continue
@@ -106,8 +186,14 @@ class FusedAdam(torch.optim.Optimizer):
             capturing = torch.cuda.is_current_stream_capturing()
             if all(have) and len(steps) == 1:
                 # the whole group in one launch; the step count lives on the device so that a captured hipGraph
-                # (train.GraphedIteration) applies fresh bias corrections at every replay
-                torch._foreach_copy_(f["gviews"], [p.grad for p in f["params"]])
+                # (train.GraphedIteration) applies fresh bias corrections at every replay.  Gradients normally ARE the
+                # views of the flat buffer; a gradient that was re-created (module.zero_grad() sets None) is copied in.
+                stray = [(gv, p.grad) for p, gv in zip(f["params"], f["gviews"])
+                         if p.grad is not gv and p.grad.data_ptr() != gv.data_ptr()]
+                if stray:
+                    torch._foreach_copy_([s[0] for s in stray], [s[1] for s in stray])
+                    for p, gv in zip(f["params"], f["gviews"]):
+                        p.grad = gv
                 t = steps.pop() + 1
                 if not capturing:
                     f["tdev"].fill_(t - 1)           # host and device counts agree outside a capture
@@ -127,7 +213,8 @@ class FusedAdam(torch.optim.Optimizer):
                     if p.grad is None:
                         continue
                     st = self.state[p]
-                    gv.copy_(p.grad)
+                    if p.grad is not gv and p.grad.data_ptr() != gv.data_ptr():
+                        gv.copy_(p.grad)
                     check(lib().dvg_adam_step(ops._p(p), ops._p(gv), ops._p(st["exp_avg"]), ops._p(st["exp_avg_sq"]),
                                               p.numel(), *hyper, int(st["step"]) + 1, None, ops._stream()),
                           "dvg_adam_step")

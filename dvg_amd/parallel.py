@@ -2,10 +2,16 @@
 on xGMI, gloo on CPU for the tests.  The reference has no distributed code at all (SURVEY.md §2a);
 this is the MI355X-side addition of §8(e).
 
-Gradients are averaged with ONE all-reduce of a flat fp32 buffer per backward pass (vgg_64: 21.1 M
-parameters = 84.6 MB; dcgan_64: 44 MB).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a single
-large message lets RCCL use all links at once, whereas per-parameter all-reduces (170 tensors, many of
-them 64-512 floats) would be latency-bound.  BatchNorm uses per-replica statistics (DDP semantics).
+Gradients live in ONE flat fp32 arena (dvg_amd/optim.py: `p.grad` of every parameter is a view of it, and the
+fused Adam kernel reads the same buffer), so averaging them across ranks is an all-reduce of a contiguous RANGE
+of that buffer, in place: no gather into a communication buffer, no scatter back, no copy into the optimiser
+(vgg_64: 21.1 M parameters = 84.6 MB; dcgan_64: 44 MB).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a
+few large messages let RCCL use all links at once, whereas per-parameter all-reduces (170 tensors, many of them
+64-512 floats) would be latency-bound.  `ArenaReducer.start()` issues the collective asynchronously (RCCL runs it
+on its own stream, ordered after the work already queued on the caller's stream) and `finish()` makes the caller's
+stream wait for it: train.Trainer starts the decoder / LSTM / GP range as soon as the decoder phase of the backward
+pass is done and the encoder range after the encoder phase, so the first - larger - collective overlaps the encoder
+backward.  BatchNorm uses per-replica statistics (DDP semantics).
 """
 from __future__ import annotations
 
@@ -40,8 +46,50 @@ def shard_batch(global_batch: int, world: int) -> int:
     return global_batch // world
 
 
+def _active(group) -> bool:
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("DVG_FORCE_ALLREDUCE") == "1")
+
+
+class ArenaReducer:
+    """Average ranges of a flat gradient buffer across ranks, in place and asynchronously."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None):
+        self.g, self.group = flat_grad, group
+        self.enabled = True
+        self.calls = 0          # collectives issued (bench.py reports it)
+        self.floats = 0
+
+    def active(self) -> bool:
+        return self.enabled and _active(self.group)
+
+    def start(self, lo: int, hi: int):
+        """Issue the all-reduce of g[lo:hi]; returns a handle for finish() (None when there is nothing to do)."""
+        if not self.active() or hi <= lo:
+            return None
+        buf = self.g[lo:hi]
+        world = dist.get_world_size(self.group)
+        self.calls += 1
+        self.floats += hi - lo
+        if dist.get_backend(self.group) == "nccl":
+            return (dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None)
+        return (dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (buf, world))
+
+    @staticmethod
+    def finish(handle) -> None:
+        if handle is None:
+            return
+        work, post = handle
+        work.wait()             # nccl: the current stream waits (the host does not); gloo: blocks
+        if post is not None:
+            post[0].div_(post[1])
+
+    def reduce(self, lo: int, hi: int) -> None:
+        self.finish(self.start(lo, hi))
+
+
 class FlatGradReducer:
-    """Average the gradients of `params` across ranks with one all-reduce of a flat buffer."""
+    """Average the gradients of an arbitrary parameter list with one all-reduce of a gathered flat buffer (for
+    parameters that do not live in a FusedAdam arena; train.Trainer uses ArenaReducer)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -56,25 +104,25 @@ class FlatGradReducer:
 
     @torch.no_grad()
     def reduce(self) -> None:
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1 or not self.params:
+        if not _active(self.group) or not self.params:
             return
         flat = self._buffer(self.params[0])
-        off = 0
+        views, grads, off = [], [], 0
         for p in self.params:  # parameters a pass did not touch contribute zeros (still averaged)
             n = p.numel()
+            v = flat[off:off + n].view(p.shape)
             if p.grad is None:
-                flat[off:off + n].zero_()
+                v.zero_()
             else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
+                views.append(v)
+                grads.append(p.grad)
             off += n
+        if views:
+            torch._foreach_copy_(views, grads)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(dist.get_world_size(self.group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is not None:
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        if views:
+            torch._foreach_copy_(grads, views)
 
 
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:

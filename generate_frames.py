@@ -60,6 +60,8 @@ def build_parser():
     p.add_argument('--nbatches', type=int, default=5)
     p.add_argument('--trigger_indices', type=int, default=None, help='GPtrigger_gen: how many batch indices')
     p.add_argument('--synthetic_ckpt', action='store_true')
+    p.add_argument('--synthetic_data', action='store_true',
+                   help='datasets other than smmnist: synthetic clips of the right shape (--data_root is not read)')
     return p
 
 
@@ -176,7 +178,14 @@ def main(argv=None):
     torch.manual_seed(opt.seed)
     torch.cuda.manual_seed_all(opt.seed)
     gen = Generator(opt, ckpt, device)
-    if getattr(opt, 'dataset', 'smmnist') == 'smmnist':
+    dataset = getattr(opt, 'dataset', 'smmnist')
+    if dataset != 'smmnist' and not args.synthetic_data:
+        raise SystemExit(f"generate_frames.py: no loader for dataset {dataset} here (--data_root {args.data_root!r} is not "
+                         "read). Pass --synthetic_data to roll out on synthetic clips of that dataset's shape.")
+    print("WARNING: synthetic data - %s; --data_root is ignored" %
+          ("Moving-MNIST trajectories over synthetic sprites (not MNIST digits)" if dataset == 'smmnist'
+           else f"random textured clips shaped like {dataset}"), file=sys.stderr)
+    if dataset == 'smmnist':
         ds = SyntheticMovingMNIST(seq_len=opt.n_eval, image_size=opt.image_width, seed=opt.seed + 7919)
         batches = (ds.batch(opt.batch_size) for _ in range(args.nbatches))
     else:

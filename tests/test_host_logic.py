@@ -67,6 +67,60 @@ def test_flat_grad_allreduce_gloo_world2():
     assert not torch.equal(a["local"][0], b["local"][0])
 
 
+def _arena_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from dvg_amd import parallel
+    from dvg_amd.optim import FlatArena
+    parallel.init_distributed("gloo")
+    # the Trainer's layout: parameters whose .grad are views of one flat gradient buffer; ranges reduced in place
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))      # "decoder side" | "encoder side"
+    params = list(net.parameters())
+    arena = FlatArena(FlatArena.size_for(params), "cpu")
+    views, off = [], 0
+    for p_ in params:
+        views.append(arena.g[off:off + p_.numel()].view(p_.shape))
+        p_.grad = views[-1]
+        off += FlatArena.padded(p_.numel())
+    split = FlatArena.padded(35) + FlatArena.padded(5)                           # end of net[0]'s range
+    net(torch.full((4, 7), float(rank + 1))).sum().backward()
+    assert all(p_.grad is v for p_, v in zip(params, views)), "backward must accumulate into the flat views"
+    local = arena.g.clone()
+    red = parallel.ArenaReducer(arena.g)
+    h1 = red.start(split, arena.g.numel())        # second range first, asynchronously ...
+    h0 = red.start(0, split)                      # ... while "the rest of backward" would still be running
+    red.finish(h1)
+    red.finish(h0)
+    red.enabled = False
+    assert red.start(0, split) is None            # bench.py's no-all-reduce leg
+    q.put({"rank": rank, "local": local.numpy().copy(), "reduced": arena.g.numpy().copy(),
+           "grad0": params[0].grad.detach().numpy().copy(), "calls": red.calls, "floats": red.floats})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_ranges_gloo_world2():
+    """dvg_amd.parallel.ArenaReducer: in-place, asynchronous averaging of RANGES of the flat gradient arena whose views
+    are the parameters' .grad (what train.Trainer does with RCCL), two ranks over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b = sorted([q.get(timeout=120) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    mean = (a["local"] + b["local"]) / 2
+    assert not np.array_equal(a["local"], b["local"])
+    assert np.allclose(a["reduced"], mean, atol=1e-6) and np.array_equal(a["reduced"], b["reduced"])
+    assert np.allclose(a["grad0"].reshape(-1), mean[:35], atol=1e-6), "p.grad IS the reduced buffer (no copy back)"
+    assert a["calls"] == 2 and a["floats"] == a["local"].size
+
+
 def test_shard_batch_rejects_uneven_split():
     from dvg_amd import parallel
     assert parallel.shard_batch(32, 8) == 4

@@ -12,11 +12,19 @@ Consciously fixed (each was unrunnable in the reference — SURVEY.md §5 quirks
   * `--dataset smmnist` works (`--num_digits`), batches may be `x` or `(x, y)`;
   * no `torch.cuda.empty_cache()` per timestep (:166,191,235);
   * `--ft` / flags are real booleans (`--no_ft`).
+Reference behaviour that is KEPT although it looks like a bug, with a switch (each has a test showing both modes):
+  * `Trainer.reference_gp_grad_leak = True`: train_model (:200-245) zeroes the encoder / decoder / LSTM gradients but
+    not the GP optimiser's, so the full-scale ELBO gradients that the previous iteration's train_GP_Frame_predictor
+    left in `.grad` (:170-171) are still there when train_model's `optimizer.step()` (:245) runs, on top of the
+    1e-4-weighted ones of :239.  False zeroes them first.
 Added: data parallelism — launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`;
-`--batch_size` is the GLOBAL batch, split evenly over the ranks; gradients are averaged with one flat
-RCCL all-reduce per backward (dvg_amd/parallel.py); BatchNorm statistics are per replica.
-Datasets are synthetic here (no network / files offline): `smmnist` = seeded Moving-MNIST trajectories,
-other names = random textured clips of the right shape.
+`--batch_size` is the GLOBAL batch, split evenly over the ranks (the ELBO's `num_data` is the global batch as well, so
+the KL weight does not change with the number of GPUs); every parameter's `.grad` is a view of one flat arena
+(dvg_amd/optim.py) whose ranges are averaged in place over RCCL, the decoder-side range while the encoder phase of the
+backward pass is still running (dvg_amd/parallel.py); BatchNorm statistics are per replica.
+Datasets are synthetic here (no network / files offline): `smmnist` = seeded Moving-MNIST trajectories with in-repo
+sprites; any other `--dataset` needs `--synthetic_data` (random textured clips of the right shape) and fails without
+it, because `--data_root` cannot be honoured.
 """
 import argparse
 import importlib
@@ -36,7 +44,7 @@ import utils  # noqa: E402
 from dvg_amd import fused, parallel  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
 from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1, VariationalELBO  # noqa: E402
-from dvg_amd.optim import FusedAdam  # noqa: E402
+from dvg_amd.optim import FlatArena, FusedAdam  # noqa: E402
 
 
 def build_parser():
@@ -71,7 +79,10 @@ def build_parser():
     p.add_argument('--save_every', type=int, default=4)
     p.add_argument('--no_save', action='store_true')
     p.add_argument('--hip_graph', action='store_true',
-                   help='replay each training iteration as one hipGraph (single-GPU validated; see GraphedIteration)')
+                   help='replay each training iteration as one hipGraph (see GraphedIteration); with more than one rank '
+                        'the graph contains the RCCL all-reduces: falls back to eager unless DVG_HIP_GRAPH_DP=1')
+    p.add_argument('--synthetic_data', action='store_true',
+                   help='datasets other than smmnist: train on synthetic clips of the right shape (--data_root is not read)')
     return p
 
 
@@ -96,6 +107,11 @@ class Trainer:
         for m in self.modules:
             m.to(device)
         parallel.broadcast_parameters(self.modules)
+        # True = the reference's behaviour: train_model does not zero the GP optimiser's gradients (see module docstring)
+        self.reference_gp_grad_leak = True
+        # True = backward in two phases (decoder / LSTM / GP side, then the encoder) so that the all-reduce of the first
+        # phase's gradients overlaps the second phase; needs share_encoder_passes
+        self.staged_backward = True
         # True = back-propagate into the encoder in the two fine-tuning closures like the reference does (and then
         # discards); kept only so that tests can show both ways give the same updates
         self.finetune_encoder_grad = False
@@ -105,22 +121,62 @@ class Trainer:
         self.share_skip_halves = True
         # True = the GP fine-tuning closure reuses the encodings of the LSTM fine-tuning closure that precedes it
         self.share_closure_encodings = True
-        # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group
+        # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group.  All groups live in ONE
+        # flat arena in the order [GP | likelihood | LSTM | decoder | encoder]: parameters, gradients (p.grad are views)
+        # and both moments; the data-parallel all-reduce works on ranges of arena.g in place.
         Adam = FusedAdam   # HIP only, like the models themselves: no CPU fallback on the product path
-        self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002)
-        self.encoder_optimizer = Adam(self.encoder.parameters(), lr=0.002)
-        self.decoder_optimizer = Adam(self.decoder.parameters(), lr=0.002)
+        allp = [p for m in self.modules for p in m.parameters()]
+        self.arena = FlatArena(FlatArena.size_for(allp), device)
         self.optimizer = Adam([{'params': self.gp_layer.parameters()},
-                               {'params': self.likelihood.parameters()}], lr=0.002)
+                               {'params': self.likelihood.parameters()}], lr=0.002, arena=self.arena)
+        self.frame_predictor_optimizer = Adam(self.frame_predictor.parameters(), lr=0.002, arena=self.arena)
+        self.decoder_optimizer = Adam(self.decoder.parameters(), lr=0.002, arena=self.arena)
+        self.encoder_optimizer = Adam(self.encoder.parameters(), lr=0.002, arena=self.arena)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[3, 5], gamma=0.1)
-        self.mll = VariationalELBO(self.likelihood, self.gp_layer, num_data=opt.local_batch, combine_terms=True)
+        # num_data = the GLOBAL batch (train.py:112 passes opt.batch_size): each rank's loss is ll_r/B_local - KL/num_data and
+        # the ranks are averaged, which gives the reference's ll/B - KL/B at the same global batch for any number of ranks
+        self.mll = VariationalELBO(self.likelihood, self.gp_layer, num_data=opt.batch_size, combine_terms=True)
         self.mse_criterion = nn.MSELoss()
         self.mse_latent_criterion = nn.MSELoss()
-        gp_params = list(self.gp_layer.parameters()) + list(self.likelihood.parameters())
-        self.red_all = parallel.FlatGradReducer(list(self.encoder.parameters()) + list(self.decoder.parameters()) +
-                                                list(self.frame_predictor.parameters()) + gp_params)
-        self.red_fp = parallel.FlatGradReducer(self.frame_predictor.parameters())
-        self.red_gp = parallel.FlatGradReducer(gp_params)
+        self.reducer = parallel.ArenaReducer(self.arena.g)
+        self.rng_gp = (self.optimizer.flat_range(0)[0], self.optimizer.flat_range(1)[1])
+        self.rng_fp = self.frame_predictor_optimizer.flat_range(0)
+        self.rng_dec = self.decoder_optimizer.flat_range(0)
+        self.rng_enc = self.encoder_optimizer.flat_range(0)
+        assert self.rng_gp[1] == self.rng_fp[0] and self.rng_fp[1] == self.rng_dec[0] and self.rng_dec[1] == self.rng_enc[0]
+
+    # ---- data-parallel switches / statistics (bench.py's training leg) --------------------------
+    def set_allreduce(self, on: bool):
+        self.reducer.enabled = bool(on)
+
+    def reset_allreduce_stats(self):
+        self.reducer.calls = self.reducer.floats = 0
+        self._iters = 0
+
+    def allreduce_stats(self):
+        """Collectives and bytes per iteration, and their standalone duration (the same ranges all-reduced back to back,
+        timed with events on the launch stream; how much of it an iteration actually waits for is a separate measurement)."""
+        if not self.reducer.active() or not getattr(self, '_iters', 0):
+            return None
+        import torch.distributed as dist
+        ranges = [(self.rng_gp[0], self.rng_dec[1]), self.rng_enc, self.rng_fp, self.rng_gp] if self.opt.ft else \
+            [(self.rng_gp[0], self.rng_dec[1]), self.rng_enc]
+        scratch = torch.zeros_like(self.arena.g)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            for lo, hi in ranges:
+                dist.all_reduce(scratch[lo:hi])
+        torch.cuda.synchronize()
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            for lo, hi in ranges:
+                dist.all_reduce(scratch[lo:hi])
+        e1.record()
+        torch.cuda.synchronize()
+        return {"allreduce_ms_per_iter": round(e0.elapsed_time(e1) / reps, 3),
+                "allreduces_per_iter": round(self.reducer.calls / self._iters, 2),
+                "allreduce_MB_per_iter": round(4e-6 * self.reducer.floats / self._iters, 2)}
 
     # ---- mode switches (train.py:342-346,372-374) -------------------------------------------
     def train_mode(self):
@@ -201,13 +257,13 @@ class Trainer:
             max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
         loss.backward()
-        self.red_gp.reduce()
+        self.reducer.reduce(*self.rng_gp)
         self.optimizer.step()
         return loss.detach()
 
     def _train_fp_dev(self, x):
         opt = self.opt
-        self.frame_predictor.zero_grad()
+        self.frame_predictor_optimizer.zero_grad()   # frame_predictor.zero_grad() (train.py:176): one fill of the flat range
         self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         mse_latent = 0
         skip = None
@@ -227,21 +283,29 @@ class Trainer:
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
-        self.red_fp.reduce()
+        self.reducer.reduce(*self.rng_fp)
         self.frame_predictor_optimizer.step()
         return mse_latent.detach()
 
     def _train_model_dev(self, x):
         opt = self.opt
-        self.encoder.zero_grad()
-        self.decoder.zero_grad()
-        self.frame_predictor.zero_grad()
-        self.optimizer.zero_grad()  # the reference lets GP grads of the previous closure leak in; we do not
+        self.encoder_optimizer.zero_grad()            # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203)
+        self.decoder_optimizer.zero_grad()
+        self.frame_predictor_optimizer.zero_grad()
+        if not self.reference_gp_grad_leak:
+            self.optimizer.zero_grad()                # the reference does NOT do this (see the module docstring)
         self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         mse = mse_latent = mse_gp = ae_mse = 0
         max_ll = 0
         skip = None
         enc_all = self._encode_sequence(x, True) if self.share_encoder_passes else None
+        staged = enc_all is not None and self.staged_backward
+        if staged:
+            # cut the graph at the encoder outputs: the decoder / LSTM / GP phase back-propagates into detached leaves,
+            # whose gradients then seed the encoder phase (same sums, same gradients)
+            enc_out = enc_all
+            enc_all = [(h.detach().requires_grad_(True), [s.detach().requires_grad_(True) for s in sk])
+                       for h, sk in enc_out]
         for i in range(1, opt.n_past + opt.n_future):
             h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1), skip)
             h_target = self._enc(enc_all, x, i)[0]
@@ -258,7 +322,21 @@ class Trainer:
             mse_gp = mse_gp + self.mse_latent_criterion(x_pred_gp, x[i])
         loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
         loss.backward()
-        self.red_all.reduce()
+        if staged:
+            # gradients of GP, likelihood, LSTM and decoder are final: their all-reduce runs under the encoder phase
+            pending = self.reducer.start(self.rng_gp[0], self.rng_dec[1])
+            outs, seeds = [], []
+            for (h, sk), (hd, skd) in zip(enc_out, enc_all):
+                for t, d in [(h, hd)] + list(zip(sk, skd)):
+                    if d.grad is not None:
+                        outs.append(t)
+                        seeds.append(d.grad)
+            torch.autograd.backward(outs, seeds)
+            pending2 = self.reducer.start(*self.rng_enc)
+            self.reducer.finish(pending)
+            self.reducer.finish(pending2)
+        else:
+            self.reducer.reduce(self.rng_gp[0], self.rng_enc[1])
         self.frame_predictor_optimizer.step()
         self.encoder_optimizer.step()
         self.decoder_optimizer.step()
@@ -276,6 +354,7 @@ class Trainer:
         opt.ft.  Returns (mse_ctrl, indices, temp_loss) as Python floats."""
         mse_ctrl, indices = self.train_model(x)
         temp_loss = self.finetune_temporal_encoders(x) if self.opt.ft else 0
+        self._iters = getattr(self, '_iters', 0) + 1
         return mse_ctrl, indices, temp_loss
 
 
@@ -360,6 +439,7 @@ class GraphedIteration:
         for dst, src in zip(self.static_x, x):
             dst.copy_(src)
         self.graph.replay()
+        tr._iters = getattr(tr, '_iters', 0) + 1
         for o in tr.optimizers():
             o.after_graph_replay()
         with torch.no_grad():
@@ -375,6 +455,16 @@ class GraphedIteration:
 
 
 def make_batch_generator(opt, seq_len, seed):
+    """`--data_root` is NOT read: there are no dataset files (nor torchvision / network) in this environment.  smmnist is
+    the reference's trajectory generator over seeded in-repo sprites; every other dataset name must be acknowledged with
+    --synthetic_data, otherwise a reference command line would silently 'train' on noise."""
+    if opt.dataset != 'smmnist' and not getattr(opt, 'synthetic_data', False):
+        raise SystemExit(f"train.py: no loader for --dataset {opt.dataset} here (--data_root {opt.data_root!r} is not read). "
+                         "Pass --synthetic_data to train on synthetic clips of that dataset's shape.")
+    if opt.rank == 0:
+        what = ("Moving-MNIST trajectories over synthetic sprites (not MNIST digits)" if opt.dataset == 'smmnist'
+                else f"random textured clips shaped like {opt.dataset}")
+        print(f"WARNING: synthetic data - {what}; --data_root is ignored", file=sys.stderr)
     if opt.dataset == 'smmnist':
         ds = SyntheticMovingMNIST(seq_len=seq_len, num_digits=opt.num_digits, image_size=opt.image_width, seed=seed)
         while True:
@@ -407,7 +497,14 @@ def main(argv=None):
     train_gen = make_batch_generator(opt, opt.n_past + opt.n_future, opt.seed + 17 * rank)
     test_gen = make_batch_generator(opt, opt.n_eval, opt.seed + 7919 + 17 * rank)
     dtype = torch.cuda.FloatTensor
-    step = GraphedIteration(tr) if opt.hip_graph else tr.iteration
+    use_graph = opt.hip_graph
+    if use_graph and world > 1 and os.environ.get("DVG_HIP_GRAPH_DP") != "1":
+        if rank == 0:
+            print("WARNING: --hip_graph with %d ranks would capture the RCCL all-reduces inside the graph; running eager "
+                  "(set DVG_HIP_GRAPH_DP=1 to enable - bench.py's training leg measures that combination)" % world,
+                  file=sys.stderr)
+        use_graph = False
+    step = GraphedIteration(tr) if use_graph else tr.iteration
     for epoch in range(opt.niter):
         tr.train_mode()
         tr.scheduler.step()   # before the epoch, as train.py:347
