@@ -82,7 +82,8 @@ class Generator:
         return self.likelihood(self.gp_layer(h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)))
 
     @torch.no_grad()
-    def make_gifs(self, x, nsample):
+    def make_gifs(self, x, nsample, eps_by_sample=None):
+        """`eps_by_sample[s][i]`: the N(0,1) base sample (D,B) of sample s at trigger step i (parity runs); None = torch RNG."""
         opt = self.opt
         post = posterior_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood, x,
                                  opt.n_past, opt.n_eval, opt.last_frame_skip)
@@ -94,7 +95,8 @@ class Generator:
         state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip)
         for s in range(nsample):
             frames = sample_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
-                                 self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip)
+                                 self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip,
+                                 eps_by_step=None if eps_by_sample is None else eps_by_sample[s])
             for t in range(T):   # utils.eval_seq (generate_frames.py:178) on device: dvg_eval_frames
                 ssim[:, s, t], psnr[:, s, t] = ops.eval_frames(x[opt.n_past + t], frames[opt.n_past + t])
             all_gen.append(torch.stack(frames))
@@ -107,40 +109,56 @@ class Generator:
         h = self.encoder(x_in)[0]
         return self.decoder([self.frame_predictor(h), skip])
 
+    @staticmethod
+    def _variance_norms(pred):
+        """generate_frames.py:230,275: `np.linalg.norm(final_pred.variance.cpu().detach().numpy().transpose(), axis=1)` -
+        per-sample L2 norm over the latent dims of the predictive variance, on the host in float32 like the reference."""
+        return np.linalg.norm(pred.variance.cpu().numpy().transpose(), axis=1)
+
     @torch.no_grad()
-    def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1):
+    def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1, eps_by_step=None, keep_batch=False):
         """generate_frames.py:249-298.  Keeps the reference's bookkeeping verbatim: the warm-up records the
-        variance norm of sample `index` (:275) while `var_value` reads sample 3 (:230); the skip tensors are
-        those of input step 4 (`i < 5`, :268-269)."""
-        opt = self.opt
+        variance norm of sample `index` (:275) while `var_value` reads sample [3] (:230 - a batch smaller than 4 is an
+        IndexError there and an error here); the skip tensors are those of loop steps `i < 5` (:268-269); the rollout is
+        autoregressive from x[0]; a triggered step decodes a GP sample and does NOT step the LSTM (:289-292).
+        `eps_by_step[i]`: base sample (D,B) for a trigger at step i (parity runs); None = torch RNG."""
         B = x[0].shape[0]
+        if B < 4:
+            raise IndexError("GPtrigger_gen reads sample [3] of the batch (generate_frames.py:230): batch_size must be >= 4")
         out = []
         for index in range(B if n_index is None else n_index):
             self.frame_predictor.hidden = self.frame_predictor.init_hidden()
-            ctx, triggers, gen_seq = [], [], []
+            ctx, triggers, gen_seq, values, thresholds = [], [], [], [], []
             x_in, skip = x[0], None
             for i in range(warmup):
                 h, sk = self.encoder(x_in)
                 if i < 5:
                     skip = sk
-                var = self._gp(h).variance            # (D,B)
-                ctx.append(float(var.t().norm(dim=1)[index]))
+                value = self._variance_norms(self._gp(h))[index]
+                ctx.append(value)
+                values.append(float(value))
                 x_in = self._generation(x_in, skip)
                 gen_seq.append(x_in)
             ctx = np.array(ctx)
             for i in range(warmup, total):
                 h = self.encoder(x_in)[0]
                 pred = self._gp(h)
-                value = float(pred.variance.t().norm(dim=1)[min(3, B - 1)])
+                value = self._variance_norms(pred)[3]
                 ctx = np.concatenate([ctx[1:], [value]])
                 threshold = np.mean(ctx) + (2 + 0.01 * depth) * np.std(ctx)
                 if value > threshold:
-                    x_in = self.decoder([pred.rsample().transpose(0, 1), skip])
+                    x_in = self.decoder([pred.rsample(None if eps_by_step is None else eps_by_step[i]).transpose(0, 1),
+                                         skip])
                     triggers.append(i)
                 else:
                     x_in = self._generation(x_in, skip)
+                values.append(float(value))
+                thresholds.append(float(threshold))
                 gen_seq.append(x_in)
-            out.append({'index': index, 'frames': torch.stack(gen_seq)[:, index].cpu(), 'triggers': triggers})
+            out.append({'index': index, 'frames': torch.stack(gen_seq)[:, index].cpu(), 'triggers': triggers,
+                        'values': values, 'thresholds': thresholds})
+            if keep_batch:        # parity tests compare the whole batch's frames, not only row `index`
+                out[-1]['batch_frames'] = gen_seq
         return out
 
 

@@ -9,9 +9,14 @@ key names), what the reference's modules compute.  Each function cites the refer
 lines it follows (paths relative to the reference tree).
 
 Pinning:
-  * encoder / decoder / LSTM restatements are pinned against golden vectors produced
+  * encoder / decoder / LSTM / gaussian_encoder restatements are pinned against golden vectors produced
     by the reference's own modules imported on CPU (tests/golden/make_golden.py,
-    committed with its outputs; checked by tests/test_oracle_golden.py).
+    committed with its outputs; checked by tests/test_oracle_golden.py) - forward outputs, BatchNorm side
+    effects AND the gradients the reference's own `.backward()` produces (B=16 train-mode encoder->decoder,
+    4-step LSTM BPTT), against which torch-autograd-of-this-restatement is checked.
+  * step closures / rollouts (train_model_loss, plot_rollout, posterior_rollout, gp_trigger_gen, best_of_n_sse,
+    best_ssim): restated from the reference SOURCE (module-level script code, not importable); their integer
+    bookkeeping is pinned by that text, their arithmetic by the pinned blocks they call (+ the GP caveat below).
   * GP (gp_models.py + gpytorch): **parity unpinned** — gpytorch is not vendored in
     the reference, not pinned by any manifest and not installable here.  The GP
     functions below restate the gpytorch 0.3.x WhitenedVariationalStrategy /
@@ -110,6 +115,15 @@ def vgg_decoder(vec: torch.Tensor, skips: Sequence[torch.Tensor], sd: SD, traini
     nb = _count_blocks(sd, last)
     d = F.conv_transpose2d(d, sd[f"{last}.{nb}.weight"], sd[f"{last}.{nb}.bias"], stride=1, padding=1)
     return torch.sigmoid(d)
+
+
+def vgg_gaussian_encoder(x: torch.Tensor, sd: SD, eps: torch.Tensor, training: bool = False):
+    """vgg_64.gaussian_encoder.forward (vgg_64.py:155-165): the encoder trunk, then mu / logvar heads on h5 and
+    z = eps * exp(0.5 * logvar) + mu (:150-153) with the N(0,1) draw passed in.  Returns (z, mu, logvar, skips)."""
+    h, skips = vgg_encoder(x, sd, training)
+    mu = F.linear(h, sd["mu_net.weight"], sd["mu_net.bias"])
+    logvar = F.linear(h, sd["logvar_net.weight"], sd["logvar_net.bias"])
+    return eps * torch.exp(0.5 * logvar) + mu, mu, logvar, skips
 
 
 # --------------------------------------------------------------------------------------
@@ -386,3 +400,194 @@ def eval_seq(gt: Sequence[torch.Tensor], pred: Sequence[torch.Tensor]):
             ssim[i, t] /= nc
             psnr[i, t] /= nc
     return ssim, psnr
+
+
+# --------------------------------------------------------------------------------------
+# Step closures and qualitative / generation rollouts: the orchestration of rows S and K restated
+# from the reference's SOURCE (these functions are module-level script code that cannot be imported; what pins
+# them is the reference text itself: loop bounds, the skip rule, which tensor feeds the GP, which index is read).
+# enc(x)->(h,skips) and dec(vec,skips)->frame are closures over the encoder/decoder restatements above; their BN mode
+# is the caller's choice (train.py keeps encoder/decoder in TRAIN mode during plot(), train.py:372-374).
+# --------------------------------------------------------------------------------------
+def train_model_loss(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n_future: int, num_data: int,
+                     last_frame_skip: bool = False, rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float32):
+    """train.py:200-239 up to the loss (no backward / optimiser): returns (loss, mse_latent)."""
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    noise = likelihood_noise(lik_sd)
+    mse = mse_latent = mse_gp = ae_mse = 0
+    max_ll = 0
+    skip = None
+    for i in range(1, n_past + n_future):
+        h, sk = enc(x[i - 1])                                   # :214
+        h_target = enc(x[i])[0]                                 # :215 (not detached)
+        if last_frame_skip or i < n_past:                       # :217-220
+            skip = sk
+        h_pred = lstm_step(h, lstm_sd, hidden)                  # :222
+        mse_latent = mse_latent + F.mse_loss(h_pred, h_target)  # :223
+        gp = gp_predict(h, gp_sd, training=True, dtype=gp_dtype)                                 # :225
+        max_ll = max_ll - variational_elbo(gp, h_target.t(), noise, num_data=num_data)           # :226
+        x_pred = dec(h_pred, skip)                              # :227
+        ae_mse = ae_mse + F.mse_loss(dec(h_target, skip), x[i])  # :229-230
+        mse = mse + F.mse_loss(x_pred, x[i])                    # :233
+        mse_gp = mse_gp + F.mse_loss(dec(gp["mean"].t().to(x[i].dtype), skip), x[i])            # :232,234
+    loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()   # :239
+    return loss, mse_latent
+
+
+def train_frame_predictor_loss(x, enc, lstm_sd: SD, n_past: int, n_future: int, last_frame_skip: bool = False,
+                               rnn_size: int = 256, n_layers: int = 2):
+    """train.py:175-193: sum over steps of MSE(lstm(h_{i-1}), h_i)."""
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    mse_latent = 0
+    for i in range(1, n_past + n_future):
+        h = enc(x[i - 1])[0]
+        h_target = enc(x[i])[0]
+        mse_latent = mse_latent + F.mse_loss(lstm_step(h, lstm_sd, hidden), h_target)
+    return mse_latent
+
+
+def train_gp_loss(x, enc, gp_sd: SD, lik_sd: SD, n_past: int, n_future: int, num_data: int, gp_dtype=torch.float32):
+    """train.py:146-169: sum over steps and latent dims of -ELBO(gp(h_{i-1}), h_i)."""
+    noise = likelihood_noise(lik_sd)
+    max_ll = 0
+    for i in range(1, n_past + n_future):
+        h = enc(x[i - 1])[0]
+        h_target = enc(x[i])[0].detach()
+        gp = gp_predict(h, gp_sd, training=True, dtype=gp_dtype)
+        max_ll = max_ll - variational_elbo(gp, h_target.t(), noise, num_data=num_data)
+    return max_ll.sum()
+
+
+def plot_rollout(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n_eval: int,
+                 eps_by_sample: Sequence[torch.Tensor], last_frame_skip: bool = False, rnn_size: int = 256,
+                 n_layers: int = 2, gp_step: int = 10, gp_dtype=torch.float64) -> List[List[torch.Tensor]]:
+    """train.py:256-289: nsample = len(eps_by_sample) rollouts; the ONE GP-sampled step is `i == 10` (:281) - not the
+    i % 15 schedule of generate_frames.py - and it only exists when 10 >= n_past; the GP is fed the ENCODER output h
+    (:283).  On conditioning steps the reference also runs `encoder(x[i])` and discards it (:273-274): a BatchNorm
+    side effect when enc is in train mode, reproduced here by calling enc.  Returns gen_seq[s][t]."""
+    noise = likelihood_noise(lik_sd)
+    gen_seq = []
+    for eps in eps_by_sample:
+        hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)      # :263
+        seq = [x[0]]
+        x_in = x[0]
+        skip = None
+        for i in range(1, n_eval):
+            h, sk = enc(x_in)                                              # :267
+            if last_frame_skip or i < n_past:                              # :268-271
+                skip = sk
+            if i < n_past:
+                enc(x[i])                                                  # :274, output discarded
+                lstm_step(h, lstm_sd, hidden)                              # :276, output discarded
+                x_in = x[i]
+            else:
+                h_pred = lstm_step(h, lstm_sd, hidden)
+                if i == gp_step:                                           # :281
+                    p = gp_predict(h, gp_sd, training=False, noise=noise, dtype=gp_dtype)
+                    x_in = dec(gp_rsample(p["mean"], p["cov"], eps).t().to(h.dtype), skip)   # :283-284
+                else:
+                    x_in = dec(h_pred, skip)                               # :288
+            seq.append(x_in)
+        gen_seq.append(seq)
+    return gen_seq
+
+
+def best_of_n_sse(gt: Sequence[torch.Tensor], gen_seq: Sequence[Sequence[torch.Tensor]], nrow: int) -> List[int]:
+    """train.py:303-310: per batch row i < nrow the sample with the smallest sum over t of squared error; strict `<`
+    from min_mse = 1e7, so ties keep the FIRST sample."""
+    best = []
+    for i in range(nrow):
+        min_mse, min_idx = 1e7, None
+        for s in range(len(gen_seq)):
+            mse = 0
+            for t in range(len(gen_seq[s])):
+                mse = mse + torch.sum((gt[t][i] - gen_seq[s][t][i]) ** 2)
+            if mse < min_mse:
+                min_mse, min_idx = mse, s
+        best.append(min_idx)
+    return best
+
+
+def posterior_rollout(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n_eval: int,
+                      last_frame_skip: bool = False, rnn_size: int = 256, n_layers: int = 2,
+                      gp_dtype=torch.float64) -> List[torch.Tensor]:
+    """generate_frames.py:110-134: after the conditioning frames EVERY step decodes the GP predictive MEAN, and the GP is
+    fed the LSTM OUTPUT h_pred (:131), unlike the sample rollouts (:170) which feed it the encoder output."""
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    frames = [x[0]]
+    x_in = x[0]
+    skip = None
+    for i in range(1, n_eval):
+        h, sk = enc(x_in)
+        if last_frame_skip or i < n_past:
+            skip = sk
+        if i < n_past:
+            lstm_step(h, lstm_sd, hidden)
+            x_in = x[i]
+        else:
+            h_pred = lstm_step(h, lstm_sd, hidden)
+            p = gp_predict(h_pred, gp_sd, training=False, noise=likelihood_noise(lik_sd), dtype=gp_dtype)   # :131
+            x_in = dec(p["mean"].t().to(h.dtype), skip)                                                      # :132
+        frames.append(x_in)
+    return frames
+
+
+def best_ssim(ssim) -> List[int]:
+    """generate_frames.py:188-189,207: per batch row, `np.argsort(np.mean(ssim[i], 1))[-1]`; ssim (B, nsample, T)."""
+    import numpy as np
+    return [int(np.argsort(np.mean(np.asarray(ssim[i]), 1))[-1]) for i in range(len(ssim))]
+
+
+def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, eps_by_step: Dict[int, torch.Tensor],
+                   warmup: int = 12, total: int = 105, depth: int = 1, skip_steps: int = 5, probe: int = 3,
+                   rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float64) -> dict:
+    """ONE pass of the `for index in range(batch_size)` body of GPtrigger_gen (generate_frames.py:249-298) with
+    `generation` (:220-224) and `var_value` (:227-232) inlined.  The reference's bookkeeping, kept verbatim:
+      * the rollout is autoregressive from x[0] alone (x_in = x_out, :280,297) - no ground-truth frame after the first;
+      * the skip tensors are those of loop steps i < 5 (:268-269), whatever n_past is;
+      * warm-up: 12 steps; the recorded value is the L2 norm over latent dims of the predictive variance (with
+        likelihood noise) of sample `index` (:275);
+      * afterwards `var_value` reads sample [3] - NOT [index] (:230) - and slides the 12-long window (:231);
+      * threshold = mean + (2 + 0.01*depth) * std of the window, numpy population std (:288); `value > threshold`
+        decodes a GP sample of the encoder output (:290-292) WITHOUT stepping the LSTM, otherwise `generation` steps it.
+    Values are float32 like the reference's `.cpu().numpy()` arrays; the window statistics use numpy on that dtype.
+    Returns dict(frames, triggers, values, thresholds)."""
+    import numpy as np
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    noise = likelihood_noise(lik_sd)
+
+    def generation(x_in, skip):                                            # :220-224
+        h = enc(x_in)[0]
+        return dec(lstm_step(h, lstm_sd, hidden), skip)
+
+    def var_norms(h):
+        p = gp_predict(h, gp_sd, training=False, noise=noise, dtype=gp_dtype)
+        return np.linalg.norm(p["var"].to(torch.float32).numpy().transpose(), axis=1), p
+
+    context, values, thresholds, triggers, gen_seq = [], [], [], [], []
+    x_in, skip = x[0], None
+    for i in range(warmup):                                                # :266-280
+        h, sk = enc(x_in)
+        if i < skip_steps:
+            skip = sk
+        value = var_norms(h)[0][index]                                     # :275
+        context.append(value)
+        values.append(float(value))
+        x_in = generation(x_in, skip)
+        gen_seq.append(x_in)
+    context = np.array(context)                                            # :283
+    for i in range(warmup, total):                                         # :285-297
+        h = enc(x_in)[0]
+        norms, p = var_norms(h)
+        value = norms[probe]                                               # :230 - sample 3, not `index`
+        context = np.concatenate([context[1:], [value]])                   # :231
+        threshold = np.mean(context) + (2 + 0.01 * depth) * np.std(context)   # :288
+        if value > threshold:                                              # :289-292
+            x_in = dec(gp_rsample(p["mean"], p["cov"], eps_by_step[i]).t().to(h.dtype), skip)
+            triggers.append(i)
+        else:
+            x_in = generation(x_in, skip)                                  # :295
+        values.append(float(value))
+        thresholds.append(float(threshold))
+        gen_seq.append(x_in)
+    return {"frames": gen_seq, "triggers": triggers, "values": values, "thresholds": thresholds}

@@ -121,6 +121,80 @@ def run_lstm(out: dict):
         print(f"{tag}: y std {np.stack(ys).std():.4f}")
 
 
+def run_gaussian_encoder(out: dict):
+    """vgg_64.gaussian_encoder (vgg_64.py:108-159): trunk + mu / logvar heads + reparameterisation.  The reference draws eps
+    with `logvar.data.new(size).normal_()` from the global RNG (:150-153); it is recovered by replaying the seed."""
+    mod = ref_import("vgg_64")
+    import dvg_amd.models.vgg_64 as ours
+    B, seed = 3, 180
+    net = mod.gaussian_encoder(90, 24, 1)
+    assert list(ours.gaussian_encoder(90, 24, 1).state_dict().keys()) == list(net.state_dict().keys())
+    sd = params.fill_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    net.eval()
+    x = params.frames(seed + 2, B, 1, 64)
+    with torch.no_grad():
+        torch.manual_seed(4321)
+        z, mu, logvar, skips = net(x)
+        torch.manual_seed(4321)
+        eps = torch.empty(B, 24).normal_()
+    assert torch.equal(z, eps * torch.exp(0.5 * logvar) + mu) or torch.allclose(z, eps * torch.exp(0.5 * logvar) + mu,
+                                                                                 rtol=0, atol=1e-6)
+    out["gaussian_encoder/zmle"] = np.stack([z.numpy(), mu.numpy(), logvar.numpy(), eps.numpy()])
+    for i, sk in enumerate(skips):
+        out[f"gaussian_encoder/skip{i}"] = summarize(sk)
+    print(f"gaussian_encoder: mu std {mu.std():.4f} logvar std {logvar.std():.4f}")
+
+
+# ---- gradients: what the REFERENCE's own `.backward()` (train.py:240) produces ------------------------------------
+GRAD_BATCH = 16   # >= 16 so that single LeakyReLU-kink flips stop dominating batch-statistics BatchNorm gradients
+
+
+def run_backbone_grads(family: str, seed: int, out: dict, tag: str):
+    """encoder -> decoder([h, skips]) in TRAIN mode at B=16, loss = sum(y * Gy) + sum(h * Gh) with seeded upstream
+    gradients, `.backward()` on the reference modules; per-parameter gradient fingerprints (sum, |sum|, sum of squares,
+    64 strided samples) are stored, plus the outputs."""
+    torch.manual_seed(0)
+    mod = ref_import(f"{family}_64")
+    enc, dec = mod.encoder(90, 1), mod.decoder(90, 1)
+    esd = params.fill_state_dict(enc.state_dict(), seed)
+    dsd = params.fill_state_dict(dec.state_dict(), seed + 1, params.decoder_transposed_keys(dec.state_dict(), family))
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    enc.train(), dec.train()
+    x = params.frames(seed + 2, GRAD_BATCH, 1, 64)
+    gy = params.normal(seed + 4, GRAD_BATCH, 1, 64, 64)
+    gh = params.normal(seed + 5, GRAD_BATCH, 90)
+    h, skips = enc(x)
+    y = dec([h, skips])
+    ((y * gy).sum() + (h * gh).sum()).backward()
+    out[f"{tag}/h"] = h.detach().numpy()
+    out[f"{tag}/y"] = summarize(y)
+    for name, net in (("enc", enc), ("dec", dec)):
+        for k, p_ in net.named_parameters():
+            out[f"{tag}/{name}/{k}"] = summarize(p_.grad)
+    print(f"{tag}: {sum(1 for k in out if k.startswith(tag + '/enc/') or k.startswith(tag + '/dec/'))} gradient fingerprints")
+
+
+def run_lstm_grads(out: dict):
+    """4-step BPTT through lstm.lstm (lstm.py:42-72) at B=16: loss = sum_t sum(y_t * G_t)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    mod = ref_import("lstm")
+    B, seed = GRAD_BATCH, 320
+    net = mod.lstm(90, 90, 256, 2, B)
+    net.load_state_dict(params.fill_state_dict(net.state_dict(), seed))
+    net.hidden = net.init_hidden()
+    xs = [params.normal(seed + 10 + t, B, 90, scale=0.5).requires_grad_(True) for t in range(4)]
+    loss = sum((net(xs[t]) * params.normal(seed + 20 + t, B, 90)).sum() for t in range(4))
+    loss.backward()
+    out["lstm_grad/loss"] = np.array([float(loss)])
+    for k, p_ in net.named_parameters():
+        out[f"lstm_grad/{k}"] = summarize(p_.grad)
+    for t in range(4):
+        out[f"lstm_grad/x{t}"] = xs[t].grad.numpy()
+    print("lstm_grad: loss", float(loss))
+
+
 def main():
     out = OrderedDict()
     run_backbone("vgg", 64, 1, 2, False, 100, out, "vgg_64/eval")
@@ -132,6 +206,10 @@ def main():
     run_backbone("vgg", 128, 3, 1, False, 160, out, "vgg_128/eval")
     run_backbone("dcgan", 128, 3, 2, False, 170, out, "dcgan_128/eval")
     run_lstm(out)
+    run_gaussian_encoder(out)
+    run_backbone_grads("dcgan", 200, out, "dcgan_64/grad")
+    run_backbone_grads("vgg", 210, out, "vgg_64/grad")
+    run_lstm_grads(out)
     path = os.path.join(HERE, "reference_outputs.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

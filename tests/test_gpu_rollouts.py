@@ -1,0 +1,197 @@
+"""GPU parity of the orchestration rows S and K of SURVEY.md §8: the step closures' values, the qualitative rollout of
+train.py (`plot`), the posterior rollout and the variance-trigger generation of generate_frames.py, best-of-N selection -
+HIP path vs the oracle's restatements (oracle/dvg_oracle.py), base samples eps passed in.  Integer results (trigger-step
+lists, argmin / argsort indices) must be EXACT; frames hold the 1e-4 bar until a GP sample's fp32 Cholesky noise is
+chained through an autoregressive rollout (5e-3 from there, as in tests/test_gpu_train.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.common import rel_err
+from tests.test_gpu_configs import _build, _oracle_fns
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cpu_state(m):
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+def _trainer(model, batch, n_past, n_future, n_eval, nc=1, width=64, seed=3):
+    import train
+    torch.manual_seed(seed)
+    o = train.build_parser().parse_args(["--model", model, "--batch_size", str(batch), "--n_past", str(n_past),
+                                         "--n_future", str(n_future), "--n_eval", str(n_eval), "--channels", str(nc),
+                                         "--image_width", str(width), "--dataset", "smmnist", "--no_save"])
+    o.ft, o.rank, o.world, o.local_batch = True, 0, 1, batch
+    tr = train.Trainer(o, torch.device(DEV))
+    tr.train_mode()
+    tr.gp_layer(torch.zeros(batch, 90, device=DEV))   # prior initialisation of the variational distribution
+    return tr, o
+
+
+def _train_mode_fns(model, width, esd, dsd):
+    if model == "vgg":
+        return (lambda t: orc.vgg_encoder(t, esd, True)), (lambda v, s: orc.vgg_decoder(v, s, dsd, True))
+    act = "tanh" if width == 64 else "sigmoid"
+    return (lambda t: orc.dcgan_encoder(t, esd, True)), (lambda v, s: orc.dcgan_decoder(v, s, dsd, True, act))
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_finetuning_closure_values_match_oracle(model):
+    """train_frame_predictor (train.py:175-198) and train_GP_Frame_predictor (:146-172): the returned VALUES against the
+    oracle composition (train-mode BatchNorm; the GP closure reuses the LSTM closure's encodings on our side)."""
+    tr, o = _trainer(model, 4, 2, 2, 4)
+    x = [params.frames(1200 + t, 4, 1, 64) for t in range(4)]
+    esd, lsd, gsd, lik = (_cpu_state(m) for m in (tr.encoder, tr.frame_predictor, tr.gp_layer, tr.likelihood))
+    enc, _ = _train_mode_fns(model, 64, esd, None)
+    T = o.n_past + o.n_future
+    with torch.no_grad():
+        ref_fp = float(orc.train_frame_predictor_loss(x, enc, lsd, o.n_past, o.n_future)) / T
+        ref_gp = float(orc.train_gp_loss(x, enc, gsd, lik, o.n_past, o.n_future, num_data=o.batch_size)) / T
+    xd = [t.to(DEV) for t in x]
+    got_fp = tr.train_frame_predictor(xd)
+    got_gp = tr.train_GP_Frame_predictor(xd)
+    assert abs(got_fp - ref_fp) < 1e-3 * abs(ref_fp), (got_fp, ref_fp)
+    assert abs(got_gp - ref_gp) < 2e-3 * abs(ref_gp), (got_gp, ref_gp)
+
+
+def test_plot_rollout_and_best_of_n_match_oracle():
+    """train.py:256-310: encoder / decoder stay in TRAIN mode, LSTM / GP / likelihood in eval (train.py:372-374); the one
+    GP-sampled step is i == 10; best-of-N by summed squared error must pick the same sample per row."""
+    n_past, n_eval, B, S = 3, 13, 4, 3
+    tr, o = _trainer("dcgan", B, n_past, 10, n_eval)
+    tr.frame_predictor.eval(), tr.gp_layer.eval(), tr.likelihood.eval()
+    x = [params.frames(1300 + t, B, 1, 64) for t in range(n_eval)]
+    eps = [params.normal(1320 + s, 90, B) for s in range(S)]
+    esd, dsd, lsd, gsd, lik = (_cpu_state(m) for m in (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer,
+                                                       tr.likelihood))
+    enc, dec = _train_mode_fns("dcgan", 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.plot_rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps)
+    ref_best = orc.best_of_n_sse(x, ref, B)
+    gen, best = tr.plot([t.to(DEV) for t in x], 0, nsample=S, eps_by_sample=[e.to(DEV) for e in eps])
+    assert gen.shape == (S, n_eval, B, 1, 64, 64)
+    for s in range(S):
+        for t in range(n_eval):
+            tol = 1e-4 if t < n_past else (2e-3 if t < 10 else 5e-3)   # train-mode BN at B=4 amplifies fp32 noise per step
+            assert rel_err(gen[s, t], ref[s][t]) < tol, (s, t, rel_err(gen[s, t], ref[s][t]))
+    assert best.tolist() == ref_best, (best.tolist(), ref_best)
+    # the frames after i == 10 differ between samples (distinct eps), the frames before do not
+    assert torch.equal(gen[0, 9], gen[1, 9]) and not torch.equal(gen[0, 10], gen[1, 10])
+    # BatchNorm side effects of plot(): the discarded encoder(x[i]) calls of train.py:273-274 count as well
+    got = tr.encoder.state_dict()
+    for k in ("c1.main.1.running_mean", "c1.main.1.running_var", "c5.1.running_mean"):
+        assert rel_err(got[k], esd[k]) < 2e-3, k
+    assert int(got["c1.main.1.num_batches_tracked"]) == int(esd["c1.main.1.num_batches_tracked"])
+
+
+@pytest.mark.parametrize("family", ["dcgan", "vgg"])
+def test_posterior_rollout_matches_oracle(family):
+    """generate_frames.py:110-134: the GP is fed the LSTM output and its predictive MEAN is decoded at every step."""
+    from dvg_amd.rollout import posterior_rollout
+    B, n_past, n_eval = 4, 3, 8
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1400)
+    xs = [params.frames(1410 + t, B, 1, 64) for t in range(n_eval)]
+    enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.posterior_rollout(xs, enc_o, dec_o, lsd, gsd, lik, n_past, n_eval)
+    for m in mods:
+        m.to(DEV).eval()
+    ours = posterior_rollout(*mods, [t.to(DEV) for t in xs], n_past, n_eval)
+    assert len(ours) == len(ref) == n_eval
+    for t in range(n_eval):
+        assert rel_err(ours[t], ref[t]) < 1e-4, (t, rel_err(ours[t], ref[t]))
+
+
+@pytest.mark.parametrize("depth,index", [(1, 0), (1, 2), (-250, 1)])
+def test_gp_trigger_generation_matches_oracle(depth, index):
+    """generate_frames.py:249-298 per batch index: variance norms (float32, host-side like the reference), thresholds, the
+    LIST OF TRIGGER STEPS (exact) and the frames.  depth = 1 is the reference's value; depth = -250 turns the threshold into
+    mean - 0.5 std so that both branches (GP sample without LSTM step / LSTM generation) are exercised densely.  The warm-up
+    reads sample `index`, the main loop sample [3] (the reference's asymmetry)."""
+    import generate_frames
+    B, total = 4, 26
+    opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", "dcgan"])
+    mods, (esd, dsd, lsd, gsd, lik) = _build("dcgan", 64, 1, B, 1500)
+    ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
+    g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
+    xs = [params.frames(1510, B, 1, 64)]
+    eps = {i: params.normal(1520 + i, 90, B) for i in range(12, total)}
+    enc_o, dec_o = _oracle_fns("dcgan", 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, index, eps, total=total, depth=depth)
+    margin = min(abs(v - th) / abs(th) for v, th in zip(ref["values"][12:], ref["thresholds"]))
+    assert margin > 2e-4, f"case too close to the threshold to be a meaningful exact-match test ({margin:.1e})"
+    res = g.gp_trigger_gen([xs[0].to(DEV)], n_index=index + 1, total=total, depth=depth,
+                           eps_by_step={k: v.to(DEV) for k, v in eps.items()}, keep_batch=True)[index]
+    assert res["index"] == index
+    assert res["triggers"] == ref["triggers"], (res["triggers"], ref["triggers"])
+    if depth != 1:
+        assert 0 < len(ref["triggers"]) < total - 12, "both branches must have been taken"
+    np.testing.assert_allclose(res["values"], ref["values"], rtol=2e-3)
+    np.testing.assert_allclose(res["thresholds"], ref["thresholds"], rtol=2e-3)
+    first = ref["triggers"][0] if ref["triggers"] else total
+    for t in range(total):
+        tol = 2e-4 if t < first else 5e-3
+        assert rel_err(res["batch_frames"][t], ref["frames"][t]) < tol, (t, rel_err(res["batch_frames"][t], ref["frames"][t]))
+    with pytest.raises(IndexError):
+        g.frame_predictor.batch_size = 2
+        g.gp_trigger_gen([xs[0][:2].to(DEV)], n_index=1, total=14)
+
+
+def test_make_gifs_best_ssim_matches_oracle():
+    """generate_frames.py:143-189,207: nsample rollouts with GP samples at i % 15 == 0, SSIM / PSNR per frame
+    (utils.eval_seq), best sample per row = np.argsort(mean SSIM)[-1] - exact index match."""
+    import generate_frames
+    B, n_past, n_eval, S = 3, 3, 17, 3
+    opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", "dcgan",
+                                                     "--n_past", str(n_past), "--n_eval", str(n_eval)])
+    mods, (esd, dsd, lsd, gsd, lik) = _build("dcgan", 64, 1, B, 1600)
+    ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
+    g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
+    xs = [params.frames(1610 + t, B, 1, 64) for t in range(n_eval)]
+    eps = [{15: params.normal(1630 + s, 90, B)} for s in range(S)]
+    enc_o, dec_o = _oracle_fns("dcgan", 64, esd, dsd)
+    ssim = np.zeros((B, S, n_eval - n_past))
+    psnr = np.zeros_like(ssim)
+    with torch.no_grad():
+        for s in range(S):
+            fr = orc.rollout(xs, enc_o, dec_o, lsd, gsd, lik, n_past, n_eval, eps[s])
+            ssim[:, s], psnr[:, s] = orc.eval_seq(xs[n_past:], fr[n_past:])
+    ref_best = orc.best_ssim(ssim)
+    res = g.make_gifs([t.to(DEV) for t in xs], S, eps_by_sample=[{15: e[15].to(DEV)} for e in eps])
+    np.testing.assert_allclose(res["ssim"].cpu().numpy(), ssim, atol=2e-4)
+    np.testing.assert_allclose(res["psnr"].cpu().numpy(), psnr, atol=2e-2)
+    gaps = np.sort(ssim.mean(2), axis=1)
+    assert float((gaps[:, -1] - gaps[:, -2]).min()) > 1e-5, "best and runner-up too close for an exact-index test"
+    assert res["best"].tolist() == ref_best, (res["best"].tolist(), ref_best)
+
+
+def test_gaussian_encoder_matches_reference_golden(golden):
+    """vgg_64.gaussian_encoder (vgg_64.py:108-159) on the HIP path against the outputs of the reference's own module."""
+    import dvg_amd.models.vgg_64 as ours
+    from tests.common import summarize
+    net = ours.gaussian_encoder(90, 24, 1)
+    net.load_state_dict(params.fill_state_dict(net.state_dict(), 180))
+    net.to(DEV).eval()
+    gz = golden["gaussian_encoder/zmle"]            # [z, mu, logvar, eps]
+    eps = torch.from_numpy(gz[3]).to(DEV)
+    net.reparameterize = lambda mu, logvar: eps * torch.exp(0.5 * logvar) + mu    # the reference's draw, replayed
+    with torch.no_grad():
+        z, mu, logvar, skips = net(params.frames(182, 3, 1, 64).to(DEV))
+    assert rel_err(mu, torch.from_numpy(gz[1])) < 1e-4 and rel_err(logvar, torch.from_numpy(gz[2])) < 1e-4
+    assert rel_err(z, torch.from_numpy(gz[0])) < 1e-4
+    assert len(skips) == 4
+    for i, sk in enumerate(skips):
+        np.testing.assert_allclose(summarize(sk), golden[f"gaussian_encoder/skip{i}"], rtol=2e-4, atol=2e-3)
+    # and with its own RNG draw: z = eps' * exp(logvar / 2) + mu for SOME standard-normal eps'
+    del net.reparameterize
+    torch.manual_seed(0)
+    with torch.no_grad():
+        z2, mu2, logvar2, _ = net(params.frames(182, 3, 1, 64).to(DEV))
+    e2 = (z2 - mu2) / torch.exp(0.5 * logvar2)
+    assert torch.equal(mu2, mu) and abs(float(e2.mean())) < 0.5 and 0.5 < float(e2.std()) < 1.5

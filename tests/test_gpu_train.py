@@ -30,25 +30,9 @@ def _oracle_loss(model, esd, dsd, lsd, gsd, lik, x, opt):
     enc = (lambda t: orc.vgg_encoder(t, esd, True)) if model == "vgg" else (lambda t: orc.dcgan_encoder(t, esd, True))
     dec = (lambda v, s: orc.vgg_decoder(v, s, dsd, True)) if model == "vgg" else \
         (lambda v, s: orc.dcgan_decoder(v, s, dsd, True, "tanh"))
-    hidden = orc.lstm_init_hidden(x[0].shape[0], opt.rnn_size, opt.predictor_rnn_layers)
-    noise = orc.likelihood_noise(lik)
-    mse = mse_latent = mse_gp = ae_mse = 0
-    max_ll = 0
-    skip = None
-    for i in range(1, opt.n_past + opt.n_future):
-        h, sk = enc(x[i - 1])
-        h_target = enc(x[i])[0]
-        if opt.last_frame_skip or i < opt.n_past:
-            skip = sk
-        h_pred = orc.lstm_step(h, lsd, hidden)
-        mse_latent = mse_latent + F.mse_loss(h_pred, h_target)
-        gp = orc.gp_predict(h, gsd, training=True, dtype=torch.float32)
-        max_ll = max_ll - orc.variational_elbo(gp, h_target.t(), noise, num_data=x[0].shape[0])
-        x_pred = dec(h_pred, skip)
-        ae_mse = ae_mse + F.mse_loss(dec(h_target, skip), x[i])
-        mse = mse + F.mse_loss(x_pred, x[i])
-        mse_gp = mse_gp + F.mse_loss(dec(gp["mean"].t().float(), skip), x[i])
-    return 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
+    return orc.train_model_loss(x, enc, dec, lsd, gsd, lik, opt.n_past, opt.n_future, num_data=opt.batch_size,
+                                last_frame_skip=opt.last_frame_skip, rnn_size=opt.rnn_size,
+                                n_layers=opt.predictor_rnn_layers)[0]
 
 
 @pytest.mark.parametrize("model", ["dcgan", "vgg"])
@@ -108,6 +92,64 @@ def test_finetune_closures_without_encoder_autograd_match_reference_structure():
     for a, b in zip(res[0][1:], res[1][1:]):
         for k in a:
             assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-6), k
+
+
+def test_elbo_num_data_is_the_global_batch_under_data_parallelism():
+    """with `--batch_size` the GLOBAL batch, every rank builds the ELBO with num_data = global batch, so that the
+    rank-averaged GP gradients equal the single-process gradients at that batch (KL weight independent of the number of
+    GPUs).  Two 'ranks' with the halves of a batch of 8 are emulated on one GPU (encoder in eval mode so that per-replica
+    BatchNorm statistics do not enter): mean of their GP gradients == gradients of one process on the whole batch."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+
+    def gp_grads(local, world, rows):
+        torch.manual_seed(3)
+        opt = _opt("dcgan", ["--batch_size", "8"])
+        opt.world, opt.local_batch = world, local
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        assert tr.mll.num_data == 8
+        tr.train_mode()
+        tr.encoder.eval()
+        seq = SyntheticMovingMNIST(seq_len=4, seed=5).batch(8)[rows]
+        x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
+        tr.optimizer.param_groups[0]["lr"] = tr.optimizer.param_groups[1]["lr"] = 0.0   # keep the gradients, do not move
+        tr.train_GP_Frame_predictor(x)
+        return [p.grad.detach().clone() for g in tr.optimizer.param_groups for p in g["params"]]
+    whole = gp_grads(8, 1, slice(0, 8))
+    halves = [gp_grads(4, 2, slice(0, 4)), gp_grads(4, 2, slice(4, 8))]
+    for gw, ga, gb in zip(whole, *halves):
+        mean = (ga + gb) / 2
+        assert float((mean - gw).abs().max()) <= 2e-4 * float(gw.abs().max()) + 1e-7
+
+
+def test_reference_gp_grad_leak_switch():
+    """train.py:200-245 never zeroes the GP optimiser's gradients in train_model: the ELBO gradients the previous
+    iteration's train_GP_Frame_predictor left behind are still in `.grad` when train_model steps the GP.
+    Trainer.reference_gp_grad_leak (default True) keeps that; False zeroes them.  Both modes, two iterations."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    out = {}
+    for leak in (True, False):
+        torch.manual_seed(3)
+        opt = _opt("dcgan")
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        assert tr.reference_gp_grad_leak is True
+        tr.reference_gp_grad_leak = leak
+        tr.train_mode()
+        x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, SyntheticMovingMNIST(seq_len=4, seed=5).batch(4))
+        tr.iteration(x)                       # iteration 1: nothing to leak yet
+        first = tr.gp_layer.variational_strategy.variational_distribution.variational_mean.detach().clone()
+        left = tr.gp_layer.variational_strategy.variational_distribution.variational_mean.grad.detach().clone()
+        tr.train_model(x)                     # iteration 2's train_model
+        g2 = tr.gp_layer.variational_strategy.variational_distribution.variational_mean.grad.detach().clone()
+        out[leak] = (first, left, g2)
+    assert torch.equal(out[True][0], out[False][0]), "the first iteration does not depend on the switch"
+    assert float(out[True][1].abs().max()) > 0
+    # leak: .grad = (ELBO gradients left by the GP closure) + (this train_model's 1e-4-weighted ones); no leak: only the latter
+    assert torch.allclose(out[True][2] - out[True][1], out[False][2], rtol=1e-3, atol=1e-6 * float(out[True][1].abs().max()))
+    assert float((out[True][2] - out[False][2]).abs().max()) > 10 * float(out[False][2].abs().max())
 
 
 def test_train_script_runs_and_checkpoint_drives_generate(tmp_path):

@@ -360,7 +360,11 @@ class Trainer:
 
     # ---- qualitative rollout of train.py:256-289 (tensors only; PNG/GIF writers are out of scope) ------
     @torch.no_grad()
-    def plot(self, x, epoch, nsample=5):
+    def plot(self, x, epoch, nsample=5, eps_by_sample=None):
+        """train.py:256-310 without the image writers: `nsample` rollouts whose ONE GP-sampled step is i == 10 (:281;
+        the GP is fed the encoder output h, :283), then per batch row the sample with the smallest summed squared error
+        (:303-310; ties keep the first sample, like the reference's strict `<`).  `eps_by_sample[s]`: base sample (D,B)
+        of rollout s (parity runs); None = torch RNG.  Returns (gen (S,T,B,C,H,W), best (B,))."""
         opt = self.opt
         gen_seq = []
         for s in range(nsample):
@@ -371,13 +375,18 @@ class Trainer:
             for i in range(1, opt.n_eval):
                 h, skip = self._skip_rule(i, self.encoder(x_in), skip)
                 if i < opt.n_past:
+                    if self.encoder.training:
+                        # train.py:273-274 encodes x[i] and discards it; with the encoder left in train mode (:372-374) that
+                        # call still updates the BatchNorm running statistics the checkpoint will carry
+                        self.encoder(x[i])
                     self.frame_predictor(h)
                     x_in = x[i]
                 else:
                     h_pred = self.frame_predictor(h)
                     if i == 10:  # train.py:281: the one GP-sampled step of the qualitative rollout
-                        x_in = self.decoder([self.likelihood(self.gp_layer(self._gp_in(h))).rsample().transpose(0, 1),
-                                             skip])
+                        pred = self.likelihood(self.gp_layer(self._gp_in(h)))
+                        z = pred.rsample(None if eps_by_sample is None else eps_by_sample[s])
+                        x_in = self.decoder([z.transpose(0, 1), skip])
                     else:
                         x_in = self.decoder([h_pred, skip])
                 seq.append(x_in)
