@@ -235,6 +235,129 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 
 
 // ------------------------------------------------------------------------------------
+// lstm_cell_x: the FIRST cell of lstm.py:65-70 with the embedding folded in.  `embed` is a plain nn.Linear (lstm.py:50,
+// no activation), so  W_ih (W_e x + b_e) + b_ih + W_hh h + b_hh  =  (W_ih W_e) x + W_hh h + (W_ih b_e + b_ih + b_hh):
+// the host folds W_x = W_ih W_e [4H][Kxp] (rows padded to Kxp floats, 16-B aligned) and the bias once per weight
+// version, and a time step loses the embed launch and 3/4 of this cell's x-side FLOPs (Kx = 90 instead of 256).
+// Same wave-level scheme as lstm_cell_kernel; the x part is one float2 per lane (x rows are Kx = 90 floats apart:
+// 8-byte aligned only), lanes >= Kx/2 contribute zeros.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_x_kernel(const float* __restrict__ x, int ldx, int Kx,
+                                                          const float* __restrict__ h, const float* __restrict__ c,
+                                                          const float* __restrict__ w_x, int Kxp,
+                                                          const float* __restrict__ w_hh,
+                                                          const float* __restrict__ bias, float* __restrict__ h_out,
+                                                          float* __restrict__ c_out, int B, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 2;
+    const int b0 = blockIdx.y * 32 + wave * 8;
+    if (b0 >= B) return;  // wave-uniform; no barriers below
+
+    float v[64];  // v[b*8 + jj*4 + g]
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = 0.f;
+    const int eb = min(b0 + (lane >> 3), B - 1), ej = j0 + ((lane >> 2) & 1), eg = lane & 3;
+    const float e_bias = bias[eg * H + ej];
+    const float e_c = c[(size_t)eb * H + ej];
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    {   // x part: Kx <= 128, one float2 per lane
+        const bool valid = 2 * lane < Kx;
+        const int k0 = valid ? 2 * lane : 0;
+        f32x2 xv[8], wx[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) xv[b] = *reinterpret_cast<const f32x2*>(x + (size_t)min(b0 + b, B - 1) * ldx + k0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            wx[r] = *reinterpret_cast<const f32x2*>(w_x + (size_t)((r & 3) * H + j0 + (r >> 2)) * Kxp + k0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f32x2 wz = valid ? wx[r] : f32x2{0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v[b * 8 + r] = fmaf(xv[b][1], wz[1], fmaf(xv[b][0], wz[0], v[b * 8 + r]));
+        }
+    }
+    for (int k0 = lane * 4; k0 < H; k0 += 256) {
+        f32x4 hv[8], wh[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) hv[b] = *reinterpret_cast<const f32x4*>(h + (size_t)min(b0 + b, B - 1) * H + k0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            wh[r] = *reinterpret_cast<const f32x4*>(w_hh + (size_t)((r & 3) * H + j0 + (r >> 2)) * H + k0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float s = v[b * 8 + r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(hv[b][e], wh[r][e], s);
+                v[b * 8 + r] = s;
+            }
+    }
+    butterfly_step<32>(v, lane);
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+    const int b = lane >> 3, jj = (lane >> 2) & 1, g = lane & 3;
+    const int j = j0 + jj;
+    const float pre = v[0] + e_bias;
+    const float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
+    const int q = lane & ~3;
+    const float gi = __shfl(a, q), gf = __shfl(a, q + 1), gg = __shfl(a, q + 2), go = __shfl(a, q + 3);
+    if (b0 + b < B && g == 0) {
+        const float cn = gf * e_c + gi * gg;
+        c_out[(size_t)(b0 + b) * H + j] = cn;
+        h_out[(size_t)(b0 + b) * H + j] = go * tanhf(cn);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// stem: the decoder's ConvTranspose2d(dim,512,4,1,0)+BN+LReLU on a 1x1 map (vgg_64.py:65-69, dcgan_64.py:62-67) for
+// eval-mode rollouts: out[b][n] = act((sum_k vec[b][k] wt[k][n]) * scale[n % period] + shift[n % period]), K = dim = 90,
+// N = 16*512.  wt is the weight TRANSPOSED to [K][N] (cached by the caller), so a thread that owns output column n loads
+// its K weights with fully coalesced 4-byte loads, all issued up front; the latent vectors sit in LDS and are read as
+// wave-wide broadcasts.  Workgroup = 32 columns x 8 batch groups; 256 workgroups at N = 8192.
+// ------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ vec, int ldv, const float* __restrict__ wt,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ out, int ldo, int M, int N, int K, int period,
+                                                   int act, float slope) {
+    __shared__ float vs[64 * KP];   // [mrows][KP], zero padded: no k predicate in the FMA loop
+    const int tid = threadIdx.x, nl = tid & 31, bg = tid >> 5;
+    const int n = blockIdx.x * 32 + nl;   // N % 32 == 0 (host check)
+    const int m0 = blockIdx.y * 64;
+    const int mrows = min(64, M - m0);
+    for (int i = tid; i < mrows * KP; i += 256) {
+        const int r = i / KP, k = i % KP;
+        vs[i] = k < K ? vec[(size_t)(m0 + r) * ldv + k] : 0.f;
+    }
+    float w[KP];   // wt is [KP][N], rows K..KP-1 zero (padded by the caller): unconditional, fully coalesced loads
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w[k] = wt[(size_t)k * N + n];
+    __syncthreads();
+    const int c = n % period;
+    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
+    for (int bb = bg; bb < mrows; bb += 8) {
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vs + bb * KP);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const f32x4 v4 = vr[k4];
+            s0 = fmaf(v4[0], w[4 * k4], s0);
+            s1 = fmaf(v4[1], w[4 * k4 + 1], s1);
+            s0 = fmaf(v4[2], w[4 * k4 + 2], s0);
+            s1 = fmaf(v4[3], w[4 * k4 + 3], s1);
+        }
+        out[(size_t)(m0 + bb) * ldo + n] = apply_act((s0 + s1) * sc + sf, act, slope);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // gemm_dot: the same product for SMALL M (the B = 64 latent path: lstm.py:50,55 embed / output, the encoder head
 // and decoder stem of vgg_64.py:44-48,65-69 / dcgan_64.py:41-45,62-66).  A 64x64-tile GEMM leaves these shapes
 // with a handful of workgroups crawling through K in serial, latency-bound steps (10-30 us for < 3 MB of
@@ -387,4 +510,37 @@ extern "C" int dvg_lstm_cell(const float* x, const float* h, const float* c, con
     hipLaunchKernelGGL(lstm_cell_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, h, c, w_ih, w_hh, b_ih, b_hh,
                        h_out, c_out, gates_out, B, H);
     return check_launch("dvg_lstm_cell");
+}
+
+extern "C" int dvg_lstm_cell_x(const float* x, int ldx, int Kx, const float* h, const float* c, const float* w_x,
+                               int Kxp, const float* w_hh, const float* bias, float* h_out, float* c_out, int B, int H,
+                               void* stream) {
+    DVG_REQUIRE(x && h && c && w_x && w_hh && bias && h_out && c_out, DVG_ERR_NULL, "dvg_lstm_cell_x: NULL pointer");
+    DVG_REQUIRE(B > 0 && H > 0 && H % 64 == 0, DVG_ERR_SHAPE, "dvg_lstm_cell_x: H=%d must be a multiple of 64", H);
+    DVG_REQUIRE(Kx > 0 && Kx <= 128 && Kx % 2 == 0 && ldx >= Kx && ldx % 2 == 0 && Kxp >= Kx && Kxp % 4 == 0,
+                DVG_ERR_SHAPE, "dvg_lstm_cell_x: Kx=%d (even, <= 128), ldx=%d (even), Kxp=%d (multiple of 4)", Kx, ldx, Kxp);
+    DVG_REQUIRE(h_out != h && c_out != c, DVG_ERR_SHAPE, "dvg_lstm_cell_x: in-place state update");
+    DVG_REQUIRE(aligned16(h) && aligned16(w_x) && aligned16(w_hh) && (reinterpret_cast<uintptr_t>(x) & 7u) == 0,
+                DVG_ERR_ALIGN, "dvg_lstm_cell_x: alignment");
+    dim3 grid(H / 2, (B + 31) / 32);
+    hipLaunchKernelGGL(lstm_cell_x_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, Kx, h, c, w_x, Kxp, w_hh, bias,
+                       h_out, c_out, B, H);
+    return check_launch("dvg_lstm_cell_x");
+}
+
+extern "C" int dvg_stem_gemm(const float* vec, int ldv, const float* w_kn, int KP, const float* scale, const float* shift,
+                             float* out, int ldo, int M, int N, int K, int period, int act, float slope, void* stream) {
+    DVG_REQUIRE(vec && w_kn && out, DVG_ERR_NULL, "dvg_stem_gemm: NULL pointer");
+    DVG_REQUIRE(M > 0 && N > 0 && N % 32 == 0 && K > 0 && K <= KP && (KP == 96 || KP == 128) && ldv >= K && ldo >= N,
+                DVG_ERR_SHAPE, "dvg_stem_gemm: bad shape M=%d N=%d K=%d KP=%d (N %% 32 == 0, KP 96 or 128)", M, N, K, KP);
+    DVG_REQUIRE(period > 0 && period <= N && N % period == 0, DVG_ERR_SHAPE, "dvg_stem_gemm: bad period");
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_stem_gemm: bad act");
+    const dim3 grid(N / 32, (M + 63) / 64);
+    if (KP == 96)
+        hipLaunchKernelGGL(stem_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, vec, ldv, w_kn, scale, shift, out, ldo,
+                           M, N, K, period, act, slope);
+    else
+        hipLaunchKernelGGL(stem_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, vec, ldv, w_kn, scale, shift, out, ldo,
+                           M, N, K, period, act, slope);
+    return check_launch("dvg_stem_gemm");
 }

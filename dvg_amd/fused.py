@@ -57,20 +57,28 @@ def gemm_weight(conv: nn.Module, kind: str) -> torch.Tensor:
         W[n][ (h*4+w)*512 + c ] = w[n][c][h][w]
     kind == "stem": ConvTranspose2d(dim,512,4,1,0) on a 1x1 map (vgg_64.py:65):
         W[ (h*4+w)*512 + c ][k] = w[k][c][h][w]
+    kind == "stem_t": the same transposed to [KP][N], rows zero-padded to KP in {96, 128} (dvg_stem_gemm), or None
+        when dim > 128 / N % 32 != 0.
     """
     slot = _slot(conv)
     key = _ver(conv.weight)
-    hit = slot.get("gw")
+    hit = slot.get("gw" + kind)
     if hit is not None and hit[0] == key:
         return hit[1]
     w = conv.weight.detach()
     if kind == "head":
         n, c, kh, kw = w.shape
         gw = w.permute(0, 2, 3, 1).reshape(n, kh * kw * c).contiguous()
+    elif kind == "stem_t":
+        k, c, kh, kw = w.shape
+        gw = None
+        if k <= 128 and (kh * kw * c) % 32 == 0:
+            gw = torch.zeros((96 if k <= 96 else 128, kh * kw * c), device=w.device, dtype=torch.float32)
+            gw[:k] = w.permute(0, 2, 3, 1).reshape(k, kh * kw * c)
     else:
         k, c, kh, kw = w.shape
         gw = w.permute(2, 3, 1, 0).reshape(kh * kw * c, k).contiguous()
-    slot["gw"] = (key, gw)
+    slot["gw" + kind] = (key, gw)
     return gw
 
 
@@ -265,6 +273,22 @@ def _upconv_packed(conv, c1: int):
     return kp
 
 
+def precompute_skip_half(conv, skip, kind: str) -> None:
+    """Compute S = conv(skip, W_skip) of a decoder block NOW for a skip tensor the caller has declared frozen
+    (declare_frozen_skips): rollout.condition() does this on a second stream while the LSTM warm-up runs, so that the
+    first decoder call finds S ready.  kind: "conv3" (vgg blocks) | "convT4s2" (dcgan blocks)."""
+    if not SKIP_HOIST or skip is None:
+        return
+    tr = isinstance(conv, nn.ConvTranspose2d)
+    c1 = (conv.weight.shape[0] if tr else conv.weight.shape[1]) - skip.shape[1]
+    _, ps = _split_packed(conv, c1)
+    if kind == "conv3":
+        s = ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE)
+    else:
+        s = ops.convT4x4s2(skip, None, ps, None, None, act=ACT_NONE)
+    _skip_seen[(id(conv), id(skip))] = [weakref.ref(skip), skip._version, _ver(conv.weight), 1, s]
+
+
 def _hoisted_skip(conv, x, skip, partial_fn):
     """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
     if not SKIP_HOIST or skip is None:
@@ -412,7 +436,11 @@ def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2):
     out2d = out.permute(0, 2, 3, 1).reshape(n, kh * kw * cout)
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
-        ops.gemm_nt(vec, gw, sc, sh, act=act, slope=slope, period=cout, out=out2d)
+        wt = gemm_weight(conv, "stem_t")
+        if wt is not None:
+            ops.stem_gemm(vec, wt, dim, sc, sh, out2d, period=cout, act=act, slope=slope)
+        else:
+            ops.gemm_nt(vec, gw, sc, sh, act=act, slope=slope, period=cout, out=out2d)
         return out
     ops.gemm_nt(vec, gw, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE, period=cout,
                 out=out2d)

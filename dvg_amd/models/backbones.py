@@ -179,6 +179,17 @@ class VggDecoder(nn.Module):
                     d = fused.convT3_last(layer, d, act=ACT_SIGMOID)
         return d
 
+    @torch.no_grad()
+    def precompute_frozen_skips(self, skip) -> None:
+        """Eval-mode rollouts: the skip halves of every block's concat conv for skip tensors that will not change any more
+        (fused.precompute_skip_half); forward() then runs only the x halves."""
+        n = 1
+        while hasattr(self, f"upc{n + 1}"):
+            n += 1
+        for s in range(2, n + 1):
+            first = next(l for l in getattr(self, f"upc{s}") if isinstance(l, vgg_layer))
+            fused.precompute_skip_half(first.main[0], ops.to_nhwc(skip[n - s]), "conv3")
+
 
 class VggGaussianEncoder(VggEncoder):
     """vgg_64.gaussian_encoder (vgg_64.py:108-159): encoder trunk + mu/logvar heads +
@@ -261,3 +272,14 @@ class DcganDecoder(nn.Module):
         last = getattr(self, f"upc{n}")
         act = ACT_SIGMOID if isinstance(last[1], nn.Sigmoid) else ACT_TANH
         return fused.convT4s2_last(last[0], d, ops.to_nhwc(skip[0]), act=act)
+
+    @torch.no_grad()
+    def precompute_frozen_skips(self, skip) -> None:
+        """Eval-mode rollouts: skip halves of the concat blocks and the skip's share of the last layer's projection for
+        skip tensors that will not change any more (see VggDecoder.precompute_frozen_skips)."""
+        n = 1
+        while hasattr(self, f"upc{n + 1}"):
+            n += 1
+        for s in range(2, n):
+            fused.precompute_skip_half(getattr(self, f"upc{s}").main[0], ops.to_nhwc(skip[n - s]), "convT4s2")
+        ops.precompute_skip_proj(ops.to_nhwc(skip[0]), getattr(self, f"upc{n}")[0].weight, 4)

@@ -411,6 +411,42 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=False):
     return (h_out, c_out, gates) if want_gates else (h_out, c_out)
 
 
+def lstm_cell_x(x, h, c, w_x, w_hh, bias):
+    """First cell of a time step with the embedding folded in (dvg_lstm_cell_x): x (B,Kx) raw LSTM input, w_x = W_ih W_e
+    zero-padded to (4H,Kxp), bias = W_ih b_e + b_ih + b_hh.  Inference path."""
+    for t, nm in ((x, "x"), (h, "h"), (c, "c")):
+        _dev_f32(t, "lstm_cell_x." + nm)
+    b, hid = h.shape
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.contiguous().view(x.shape[0], -1)
+    h = h if h.is_contiguous() else h.contiguous()
+    c = c if c.is_contiguous() else c.contiguous()
+    kx = x.shape[1]
+    if x.shape[0] != b or tuple(w_x.shape) != (4 * hid, w_x.shape[1]) or w_x.shape[1] < kx or \
+            tuple(w_hh.shape) != (4 * hid, hid) or bias.numel() != 4 * hid:
+        raise RuntimeError("lstm_cell_x: shape mismatch")
+    h_out, c_out = torch.empty_like(h), torch.empty_like(c)
+    _run("lstm_cell", 2.0 * b * 4 * hid * (kx + hid), 4.0 * (4 * hid * (kx + hid) + 5 * b * hid), lib().dvg_lstm_cell_x,
+         _p(x), x.stride(0), kx, _p(h), _p(c), _p(w_x), w_x.shape[1], _p(w_hh.detach()), _p(bias), _p(h_out), _p(c_out),
+         b, hid, _stream())
+    return h_out, c_out
+
+
+def stem_gemm(vec, w_kn, k, scale, shift, out, *, period, act=ACT_LRELU, slope=0.2):
+    """out[m][n] = act((vec[m][:k] . w_kn[:k][n]) * scale[n % period] + shift[n % period]) (dvg_stem_gemm); w_kn is the
+    zero-padded transposed GEMM weight (KP,N), KP in {96, 128}."""
+    _dev_f32(vec, "stem_gemm.vec")
+    if vec.dim() != 2 or vec.stride(1) != 1:
+        vec = vec.contiguous().view(vec.shape[0], -1)
+    m = vec.shape[0]
+    kp, n = w_kn.shape
+    if vec.shape[1] != k or tuple(out.shape) != (m, n) or out.stride(1) != 1:
+        raise RuntimeError("stem_gemm: shape mismatch")
+    _run("gemm_nt", 2.0 * m * n * k, 4.0 * (m * k + n * k + m * n), lib().dvg_stem_gemm, _p(vec), vec.stride(0), _p(w_kn),
+         kp, _p(scale), _p(shift), _p(out), out.stride(0), m, n, k, period, act, slope, _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------------
 # GP
 # ----------------------------------------------------------------------------------
@@ -601,6 +637,37 @@ def _cached_skip_proj(skip, wm_fn, w):
     return d2
 
 
+def _last_wmat(wpart, t):
+    return wpart.permute(2, 3, 1, 0).reshape(t, wpart.shape[0]).contiguous()          # [(kh,kw,co)][ci]
+
+
+_WMAT_CACHE = {}   # (id(w), lo, hi) -> (weakref(w), version, data_ptr, matrix)
+
+
+def _last_wmat_cached(w, lo, hi, t):
+    """[(kh,kw,co)][ci] projection matrix of rows lo:hi of the last layer's ConvTranspose2d weight, per weight version (it
+    used to be re-permuted and copied on every decoder call)."""
+    import weakref
+    key = (id(w), lo, hi)
+    hit = _WMAT_CACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+        return hit[3]
+    m = _last_wmat(w.detach()[lo:hi], t)
+    if len(_WMAT_CACHE) > 64:
+        _WMAT_CACHE.clear()
+    _WMAT_CACHE[key] = (weakref.ref(w), w._version, w.data_ptr(), m)
+    return m
+
+
+def precompute_skip_proj(skip, w, ks: int) -> None:
+    """The frozen skip tensor's share of the last layer's per-pixel projection, computed ahead of the first decoder call
+    (rollout.condition(), second stream); convT_last_two_step then finds it in the cache."""
+    wdet = w.detach()
+    c1 = wdet.shape[0] - skip.shape[1]
+    t = ks * ks * wdet.shape[1]
+    _cached_skip_proj(skip, lambda: _last_wmat_cached(w, c1, wdet.shape[0], t), w)
+
+
 def convT_last_two_step(x, skip, w, bias, nc, ks, *, act):
     """Last layer as per-pixel projection (dvg_pixel_proj: reads the activation once) + shifted sum
     (dvg_convT_gather).  x / skip NHWC-in-memory; w the original ConvTranspose2d weight (Cin,nc,ks,ks); returns
@@ -609,13 +676,10 @@ def convT_last_two_step(x, skip, w, bias, nc, ks, *, act):
     n, c1, h, wd = x.shape
     wdet = w.detach()
     t = ks * ks * nc
-
-    def wmat(wpart):
-        return wpart.permute(2, 3, 1, 0).reshape(t, wpart.shape[0]).contiguous()          # [(kh,kw,co)][ci]
-    d1 = pixel_proj(x, wmat(wdet[:c1]))
+    d1 = pixel_proj(x, _last_wmat_cached(w, 0, c1, t))
     d2 = None
     if skip is not None:
-        d2 = _cached_skip_proj(skip, lambda: wmat(wdet[c1:]), w)
+        d2 = _cached_skip_proj(skip, lambda: _last_wmat_cached(w, c1, wdet.shape[0], t), w)
     s = 2 if ks == 4 else 1
     y = torch.empty((n, nc, s * h, s * wd), device=x.device, dtype=torch.float32)
     _run("convT_gather", 0.0, 4.0 * (d1.numel() * (2 if skip is not None else 1) + y.numel()), lib().dvg_convT_gather,

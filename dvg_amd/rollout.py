@@ -41,9 +41,27 @@ def _encode_conditioning(encoder, x, n_past, last_frame_skip):
     return hs, skip
 
 
+_side_stream = None
+
+
+def _hoist_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def _step_discard(frame_predictor, h):
+    """LSTM stepped on a conditioning frame, output discarded (generate_frames.py:125,162): skip the output GEMM."""
+    if hasattr(frame_predictor, "step_state_only"):
+        frame_predictor.step_state_only(h)
+    else:
+        frame_predictor(h)
+
+
 @torch.no_grad()
 def condition(encoder, frame_predictor, x: Sequence[torch.Tensor], n_past: int, last_frame_skip: bool = False,
-              batch_conditioning: bool = True) -> dict:
+              batch_conditioning: bool = True, decoder=None) -> dict:
     """The part of a sample rollout that does not depend on the sample (generate_frames.py:147-162 for i < n_past):
     the LSTM is reset and stepped on the encodings of the conditioning frames x[0..n_past-2] (outputs discarded), the
     skip tensors are those of x[n_past-2].  Deterministic in eval mode, so `make_gifs` (nsample rollouts of the SAME
@@ -52,12 +70,26 @@ def condition(encoder, frame_predictor, x: Sequence[torch.Tensor], n_past: int, 
     skip = None
     if batch_conditioning and n_past >= 3 and not encoder.training:
         hs, skip = _encode_conditioning(encoder, x, n_past, last_frame_skip)
+        side = None
+        if (decoder is not None and not last_frame_skip and not decoder.training and fused.SKIP_HOIST and
+                hasattr(decoder, "precompute_frozen_skips")):
+            # The skip tensors are final here (generate_frames.py:154-157) and the LSTM warm-up below is a serial chain of
+            # small latency-bound launches: the decoder's loop-invariant skip halves (fused._hoisted_skip) are computed
+            # meanwhile on a second stream (a parallel branch of the hipGraph when captured) instead of on the critical
+            # path of the first decoder call.
+            side, cur = _hoist_stream(), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fused.declare_frozen_skips(skip)
+                decoder.precompute_frozen_skips(skip)
         for i in range(1, n_past):
-            frame_predictor(hs[i - 1])          # LSTM stepped on conditioning frames, output discarded (:162)
+            _step_discard(frame_predictor, hs[i - 1])   # LSTM stepped on conditioning frames, output discarded (:162)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
     else:
         for i in range(1, n_past):
             h, skip = encoder(x[i - 1])
-            frame_predictor(h)
+            _step_discard(frame_predictor, h)
     return {"hidden": list(frame_predictor.hidden), "skip": skip, "frames": [x[i] for i in range(n_past)]}
 
 
@@ -94,7 +126,7 @@ def sample_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x: S
                    batch_conditioning: bool = True) -> List[torch.Tensor]:
     """Returns the n_eval frames [x0, ..] of one sample (conditioning frames are the inputs themselves): one complete
     rollout = condition() + sample_from()."""
-    state = condition(encoder, frame_predictor, x, n_past, last_frame_skip, batch_conditioning)
+    state = condition(encoder, frame_predictor, x, n_past, last_frame_skip, batch_conditioning, decoder)
     return sample_from(state, encoder, decoder, frame_predictor, gp_layer, likelihood, n_past, n_eval, last_frame_skip,
                        period, eps_by_step)
 
@@ -114,7 +146,7 @@ def posterior_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x
         if i == n_past and not last_frame_skip and not decoder.training:
             fused.declare_frozen_skips(skip)
         if i < n_past:
-            frame_predictor(h)
+            _step_discard(frame_predictor, h)
             x_in = x[i]
         else:
             h_pred = frame_predictor(h)

@@ -92,7 +92,7 @@ class Generator:
         psnr = torch.zeros(B, nsample, T, device=self.dev)
         all_gen = []
         # everything before the first predicted frame is the same for all nsample rollouts of this batch: once per batch
-        state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip)
+        state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip, decoder=self.decoder)
         for s in range(nsample):
             frames = sample_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
                                  self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip,

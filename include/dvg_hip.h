@@ -238,6 +238,19 @@ int dvg_lstm_cell(const float* x, const float* h, const float* c, const float* w
                   float* h_out, float* c_out, float* gates_out, int B, int H,
                   void* stream);
 
+/* The FIRST cell of a time step with the embedding folded in (lstm.py:50,66-70: `embed` is a plain nn.Linear, so
+ * W_ih (W_e x + b_e) + b_ih + W_hh h + b_hh = (W_ih W_e) x + W_hh h + bias): x [B][Kx] (row stride ldx floats, 8-byte
+ * aligned, Kx even and <= 128), w_x = W_ih W_e as [4H][Kxp] (Kxp % 4 == 0, zero padded), bias = W_ih b_e + b_ih + b_hh
+ * [4H], both folded by the caller once per weight version.  Inference path (no gates output).                    */
+int dvg_lstm_cell_x(const float* x, int ldx, int Kx, const float* h, const float* c, const float* w_x, int Kxp,
+                    const float* w_hh, const float* bias, float* h_out, float* c_out, int B, int H, void* stream);
+
+/* Decoder stem ConvTranspose2d(dim,512,4,1,0)+BN+LReLU on a 1x1 map (vgg_64.py:65-69, dcgan_64.py:62-67), eval mode:
+ * out[m][n] = act((sum_k vec[m][k] * w_kn[k][n]) * scale[n % period] + shift[n % period]); w_kn is the GEMM weight
+ * TRANSPOSED to [KP][N] (N = 16*512 in NHWC flatten order, N % 32 == 0; KP = 96 or 128 rows, rows K.. zero), K = dim. */
+int dvg_stem_gemm(const float* vec, int ldv, const float* w_kn, int KP, const float* scale, const float* shift,
+                  float* out, int ldo, int M, int N, int K, int period, int act, float slope, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Sparse variational GP trigger (gp_models.py:10-24 + gpytorch 0.3.x
  * WhitenedVariationalStrategy / GaussianLikelihood / MultivariateNormal;

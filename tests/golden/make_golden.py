@@ -195,6 +195,55 @@ def run_lstm_grads(out: dict):
     print("lstm_grad: loss", float(loss))
 
 
+def write_reference_checkpoint():
+    """A checkpoint exactly as the reference's train.py:380-388 writes it - WHOLE pickled nn.Module objects of the reference's
+    own classes (models.dcgan_64.encoder / decoder, models.lstm.lstm: train.py:75 hard-codes dcgan_64) plus the GP /
+    likelihood state_dicts under gpytorch-0.3.x key names and an `opt` Namespace with train.py:17-46's fields - with every
+    tensor ZEROED so that the gzip'ed file is a few KB: the test fills the weights from oracle/params.py seeds after
+    loading.  The fixture is data (class paths + zero tensors); unpickling it on the GPU box resolves the class paths to
+    this repository's alias package."""
+    import argparse
+    import gzip
+    import io
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    mod, lmod = ref_import("dcgan_64"), ref_import("lstm")
+    enc, dec = mod.encoder(90, 1), mod.decoder(90, 1)
+    fp = lmod.lstm(90, 90, 256, 2, 50)
+    with torch.no_grad():
+        for m in (enc, dec, fp):
+            for t in list(m.parameters()) + list(m.buffers()):
+                t.zero_()
+        fp.hidden = fp.init_hidden()
+    gsd, lik = params.gp_state(0)
+    gsd = OrderedDict((k, torch.zeros_like(v)) for k, v in gsd.items())
+    lik = OrderedDict((k, torch.zeros_like(v)) for k, v in lik.items())
+    opt = argparse.Namespace(lr=0.002, beta1=0.9, batch_size=50, log_dir='logs', model_dir='', name='', output_path='.',
+                             data_root='path/to/data/', optimizer='adam', niter=601, seed=1, epoch_size=300, image_width=64,
+                             channels=1, dataset='kth', n_past=5, ft=True, n_future=10, n_eval=15, rnn_size=256,
+                             predictor_rnn_layers=2, z_dim=10, g_dim=90, model='dcgan', data_threads=5,
+                             last_frame_skip=False)
+    # pickling by reference needs `models.<name>` importable as the REFERENCE's modules at dump time
+    saved = {k: v for k, v in sys.modules.items() if k == "models" or k.startswith("models.")}
+    for k in saved:
+        del sys.modules[k]
+    import types
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules.update({"models": pkg, "models.dcgan_64": mod, "models.lstm": lmod})
+    try:
+        buf = io.BytesIO()
+        torch.save({'encoder': enc, 'decoder': dec, 'frame_predictor': fp, 'likelihood': lik, 'gp_layer': gsd,
+                    'gp_layer_optimizer': {}, 'opt': opt}, buf)
+    finally:
+        for k in ("models", "models.dcgan_64", "models.lstm"):
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+    path = os.path.join(HERE, "reference_checkpoint_zeroed.pth.gz")
+    with gzip.open(path, "wb", compresslevel=9) as f:
+        f.write(buf.getvalue())
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB (", len(buf.getvalue()) // 2**20, "MiB raw )")
+
+
 def main():
     out = OrderedDict()
     run_backbone("vgg", 64, 1, 2, False, 100, out, "vgg_64/eval")
@@ -213,6 +262,7 @@ def main():
     path = os.path.join(HERE, "reference_outputs.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    write_reference_checkpoint()
 
 
 if __name__ == "__main__":

@@ -467,3 +467,78 @@ def test_upsample_conv3x3_as_transposed_conv(H, C1, Cout, N):
     y2 = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(conv.weight.detach()[:, :C1].contiguous()), sc.to(dev()),
                      sh.to(dev()), upsample=True, addend=nhwc(S))
     assert rel_err(y2, ref) < 2e-5
+
+
+def test_lstm_folded_first_cell_and_state_only_step():
+    """Inference runs the first LSTMCell with the embedding folded in (dvg_lstm_cell_x: W_x = W_ih W_e); it must agree with
+    the unfolded path (embed GEMM + dvg_lstm_cell, what autograd mode runs) and with the oracle, for several batch sizes
+    incl. one that is not a multiple of the 8-row wave block; step_state_only() advances the state exactly like forward()."""
+    import dvg_amd.models.lstm as ours
+    for B in (5, 64):
+        net = ours.lstm(90, 90, 256, 2, B)
+        sd = params.fill_state_dict(net.state_dict(), 300)
+        net.load_state_dict(sd)
+        net.to(dev()).eval()
+        xs = [params.normal(330 + t, B, 90, scale=0.5) for t in range(3)]
+        hidden = orc.lstm_init_hidden(B, 256, 2)
+        ref = [orc.lstm_step(x, sd, hidden) for x in xs]
+        net.hidden = net.init_hidden()
+        with torch.no_grad():
+            folded = [net(x.to(dev())) for x in xs]
+        h_folded = [t.clone() for pair in net.hidden for t in pair]
+        net.hidden = net.init_hidden()
+        unfolded = [net(x.to(dev()).requires_grad_(True)) for x in xs]     # autograd mode: embed GEMM + dvg_lstm_cell
+        for a, b, r in zip(folded, unfolded, ref):
+            assert rel_err(a, r) < 1e-5 and rel_err(b, r) < 1e-5 and rel_err(a, b) < 1e-5
+        net.hidden = net.init_hidden()
+        with torch.no_grad():
+            for x in xs:
+                net.step_state_only(x.to(dev()))
+        for a, b in zip(h_folded, [t for pair in net.hidden for t in pair]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_decoder_stem_kernel_matches_generic_gemm(family):
+    """Eval-mode decoder stem through dvg_stem_gemm (transposed, zero-padded weight) against the generic small-M GEMM."""
+    import importlib
+    from dvg_amd import fused, ops
+    mod = importlib.import_module(f"dvg_amd.models.{family}_64")
+    dec = mod.decoder(90, 1)
+    dec.load_state_dict(params.fill_state_dict(dec.state_dict(), 77, params.decoder_transposed_keys(dec.state_dict(), family)))
+    dec.to(dev()).eval()
+    conv, bn = dec.upc1[0], dec.upc1[1]
+    for B in (3, 64, 100):
+        vec = params.normal(78, B, 90, scale=0.5).to(dev())
+        with torch.no_grad():
+            got = fused.stem_bn_act(conv, bn, vec)
+            sc, sh = fused.folded_affine(conv, bn)
+            ref = ops.gemm_nt(vec, fused.gemm_weight(conv, "stem"), sc, sh, act=ops.ACT_LRELU, slope=0.2, period=512)
+        assert got.shape == (B, 512, 4, 4)
+        assert rel_err(got.permute(0, 2, 3, 1).reshape(B, -1), ref) < 1e-5
+
+
+def test_rollout_precomputes_frozen_skip_halves_on_a_second_stream():
+    """rollout.condition() computes the decoder's loop-invariant skip halves on a side stream while the LSTM warm-up runs;
+    the rollout must equal the one without hoisting, eager and as a hipGraph."""
+    from dvg_amd import fused
+    from dvg_amd.rollout import GraphedRollout, sample_rollout
+    from tests.test_gpu_configs import _build
+    B, n_past, n_eval = 8, 4, 9
+    for family in ("dcgan", "vgg"):
+        mods, _ = _build(family, 64, 1, B, 1900)
+        for m in mods:
+            m.to(dev()).eval()
+        xs = [params.frames(1910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
+        fused.SKIP_HOIST = False
+        try:
+            plain = sample_rollout(*mods, xs, n_past, n_eval, period=0)
+        finally:
+            fused.SKIP_HOIST = True
+        fused.clear_skip_hoist_cache()
+        hoisted = sample_rollout(*mods, xs, n_past, n_eval, period=0)
+        assert any(e[4] is not None for e in fused._skip_seen.values()), "skip halves must have been precomputed"
+        g = GraphedRollout(*mods, xs, n_past, n_eval, period=0)
+        replay = [f.clone() for f in g()]
+        for t in range(n_eval):
+            assert rel_err(hoisted[t], plain[t]) < 2e-5 and rel_err(replay[t], plain[t]) < 2e-5, (family, t)
