@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-families", action="store_true", help="skip the other model family")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the eager HIP-event leg (timeline profiling runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training leg")
     ap.add_argument("--train-iters", type=int, default=6)
     ap.add_argument("--train-graph-timeout", type=float, default=240.0,
@@ -238,7 +239,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     assert bool(torch.isfinite(out[-1]).all())
     frames = args.batch * args.n_future * steps * ctx.world
     res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3)}
-    if ctx.rank != 0:
+    if ctx.rank != 0 or args.no_roofline:
         return res
     # roofline leg: the same rollout with every launch bracketed by HIP events on the launch stream
     timer = ops.KernelTimer()

@@ -1,4 +1,4 @@
-// v2 schedule of the fp32-MFMA implicit-GEMM convolutions (same math, same epilogue as conv_igemm.hip).
+// fp32-MFMA implicit-GEMM convolutions ("v2" schedule; the first schedule, conv_igemm.hip, was retired in ABI 3).
 //
 // What changed, and why (profiles/r01_pmc_conv3x3.md: matrix pipe 2/3 busy, the rest were
 // `ds_read -> s_waitcnt -> 8 MFMA` groups and one workgroup barrier per tap):
@@ -31,6 +31,10 @@
 #ifndef DVG_WRITE_OVERLAP
 #define DVG_WRITE_OVERLAP 1
 #endif
+//  DVG_STAGE_PRIO 1: s_setprio(3 - (stage & 3)) at every stage start (see the stage loop)
+#ifndef DVG_STAGE_PRIO
+#define DVG_STAGE_PRIO 1
+#endif
 
 namespace dvg {
 
@@ -55,6 +59,7 @@ struct Igemm2Params {
     unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
     unsigned clk_cap;         // records the buffer holds (workgroups beyond it do not stamp)
     int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
+    int stage_prio;  // progress-based s_setprio in the stage loop (launch2 decides; see the stage loop)
 };
 
 static unsigned long long* g_clk = nullptr;
@@ -304,17 +309,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         }
     };
     using std::integral_constant;
-    int chunk = chunk_begin;
+    // Progress-based wave priority.  The MFMA issue arbiter breaks ties by wave age, so of the two workgroups that share a
+    // CU the one dispatched first won every contested slot: it finished ~7 us before its partner (27 vs 34 us on the B = 64
+    // dcgan layers, tools/diag_clocks_dcgan.py DIAG_PAIRS=1), which then ran its tail alone - one MFMA-issuing wave per
+    // SIMD, which cannot saturate the f32 pipe.  With priority 3 - (stage & 3) a workgroup that is one stage AHEAD of its
+    // neighbour has the lower priority on 3 of every 4 stages: the pair stays within a stage of each other and both
+    // finish together.  Needs no knowledge of who the neighbour is.
+#if DVG_STAGE_PRIO
+    const bool prio_on = p.stage_prio != 0;
+    auto set_prio = [&](int st) {
+        if (!prio_on) return;
+        switch (st & 3) {
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    };
+#else
+    auto set_prio = [](int) {};
+#endif
+    int chunk = chunk_begin, st = 0;
     for (; chunk + 1 < chunk_end; ++chunk) {
+        set_prio(st++);
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
-        if constexpr (NG == 2) stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        if constexpr (NG == 2) {
+            set_prio(st++);
+            stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        }
     }
+    set_prio(st++);
     if constexpr (NG == 2) {
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+        set_prio(st++);
         stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, false>{});
     } else {
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, false>{});
     }
+#if DVG_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     unsigned long long clk_loop = 0;
     if (p.clk && threadIdx.x == 0) clk_loop = clock64();
     auto clk_exit = [&]() {
@@ -609,6 +643,10 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     float* y_pool = p.y_pool;
     float* stats = p.stats;
     const unsigned grid = (unsigned)(wgs * S);
+    // Stage priority (see the stage loop): measured +2..5 % wherever co-resident workgroups run in lockstep (single-round
+    // launches of every mode) and on all 9-tap layers (144 MFMAs per stage); on multi-round launches of the short-stage
+    // modes (4 / 8 taps, 64 MFMAs per stage) a starved workgroup's next-stage loads issue late: -3..-18 % -> off there.
+    p.stage_prio = (MODE == M2_CONV3 || grid <= 3 * 256) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW>),

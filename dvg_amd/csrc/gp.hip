@@ -34,6 +34,7 @@ struct GpParams {
     float* kl;           // [D]
     int B, D, M, train_mode;
     float jitter;
+    int raw_hypers;  // outputscale / lengthscale / noise point at the RAW parameters: soft-plus (+ noise floor) in-kernel
     unsigned long long* clk;  // debug only: 12 x u64 per workgroup (latent dim), for the first clk_cap workgroups
     unsigned clk_cap;
 };
@@ -197,11 +198,15 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     float* red = mu + B;           // [8]
     float* Sg = red + 8;           // [B][LS]   predictive covariance (only when needed)
 
-    const float s = p.outputscale[d];
-    const float ell = p.lengthscale[d];
+    // torch.nn.functional.softplus (beta 1, threshold 20) of the raw parameters when the caller passes them as they are
+    // (gp_models.py hyper-parameters / GaussianLikelihood noise with its GreaterThan(1e-4) floor): saves three
+    // 90-element launches per GP call
+    auto softplus = [](float x) { return x > 20.f ? x : log1pf(expf(x)); };
+    const float s = p.raw_hypers ? softplus(p.outputscale[d]) : p.outputscale[d];
+    const float ell = p.raw_hypers ? softplus(p.lengthscale[d]) : p.lengthscale[d];
     const float ninv = -0.5f / (ell * ell);
     const float c0 = p.mean_const[d];
-    const float noise = p.noise ? p.noise[d] : 0.f;
+    const float noise = p.noise ? (p.raw_hypers ? softplus(p.noise[d]) + 1e-4f : p.noise[d]) : 0.f;
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
@@ -642,8 +647,9 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
         if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_lds = lds;
     }
+    DVG_REQUIRE(train_mode >= 0 && train_mode <= 3, DVG_ERR_SHAPE, "dvg_gp_predict: train_mode flags must be 0..3");
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
-               B, D, M, train_mode, jitter, g_gp_clk, g_gp_clk_cap};
+               B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, g_gp_clk, g_gp_clk_cap};
     hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("dvg_gp_predict");
 }

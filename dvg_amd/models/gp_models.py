@@ -39,8 +39,9 @@ class GPPrediction:
     `.variance` (D,B), `.rsample()` (D,B), `.covariance_matrix` (D,B,B).  Evaluation is lazy
     so that `likelihood(gp_layer(x)).rsample()` is a single kernel launch."""
 
-    def __init__(self, layer: "GPRegressionLayer1", h: torch.Tensor, noise=None, training=False):
+    def __init__(self, layer: "GPRegressionLayer1", h: torch.Tensor, noise=None, training=False, raw_noise=None):
         self._layer, self._h, self._noise, self._training = layer, h, noise, training
+        self._raw_noise = raw_noise        # inference: the likelihood's RAW noise parameter (soft-plus'ed in the kernel)
         self._res = None
         self._cov = None
 
@@ -50,11 +51,21 @@ class GPPrediction:
         if self._training and lay._grad_needed(self._h):
             from ..autograd import gp_train_autograd
             return gp_train_autograd(lay, self._h, self._noise)
+        vs = lay.variational_strategy
+        if self._noise is None and not torch.is_grad_enabled():
+            # inference: raw hyper-parameters straight into the kernel (it soft-pluses them; no 90-element torch launches)
+            return ops.gp_predict(self._h, vs.inducing_points, vs.variational_distribution.variational_mean,
+                                  vs.variational_distribution.chol_variational_covar, lay.mean_module.constant,
+                                  lay.covar_module.raw_outputscale, lay.covar_module.base_kernel.raw_lengthscale,
+                                  noise=self._raw_noise, eps=eps, want_cov=want_cov, want_kl=self._training,
+                                  train_mode=self._training, jitter=JITTER, raw_hypers=True)
         s, ell, c = lay.hypers()
-        return ops.gp_predict(self._h, lay.variational_strategy.inducing_points,
-                              lay.variational_strategy.variational_distribution.variational_mean,
-                              lay.variational_strategy.variational_distribution.chol_variational_covar, c, s, ell,
-                              noise=self._noise, eps=eps, want_cov=want_cov, want_kl=self._training,
+        noise = self._noise
+        if noise is None and self._raw_noise is not None:
+            noise = F.softplus(self._raw_noise).reshape(-1) + NOISE_FLOOR
+        return ops.gp_predict(self._h, vs.inducing_points, vs.variational_distribution.variational_mean,
+                              vs.variational_distribution.chol_variational_covar, c, s, ell,
+                              noise=noise, eps=eps, want_cov=want_cov, want_kl=self._training,
                               train_mode=self._training, jitter=JITTER)
 
     def _moments(self):
@@ -99,6 +110,9 @@ class GPPrediction:
 
     def with_noise(self, noise):
         return GPPrediction(self._layer, self._h, noise, self._training)
+
+    def with_raw_noise(self, raw_noise):
+        return GPPrediction(self._layer, self._h, None, self._training, raw_noise=raw_noise)
 
 
 class GPRegressionLayer1(nn.Module):
@@ -190,6 +204,8 @@ class GaussianLikelihood(nn.Module):
         return F.softplus(self.noise_covar.raw_noise).reshape(-1) + NOISE_FLOOR
 
     def forward(self, pred: GPPrediction) -> GPPrediction:
+        if not torch.is_grad_enabled():
+            return pred.with_raw_noise(self.noise_covar.raw_noise)    # soft-plus + floor happen inside dvg_gp_predict
         return pred.with_noise(self.noise)
 
     def expected_log_prob(self, target, pred: GPPrediction):

@@ -451,8 +451,9 @@ def stem_gemm(vec, w_kn, k, scale, shift, out, *, period, act=ACT_LRELU, slope=0
 # GP
 # ----------------------------------------------------------------------------------
 def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *, noise=None, eps=None,
-               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3):
-    """h [B][D] (any strides); returns dict(mean [D][B], var, sample, cov, kl)."""
+               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3, raw_hypers=False):
+    """h [B][D] (any strides); returns dict(mean [D][B], var, sample, cov, kl).  raw_hypers: outputscale / lengthscale /
+    noise are the RAW parameters, soft-plus'ed (noise: + 1e-4 floor) inside the kernel."""
     _dev_f32(h, "gp_predict.h")
     h = h if h.is_contiguous() else h.contiguous()
     b, d = h.shape
@@ -473,7 +474,7 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
     nz = None if noise is None else noise.detach().contiguous().view(-1)
     _run("gp_predict", 0.0, 4.0 * (b * d + d * m * (m + 2) + 3 * d * b), lib().dvg_gp_predict, _p(h),
          *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov), _p(kl), b, d, m,
-         int(train_mode), jitter, _stream())
+         int(train_mode) | (2 if raw_hypers else 0), jitter, _stream())
     return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}
 
 

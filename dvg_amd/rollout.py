@@ -27,13 +27,51 @@ def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
     return [i for i in range(n_past, n_eval) if i % period == 0]
 
 
+def _adjacent_view(frames):
+    """If the frames are consecutive contiguous slices of ONE buffer (data.batch_device(), GraphedRollout's static inputs),
+    the batch of all of them is a view: no concat launch per rollout.  None otherwise."""
+    f0 = frames[0]
+    if not all(t.is_contiguous() and t.shape == f0.shape and t.dtype == f0.dtype for t in frames):
+        return None
+    step = f0.numel() * f0.element_size()
+    st = f0.untyped_storage()
+    for i, t in enumerate(frames):
+        if t.untyped_storage().data_ptr() != st.data_ptr() or t.data_ptr() != f0.data_ptr() + i * step:
+            return None
+    shape = (len(frames) * f0.shape[0],) + tuple(f0.shape[1:])
+    return torch.as_strided(f0, shape, torch.empty(shape, device="meta").stride(), f0.storage_offset())
+
+
+_ZERO_STATE = {}
+
+
+def _zero_hidden(frame_predictor):
+    """init_hidden() (lstm.py:58-63) without its 2 x n_layers fill launches per rollout: one cached all-zero tensor per
+    (device, batch, hidden size).  Safe to share: no kernel of the recurrent path writes its state in place (dvg_lstm_cell
+    rejects in-place updates), and the tensors are only ever replaced in the `hidden` list."""
+    if not hasattr(frame_predictor, "step_state_only"):
+        return frame_predictor.init_hidden()
+    dev = frame_predictor.embed.weight.device
+    key = (dev, frame_predictor.batch_size, frame_predictor.hidden_size)
+    z = _ZERO_STATE.get(key)
+    if z is None:
+        if torch.cuda.is_current_stream_capturing():
+            return frame_predictor.init_hidden()    # never cache a tensor that lives in a graph's private pool
+        if len(_ZERO_STATE) > 16:
+            _ZERO_STATE.clear()
+        z = _ZERO_STATE[key] = torch.zeros(frame_predictor.batch_size, frame_predictor.hidden_size, device=dev)
+    return [(z, z) for _ in range(frame_predictor.n_layers)]
+
+
 def _encode_conditioning(encoder, x, n_past, last_frame_skip):
     """Eval-mode only: BatchNorm uses running statistics, so encoder outputs are independent across samples and the
     n_past-1 conditioning frames x[0..n_past-2] (all known before the rollout starts) can go through the encoder as
     ONE batch of B*(n_past-1) frames — bit-identical per-sample math, 9 passes' worth of launches folded into one and
     9x more tiles per launch for the deep 8x8 layers.  Returns ([h_1 .. h_{n_past-1}], skip of the last step)."""
     b = x[0].shape[0]
-    frames = torch.cat([x[i] for i in range(n_past - 1)], 0)
+    frames = _adjacent_view(x[:n_past - 1])
+    if frames is None:
+        frames = torch.cat([x[i] for i in range(n_past - 1)], 0)
     h_all, skips = encoder(frames)
     hs = [h_all[i * b:(i + 1) * b] for i in range(n_past - 1)]
     last = n_past - 2
@@ -66,7 +104,7 @@ def condition(encoder, frame_predictor, x: Sequence[torch.Tensor], n_past: int, 
     the LSTM is reset and stepped on the encodings of the conditioning frames x[0..n_past-2] (outputs discarded), the
     skip tensors are those of x[n_past-2].  Deterministic in eval mode, so `make_gifs` (nsample rollouts of the SAME
     batch) computes it once per batch and draws every sample with `sample_from`."""
-    frame_predictor.hidden = frame_predictor.init_hidden()
+    frame_predictor.hidden = _zero_hidden(frame_predictor)
     skip = None
     if batch_conditioning and n_past >= 3 and not encoder.training:
         hs, skip = _encode_conditioning(encoder, x, n_past, last_frame_skip)
@@ -167,7 +205,8 @@ class GraphedRollout:
                  last_frame_skip=False, period=15, warmup=2):
         self._args = (encoder, decoder, frame_predictor, gp_layer, likelihood)
         self._kw = dict(n_past=n_past, n_eval=n_eval, last_frame_skip=last_frame_skip, period=period)
-        self.static_x = [t.clone() for t in x]
+        buf = torch.stack([t.contiguous() for t in x])      # one buffer: the conditioning batch is a view of it
+        self.static_x = [buf[i] for i in range(len(x))]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

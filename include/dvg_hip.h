@@ -272,6 +272,9 @@ int dvg_stem_gemm(const float* vec, int ldv, const float* w_kn, int KP, const fl
  *   eps [D][B] supplied by the caller (MultivariateNormal.rsample);
  *   cov [D][B][B] full predictive covariance (eval mode only).
  *   kl [D] (train mode: KL(q(u)||p(u))).
+ * train_mode is a flag word: bit 0 = train-mode prediction (diagonal variance with the clamp, KL); bit 1 = outputscale /
+ * lengthscale / noise point at the RAW parameters (covar_module.raw_outputscale, base_kernel.raw_lengthscale,
+ * noise_covar.raw_noise) and the kernel applies soft-plus itself (noise: + the 1e-4 floor of GaussianLikelihood).
  * Limits: M <= 64, B <= 128 and dvg_gp_lds_bytes(B, M, cov||sample) <= 160 KiB. */
 size_t dvg_gp_lds_bytes(int B, int M, int need_cov);
 int dvg_gp_predict(const float* h, const float* z, const float* var_mean,

@@ -63,6 +63,27 @@ def main():
     w9 = r(9, 64)
     us = graph_time(lambda: ops.pixel_proj(xp, w9), n=20)
     print(f"pixel_proj (262144,9,64)     {us:7.2f} us/launch  {(xp.numel() + B * 4096 * 9) * 4 / us / 1e3:7.1f} GB/s")
+    wx, bias = r(1024, 92), r(1024)
+    x90 = r(B, 90)
+
+    def cellx():
+        state["h"], state["c"] = ops.lstm_cell_x(x90, state["h"], state["c"], wx, wh, bias)
+    print(f"lstm_cell_x (chain)          {graph_time(cellx):7.2f} us/launch")
+    wt = torch.zeros(96, 8192, device=dev)
+    wt[:90].normal_()
+    out = torch.empty(B, 8192, device=dev)
+    sc8, sh8 = torch.rand(512, device=dev) + 0.5, r(512) * 0.1
+    print(f"stem_gemm (64,8192,90)       {graph_time(lambda: ops.stem_gemm(a90, wt, 90, sc8, sh8, out, period=512)):7.2f} us/launch")
+    x4 = ops.nhwc_empty(B, 512, 4, 4, dev).normal_()
+    from dvg_amd import fused
+    import torch.nn as nn
+    conv, bn = nn.Conv2d(512, 90, 4, 1, 0).to(dev), nn.BatchNorm2d(90).to(dev).eval()
+    with torch.no_grad():
+        print(f"encoder head (fused.head_bn_tanh) {graph_time(lambda: fused.head_bn_tanh(conv, bn, x4)):7.2f} us/call (2 kernels)")
+    x1 = torch.rand(B, 1, 64, 64, device=dev)
+    w4 = r(64, 1, 4, 4) * 0.1
+    us = graph_time(lambda: ops.conv4x4s2_first(x1, w4, sc, sh), n=20)
+    print(f"conv4x4s2_first (64,1,64,64)->64 {us:7.2f} us/launch  {(x1.numel() + B * 1024 * 64) * 4 / us / 1e3:7.1f} GB/s")
     t = torch.zeros(64, device=dev)
     print(f"torch fill (64 floats)       {graph_time(lambda: t.fill_(1.0)):7.2f} us/launch")
 

@@ -62,6 +62,25 @@ def main():
         span = (w1.max() - w0.min()) / 100.0
         print(f"{kind} {H}x{H} Cin {C1 + C2} Cout {Cout}: {len(d)} wgs, {us:.1f} us/launch = {fl / us / 1e6:.1f} TF "
               f"({fl / us / 1e6 / 157.3:.1%}); wg span {span:.1f} us")
+        mhz = ((c3 - c0) / np.maximum(w1 - w0, 1) * 100.0)
+        print(f"   shader clock during the kernel: {np.median(mhz):.0f} MHz (clock64 cycles / wall_clock64 ticks @100 MHz)")
+        st, en = (w0 - w0.min()) / 100.0, (w1 - w0.min()) / 100.0
+        pc = lambda a: " ".join(f"{np.percentile(a, q):5.1f}" for q in (0, 10, 50, 90, 100))   # noqa: E731
+        print(f"   wg start us (p0 p10 p50 p90 p100): {pc(st)}   end: {pc(en)}   duration: {pc(en - st)}")
+        if os.environ.get("DIAG_PAIRS"):
+            # co-residency: group workgroups by (XCC, SE, CU) from HW_ID (bits 8-11 CU, 13-15 SE on gfx9) and compare the
+            # durations inside each CU
+            hw = d[:, 7].astype(np.int64)
+            key = d[:, 6].astype(np.int64) * 4096 + ((hw >> 8) & 0xF) + 16 * ((hw >> 13) & 0x7) + 256 * ((hw >> 12) & 1)
+            dur = (w1 - w0) / 100.0
+            groups = {}
+            for k, t, s0 in zip(key, dur, w0):
+                groups.setdefault(int(k), []).append((s0, t))
+            sizes = np.bincount([len(v) for v in groups.values()])
+            firsts = [sorted(v)[0][1] for v in groups.values() if len(v) == 2]
+            seconds = [sorted(v)[1][1] for v in groups.values() if len(v) == 2]
+            print(f"   CUs by resident workgroups {dict(enumerate(sizes))}; pairs: first-started {np.mean(firsts):.1f} us, "
+                  f"second-started {np.mean(seconds):.1f} us, |diff| mean {np.mean(np.abs(np.array(firsts) - np.array(seconds))):.1f} us")
         nst = (c2 - c1).mean() / max(1, stages)
         print(f"   cycles: prologue {np.mean(c1 - c0):7.0f}  loop {np.mean(c2 - c1):8.0f}  epilogue {np.mean(c3 - c2):7.0f}"
               f"   (loop / (chunks x stages-per-chunk) = {nst:.0f})")
