@@ -47,9 +47,9 @@ SIGNATURES = {
     "dvg_convT_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_channel_stats_rows": (_i, [_l]),
     "dvg_channel_stats": (_i, [_p, _p, _l, _i, _p]),
-    "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p]),
+    "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p, _i, _p]),
     "dvg_bn_act_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "dvg_gemm_nt_bias_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_gemm_nt_bias_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_lstm_cell_x": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_stem_gemm": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
@@ -59,11 +59,13 @@ SIGNATURES = {
     "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _p]),
     "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
     "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _p]),
+    "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _p]),
     "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p]),
     "dvg_act_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "dvg_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "dvg_colsum": (_i, [_p, _p, _i, _i, _p]),
+    "dvg_colsum": (_i, [_p, _p, _i, _i, _i, _p]),
+    "dvg_wgrad_finish": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_k4_to_w3": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "dvg_reduce_partials": (_i, [_p, _p, _i, _l, _p]),
     "dvg_conv_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "dvg_conv_wgrad": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

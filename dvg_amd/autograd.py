@@ -10,8 +10,16 @@ Gradient recipe per conv block  y = act(BN(conv(cat(up(x), skip)) + b)):
   4. dx  = the forward implicit-GEMM kernel with re-packed weights           dvg_conv3x3_bn_act_v2 / conv4x4s2 / convT4x4s2
            (+ dvg_upsample2x_bwd when x entered through the fused nearest-x2)
 """
+Parameter gradients are written IN PLACE: the kernel that finishes a gradient (dvg_wgrad_finish, dvg_bn_bwd_finalize,
+dvg_gemm_nt_bias_act / dvg_colsum with `accumulate`) adds it straight into the parameter's `.grad` buffer - a view of the
+optimiser's flat gradient arena under train.Trainer - and the Function returns None for that input.  The reference's
+`loss.backward()` (train.py:240) accumulates one gradient tensor per USE of a parameter (a decoder weight is used 3 S times
+per iteration): that was 18 468 `at::native` add launches per 4 iterations here (5.5 % of the GPU time of a vgg_64 iteration).
+DVG_DIRECT_GRADS=0 returns the gradients to autograd instead (same values; tests run both).
+"""
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -19,9 +27,24 @@ import torch
 from . import fused, ops
 from .ops import ACT_NONE, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2
 
+DIRECT_PARAM_GRADS = os.environ.get("DVG_DIRECT_GRADS", "1") != "0"
+
 
 def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def _sink(p, needed=True):
+    """The buffer to accumulate parameter p's gradient into (its `.grad`, created zero-filled when missing), or None when
+    in-place accumulation does not apply (switch off, not a leaf parameter, gradient not needed, odd layout)."""
+    if not (DIRECT_PARAM_GRADS and needed and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_leaf):
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    g = p.grad
+    if g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or g.device != p.device:
+        return None
+    return g
 
 
 # Packed-weight cache for the training path: a parameter is re-packed once per optimizer step (its `_version`
@@ -51,8 +74,7 @@ def _bn_forward(bn, u, stats, count, act, slope, pool):
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, bn.weight.detach(), bn.bias.detach(), bn.running_mean if bn.track_running_stats else None,
             bn.running_var if bn.track_running_stats else None, count, bn.eps,
-            fused.bn_momentum(bn), save=True)
-        fused.bn_count_passes(bn)
+            fused.bn_momentum(bn), save=True, num_batches_tracked=fused.bn_counter(bn), passes=fused.bn_passes_now())
     else:
         with torch.no_grad():
             mean = bn.running_mean.clone()
@@ -125,6 +147,7 @@ class _ConvBlock(torch.autograd.Function):
         out, mean, invstd = _bn_forward(bn, u, st, n * h * w, act, slope, pool)
         y = out[0] if pool else out
         ctx.save_for_backward(x, skip, weight, gamma, u, y, mean, invstd)
+        ctx.params = (weight, bias, gamma, beta)     # the Parameter objects: backward accumulates into their .grad
         ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None, x_half=addend is not None)
         return out if pool else y
 
@@ -137,34 +160,57 @@ class _ConvBlock(torch.autograd.Function):
         dyp = None if dyp is None else ops.to_nhwc(dyp)
         if dy is None and dyp is None:
             return (None,) * 8
+        p_w, p_b, p_g, p_be = ctx.params
+        ng = ctx.needs_input_grad
+        # in-place sinks: BatchNorm weight / bias and the conv bias together (one finalize launch), the conv weight on its own
+        s_g, s_be = _sink(p_g, ng[4]), _sink(p_be, ng[5])
+        s_b = _sink(p_b, ng[3]) if cfg["has_bias"] else None
+        bn_direct = s_g is not None and s_be is not None and (s_b is not None or not cfg["has_bias"])
         du, dgamma, dbeta, dbias = ops.bn_act_bwd(dy, dyp, y, u, gamma.detach(), mean, invstd, cfg["count"], act=act,
-                                                  slope=slope, train=cfg["train"])
-        need_x, need_skip = ctx.needs_input_grad[0], skip is not None and ctx.needs_input_grad[1]
+                                                  slope=slope, train=cfg["train"],
+                                                  sinks=(s_g, s_be, s_b) if bn_direct else None)
+        if not cfg["has_bias"]:
+            dbias = None
+        s_w = _sink(p_w, ng[2])
+        beta_w = 1.0
+        dW = None
+        if s_w is None and ng[2]:          # gradient handed back to autograd: finished into a fresh tensor
+            s_w, beta_w = torch.zeros_like(weight, memory_format=torch.contiguous_format), 0.0
+            dW = s_w
+        need_x, need_skip = ng[0], skip is not None and ng[1]
         dx = dskip = None
         c1 = x.shape[1]
         if cfg["x_half"]:
             # gradient of the x half only; the skip half's dgrad / wgrad happen once per step in _SkipHalf.backward,
-            # which receives du (d addend = du) summed over the decoder calls that shared it
-            dW = torch.zeros_like(weight)
+            # which receives du (d addend = du) summed over the decoder calls that shared it.  dW lands in the
+            # channel slice [0, c1) of the weight's gradient.
+            if dW is not None:
+                beta_w = 1.0               # fresh zero tensor: only the slice is written
             if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
-                dk4 = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, None, du), 4, 4)   # (C1, Cout, 4, 4)
-                # K4[.., 2-t+a, ..] += W[.., t, ..] (a = 0,1)  =>  dW[t] = sum of the 2x2 window of dK4 at (2-t), per axis
-                dW[:, :c1] = torch.flip(torch.nn.functional.avg_pool2d(dk4.permute(1, 0, 2, 3), 2, stride=1) * 4.0, (2, 3))
+                if s_w is not None:
+                    part = ops.conv_wgrad_partial(MODE_CONVT4S2, x, None, du)
+                    dk4 = ops.wgrad_finish(part, torch.empty(part.shape[1:], device=part.device), 2, 4, 4)
+                    # K4[.., 2-t+a, ..] += W[.., t, ..] (a = 0,1)  =>  dW[t] = sum of the 2x2 window of dK4 at (2-t), per axis
+                    ops.k4_to_w3(dk4, s_w, 0, beta_w)
                 if need_x:
                     dx = ops.conv4x4s2(du, _upconv_weights(weight, c1)[1], None, None, act=ACT_NONE)
             elif kind == "conv3":
-                dW[:, :c1] = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, None, du, upsample=up), 3, 3)
+                if s_w is not None:
+                    ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, x, None, du, upsample=up), s_w, 0, 3, 3,
+                                     ctot=weight.shape[1], c_lo=0, beta=beta_w)
                 if need_x:
                     dxu = ops.conv3x3(du, None, _packed(weight, True, 0, c1, 1), None, None, act=ACT_NONE)
                     dx = ops.upsample2x_bwd(dxu) if up else dxu
             else:
-                dW[:c1] = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, None, du), 4, 4)
+                if s_w is not None:
+                    ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, x, None, du), s_w, 1, 4, 4,
+                                     ctot=weight.shape[0], c_lo=0, beta=beta_w)
                 if need_x:
                     dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
-            return (dx, None, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta,
-                    du if ctx.needs_input_grad[6] else None, None)
+            return (dx, None, dW, dbias, dgamma, dbeta, du if ng[6] else None, None)
         if kind == "conv3":
-            dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, x, skip, du, upsample=up), 3, 3)
+            if s_w is not None:
+                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, x, skip, du, upsample=up), s_w, 0, 3, 3, beta=beta_w)
             if need_x:  # dgrad = the same igemm with the flipped / transposed weights
                 wd = _packed(weight, True, 0, c1, 1)
                 dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
@@ -173,11 +219,13 @@ class _ConvBlock(torch.autograd.Function):
                 dskip = ops.conv3x3(du, None, _packed(weight, True, c1, weight.shape[1], 1), None, None,
                                     act=ACT_NONE)
         elif kind == "conv4s2":
-            dW = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV4S2, x, None, du), 4, 4)
+            if s_w is not None:
+                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV4S2, x, None, du), s_w, 0, 4, 4, beta=beta_w)
             if need_x:
                 dx = ops.convT4x4s2(du, None, _packed(weight, True), None, None, act=ACT_NONE)
         elif kind == "convT4s2":
-            dW = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, x, skip, du), 4, 4)
+            if s_w is not None:
+                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, x, skip, du), s_w, 1, 4, 4, beta=beta_w)
             if need_x:
                 dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
             if need_skip:
@@ -185,10 +233,11 @@ class _ConvBlock(torch.autograd.Function):
         elif kind in ("conv3_first", "conv4s2_first"):
             if need_x:
                 raise RuntimeError("gradients w.r.t. the input frames are not part of the DVG training path")
-            dW = ops.wgrad_thin(x, du, 3 if kind == "conv3_first" else 4)
+            if s_w is not None:
+                ops.wgrad_thin(x, du, 3 if kind == "conv3_first" else 4, out=s_w, beta=beta_w)
         else:
             raise RuntimeError(kind)
-        return dx, dskip, dW, (dbias if cfg["has_bias"] else None), dgamma, dbeta, None, None
+        return dx, dskip, dW, dbias, dgamma, dbeta, None, None
 
 
 class _SkipHalf(torch.autograd.Function):
@@ -205,6 +254,7 @@ class _SkipHalf(torch.autograd.Function):
         else:
             s = ops.convT4x4s2(skip, None, _packed(weight, True, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         ctx.save_for_backward(skip, weight)
+        ctx.param = weight
         ctx.cfg = cfg
         return s
 
@@ -213,14 +263,20 @@ class _SkipHalf(torch.autograd.Function):
         skip, weight = ctx.saved_tensors
         kind, c1 = ctx.cfg["kind"], ctx.cfg["c1"]
         ds = ops.to_nhwc(ds)
-        dW = torch.zeros_like(weight)
+        s_w, dW = _sink(ctx.param, ctx.needs_input_grad[1]), None
+        if s_w is None and ctx.needs_input_grad[1]:
+            s_w = dW = torch.zeros_like(weight, memory_format=torch.contiguous_format)
         dskip = None
-        if kind == "conv3":
-            dW[:, c1:] = ops.unpack_conv_weight(ops.conv_wgrad(MODE_CONV3, skip, None, ds), 3, 3)
+        if kind == "conv3":     # the channel slice [c1, Ctot) of the weight's gradient
+            if s_w is not None:
+                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, skip, None, ds), s_w, 0, 3, 3, ctot=weight.shape[1],
+                                 c_lo=c1, beta=1.0)
             if ctx.needs_input_grad[0]:
                 dskip = ops.conv3x3(ds, None, _packed(weight, True, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
         else:
-            dW[c1:] = ops.unpack_convT_weight(ops.conv_wgrad(MODE_CONVT4S2, skip, None, ds), 4, 4)
+            if s_w is not None:
+                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, skip, None, ds), s_w, 1, 4, 4, ctot=weight.shape[0],
+                                 c_lo=c1, beta=1.0)
             if ctx.needs_input_grad[0]:
                 dskip = ops.conv4x4s2(ds, _packed(weight, False, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         return dskip, dW, None
@@ -267,6 +323,7 @@ class _DenseBlock(torch.autograd.Function):
         st = ops.channel_stats(u2) if bn.training else None
         y4, mean, invstd = _bn_forward(bn, u4, st, rows, act, slope, False)
         ctx.save_for_backward(a, gw, gamma, u4, y4, mean, invstd)
+        ctx.params = (bias, gamma, beta)
         ctx.cfg = dict(cfg, train=bn.training, rows=rows, ch=ch, xshape=tuple(x.shape), wshape=tuple(w.shape),
                        has_bias=bias is not None)
         if kind == "head":
@@ -282,8 +339,14 @@ class _DenseBlock(torch.autograd.Function):
             dy4 = _c(dy).view(rows, 1, 1, ch).permute(0, 3, 1, 2)
         else:
             dy4 = ops.to_nhwc(dy).permute(0, 2, 3, 1).reshape(rows, 1, 1, ch).permute(0, 3, 1, 2)
+        p_b, p_g, p_be = ctx.params
+        ng = ctx.needs_input_grad
+        s_g, s_be = _sink(p_g, ng[3]), _sink(p_be, ng[4])
+        s_b = _sink(p_b, ng[2]) if cfg["has_bias"] else None
+        bn_direct = s_g is not None and s_be is not None and (s_b is not None or not cfg["has_bias"])
         du4, dgamma, dbeta, dbias = ops.bn_act_bwd(dy4, None, y4, u4, gamma.detach(), mean, invstd, rows,
-                                                   act=cfg["act"], slope=cfg["slope"], train=cfg["train"])
+                                                   act=cfg["act"], slope=cfg["slope"], train=cfg["train"],
+                                                   sinks=(s_g, s_be, s_b) if bn_direct else None)
         if kind == "head":
             du = du4.reshape(rows, ch)                                   # [N][dim]
             dgw = ops.gemm_nt(ops.transpose2d(du), ops.transpose2d(a), None, None)   # [dim][K]
@@ -324,6 +387,7 @@ class _LastLayer(torch.autograd.Function):
         ks = 3 if cfg["kind"] == "convT3" else 4
         y = ops.convT_last_two_step(x, skip if ks == 4 else None, weight, b, nc, ks, act=cfg["act"])
         ctx.save_for_backward(x, skip, weight, y)
+        ctx.param = weight
         ctx.cfg = dict(cfg, has_bias=bias is not None)
         return y
 
@@ -341,9 +405,15 @@ class _LastLayer(torch.autograd.Function):
             dx = first(dpre, _c(w[:c1]), None, None, act=ACT_NONE)
         if skip is not None and ctx.needs_input_grad[1]:
             dskip = first(dpre, _c(w[c1:]), None, None, act=ACT_NONE)
-        dW = ops.wgrad_thin(dpre, x, ks)
-        if skip is not None:
-            dW = torch.cat([dW, ops.wgrad_thin(dpre, skip, ks)], 0)
+        s_w, dW = _sink(ctx.param, ctx.needs_input_grad[2]), None
+        if s_w is not None:     # rows [0, c1) and [c1, Cin) of the ConvTranspose2d weight's gradient, in place
+            ops.wgrad_thin(dpre, x, ks, out=s_w[:c1], beta=1.0)
+            if skip is not None:
+                ops.wgrad_thin(dpre, skip, ks, out=s_w[c1:], beta=1.0)
+        elif ctx.needs_input_grad[2]:
+            dW = ops.wgrad_thin(dpre, x, ks)
+            if skip is not None:
+                dW = torch.cat([dW, ops.wgrad_thin(dpre, skip, ks)], 0)
         db = dpre.sum((0, 2, 3)) if cfg["has_bias"] else None  # nc floats
         return dx, dskip, dW, db, None
 
@@ -360,6 +430,7 @@ class _Linear(torch.autograd.Function):
         x = _c(x)
         y = ops.gemm_nt(x, weight.detach(), None, bias.detach() if bias is not None else None, act=act)
         ctx.save_for_backward(x, weight, y)
+        ctx.params = (weight, bias)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
 
@@ -368,9 +439,14 @@ class _Linear(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act != ACT_NONE else _c(dy)
         dx = ops.gemm_nt(dpre, ops.transpose2d(weight.detach()), None, None) if ctx.needs_input_grad[0] else None
-        dW = ops.gemm_nt(ops.transpose2d(dpre), ops.transpose2d(x), None, None)
-        db = ops.colsum(dpre) if ctx.has_bias else None
-        return dx, dW, db, None
+        s_w = _sink(ctx.params[0], ctx.needs_input_grad[1])
+        dW = ops.gemm_nt(ops.transpose2d(dpre), ops.transpose2d(x), None, None, out=s_w, accumulate=s_w is not None)
+        db = None
+        if ctx.has_bias:
+            s_b = _sink(ctx.params[1], ctx.needs_input_grad[2])
+            db = ops.colsum(dpre, out=s_b, accumulate=s_b is not None)
+            db = None if s_b is not None else db
+        return dx, (None if s_w is not None else dW), db, None
 
 
 def linear_autograd(x, weight, bias, act):
@@ -383,6 +459,7 @@ class _LSTMCell(torch.autograd.Function):
         x, h, c = _c(x), _c(h), _c(c)
         h2, c2, gates = ops.lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=True)
         ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c2)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
         return h2, c2
 
     @staticmethod
@@ -392,10 +469,21 @@ class _LSTMCell(torch.autograd.Function):
         dGt = ops.transpose2d(dG)
         dx = ops.gemm_nt(dG, ops.transpose2d(w_ih.detach()), None, None) if ctx.needs_input_grad[0] else None
         dh = ops.gemm_nt(dG, ops.transpose2d(w_hh.detach()), None, None) if ctx.needs_input_grad[1] else None
-        dw_ih = ops.gemm_nt(dGt, ops.transpose2d(x), None, None)
-        dw_hh = ops.gemm_nt(dGt, ops.transpose2d(h), None, None)
-        db = ops.colsum(dG)
-        return dx, dh, (dc if ctx.needs_input_grad[2] else None), dw_ih, dw_hh, db, db
+        ng = ctx.needs_input_grad
+        sinks = [_sink(p, n) for p, n in zip(ctx.params, ng[3:7])]
+        dw_ih = ops.gemm_nt(dGt, ops.transpose2d(x), None, None, out=sinks[0], accumulate=sinks[0] is not None)
+        dw_hh = ops.gemm_nt(dGt, ops.transpose2d(h), None, None, out=sinks[1], accumulate=sinks[1] is not None)
+        dbs = []
+        db = None
+        for s_b in sinks[2:]:
+            if s_b is not None:
+                ops.colsum(dG, out=s_b, accumulate=True)
+                dbs.append(None)
+            else:
+                db = ops.colsum(dG) if db is None else db
+                dbs.append(db)
+        return (dx, dh, (dc if ng[2] else None), None if sinks[0] is not None else dw_ih,
+                None if sinks[1] is not None else dw_hh, dbs[0], dbs[1])
 
 
 def lstm_cell_autograd(x, h, c, w_ih, w_hh, b_ih, b_hh):

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ coefA, float* __restrict__ coefB,
                                                                float* __restrict__ coefC, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                               int C, double count, int train) {
+                                                               int C, double count, int train, int accumulate) {
     __shared__ double red[64 * 16 * 2];
     // 16 channels x 64 row lanes per workgroup, C/16 workgroups (misc_kernels.hip partial_colsums has the history)
     const int lc = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -164,19 +164,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const double g = gamma ? gamma[c] : 1.0;
     const double G = is * (s2 - mu * s1);  // sum dp * xhat
     const double A = g * is;
-    if (dgamma) dgamma[c] = (float)G;
-    if (dbeta) dbeta[c] = (float)s1;
+    // accumulate != 0: the three outputs ARE the parameters' .grad buffers (autograd.py writes gradients in place: no
+    // per-use gradient tensor, no accumulation launch)
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)G;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
     if (train) {
         const double B = -A * is * G / count;
         coefA[c] = (float)A;
         coefB[c] = (float)B;
         coefC[c] = (float)(-A * s1 / count - B * mu);
-        if (dbias) dbias[c] = 0.f;  // sum_c du == 0 identically under batch statistics
+        if (dbias && !accumulate) dbias[c] = 0.f;  // sum_c du == 0 identically under batch statistics
     } else {
         coefA[c] = (float)A;
         coefB[c] = 0.f;
         coefC[c] = 0.f;
-        if (dbias) dbias[c] = (float)(A * s1);
+        if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)(A * s1);
     }
 }
 
@@ -256,12 +258,109 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dxu, float* __re
 }
 
 // out[c] = sum_r a[r][c]   (bias gradients; rows = batch)
-__global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int C) {
+__global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += a[(size_t)r * C + c];
-    out[c] = s;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// Weight-gradient finish: dW (nn layout, possibly a channel slice of a wider weight) = beta * dW + sum_s partial[s], with
+// partial[s] the packed [tap][Cout][Cin] slabs of dvg_conv_wgrad.  One launch replaces reduce_partials + unpack + the
+// autograd accumulation add.  Same reduction scheme as reduce_partials_kernel (16 float4 columns x 16 slab lanes, fixed
+// combination order); a float4 column is 4 consecutive ci of one (tap, co).
+//   KIND 0: Conv2d weight (Cout, Ctot, KH, KW):          dst[co][c_lo + ci][a][b]           <- packed[a*KW + b][co][ci]
+//   KIND 1: ConvTranspose2d weight (Ctot, Cout, KH, KW): dst[c_lo + ci][co][KH-1-a][KW-1-b] <- packed[a*KW + b][co][ci]
+//   KIND 2: plain packed output (contiguous, same indexing as the slabs)
+template <int KIND>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dst,
+                                                           int S, long n4, int kh, int kw, int cout, int cin, int ctot,
+                                                           int c_lo, float beta) {
+    __shared__ f32x4 red[16 * 16];
+    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + lc;
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = sl;
+        for (; s + 48 < S; s += 64) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const f32x4*>(partial)[(size_t)(s + 16 * k) * n4 + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[k][e] += v[k][e];
+        }
+        for (; s < S; s += 16) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(size_t)s * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
+        }
+    }
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    red[sl * 16 + lc] = t;
+    __syncthreads();
+    if (sl != 0 || i >= n4) return;
+    f32x4 o = red[lc];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const f32x4 v = red[k * 16 + lc];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += v[e];
+    }
+    if (KIND == 2) {
+        f32x4* d = reinterpret_cast<f32x4*>(dst) + i;
+        if (beta != 0.f) {
+            const f32x4 old = *d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(beta, old[e], o[e]);
+        }
+        *d = o;
+        return;
+    }
+    const long e0 = i * 4;                 // packed element index of lane 0 of the column: (t, co, ci0)
+    const int ci0 = (int)(e0 % cin);
+    const long r = e0 / cin;
+    const int co = (int)(r % cout), tp = (int)(r / cout);
+    const int a = tp / kw, b = tp % kw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ci = c_lo + ci0 + e;
+        const long j = KIND == 0 ? ((((long)co * ctot + ci) * kh + a) * kw + b)
+                                 : ((((long)ci * cout + co) * kh + (kh - 1 - a)) * kw + (kw - 1 - b));
+        dst[j] = beta != 0.f ? fmaf(beta, dst[j], o[e]) : o[e];
+    }
+}
+
+// dW3 (Cout, Ctot, 3, 3)[:, c_lo : c_lo + C1] = beta * dW3 + the 2x2 window sums of dK4, the gradient w.r.t. the 4x4
+// stride-2 transposed-conv kernel K4 = W (*) ones(2x2) that an upsample + conv3x3 runs as (fused._upconv_packed):
+//   K4[co][ci][2 - ty + al][2 - tx + be] += W[co][ci][ty][tx]   =>   dW[co][ci][ty][tx] = sum_{al,be} dK4[co][ci][2-ty+al][2-tx+be]
+// dk4p is dK4 in the packed transposed layout of dvg_conv_wgrad(CONVT4S2) after the slab reduction: [16][Cout][C1] with
+// tap t = (3 - r) * 4 + (3 - s) holding dK4[co][ci][r][s].
+__global__ void k4_to_w3_kernel(const float* __restrict__ dk4p, float* __restrict__ dw, int cout, int c1, int ctot,
+                                int c_lo, float beta) {
+    const long total = (long)9 * cout * c1;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c1);
+        long r = i / c1;
+        const int co = (int)(r % cout);
+        const int t3 = (int)(r / cout), ty = t3 / 3, tx = t3 % 3;
+        float s = 0.f;
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+            for (int be = 0; be < 2; ++be) {
+                const int rr = 2 - ty + al, ss = 2 - tx + be;
+                s += dk4p[((size_t)((3 - rr) * 4 + (3 - ss)) * cout + co) * c1 + ci];
+            }
+        const long j = (((long)co * ctot + c_lo + ci) * 3 + ty) * 3 + tx;
+        dw[j] = beta != 0.f ? fmaf(beta, dw[j], s) : s;
+    }
 }
 
 // out[i] = sum_s partial[s][i].  Workgroup = 64 float4 columns x 4 slab lanes; every lane walks its slabs with
@@ -497,11 +596,12 @@ extern "C" int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const fl
 
 extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
                                    const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
-                                   float* dbeta, float* dbias, int C, double count, int train, void* stream) {
+                                   float* dbeta, float* dbias, int C, double count, int train, int accumulate,
+                                   void* stream) {
     DVG_REQUIRE(partial && mean && invstd && coefA && coefB && coefC, DVG_ERR_NULL, "dvg_bn_bwd_finalize: NULL");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
-                       gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train);
+                       gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train, accumulate);
     return check_launch("dvg_bn_bwd_finalize");
 }
 
@@ -535,11 +635,41 @@ extern "C" int dvg_upsample2x_bwd(const float* dxu, float* dx, int N, int H, int
     return check_launch("dvg_upsample2x_bwd");
 }
 
-extern "C" int dvg_colsum(const float* a, float* out, int rows, int C, void* stream) {
+extern "C" int dvg_colsum(const float* a, float* out, int rows, int C, int accumulate, void* stream) {
     DVG_REQUIRE(a && out, DVG_ERR_NULL, "dvg_colsum: NULL pointer");
     DVG_REQUIRE(rows > 0 && C > 0, DVG_ERR_SHAPE, "dvg_colsum: bad shape");
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, out, rows, C);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, out, rows, C, accumulate);
     return check_launch("dvg_colsum");
+}
+
+extern "C" int dvg_wgrad_finish(const float* partial, int S, float* dst, int kind, int kh, int kw, int cout, int cin,
+                                int ctot, int c_lo, float beta, void* stream) {
+    DVG_REQUIRE(partial && dst, DVG_ERR_NULL, "dvg_wgrad_finish: NULL pointer");
+    DVG_REQUIRE(S > 0 && kh > 0 && kw > 0 && cout > 0 && cin > 0 && cin % 4 == 0 && kind >= 0 && kind <= 2, DVG_ERR_SHAPE,
+                "dvg_wgrad_finish: bad shape (Cin %% 4 == 0)");
+    DVG_REQUIRE(kind == 2 || (c_lo >= 0 && c_lo + cin <= ctot), DVG_ERR_SHAPE, "dvg_wgrad_finish: channel slice out of range");
+    DVG_REQUIRE(aligned16(partial) && (kind != 2 || aligned16(dst)), DVG_ERR_ALIGN, "dvg_wgrad_finish: alignment");
+    const long n4 = (long)kh * kw * cout * cin / 4;
+    const dim3 grid((unsigned)((n4 + 15) / 16));
+    if (kind == 0)
+        hipLaunchKernelGGL(wgrad_finish_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, partial, dst, S, n4, kh, kw, cout,
+                           cin, ctot, c_lo, beta);
+    else if (kind == 1)
+        hipLaunchKernelGGL(wgrad_finish_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, partial, dst, S, n4, kh, kw, cout,
+                           cin, ctot, c_lo, beta);
+    else
+        hipLaunchKernelGGL(wgrad_finish_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, partial, dst, S, n4, kh, kw, cout,
+                           cin, ctot, c_lo, beta);
+    return check_launch("dvg_wgrad_finish");
+}
+
+extern "C" int dvg_k4_to_w3(const float* dk4_packed, float* dw, int cout, int c1, int ctot, int c_lo, float beta,
+                            void* stream) {
+    DVG_REQUIRE(dk4_packed && dw, DVG_ERR_NULL, "dvg_k4_to_w3: NULL pointer");
+    DVG_REQUIRE(cout > 0 && c1 > 0 && c_lo >= 0 && c_lo + c1 <= ctot, DVG_ERR_SHAPE, "dvg_k4_to_w3: bad shape");
+    hipLaunchKernelGGL(k4_to_w3_kernel, dim3(grid_for((long)9 * cout * c1)), dim3(256), 0, (hipStream_t)stream, dk4_packed, dw,
+                       cout, c1, ctot, c_lo, beta);
+    return check_launch("dvg_k4_to_w3");
 }
 
 extern "C" int dvg_reduce_partials(const float* partial, float* out, int S, long n, void* stream) {

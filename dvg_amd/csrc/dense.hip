@@ -29,6 +29,7 @@ struct GemmParams {
     float slope;
     int vec;    // w rows are 16-B aligned and K % 4 == 0
     int vec_a;  // a rows are 16-B aligned (lda % 4 == 0)
+    int accum;  // out += result (the output IS a parameter's .grad buffer: autograd.py accumulates gradients in place)
 };
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
             } else {
                 const int c = n % p.period;
                 const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
-                p.out[(size_t)m * p.ldo + n] = apply_act(acc[i][j] * sc + sf, p.act, p.slope);
+                float* o = p.out + (size_t)m * p.ldo + n;
+                const float v = apply_act(acc[i][j] * sc + sf, p.act, p.slope);
+                *o = p.accum ? *o + v : v;
             }
         }
     }
@@ -133,7 +136,9 @@ __global__ void gemm_splitk_reduce_kernel(const GemmParams p) {
         for (; z < p.splitk; ++z) s += p.ws[(size_t)z * total + i];
         const int c = n % p.period;
         const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
-        p.out[(size_t)m * p.ldo + n] = apply_act(s * sc + sf, p.act, p.slope);
+        float* o = p.out + (size_t)m * p.ldo + n;
+        const float v = apply_act(s * sc + sf, p.act, p.slope);
+        *o = p.accum ? *o + v : v;
     }
 }
 
@@ -446,7 +451,9 @@ __global__ __launch_bounds__(256) void gemm_dot_kernel(const GemmParams p) {
         } else {
             const int c = n % p.period;
             const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
-            p.out[(size_t)m * p.ldo + n] = apply_act(v[0] * sc + sf, p.act, p.slope);
+            float* o = p.out + (size_t)m * p.ldo + n;
+            const float r = apply_act(v[0] * sc + sf, p.act, p.slope);
+            *o = p.accum ? *o + r : r;
         }
     }
 }
@@ -457,14 +464,15 @@ using namespace dvg;
 
 extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float* scale, const float* shift, float* out,
                                     float* workspace, int M, int N, int K, int lda, int ldo, int period, int splitk,
-                                    int act, float slope, void* stream) {
+                                    int act, float slope, int accumulate, void* stream) {
     DVG_REQUIRE(a && w && out, DVG_ERR_NULL, "dvg_gemm_nt_bias_act: NULL pointer");
     DVG_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldo >= N, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad shape");
     DVG_REQUIRE(period > 0 && period <= N && N % period == 0, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad period");
     DVG_REQUIRE(splitk >= 1 && splitk <= 256, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad splitk");
     DVG_REQUIRE(splitk == 1 || workspace != nullptr, DVG_ERR_NULL, "dvg_gemm_nt_bias_act: workspace needed");
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_gemm_nt_bias_act: bad act");
-    GemmParams p{a, w, scale, shift, out, workspace, M, N, K, lda, ldo, period, splitk, 0, act, slope, 0, 0};
+    GemmParams p{a, w, scale, shift, out, workspace, M, N, K, lda, ldo, period, splitk, 0, act, slope, 0, 0,
+                 accumulate ? 1 : 0};
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + 31) / 32) * 32;
     p.kper = kper;

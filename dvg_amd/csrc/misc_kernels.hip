@@ -135,8 +135,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_var,
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, int C, double count,
-                                                           float eps, float momentum) {
+                                                           float eps, float momentum, long long* __restrict__ nbt,
+                                                           int nbt_inc) {
     __shared__ double red[64 * DVG_COLSUM_CT * 2];
+    // num_batches_tracked += passes (nn.BatchNorm2d's int64 counter): one lane of the launch, instead of a torch add
+    if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += nbt_inc;
     const int c = blockIdx.x * DVG_COLSUM_CT + (threadIdx.x & (DVG_COLSUM_CT - 1)), rl = threadIdx.x >> 4;
     double s1, s2;
     partial_colsums(partial, nrows, C, c, rl, red, s1, s2);
@@ -385,12 +388,12 @@ extern "C" int dvg_channel_stats(const float* u, float* stats_partial, long rows
 extern "C" int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma, const float* beta,
                                float* scale, float* shift, float* running_mean, float* running_var,
                                float* save_mean, float* save_invstd, int C, double count, float eps, float momentum,
-                               void* stream) {
+                               int64_t* num_batches_tracked, int nbt_inc, void* stream) {
     DVG_REQUIRE(stats_partial && scale && shift, DVG_ERR_NULL, "dvg_bn_finalize: NULL pointer");
     DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + DVG_COLSUM_CT - 1) / DVG_COLSUM_CT), dim3(1024), 0, (hipStream_t)stream, stats_partial, nrows,
                        gamma, beta, scale, shift, running_mean, running_var, save_mean, save_invstd, C, count, eps,
-                       momentum);
+                       momentum, (long long*)num_batches_tracked, nbt_inc);
     return check_launch("dvg_bn_finalize");
 }
 

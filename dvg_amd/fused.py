@@ -130,9 +130,13 @@ def bn_momentum(bn) -> float:
     return 1.0 - (1.0 - m) ** _BN_PASSES
 
 
-def bn_count_passes(bn) -> None:
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += _BN_PASSES
+def bn_passes_now() -> int:
+    return _BN_PASSES
+
+
+def bn_counter(bn):
+    """The device int64 `num_batches_tracked` of a BatchNorm2d (advanced inside dvg_bn_finalize), or None."""
+    return bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None) else None
 
 
 # Recording / replaying the BatchNorm side effects of a no-grad train-mode forward: the GP fine-tuning closure encodes
@@ -173,8 +177,7 @@ def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
                           bn.bias.detach() if bn.bias is not None else None,
                           bn.running_mean if bn.track_running_stats else None,
                           bn.running_var if bn.track_running_stats else None, count, bn.eps,
-                          bn_momentum(bn), save=save)
-    bn_count_passes(bn)
+                          bn_momentum(bn), save=save, num_batches_tracked=bn_counter(bn), passes=_BN_PASSES)
     return res
 
 

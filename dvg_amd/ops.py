@@ -344,7 +344,9 @@ def channel_stats(u2d: torch.Tensor) -> torch.Tensor:
     return st
 
 
-def bn_finalize(stats_partial, gamma, beta, running_mean, running_var, count, eps, momentum, save=False):
+def bn_finalize(stats_partial, gamma, beta, running_mean, running_var, count, eps, momentum, save=False,
+                num_batches_tracked=None, passes=0):
+    """`num_batches_tracked` (int64 device scalar of nn.BatchNorm2d) is advanced by `passes` inside the same launch."""
     rows, _, c = stats_partial.shape
     dev = stats_partial.device
     scale = torch.empty(c, device=dev, dtype=torch.float32)
@@ -352,7 +354,8 @@ def bn_finalize(stats_partial, gamma, beta, running_mean, running_var, count, ep
     sm = torch.empty(c, device=dev, dtype=torch.float32) if save else None
     si = torch.empty(c, device=dev, dtype=torch.float32) if save else None
     check(lib().dvg_bn_finalize(_p(stats_partial), rows, _p(gamma), _p(beta), _p(scale), _p(shift), _p(running_mean),
-                                _p(running_var), _p(sm), _p(si), c, float(count), eps, momentum, _stream()),
+                                _p(running_var), _p(sm), _p(si), c, float(count), eps, momentum,
+                                _p(num_batches_tracked), int(passes), _stream()),
           "bn_finalize")
     return (scale, shift, sm, si) if save else (scale, shift)
 
@@ -371,8 +374,8 @@ def bn_act_apply(u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, inpla
 # ----------------------------------------------------------------------------------
 # dense / recurrent
 # ----------------------------------------------------------------------------------
-def gemm_nt(a, w, scale, shift, *, act=ACT_NONE, slope=0.0, period=None, splitk=1, out=None):
-    """out[m][n] = act((sum_k a[m][k] w[n][k]) * scale[n%period] + shift[n%period])."""
+def gemm_nt(a, w, scale, shift, *, act=ACT_NONE, slope=0.0, period=None, splitk=1, out=None, accumulate=False):
+    """out[m][n] = act((sum_k a[m][k] w[n][k]) * scale[n%period] + shift[n%period]); accumulate: out += (needs `out`)."""
     _dev_f32(a, "gemm_nt.a")
     _dev_f32(w, "gemm_nt.w")
     if a.dim() != 2 or a.stride(1) != 1:
@@ -389,7 +392,7 @@ def gemm_nt(a, w, scale, shift, *, act=ACT_NONE, slope=0.0, period=None, splitk=
     ws = torch.empty((splitk, m, n), device=a.device, dtype=torch.float32) if splitk > 1 else None
     _run("gemm_nt", 2.0 * m * n * k, 4.0 * (m * k + n * k + m * n), lib().dvg_gemm_nt_bias_act, _p(a), _p(w),
          _p(scale), _p(shift), _p(out), _p(ws), m, n, k, a.stride(0), out.stride(0), period, splitk, act, slope,
-         _stream())
+         int(accumulate), _stream())
     return out
 
 
@@ -491,9 +494,11 @@ def transpose2d(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=True):
+def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=True, sinks=None):
     """BatchNorm(+act, +2x2 max-pool) backward.  dy/dyp/y/u NHWC-in-memory (N,C,H,W) tensors (2-D [rows][C]
-    tensors are passed as (rows,C,1,1)).  Returns (du, dgamma, dbeta, dbias)."""
+    tensors are passed as (rows,C,1,1)).  Returns (du, dgamma, dbeta, dbias); with `sinks` = (g_gamma, g_beta, g_bias or
+    None) the three parameter gradients are ACCUMULATED into those buffers by the finalize kernel and None is returned
+    in their place."""
     n, c, h, w = y.shape
     pool = dyp is not None
     rows = lib().dvg_bn_act_bwd_rows(n, h, w, int(pool))
@@ -503,15 +508,65 @@ def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=T
     _run("bn_act_bwd_reduce", 0.0, 4.0 * 4 * y.numel(), lib().dvg_bn_act_bwd_reduce, _p(dy), _p(dyp), _p(y), _p(u),
          _p(dp), _p(partial), n, h, w, c, act, slope, _stream())
     coef = torch.empty((3, c), device=dev, dtype=torch.float32)
-    dgamma = torch.empty(c, device=dev, dtype=torch.float32)
-    dbeta = torch.empty(c, device=dev, dtype=torch.float32)
-    dbias = torch.empty(c, device=dev, dtype=torch.float32)
+    if sinks is None:
+        dgamma = torch.empty(c, device=dev, dtype=torch.float32)
+        dbeta = torch.empty(c, device=dev, dtype=torch.float32)
+        dbias = torch.empty(c, device=dev, dtype=torch.float32)
+        outs, acc = (dgamma, dbeta, dbias), 0
+    else:
+        dgamma = dbeta = dbias = None
+        outs, acc = sinks, 1
     check(lib().dvg_bn_bwd_finalize(_p(partial), rows, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]),
-                                    _p(coef[2]), _p(dgamma), _p(dbeta), _p(dbias), c, float(count), int(train),
-                                    _stream()), "bn_bwd_finalize")
+                                    _p(coef[2]), _p(outs[0]), _p(outs[1]), _p(outs[2]), c, float(count), int(train),
+                                    acc, _stream()), "bn_bwd_finalize")
     _run("affine3_apply", 0.0, 4.0 * 3 * y.numel(), lib().dvg_affine3_apply, _p(dp), _p(u), _p(coef[0]), _p(coef[1]),
          _p(coef[2]), _p(dp), dp.numel(), c, _stream())
     return dp, dgamma, dbeta, dbias
+
+
+def conv_wgrad_partial(mode, x, skip, du, *, upsample=False):
+    """The K-split partial slabs (S, taps, Cout, Cin) of a dense conv's weight gradient (dvg_conv_wgrad); finish them
+    with wgrad_finish / k4_to_w3."""
+    n, c1, hx, wx = x.shape
+    h, w = (hx * 2, wx * 2) if upsample else (hx, wx)
+    c2 = 0 if skip is None else skip.shape[1]
+    cout = du.shape[1]
+    cin = c1 + c2
+    taps = 9 if mode == MODE_CONV3 else 16
+    s = lib().dvg_conv_wgrad_splits(mode, n, h, w, cin, cout)
+    if s <= 0:
+        raise RuntimeError(f"conv_wgrad: unsupported shape N={n} H={h} W={w} Cin={cin} Cout={cout}")
+    partial = torch.empty((s, taps, cout, cin), device=x.device, dtype=torch.float32)
+    _run("conv_wgrad", 2.0 * du.numel() * taps * cin / (4 if mode == MODE_CONVT4S2 else 1),
+         4.0 * (x.numel() + du.numel() + partial.numel()), lib().dvg_conv_wgrad, mode, _p(x), _p(skip), _p(du),
+         _p(partial), n, h, w, c1, c2, cout, int(upsample), _stream())
+    return partial
+
+
+def wgrad_finish(partial, dst, kind, kh, kw, *, ctot=None, c_lo=0, beta=0.0):
+    """dst = beta * dst + sum of the partial slabs (S, kh*kw, Cout, Cin), addressed as kind 0: Conv2d weight
+    (Cout, Ctot, kh, kw)[:, c_lo:c_lo+Cin]; 1: ConvTranspose2d weight (Ctot, Cout, kh, kw)[c_lo:c_lo+Cin] (flipped);
+    2: plain packed (kh*kw, Cout, Cin) (dvg_wgrad_finish)."""
+    s, taps, cout, cin = partial.shape
+    if taps != kh * kw:
+        raise RuntimeError("wgrad_finish: tap count mismatch")
+    if ctot is None:
+        ctot = cin
+    want = (cout, ctot, kh, kw) if kind == 0 else ((ctot, cout, kh, kw) if kind == 1 else (taps, cout, cin))
+    if tuple(dst.shape) != want or not dst.is_contiguous():
+        raise RuntimeError(f"wgrad_finish: destination {tuple(dst.shape)} must be contiguous {want}")
+    check(lib().dvg_wgrad_finish(_p(partial), s, _p(dst), kind, kh, kw, cout, cin, ctot, c_lo, float(beta), _stream()),
+          "wgrad_finish")
+    return dst
+
+
+def k4_to_w3(dk4_packed, dw, c_lo=0, beta=0.0):
+    """dw (Cout, Ctot, 3, 3)[:, c_lo:c_lo+C1] = beta * dw + 2x2 window sums of dK4 (packed (16, Cout, C1)) (dvg_k4_to_w3)."""
+    t, cout, c1 = dk4_packed.shape
+    if t != 16 or dw.dim() != 4 or dw.shape[0] != cout or tuple(dw.shape[2:]) != (3, 3) or not dw.is_contiguous():
+        raise RuntimeError("k4_to_w3: shape mismatch")
+    check(lib().dvg_k4_to_w3(_p(dk4_packed), _p(dw), cout, c1, dw.shape[1], c_lo, float(beta), _stream()), "k4_to_w3")
+    return dw
 
 
 def conv_wgrad(mode, x, skip, du, *, upsample=False):
@@ -536,8 +591,8 @@ def conv_wgrad(mode, x, skip, du, *, upsample=False):
     return out
 
 
-def wgrad_thin(inp_nchw, dout_nhwc, ks):
-    """dW (C, nc, ks, ks) of a thin layer (see dvg_wgrad_thin)."""
+def wgrad_thin(inp_nchw, dout_nhwc, ks, out=None, beta=0.0):
+    """dW (C, nc, ks, ks) of a thin layer (see dvg_wgrad_thin); `out` (contiguous, same shape): out = beta * out + dW."""
     inp = inp_nchw if inp_nchw.is_contiguous() else inp_nchw.contiguous()
     n, nc, hi, wi = inp.shape
     c = dout_nhwc.shape[1]
@@ -546,8 +601,14 @@ def wgrad_thin(inp_nchw, dout_nhwc, ks):
     partial = torch.empty((rows, c, nc * ks * ks), device=inp.device, dtype=torch.float32)
     _run("wgrad_thin", 2.0 * dout_nhwc.numel() * nc * ks * ks, 4.0 * (inp.numel() + dout_nhwc.numel()),
          lib().dvg_wgrad_thin, _p(inp), _p(dout_nhwc), _p(partial), ks, n, hi, wi, nc, c, _stream())
-    out = torch.empty((c, nc, ks, ks), device=inp.device, dtype=torch.float32)
-    check(lib().dvg_reduce_partials(_p(partial), _p(out), rows, out.numel(), _stream()), "reduce_partials")
+    if out is None:
+        out = torch.empty((c, nc, ks, ks), device=inp.device, dtype=torch.float32)
+        beta = 0.0
+    elif tuple(out.shape) != (c, nc, ks, ks) or not out.is_contiguous():
+        raise RuntimeError("wgrad_thin: bad destination")
+    n = out.numel()
+    check(lib().dvg_wgrad_finish(_p(partial), rows, _p(out), 2, 1, 1, 1, n, n, 0, float(beta), _stream()),
+          "wgrad_finish(thin)")
     return out
 
 
@@ -567,11 +628,12 @@ def upsample2x_bwd(dxu):
     return dx
 
 
-def colsum(a):
+def colsum(a, out=None, accumulate=False):
     a = a if a.is_contiguous() else a.contiguous()
     rows, c = a.shape
-    out = torch.empty(c, device=a.device, dtype=torch.float32)
-    check(lib().dvg_colsum(_p(a), _p(out), rows, c, _stream()), "colsum")
+    if out is None:
+        out, accumulate = torch.empty(c, device=a.device, dtype=torch.float32), False
+    check(lib().dvg_colsum(_p(a), _p(out), rows, c, int(accumulate), _stream()), "colsum")
     return out
 
 

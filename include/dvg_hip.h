@@ -201,7 +201,8 @@ int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, vo
 int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma,
                     const float* beta, float* scale, float* shift, float* running_mean,
                     float* running_var, float* save_mean, float* save_invstd,
-                    int C, double count, float eps, float momentum, void* stream);
+                    int C, double count, float eps, float momentum,
+                    int64_t* num_batches_tracked /* may be NULL; += nbt_inc */, int nbt_inc, void* stream);
 
 /* y = act(u*scale[c]+shift[c]) elementwise over an NHWC tensor of `npix`
  * pixels (train-mode BN apply + activation), optional fused 2x2 max-pool
@@ -224,7 +225,7 @@ int dvg_bn_act_apply(const float* u, const float* scale, const float* shift, flo
 int dvg_gemm_nt_bias_act(const float* a, const float* w, const float* scale,
                          const float* shift, float* out, float* workspace, int M,
                          int N, int K, int lda, int ldo, int period, int splitk,
-                         int act, float slope, void* stream);
+                         int act, float slope, int accumulate /* out += result */, void* stream);
 
 /* One nn.LSTMCell step (lstm.py:51,68-70; gate order i,f,g,o):
  *   g = W_ih x + b_ih + W_hh h + b_hh ; c' = sig(f)*c + sig(i)*tanh(g~) ;
@@ -307,7 +308,7 @@ int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const float* y, con
 int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
                         const float* invstd, float* coefA, float* coefB, float* coefC,
                         float* dgamma, float* dbeta, float* dbias, int C, double count,
-                        int train, void* stream);
+                        int train, int accumulate /* dgamma / dbeta / dbias += */, void* stream);
 /* pass 3: du = A[c]*dp + B[c]*u + Cc[c] over n elements (n %% C == 0); du may alias dp. */
 int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B,
                       const float* Cc, float* du, long n, int C, void* stream);
@@ -317,7 +318,7 @@ int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, f
 /* nn.UpsamplingNearest2d(2) backward: dx (N,H,W,C) = 2x2 block sums of dxu (N,2H,2W,C). */
 int dvg_upsample2x_bwd(const float* dxu, float* dx, int N, int H, int W, int C, void* stream);
 /* out[c] = sum_r a[r][c]  (bias gradients)                                       */
-int dvg_colsum(const float* a, float* out, int rows, int C, void* stream);
+int dvg_colsum(const float* a, float* out, int rows, int C, int accumulate /* out += */, void* stream);
 /* out[i] = sum_s partial[s][i], n %% 4 == 0                                       */
 int dvg_reduce_partials(const float* partial, float* out, int S, long n, void* stream);
 
@@ -331,6 +332,20 @@ int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout);
 int dvg_conv_wgrad(int mode, const float* x, const float* skip, const float* dout,
                    float* partial, int N, int H, int W, int C1, int C2, int Cout,
                    int upsample_x, void* stream);
+
+/* Finish of a weight gradient IN PLACE in the parameter's gradient buffer (train.py:240 `loss.backward()` accumulates
+ * into .grad; here the kernel that finishes the gradient does it, so no per-use gradient tensor and no accumulation
+ * launch exist):  dst = beta * dst + sum_s partial[s],  partial = the S packed [KH*KW][Cout][Cin] slabs of dvg_conv_wgrad,
+ * dst addressed in the nn layout, optionally as the channel slice [c_lo, c_lo + Cin) of a weight with Ctot input channels
+ * (the x / skip halves of a concat conv):
+ *   kind 0: Conv2d weight (Cout, Ctot, KH, KW); kind 1: ConvTranspose2d weight (Ctot, Cout, KH, KW) (spatially flipped,
+ *   as dvg_unpack_convT_weight); kind 2: plain packed [KH*KW][Cout][Cin] (contiguous).  Cin % 4 == 0.                */
+int dvg_wgrad_finish(const float* partial, int S, float* dst, int kind, int kh, int kw, int cout, int cin, int ctot,
+                     int c_lo, float beta, void* stream);
+/* dW (Cout, Ctot, 3, 3)[:, c_lo : c_lo + C1] = beta * dW + 2x2 window sums of dK4, the gradient w.r.t. the 4x4 stride-2
+ * transposed-conv kernel that `nearest-x2 upsample + conv3x3` (vgg_64.py:93,98-105) runs as; dk4_packed [16][Cout][C1] is
+ * the reduced packed output of dvg_conv_wgrad(DVG_MODE_CONVT4S2).                                                    */
+int dvg_k4_to_w3(const float* dk4_packed, float* dw, int cout, int c1, int ctot, int c_lo, float beta, void* stream);
 
 /* Weight gradient of the thin first / last layers (ks = 3: stride 1, ks = 4: stride 2, pad 1):
  *   dW[c][ci][a][b] = sum dout[n][oy][ox][c] * inp[n][ci][S*oy+a-1][S*ox+b-1]

@@ -248,3 +248,56 @@ def test_gp_train_backward(B, D, M):
     ref["variational_strategy.variational_distribution.chol_variational_covar"] = torch.tril(
         ref["variational_strategy.variational_distribution.chol_variational_covar"])
     grads_close(ours, ref, tol=5e-3)
+
+
+@pytest.mark.parametrize("family", ["dcgan", "vgg"])
+def test_in_place_parameter_gradients_equal_autograd_accumulation(family):
+    """autograd.DIRECT_PARAM_GRADS: the backward kernels add parameter gradients straight into `.grad` (None returned to
+    autograd).  Same gradients as handing them back to autograd, also when `.grad` already holds something (a second
+    backward accumulates), when it starts as None, and through the shared-skip-half / upsample-as-transposed-conv paths."""
+    from dvg_amd import autograd as ag
+    from dvg_amd import fused
+    mod = our_module(family, 64)
+    x = params.frames(2100, 4, 1, 64).to(dev())
+    gy = params.normal(2101, 4, 1, 64, 64).to(dev())
+    res = {}
+    for direct in (True, False):
+        ag.DIRECT_PARAM_GRADS = direct
+        try:
+            enc, dec = mod.encoder(90, 1), mod.decoder(90, 1)
+            enc.load_state_dict(params.fill_state_dict(enc.state_dict(), 2110))
+            dec.load_state_dict(params.fill_state_dict(dec.state_dict(), 2111, params.decoder_transposed_keys(dec.state_dict(), family)))
+            enc.to(dev()).train(), dec.to(dev()).train()
+            for rep in range(2):                      # second pass accumulates on top of the first
+                h, skips = enc(x)
+                with fused.share_skip_halves():       # two decoder calls share the skip halves (train.py:227-231)
+                    y = dec([h, skips]) + dec([h * 0.5, skips])
+                ((y * gy).sum() + h.sum()).backward()
+            res[direct] = {k: p.grad.detach().clone() for m_ in (enc, dec) for k, p in m_.named_parameters()}
+            assert all(p.grad is not None for m_ in (enc, dec) for p in m_.parameters())
+        finally:
+            ag.DIRECT_PARAM_GRADS = True
+    for k, g in res[False].items():
+        scale = max(float(g.abs().max()), 1e-20)
+        assert float((res[True][k] - g).abs().max()) <= 2e-5 * scale + 1e-9, k
+
+
+def test_in_place_gradients_lstm_linear():
+    from dvg_amd import autograd as ag
+    import dvg_amd.models.lstm as ours
+    res = {}
+    for direct in (True, False):
+        ag.DIRECT_PARAM_GRADS = direct
+        try:
+            net = ours.lstm(90, 90, 256, 2, 6)
+            net.load_state_dict(params.fill_state_dict(net.state_dict(), 2200))
+            net.to(dev())
+            for rep in range(2):
+                net.hidden = net.init_hidden()
+                loss = sum((net(params.normal(2210 + t, 6, 90, scale=0.5).to(dev())) ** 2).sum() for t in range(3))
+                loss.backward()
+            res[direct] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        finally:
+            ag.DIRECT_PARAM_GRADS = True
+    for k, g in res[False].items():
+        assert float((res[True][k] - g).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-20) + 1e-9, k
