@@ -9,7 +9,7 @@ Gradient recipe per conv block  y = act(BN(conv(cat(up(x), skip)) + b)):
   3. dW  = MFMA GEMM over pixels (K split + deterministic reduce)             dvg_conv_wgrad / dvg_reduce_partials
   4. dx  = the forward implicit-GEMM kernel with re-packed weights           dvg_conv3x3_bn_act_v2 / conv4x4s2 / convT4x4s2
            (+ dvg_upsample2x_bwd when x entered through the fused nearest-x2)
-"""
+
 Parameter gradients are written IN PLACE: the kernel that finishes a gradient (dvg_wgrad_finish, dvg_bn_bwd_finalize,
 dvg_gemm_nt_bias_act / dvg_colsum with `accumulate`) adds it straight into the parameter's `.grad` buffer - a view of the
 optimiser's flat gradient arena under train.Trainer - and the Function returns None for that input.  The reference's
