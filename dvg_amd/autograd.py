@@ -34,6 +34,54 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+# Deferred, batched weight gradients.  A layer's weight gradient is one launch PER USE in the reference (every time step and
+# every decoder call back-propagates through the same weights, train.py:213-232,240).  Our wgrad kernel splits its GEMM K
+# dimension (pixels) over ~512 workgroups whose partial slabs - 75 MB per launch whatever the layer - are written and then
+# reduced: 17 % of the kernel family's time.  So uses are queued per (parameter, shape) and run as ONE launch over up to
+# WGRAD_BATCH of them (dvg_conv_wgrad_multi: K grows, the slabs do not), flushed when a queue is full and, through the
+# autograd engine's end-of-backward callback, when the backward pass that queued them completes - `.grad` is final when
+# `loss.backward()` returns, as always.  Only with in-place gradients (the finish kernel accumulates into `.grad`).
+WGRAD_BATCH = int(os.environ.get("DVG_WGRAD_BATCH", "8"))
+_wgrad_queues = {}
+_wgrad_flush_queued = False
+
+
+def _flush_one(key):
+    q = _wgrad_queues.pop(key, None)
+    if not q:
+        return
+    mode, up, finish = q[0][0], q[0][1], q[0][2]
+    xs, skips, dus = [e[3] for e in q], [e[4] for e in q], [e[5] for e in q]
+    part = ops.conv_wgrad_partial_multi(mode, xs, None if skips[0] is None else skips, dus, upsample=up)
+    finish(part)
+
+
+def flush_wgrads():
+    global _wgrad_flush_queued
+    _wgrad_flush_queued = False
+    for key in list(_wgrad_queues):
+        _flush_one(key)
+
+
+def _wgrad(mode, x, skip, du, up, sink, finish, tag):
+    """Weight gradient of one use: queued for a batched launch when it accumulates in place into `sink`, immediate
+    otherwise.  finish(partial) reduces the partial slabs into the destination."""
+    global _wgrad_flush_queued
+    if WGRAD_BATCH <= 1 or sink is None or not DIRECT_PARAM_GRADS:
+        finish(ops.conv_wgrad_partial(mode, x, skip, du, upsample=up))
+        return
+    key = (sink.data_ptr(), tag, mode, up, tuple(x.shape), tuple(du.shape), None if skip is None else tuple(skip.shape))
+    q = _wgrad_queues.setdefault(key, [])
+    q.append((mode, up, finish, x, skip, du))
+    if len(q) >= WGRAD_BATCH:
+        _flush_one(key)
+    elif len(q) == 1 or not _wgrad_flush_queued:
+        # end-of-backward flush; queued again for every fresh queue so that a pass that died half way cannot leave a
+        # later pass without its flush (a second flush of the same pass finds empty queues)
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        _wgrad_flush_queued = True
+
+
 def _sink(p, needed=True):
     """The buffer to accumulate parameter p's gradient into (its `.grad`, created zero-filled when missing), or None when
     in-place accumulation does not apply (switch off, not a leaf parameter, gradient not needed, odd layout)."""
@@ -172,6 +220,7 @@ class _ConvBlock(torch.autograd.Function):
         if not cfg["has_bias"]:
             dbias = None
         s_w = _sink(p_w, ng[2])
+        q_w = s_w                          # queue key for batched launches (None: immediate)
         beta_w = 1.0
         dW = None
         if s_w is None and ng[2]:          # gradient handed back to autograd: finished into a fresh tensor
@@ -188,29 +237,33 @@ class _ConvBlock(torch.autograd.Function):
                 beta_w = 1.0               # fresh zero tensor: only the slice is written
             if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
                 if s_w is not None:
-                    part = ops.conv_wgrad_partial(MODE_CONVT4S2, x, None, du)
-                    dk4 = ops.wgrad_finish(part, torch.empty(part.shape[1:], device=part.device), 2, 4, 4)
-                    # K4[.., 2-t+a, ..] += W[.., t, ..] (a = 0,1)  =>  dW[t] = sum of the 2x2 window of dK4 at (2-t), per axis
-                    ops.k4_to_w3(dk4, s_w, 0, beta_w)
+                    def fin(part, s_w=s_w, beta_w=beta_w):
+                        dk4 = ops.wgrad_finish(part, torch.empty(part.shape[1:], device=part.device), 2, 4, 4)
+                        # K4[.., 2-t+a, ..] += W[.., t, ..] (a = 0,1)  =>  dW[t] = sum of the 2x2 window of dK4 at (2-t), per axis
+                        ops.k4_to_w3(dk4, s_w, 0, beta_w)
+                    _wgrad(MODE_CONVT4S2, x, None, du, False, q_w, fin, "k4")
                 if need_x:
                     dx = ops.conv4x4s2(du, _upconv_weights(weight, c1)[1], None, None, act=ACT_NONE)
             elif kind == "conv3":
                 if s_w is not None:
-                    ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, x, None, du, upsample=up), s_w, 0, 3, 3,
-                                     ctot=weight.shape[1], c_lo=0, beta=beta_w)
+                    _wgrad(MODE_CONV3, x, None, du, up, q_w,
+                           lambda part, s_w=s_w, beta_w=beta_w, ct=weight.shape[1]: ops.wgrad_finish(
+                               part, s_w, 0, 3, 3, ctot=ct, c_lo=0, beta=beta_w), "xh")
                 if need_x:
                     dxu = ops.conv3x3(du, None, _packed(weight, True, 0, c1, 1), None, None, act=ACT_NONE)
                     dx = ops.upsample2x_bwd(dxu) if up else dxu
             else:
                 if s_w is not None:
-                    ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, x, None, du), s_w, 1, 4, 4,
-                                     ctot=weight.shape[0], c_lo=0, beta=beta_w)
+                    _wgrad(MODE_CONVT4S2, x, None, du, False, q_w,
+                           lambda part, s_w=s_w, beta_w=beta_w, ct=weight.shape[0]: ops.wgrad_finish(
+                               part, s_w, 1, 4, 4, ctot=ct, c_lo=0, beta=beta_w), "xh")
                 if need_x:
                     dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
             return (dx, None, dW, dbias, dgamma, dbeta, du if ng[6] else None, None)
         if kind == "conv3":
             if s_w is not None:
-                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, x, skip, du, upsample=up), s_w, 0, 3, 3, beta=beta_w)
+                _wgrad(MODE_CONV3, x, skip, du, up, q_w,
+                       lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 0, 3, 3, beta=beta_w), "full")
             if need_x:  # dgrad = the same igemm with the flipped / transposed weights
                 wd = _packed(weight, True, 0, c1, 1)
                 dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
@@ -220,12 +273,14 @@ class _ConvBlock(torch.autograd.Function):
                                     act=ACT_NONE)
         elif kind == "conv4s2":
             if s_w is not None:
-                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV4S2, x, None, du), s_w, 0, 4, 4, beta=beta_w)
+                _wgrad(MODE_CONV4S2, x, None, du, False, q_w,
+                       lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 0, 4, 4, beta=beta_w), "full")
             if need_x:
                 dx = ops.convT4x4s2(du, None, _packed(weight, True), None, None, act=ACT_NONE)
         elif kind == "convT4s2":
             if s_w is not None:
-                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, x, skip, du), s_w, 1, 4, 4, beta=beta_w)
+                _wgrad(MODE_CONVT4S2, x, skip, du, False, q_w,
+                       lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 1, 4, 4, beta=beta_w), "full")
             if need_x:
                 dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
             if need_skip:
@@ -264,19 +319,22 @@ class _SkipHalf(torch.autograd.Function):
         kind, c1 = ctx.cfg["kind"], ctx.cfg["c1"]
         ds = ops.to_nhwc(ds)
         s_w, dW = _sink(ctx.param, ctx.needs_input_grad[1]), None
+        q_w = s_w
         if s_w is None and ctx.needs_input_grad[1]:
             s_w = dW = torch.zeros_like(weight, memory_format=torch.contiguous_format)
         dskip = None
         if kind == "conv3":     # the channel slice [c1, Ctot) of the weight's gradient
             if s_w is not None:
-                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONV3, skip, None, ds), s_w, 0, 3, 3, ctot=weight.shape[1],
-                                 c_lo=c1, beta=1.0)
+                _wgrad(MODE_CONV3, skip, None, ds, False, q_w,
+                       lambda part, s_w=s_w, ct=weight.shape[1]: ops.wgrad_finish(part, s_w, 0, 3, 3, ctot=ct, c_lo=c1,
+                                                                                  beta=1.0), "sk")
             if ctx.needs_input_grad[0]:
                 dskip = ops.conv3x3(ds, None, _packed(weight, True, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
         else:
             if s_w is not None:
-                ops.wgrad_finish(ops.conv_wgrad_partial(MODE_CONVT4S2, skip, None, ds), s_w, 1, 4, 4, ctot=weight.shape[0],
-                                 c_lo=c1, beta=1.0)
+                _wgrad(MODE_CONVT4S2, skip, None, ds, False, q_w,
+                       lambda part, s_w=s_w, ct=weight.shape[0]: ops.wgrad_finish(part, s_w, 1, 4, 4, ctot=ct, c_lo=c1,
+                                                                                  beta=1.0), "sk")
             if ctx.needs_input_grad[0]:
                 dskip = ops.conv4x4s2(ds, _packed(weight, False, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         return dskip, dW, None

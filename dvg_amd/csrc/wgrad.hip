@@ -17,10 +17,17 @@ namespace dvg {
 
 enum { W_CONV3 = 0, W_CONV4S2 = 1, W_CONVT4S2 = 2 };
 
+constexpr int WGRAD_MAX_ITEMS = 8;
+
 struct WgradParams {
-    const float* x;     // forward input, (N, H>>up, W>>up, C1)
-    const float* skip;  // concat input (N,H,W,C2) or nullptr
-    const float* dout;  // gradient w.r.t. the conv output, NHWC on the output grid
+    // `items` (x, skip, dout) triples of IDENTICAL shape: dW = sum over items of dOut_i (x) In_i.  One launch over several
+    // uses of the same layer (the time steps / decoder calls of train.py:213-232 share their weights) makes the GEMM K
+    // dimension `items` times longer, i.e. the K-split partial slabs - 75 MB written and read back per launch whatever
+    // the layer, 17 % of this kernel family's time at one item per launch - are amortised over `items` uses.
+    const float* x[WGRAD_MAX_ITEMS];     // forward input, (N, H>>up, W>>up, C1)
+    const float* skip[WGRAD_MAX_ITEMS];  // concat input (N,H,W,C2) or nullptr
+    const float* dout[WGRAD_MAX_ITEMS];  // gradient w.r.t. the conv output, NHWC on the output grid
+    int items, tiles_item;
     float* partial;     // [S][taps][Cout][Cin]
     int N, H, W;        // forward INPUT grid
     int C1, C2, Cout, upsample;
@@ -72,10 +79,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
     else { Ho = p.H * 2; Wo = p.W * 2; }
 
     // which input tensor holds this ci tile
-    const float* src;
+    const bool from_x = ci0 < p.C1;
     int Cs, cc, sh;
-    if (ci0 < p.C1) { src = p.x; Cs = p.C1; cc = ci0; sh = p.upsample; }
-    else { src = p.skip; Cs = p.C2; cc = ci0 - p.C1; sh = 0; }
+    if (from_x) { Cs = p.C1; cc = ci0; sh = p.upsample; }
+    else { Cs = p.C2; cc = ci0 - p.C1; sh = 0; }
     const int Hs = p.H >> sh, Ws = p.W >> sh;
 
     f32x16 acc[GT];
@@ -104,7 +111,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
     };
     unsigned long long c_stage = 0, c_mfma = 0, c_t0 = p.clk ? clock64() : 0, c_mark = c_t0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        int t = tile;
+        const int item = tile / p.tiles_item;     // wave-uniform: the pointers below are scalar loads from the kernel arguments
+        const float* const src = from_x ? p.x[item] : p.skip[item];
+        const float* const dsrc = p.dout[item];
+        int t = tile - item * p.tiles_item;
         const int tx_i = t % p.tiles_x; t /= p.tiles_x;
         const int ty_i = t % p.tiles_y; t /= p.tiles_y;
         const int n0 = t * TI;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
                 int oy, ox;
                 if (MODE == W_CONVT4S2) { oy = 2 * (y0 + d_ty) + py; ox = 2 * (x0 + d_tx) + px; }
                 else { oy = y0 + d_ty; ox = x0 + d_tx; }
-                return *reinterpret_cast<const f32x4*>(p.dout + (((size_t)min(n, p.N - 1) * Ho + oy) * Wo + ox) * p.Cout + co0 + q4);
+                return *reinterpret_cast<const f32x4*>(dsrc + (((size_t)min(n, p.N - 1) * Ho + oy) * Wo + ox) * p.Cout + co0 + q4);
             }
             const int hp = min((tid + (i - NLD) * 256) >> 4, HP - 1);
             const int n = n0 + hp / (HH * HW), yy = yin0 + (hp % (HH * HW)) / HW, xx = xin0 + hp % HW;
@@ -221,7 +231,8 @@ static int wlaunch(WgradParams p, int Hg, int Wg, hipStream_t stream) {
     p.tiles_y = Hg / TH;
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
-    p.tiles_total = p.tiles_y * p.tiles_x * p.tiles_n;
+    p.tiles_item = p.tiles_y * p.tiles_x * p.tiles_n;
+    p.tiles_total = p.tiles_item * p.items;
     p.tiles_per_split = (p.tiles_total + p.S - 1) / p.S;
     const unsigned grid = (unsigned)p.S * C::NG * p.n_co * p.n_ci;
     static bool attr_set = false;
@@ -254,14 +265,14 @@ static int wgrad_tile(int mode, int Hg, int Wg, int* ti, int* th, int* tw) {
 
 using namespace dvg;
 
-// number of K splits (= leading dimension of `partial`) the wgrad call will use
-extern "C" int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout) {
+// number of K splits (= leading dimension of `partial`) a wgrad call over `items` same-shape uses will make
+extern "C" int dvg_conv_wgrad_splits_multi(int mode, int N, int H, int W, int Cin, int Cout, int items) {
     int Hg = H, Wg = W;
     if (mode == W_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
     if (wgrad_tile(mode, Hg, Wg, &ti, &th, &tw)) return -1;
-    if (Cin % 64 || Cout % 64) return -1;
-    const long tiles = (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw);
+    if (Cin % 64 || Cout % 64 || items < 1 || items > WGRAD_MAX_ITEMS) return -1;
+    const long tiles = (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * items;
     const int groups = mode == W_CONV3 ? 1 : (mode == W_CONV4S2 ? 2 : 4);
     const long base = (long)(Cin / 64) * (Cout / 64) * groups;
     // two workgroups fit a CU (78 KB of LDS each): aim at <= 512 workgroups in ONE residency round — a grid of
@@ -275,13 +286,37 @@ extern "C" int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int
     return (int)S;
 }
 
+extern "C" int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout) {
+    return dvg_conv_wgrad_splits_multi(mode, N, H, W, Cin, Cout, 1);
+}
+
 #define W_DISPATCH(MODE, TI_, TH_, TW_) \
     if (ti == TI_ && th == TH_ && tw == TW_) return wlaunch<MODE, TI_, TH_, TW_>(p, Hg, Wg, (hipStream_t)stream);
 
+extern "C" int dvg_conv_wgrad_multi(int mode, int items, const float* const* x, const float* const* skip,
+                                    const float* const* dout, float* partial, int N, int H, int W, int C1, int C2,
+                                    int Cout, int upsample_x, void* stream);
+
 extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const float* dout, float* partial, int N,
                               int H, int W, int C1, int C2, int Cout, int upsample_x, void* stream) {
-    DVG_REQUIRE(x && dout && partial, DVG_ERR_NULL, "dvg_conv_wgrad: NULL pointer");
-    DVG_REQUIRE((skip != nullptr) == (C2 > 0), DVG_ERR_SHAPE, "dvg_conv_wgrad: skip pointer / C2 mismatch");
+    return dvg_conv_wgrad_multi(mode, 1, &x, skip ? &skip : nullptr, &dout, partial, N, H, W, C1, C2, Cout, upsample_x,
+                                stream);
+}
+
+extern "C" int dvg_conv_wgrad_multi(int mode, int items, const float* const* xs, const float* const* skips,
+                                    const float* const* douts, float* partial, int N, int H, int W, int C1, int C2,
+                                    int Cout, int upsample_x, void* stream) {
+    DVG_REQUIRE(xs && douts && partial, DVG_ERR_NULL, "dvg_conv_wgrad: NULL pointer");
+    DVG_REQUIRE(items >= 1 && items <= WGRAD_MAX_ITEMS, DVG_ERR_SHAPE, "dvg_conv_wgrad: 1 <= items <= %d", WGRAD_MAX_ITEMS);
+    DVG_REQUIRE((skips != nullptr) == (C2 > 0), DVG_ERR_SHAPE, "dvg_conv_wgrad: skip pointer / C2 mismatch");
+    for (int i = 0; i < items; ++i) {
+        DVG_REQUIRE(xs[i] && douts[i] && (C2 == 0 || skips[i]), DVG_ERR_NULL, "dvg_conv_wgrad: NULL pointer in item %d", i);
+        DVG_REQUIRE(aligned16(xs[i]) && aligned16(douts[i]) && (C2 == 0 || aligned16(skips[i])), DVG_ERR_ALIGN,
+                    "dvg_conv_wgrad: alignment of item %d", i);
+    }
+    const float* x = xs[0];
+    const float* skip = C2 ? skips[0] : nullptr;
+    const float* dout = douts[0];
     DVG_REQUIRE(mode >= 0 && mode <= 2, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad mode");
     DVG_REQUIRE(N > 0 && H > 0 && W > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: empty shape");
     DVG_REQUIRE(C1 > 0 && C1 % 64 == 0 && C2 % 64 == 0 && Cout % 64 == 0, DVG_ERR_SHAPE,
@@ -294,21 +329,28 @@ extern "C" int dvg_conv_wgrad(int mode, const float* x, const float* skip, const
     int ti, th, tw;
     DVG_REQUIRE(wgrad_tile(mode, Hg, Wg, &ti, &th, &tw) == 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: unsupported map %dx%d",
                 H, W);
-    WgradParams p{x, skip, dout, partial, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, 0, 0, 0, 0, 0, 0, 0, 0, g_wclk, g_wclk_cap};
-    p.S = dvg_conv_wgrad_splits(mode, N, H, W, C1 + C2, Cout);
+    WgradParams p{};
+    for (int i = 0; i < items; ++i) {
+        p.x[i] = xs[i];
+        p.skip[i] = C2 ? skips[i] : nullptr;
+        p.dout[i] = douts[i];
+    }
+    p.items = items;
+    p.partial = partial;
+    p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Cout = Cout; p.upsample = upsample_x ? 1 : 0;
+    p.clk = g_wclk; p.clk_cap = g_wclk_cap;
+    p.S = dvg_conv_wgrad_splits_multi(mode, N, H, W, C1 + C2, Cout, items);
     DVG_REQUIRE(p.S > 0, DVG_ERR_SHAPE, "dvg_conv_wgrad: bad split");
     p.n_co = Cout / 64;
     p.n_ci = (C1 + C2) / 64;
     if (mode == W_CONV3) {
         W_DISPATCH(W_CONV3, 1, 8, 16)
-        W_DISPATCH(W_CONV3, 2, 8, 8)
         W_DISPATCH(W_CONV3, 1, 8, 8)
     } else if (mode == W_CONV4S2) {
         W_DISPATCH(W_CONV4S2, 1, 4, 8)
         W_DISPATCH(W_CONV4S2, 2, 4, 4)
     } else {
         W_DISPATCH(W_CONVT4S2, 1, 8, 16)
-        W_DISPATCH(W_CONVT4S2, 2, 8, 8)
         W_DISPATCH(W_CONVT4S2, 1, 8, 8)
         W_DISPATCH(W_CONVT4S2, 4, 4, 4)
     }

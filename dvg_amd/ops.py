@@ -543,6 +543,34 @@ def conv_wgrad_partial(mode, x, skip, du, *, upsample=False):
     return partial
 
 
+def conv_wgrad_partial_multi(mode, xs, skips, dus, *, upsample=False):
+    """conv_wgrad_partial over several same-shape uses of ONE layer in one launch (dvg_conv_wgrad_multi): the partial
+    slabs hold sum_i dOut_i (x) In_i.  xs / dus: lists of 1..8 tensors; skips: list or None."""
+    import ctypes as C
+    items = len(xs)
+    x, du = xs[0], dus[0]
+    n, c1, hx, wx = x.shape
+    h, w = (hx * 2, wx * 2) if upsample else (hx, wx)
+    c2 = 0 if skips is None else skips[0].shape[1]
+    cout, cin = du.shape[1], c1 + c2
+    taps = 9 if mode == MODE_CONV3 else 16
+    for i in range(items):
+        if xs[i].shape != x.shape or dus[i].shape != du.shape or not is_nhwc(xs[i]) or not is_nhwc(dus[i]) or \
+                (c2 and (skips[i].shape != skips[0].shape or not is_nhwc(skips[i]))):
+            raise RuntimeError("conv_wgrad_partial_multi: items must share one NHWC shape")
+    s = lib().dvg_conv_wgrad_splits_multi(mode, n, h, w, cin, cout, items)
+    if s <= 0:
+        raise RuntimeError(f"conv_wgrad: unsupported shape N={n} H={h} W={w} Cin={cin} Cout={cout} items={items}")
+    partial = torch.empty((s, taps, cout, cin), device=x.device, dtype=torch.float32)
+    arr = C.c_void_p * items
+    px, pd = arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dus])
+    ps = arr(*[t.data_ptr() for t in skips]) if c2 else None
+    _run("conv_wgrad", items * 2.0 * du.numel() * taps * cin / (4 if mode == MODE_CONVT4S2 else 1),
+         4.0 * (items * (x.numel() + du.numel()) + partial.numel()), lib().dvg_conv_wgrad_multi, mode, items, px, ps, pd,
+         _p(partial), n, h, w, c1, c2, cout, int(upsample), _stream())
+    return partial
+
+
 def wgrad_finish(partial, dst, kind, kh, kw, *, ctot=None, c_lo=0, beta=0.0):
     """dst = beta * dst + sum of the partial slabs (S, kh*kw, Cout, Cin), addressed as kind 0: Conv2d weight
     (Cout, Ctot, kh, kw)[:, c_lo:c_lo+Cin]; 1: ConvTranspose2d weight (Ctot, Cout, kh, kw)[c_lo:c_lo+Cin] (flipped);

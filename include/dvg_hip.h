@@ -332,6 +332,14 @@ int dvg_conv_wgrad_splits(int mode, int N, int H, int W, int Cin, int Cout);
 int dvg_conv_wgrad(int mode, const float* x, const float* skip, const float* dout,
                    float* partial, int N, int H, int W, int C1, int C2, int Cout,
                    int upsample_x, void* stream);
+/* The same over `items` (1..8) uses of ONE layer with identical shapes - dW = sum_i dOut_i (x) In_i, e.g. the time steps
+ * / decoder calls of train.py:213-232, which share their weights: x / skip / dout are HOST arrays of `items` device
+ * pointers (skip == NULL when C2 == 0).  The GEMM K dimension grows `items`-fold, so the K-split partial slabs
+ * (dvg_conv_wgrad_splits_multi(..., items) of them) are written and reduced once per `items` uses.                */
+int dvg_conv_wgrad_splits_multi(int mode, int N, int H, int W, int Cin, int Cout, int items);
+int dvg_conv_wgrad_multi(int mode, int items, const float* const* x, const float* const* skip,
+                         const float* const* dout, float* partial, int N, int H, int W, int C1, int C2,
+                         int Cout, int upsample_x, void* stream);
 
 /* Finish of a weight gradient IN PLACE in the parameter's gradient buffer (train.py:240 `loss.backward()` accumulates
  * into .grad; here the kernel that finishes the gradient does it, so no per-use gradient tensor and no accumulation

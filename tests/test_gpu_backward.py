@@ -261,8 +261,9 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(family):
     x = params.frames(2100, 4, 1, 64).to(dev())
     gy = params.normal(2101, 4, 1, 64, 64).to(dev())
     res = {}
-    for direct in (True, False):
-        ag.DIRECT_PARAM_GRADS = direct
+    for direct in (True, False, "batch3"):
+        ag.DIRECT_PARAM_GRADS = bool(direct)
+        old_batch, ag.WGRAD_BATCH = ag.WGRAD_BATCH, (3 if direct == "batch3" else (8 if direct else 1))
         try:
             enc, dec = mod.encoder(90, 1), mod.decoder(90, 1)
             enc.load_state_dict(params.fill_state_dict(enc.state_dict(), 2110))
@@ -275,11 +276,13 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(family):
                 ((y * gy).sum() + h.sum()).backward()
             res[direct] = {k: p.grad.detach().clone() for m_ in (enc, dec) for k, p in m_.named_parameters()}
             assert all(p.grad is not None for m_ in (enc, dec) for p in m_.parameters())
+            assert not ag._wgrad_queues, "every queued weight gradient is flushed when backward() returns"
         finally:
-            ag.DIRECT_PARAM_GRADS = True
+            ag.DIRECT_PARAM_GRADS, ag.WGRAD_BATCH = True, old_batch
     for k, g in res[False].items():
         scale = max(float(g.abs().max()), 1e-20)
-        assert float((res[True][k] - g).abs().max()) <= 2e-5 * scale + 1e-9, k
+        assert float((res[True][k] - g).abs().max()) <= 2e-5 * scale + 1e-9, k          # batches of up to 8 uses per launch
+        assert float((res["batch3"][k] - g).abs().max()) <= 2e-5 * scale + 1e-9, k      # batches of 3 (+ a remainder)
 
 
 def test_in_place_gradients_lstm_linear():
