@@ -60,7 +60,7 @@ SIGNATURES = {
     "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
     "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _p]),
-    "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _p]),
     "dvg_act_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "dvg_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_colsum": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -214,9 +214,19 @@ class _ConvBlock(torch.autograd.Function):
         s_g, s_be = _sink(p_g, ng[4]), _sink(p_be, ng[5])
         s_b = _sink(p_b, ng[3]) if cfg["has_bias"] else None
         bn_direct = s_g is not None and s_be is not None and (s_b is not None or not cfg["has_bias"])
+        # x half of a shared concat conv: d(addend) = du of the sharing decoder calls is summed by the same pass that
+        # produces du, into one buffer owned by the share (first call stores, later calls add)
+        holder = cfg.get("ds_holder") if cfg["x_half"] and ng[6] else None
+        du_sum = None
+        if holder is not None:
+            if holder["ds"] is None:
+                holder["ds"] = torch.empty_like(u)
+                du_sum = (holder["ds"], 1)
+            else:
+                du_sum = (holder["ds"], 2)
         du, dgamma, dbeta, dbias = ops.bn_act_bwd(dy, dyp, y, u, gamma.detach(), mean, invstd, cfg["count"], act=act,
                                                   slope=slope, train=cfg["train"],
-                                                  sinks=(s_g, s_be, s_b) if bn_direct else None)
+                                                  sinks=(s_g, s_be, s_b) if bn_direct else None, du_sum=du_sum)
         if not cfg["has_bias"]:
             dbias = None
         s_w = _sink(p_w, ng[2])
@@ -259,7 +269,7 @@ class _ConvBlock(torch.autograd.Function):
                                part, s_w, 1, 4, 4, ctot=ct, c_lo=0, beta=beta_w), "xh")
                 if need_x:
                     dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
-            return (dx, None, dW, dbias, dgamma, dbeta, du if ng[6] else None, None)
+            return (dx, None, dW, dbias, dgamma, dbeta, (du if ng[6] and holder is None else None), None)
         if kind == "conv3":
             if s_w is not None:
                 _wgrad(MODE_CONV3, x, skip, du, up, q_w,
@@ -311,12 +321,18 @@ class _SkipHalf(torch.autograd.Function):
         ctx.save_for_backward(skip, weight)
         ctx.param = weight
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)     # d S arrives through cfg["ds_holder"] (summed in-kernel), not through autograd
         return s
 
     @staticmethod
     def backward(ctx, ds):
         skip, weight = ctx.saved_tensors
         kind, c1 = ctx.cfg["kind"], ctx.cfg["c1"]
+        held = ctx.cfg["ds_holder"]["ds"]
+        if held is not None:
+            ds = held if ds is None else ds + held
+        if ds is None:
+            return None, None, None
         ds = ops.to_nhwc(ds)
         s_w, dW = _sink(ctx.param, ctx.needs_input_grad[1]), None
         q_w = s_w
@@ -349,9 +365,10 @@ def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, 
         key = (id(conv), id(skip), skip._version)
         ent = share.get(key)
         if ent is None or ent[0] is not skip:
-            s = _SkipHalf.apply(ops.to_nhwc(skip), conv.weight, {"kind": kind, "c1": x.shape[1]})
-            share[key] = ent = (skip, s)        # holds the skip alive while the scope lives: ids cannot be recycled
-        return _ConvBlock.apply(x, None, conv.weight, conv.bias, bn.weight, bn.bias, ent[1], cfg)
+            holder = {"ds": None}
+            s = _SkipHalf.apply(ops.to_nhwc(skip), conv.weight, {"kind": kind, "c1": x.shape[1], "ds_holder": holder})
+            share[key] = ent = (skip, s, holder)   # holds the skip alive while the scope lives: ids cannot be recycled
+        return _ConvBlock.apply(x, None, conv.weight, conv.bias, bn.weight, bn.bias, ent[1], dict(cfg, ds_holder=ent[2]))
     return _ConvBlock.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, None, cfg)
 
 

@@ -182,9 +182,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
+// `sum` (optional): a second output shared by several calls - sum_mode 1: sum = du, 2: sum += du.  It collects d(addend)
+// of the decoder calls that share one skip half (autograd._SkipHalf): their three du tensors used to be added by two
+// separate full-tensor launches per block and time step.
 __global__ void affine3_kernel(const float* __restrict__ dp, const float* __restrict__ u,
                                const float* __restrict__ A, const float* __restrict__ B,
-                               const float* __restrict__ Cc, float* __restrict__ du, long n4, int C4) {
+                               const float* __restrict__ Cc, float* __restrict__ du, long n4, int C4,
+                               float* __restrict__ sum, int sum_mode) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         const f32x4 d = reinterpret_cast<const f32x4*>(dp)[i];
@@ -195,6 +199,14 @@ __global__ void affine3_kernel(const float* __restrict__ dp, const float* __rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = fmaf(a[k], d[k], fmaf(b[k], uv[k], cc[k]));
         reinterpret_cast<f32x4*>(du)[i] = o;
+        if (sum_mode == 1) {
+            reinterpret_cast<f32x4*>(sum)[i] = o;
+        } else if (sum_mode == 2) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(sum)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += t[k];
+            reinterpret_cast<f32x4*>(sum)[i] = o;
+        }
     }
 }
 
@@ -606,12 +618,17 @@ extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float*
 }
 
 extern "C" int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B, const float* Cc,
-                                 float* du, long n, int C, void* stream) {
+                                 float* du, long n, int C, float* sum, int sum_mode, void* stream) {
     DVG_REQUIRE(dp && u && A && B && Cc && du, DVG_ERR_NULL, "dvg_affine3_apply: NULL pointer");
     DVG_REQUIRE(n > 0 && C > 0 && n % C == 0, DVG_ERR_SHAPE, "dvg_affine3_apply: bad shape");
-    if (C % 4 == 0 && aligned16(dp) && aligned16(u) && aligned16(du) && aligned16(A) && aligned16(B) && aligned16(Cc))
+    DVG_REQUIRE(sum_mode >= 0 && sum_mode <= 2 && (sum_mode == 0 || (sum != nullptr && sum != du)), DVG_ERR_SHAPE,
+                "dvg_affine3_apply: bad sum_mode / sum");
+    const bool vec = C % 4 == 0 && aligned16(dp) && aligned16(u) && aligned16(du) && aligned16(A) && aligned16(B) &&
+                     aligned16(Cc) && aligned16(sum);
+    DVG_REQUIRE(sum_mode == 0 || vec, DVG_ERR_ALIGN, "dvg_affine3_apply: the sum output needs C %% 4 == 0 and 16-byte alignment");
+    if (vec)
         hipLaunchKernelGGL(affine3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B, Cc,
-                           du, n / 4, C / 4);
+                           du, n / 4, C / 4, sum, sum_mode);
     else
         hipLaunchKernelGGL(affine3_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B,
                            Cc, du, n, C);

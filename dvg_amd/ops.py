@@ -494,11 +494,11 @@ def transpose2d(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=True, sinks=None):
+def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=True, sinks=None, du_sum=None):
     """BatchNorm(+act, +2x2 max-pool) backward.  dy/dyp/y/u NHWC-in-memory (N,C,H,W) tensors (2-D [rows][C]
     tensors are passed as (rows,C,1,1)).  Returns (du, dgamma, dbeta, dbias); with `sinks` = (g_gamma, g_beta, g_bias or
     None) the three parameter gradients are ACCUMULATED into those buffers by the finalize kernel and None is returned
-    in their place."""
+    in their place.  du_sum = (tensor like du, mode): a second output, mode 1: du_sum = du, 2: du_sum += du."""
     n, c, h, w = y.shape
     pool = dyp is not None
     rows = lib().dvg_bn_act_bwd_rows(n, h, w, int(pool))
@@ -519,8 +519,11 @@ def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=T
     check(lib().dvg_bn_bwd_finalize(_p(partial), rows, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]),
                                     _p(coef[2]), _p(outs[0]), _p(outs[1]), _p(outs[2]), c, float(count), int(train),
                                     acc, _stream()), "bn_bwd_finalize")
+    sum_t, sum_mode = (None, 0) if du_sum is None else du_sum
+    if sum_t is not None and (sum_t.shape != dp.shape or sum_t.stride() != dp.stride()):
+        raise RuntimeError("bn_act_bwd: du_sum must have du's shape and layout")
     _run("affine3_apply", 0.0, 4.0 * 3 * y.numel(), lib().dvg_affine3_apply, _p(dp), _p(u), _p(coef[0]), _p(coef[1]),
-         _p(coef[2]), _p(dp), dp.numel(), c, _stream())
+         _p(coef[2]), _p(dp), dp.numel(), c, _p(sum_t), int(sum_mode), _stream())
     return dp, dgamma, dbeta, dbias
 
 

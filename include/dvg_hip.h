@@ -309,9 +309,11 @@ int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, con
                         const float* invstd, float* coefA, float* coefB, float* coefC,
                         float* dgamma, float* dbeta, float* dbias, int C, double count,
                         int train, int accumulate /* dgamma / dbeta / dbias += */, void* stream);
-/* pass 3: du = A[c]*dp + B[c]*u + Cc[c] over n elements (n %% C == 0); du may alias dp. */
+/* pass 3: du = A[c]*dp + B[c]*u + Cc[c] over n elements (n %% C == 0); du may alias dp.  `sum` (optional second output,
+ * same shape, not aliasing du): sum_mode 1: sum = du, 2: sum += du, 0: unused - d(addend) of the decoder calls of one
+ * time step that share a skip half (train.py:227-231) is collected there instead of by separate additions.           */
 int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B,
-                      const float* Cc, float* du, long n, int C, void* stream);
+                      const float* Cc, float* du, long n, int C, float* sum, int sum_mode, void* stream);
 /* dpre = dy * act'(y), flat tensors (last layers, nn.Linear+Tanh).               */
 int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope,
                 void* stream);
