@@ -38,7 +38,10 @@
 
 namespace dvg {
 
-enum { M2_CONV3 = 0, M2_CONV4S2 = 1, M2_CONVT4S2 = 2 };
+// M2_GEMM: batched GEMM y[n][px][co] = sum_ci x[n][px][ci] * w[n][ci][co] on the same machinery (a "1x1 conv" whose weight
+// depends on the image index n): the 16 Winograd-domain products of dvg_winograd_* (n = transform position).  A stage is
+// GT consecutive 16-channel slabs (K = 64) instead of the taps of one chunk.
+enum { M2_CONV3 = 0, M2_CONV4S2 = 1, M2_CONVT4S2 = 2, M2_GEMM = 3 };
 
 struct Igemm2Params {
     const float* x;
@@ -60,6 +63,7 @@ struct Igemm2Params {
     unsigned clk_cap;         // records the buffer holds (workgroups beyond it do not stamp)
     int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
     int stage_prio;  // progress-based s_setprio in the stage loop (launch2 decides; see the stage loop)
+    long w_image_stride;  // M2_GEMM: floats between the packed weights of consecutive images n
 };
 
 static unsigned long long* g_clk = nullptr;
@@ -67,16 +71,20 @@ static unsigned g_clk_cap = 0;
 
 template <int MODE, int TI, int TH, int TW>
 struct Cfg2 {
+    static constexpr bool GEMM = MODE == M2_GEMM;
     static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;
-    static constexpr int SPAN = (MODE == M2_CONV4S2) ? 4 : 3;
+    static constexpr int SPAN = GEMM ? 1 : ((MODE == M2_CONV4S2) ? 4 : 3);
     static constexpr int HH = (TH - 1) * S + SPAN, HW = (TW - 1) * S + SPAN;
     static constexpr int HP = TI * HH * HW;
     static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64;
-    static constexpr int NTAPS = (MODE == M2_CONV3) ? 9 : 16;
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : 4);  // taps resident per stage
+    static constexpr int NTAPS = GEMM ? 1 : ((MODE == M2_CONV3) ? 9 : 16);
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : 4);  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
+    static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr int KC = 16, LD = 20;  // 80-B LDS rows: b128 lane groups land on distinct 16-B slots
-    static constexpr int NLA = (HP * 4 + 255) / 256;
+    static constexpr int NLA1 = (HP * 4 + 255) / 256;                                 // float4 loads per thread per slab
+    static constexpr int NLA = NLA1 * (GEMM ? GT : 1);
+    static constexpr int SLAB = NLA1 * 64 * LD;                                       // floats of one A slab (GEMM mode)
     // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
     static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LD;
     static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
@@ -87,7 +95,8 @@ template <int MODE, int TI, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params p) {
     using C = Cfg2<MODE, TI, TH, TW>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
-                  BN = C::BN, NLA = C::NLA;
+                  BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1;
+    constexpr bool GEMM = C::GEMM;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + C::A_FLOATS;
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     const int tx_i = t % p.tiles_x; t /= p.tiles_x;
     const int ty_i = t % p.tiles_y; t /= p.tiles_y;
     const int n0 = (int)t * TI, y0 = ty_i * TH, x0 = tx_i * TW;
-    const int yin0 = y0 * S - 1, xin0 = x0 * S - 1, nb0 = nb * BN;
+    const int yin0 = y0 * S - (GEMM ? 0 : 1), xin0 = x0 * S - (GEMM ? 0 : 1), nb0 = nb * BN;
+    const float* const wbase = p.w + (GEMM ? (size_t)n0 * p.w_image_stride : 0);
     const int py = par >> 1, px = par & 1;
     const int Cin = p.C1 + p.C2;
 
@@ -139,14 +149,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     unsigned okmask = 0;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-        const int idx = tid + i * 256;
+        const int slab = i / NLA1;                      // GEMM mode: 16-channel slab of the stage this load belongs to
+        const int idx = tid + (i % NLA1) * 256;
         const int hp = idx >> 2, q = idx & 3;
         const int ti = hp / (HH * HW), r = hp % (HH * HW);
         const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
         const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         const int sh = p.upsample;
         okmask |= ok ? (1u << i) : 0u;
-        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : 0;
+        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4 + slab * 16) : 0;
         offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
     }
     const int brow = tid >> 2, bq = tid & 3;  // weight tile: one float4 per thread per tap
@@ -156,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         return grp * GT + tt;
     };
     auto tap_lds = [&](int grp, int tt) -> int {
+        if (GEMM) return tt * C::SLAB;
         int th, tw;
         if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
         else if (MODE == M2_CONV4S2) { th = grp * 2 + (tt >> 2); tw = tt & 3; }
@@ -172,14 +184,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 #pragma unroll
         for (int tt = 0; tt < GT; ++tt)
             rb[tt] = *reinterpret_cast<const f32x4*>(
-                p.w + (((size_t)chunk * C::NTAPS + tap_w(grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4);
+                wbase + (GEMM ? ((size_t)(chunk + tt) * p.Cout + nb0 + brow) * 16 + bq * 4
+                              : (((size_t)chunk * C::NTAPS + tap_w(grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4));
     };
     auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + (i % NLA1) * 256;
             const f32x4 v = ((okmask >> i) & 1u) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&As[(idx >> 2) * LD + (idx & 3) * 4]) = v;  // rows >= HP: padding
+            *reinterpret_cast<f32x4*>(&As[(i / NLA1) * C::SLAB + (idx >> 2) * LD + (idx & 3) * 4]) = v;  // rows >= HP: padding
         }
     };
     auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
@@ -187,6 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         for (int tt = 0; tt < GT; ++tt) *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
     };
 
+    // chunk = index of a 16-channel chunk; a stage consumes CPS of them (1, or GT slabs in GEMM mode)
+    constexpr int CPS = C::CHUNKS_PER_STAGE;
     const int chunk_begin = split * p.cps;
     const int chunk_end = min(Cin / C::KC, chunk_begin + p.cps);
     f32x4 ra[NLA], rb[GT];
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int ngrp = (grp + 1) % NG;
         constexpr bool next_a = has_next && ngrp == 0;
-        const int nchunk = chunk + (ngrp == 0 ? 1 : 0);
+        const int nchunk = chunk + (ngrp == 0 ? CPS : 0);
         if constexpr (next_a) gload_a(nchunk * C::KC, ra);
         if constexpr (has_next) gload_b(nchunk, ngrp, rb);
 
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     auto set_prio = [](int) {};
 #endif
     int chunk = chunk_begin, st = 0;
-    for (; chunk + 1 < chunk_end; ++chunk) {
+    for (; chunk + CPS < chunk_end; chunk += CPS) {
         set_prio(st++);
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
         if constexpr (NG == 2) {
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 
     // ---- epilogue (identical math to v1) --------------------------------------------------------------
     int Ho, Wo;
-    if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
+    if (MODE == M2_CONV3 || MODE == M2_GEMM) { Ho = p.H; Wo = p.W; }
     else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
     else { Ho = p.H * 2; Wo = p.W * 2; }
     const int c = nb0 + wn * 32 + l31;
@@ -630,13 +645,14 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     }
     const int nchunks = (p.C1 + p.C2) / C::KC;
     int Ho, Wo;
-    if (MODE == M2_CONV3) { Ho = p.H; Wo = p.W; }
+    if (MODE == M2_CONV3 || MODE == M2_GEMM) { Ho = p.H; Wo = p.W; }
     else if (MODE == M2_CONV4S2) { Ho = p.H >> 1; Wo = p.W >> 1; }
     else { Ho = p.H * 2; Wo = p.W * 2; }
     const long out_floats = (long)p.N * Ho * Wo * p.Cout;
     int S = (ws != nullptr) ? choose_splitk(wgs, nchunks) : 1;
     if (S > 1 && (long)S * out_floats > ws_floats) return fail(DVG_ERR_SHAPE, "conv_igemm2: split-K workspace too small");
     p.cps = (nchunks + S - 1) / S;
+    p.cps = (p.cps + C::CHUNKS_PER_STAGE - 1) / C::CHUNKS_PER_STAGE * C::CHUNKS_PER_STAGE;   // whole stages per split
     S = (nchunks + p.cps - 1) / p.cps;  // no empty split: the kernel's peeled stage loop needs >= 1 chunk per workgroup
     p.splitk = S;
     p.ws = ws;
@@ -823,4 +839,26 @@ extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const
     D2(M2_CONVT4S2, 1, 8, 8)
     D2(M2_CONVT4S2, 4, 4, 4)
     return fail(DVG_ERR_SHAPE, "dvg_convT4x4s2_bn_act_v2: no kernel");
+}
+
+// Batched GEMM on the igemm machinery: y[b][px][co] = sum_ci x[b][px][ci] * w[b][ci][co] for b < NB "images" of H x W
+// pixels each (x NHWC (NB,H,W,Cin), y NHWC (NB,H,W,Cout), w = NB packed slabs [Cin/16][1][Cout][16] as
+// dvg_pack_conv_weight_k16 writes them for a 1x1 kernel).  The 16 Winograd-domain products of dvg_winograd_* below.
+// Cin % 64 == 0, Cout % 64 == 0, H % 8 == 0, W % 8 == 0.
+extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y, int NB, int H, int W, int Cin, int Cout,
+                                    void* stream) {
+    Igemm2Params p{x, nullptr, w_k16, nullptr, nullptr, y, nullptr, nullptr, NB, H, W, Cin, 0, Cout, 0, DVG_ACT_NONE, 0.f,
+                   0, 0, 0, 0, 0, 1, 0, nullptr};
+    if (int e = checks2(p, "dvg_gemm_batched_k16")) return e;
+    DVG_REQUIRE(Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE,
+                "dvg_gemm_batched_k16: Cin=%d must be a multiple of 64, H=%d W=%d multiples of 8", Cin, H, W);
+    p.w_image_stride = (long)Cin * Cout;
+    float* workspace = nullptr;
+    const long workspace_floats = 0;
+    int Hg = H, Wg = W, ti, th, tw;
+    DVG_REQUIRE(tile2(M2_GEMM, NB, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
+                "dvg_gemm_batched_k16: no tile for %dx%d", H, W);
+    D2(M2_GEMM, 1, 8, 16)
+    D2(M2_GEMM, 1, 8, 8)
+    return fail(DVG_ERR_SHAPE, "dvg_gemm_batched_k16: no kernel");
 }

@@ -1,0 +1,180 @@
+// Winograd F(2x2, 3x3) for the deep 3x3 layers of the eval-mode rollout (vgg_64.py:5-15 at 16x16 and 8x8, 256-512
+// channels: 60 % of the rollout's conv FLOPs).  Exact fp32 arithmetic, 2.25x fewer multiply-adds than the direct form:
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, d = the 4x4 input patch around it (pad 1)
+//
+//   U[xi][ci][co] = (G g G^T)[xi]             dvg_winograd_weight   once per weight version, written in the k16 layout
+//   V[xi][t][ci]  = (B^T d B)[xi]             dvg_winograd_input    one HBM pass: reads x (L2 absorbs the 4x tile overlap), writes 4x its size
+//   M[xi][t][co]  = sum_ci V U                dvg_gemm_batched_k16  16 GEMMs on the igemm machinery (conv_igemm2.hip, M2_GEMM)
+//   y             = act(scale * A^T M A + shift) (+ 2x2 max-pool: a Winograd tile IS a pool window)   dvg_winograd_output
+//
+// xi = 4*a + b over the 4x4 transform positions; t = (n * H/2 + ty) * W/2 + tx over the output tiles.
+// The transforms are HBM-bound elementwise passes (thread = one tile x 4 channels, float4 everywhere).
+#include "dvg_common.h"
+
+namespace dvg {
+
+__global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
+    // thread = (ci, co); writes the 16 transform positions of this filter
+    const long total = (long)cout * cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin), co = (int)(i / cin);
+        const float* g = w + ((size_t)co * cin + ci) * 9;
+        float t[4][3];   // G g
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float g0 = g[s], g1 = g[3 + s], g2 = g[6 + s];
+            t[0][s] = g0;
+            t[1][s] = 0.5f * (g0 + g1 + g2);
+            t[2][s] = 0.5f * (g0 - g1 + g2);
+            t[3][s] = g2;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float r[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                u[(((size_t)(a * 4 + b) * (cin / 16) + ci / 16) * cout + co) * 16 + (ci & 15)] = r[b];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
+                                                             int H, int W, int C4) {
+    const int Ht = H >> 1, Wt = W >> 1;
+    const long T = (long)N * Ht * Wt, total = T * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % Wt);
+        const long r = t / Wt;
+        const int ty = (int)(r % Ht), n = (int)(r / Ht);
+        f32x4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = 2 * ty - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xx = 2 * tx - 1 + b;
+                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                d[a][b] = ok ? reinterpret_cast<const f32x4*>(x)[(((size_t)n * H + yy) * W + xx) * C4 + c4]
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), then the same on columns
+        f32x4 e[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            e[0][b] = d[0][b] - d[2][b];
+            e[1][b] = d[1][b] + d[2][b];
+            e[2][b] = d[2][b] - d[1][b];
+            e[3][b] = d[1][b] - d[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 o0 = e[a][0] - e[a][2], o1 = e[a][1] + e[a][2], o2 = e[a][2] - e[a][1], o3 = e[a][1] - e[a][3];
+            f32x4* dst = reinterpret_cast<f32x4*>(v) + ((size_t)(a * 4) * T + t) * C4 + c4;
+            dst[0] = o0;
+            dst[(size_t)T * C4] = o1;
+            dst[(size_t)2 * T * C4] = o2;
+            dst[(size_t)3 * T * C4] = o3;
+        }
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ y,
+                                                              float* __restrict__ y_pool, int N, int H, int W, int C4,
+                                                              int act, float slope) {
+    const int Ht = H >> 1, Wt = W >> 1;
+    const long T = (long)N * Ht * Wt, total = T * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % Wt);
+        const long r = t / Wt;
+        const int ty = (int)(r % Ht), n = (int)(r / Ht);
+        f32x4 q[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) q[a][b] = reinterpret_cast<const f32x4*>(m)[((size_t)(a * 4 + b) * T + t) * C4 + c4];
+        // A^T q: rows (q0 + q1 + q2, q1 - q2 - q3), then columns
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s0[b] = q[0][b] + q[1][b] + q[2][b];
+            s1[b] = q[1][b] - q[2][b] - q[3][b];
+        }
+        f32x4 o[2][2];
+        o[0][0] = s0[0] + s0[1] + s0[2];
+        o[0][1] = s0[1] - s0[2] - s0[3];
+        o[1][0] = s1[0] + s1[1] + s1[2];
+        o[1][1] = s1[1] - s1[2] - s1[3];
+        const f32x4 sc = scale ? reinterpret_cast<const f32x4*>(scale)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sf = shift ? reinterpret_cast<const f32x4*>(shift)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 mx;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                f32x4 val;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = apply_act(o[pp][qq][k] * sc[k] + sf[k], act, slope);
+                reinterpret_cast<f32x4*>(y)[(((size_t)n * H + 2 * ty + pp) * W + 2 * tx + qq) * C4 + c4] = val;
+                if (POOL) {
+                    if (pp == 0 && qq == 0) mx = val;
+                    else
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], val[k]);
+                }
+            }
+        if (POOL) reinterpret_cast<f32x4*>(y_pool)[(((size_t)n * Ht + ty) * Wt + tx) * C4 + c4] = mx;
+    }
+}
+
+static inline unsigned wgrid(long n) {
+    long g = (n + 255) / 256;
+    return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, void* stream) {
+    DVG_REQUIRE(w_oihw && u_k16, DVG_ERR_NULL, "dvg_winograd_weight: NULL pointer");
+    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0, DVG_ERR_SHAPE, "dvg_winograd_weight: Cin must be a multiple of 16");
+    hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, u_k16,
+                       cout, cin);
+    return check_launch("dvg_winograd_weight");
+}
+
+extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, void* stream) {
+    DVG_REQUIRE(x && v, DVG_ERR_NULL, "dvg_winograd_input: NULL pointer");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_input: even H, W and C %% 4 == 0 needed");
+    DVG_REQUIRE(aligned16(x) && aligned16(v), DVG_ERR_ALIGN, "dvg_winograd_input: alignment");
+    hipLaunchKernelGGL(winograd_input_kernel, dim3(wgrid((long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, v, N, H, W, C / 4);
+    return check_launch("dvg_winograd_input");
+}
+
+extern "C" int dvg_winograd_output(const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
+                                   int H, int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(m && y, DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_output: even H, W and C %% 4 == 0 needed");
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output: bad act");
+    DVG_REQUIRE(aligned16(m) && aligned16(y) && aligned16(y_pool) && aligned16(scale) && aligned16(shift), DVG_ERR_ALIGN,
+                "dvg_winograd_output: alignment");
+    const unsigned g = wgrid((long)N * (H / 2) * (W / 2) * (C / 4));
+    if (y_pool)
+        hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, m, scale, shift, y, y_pool,
+                           N, H, W, C / 4, act, slope);
+    else
+        hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, m, scale, shift, y,
+                           y_pool, N, H, W, C / 4, act, slope);
+    return check_launch("dvg_winograd_output");
+}

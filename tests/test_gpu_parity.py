@@ -542,3 +542,27 @@ def test_rollout_precomputes_frozen_skip_halves_on_a_second_stream():
         replay = [f.clone() for f in g()]
         for t in range(n_eval):
             assert rel_err(hoisted[t], plain[t]) < 2e-5 and rel_err(replay[t], plain[t]) < 2e-5, (family, t)
+
+
+@pytest.mark.parametrize("N,H,C,Cout,pool", [(8, 8, 64, 64, False), (8, 8, 512, 256, True), (4, 16, 256, 256, False),
+                                             (64, 8, 256, 512, True), (2, 32, 128, 64, False)])
+def test_winograd_conv3x3_matches_direct_and_fp64(N, H, C, Cout, pool):
+    """Winograd F(2x2,3x3) path (input transform -> 16 batched GEMMs in the igemm kernel's GEMM mode -> output transform with
+    scale / shift / activation / 2x2 max-pool) against the fp64 reference and the direct implicit-GEMM kernel."""
+    from dvg_amd import ops
+    x = params.normal(2300, N, C, H, H)
+    w = params.normal(2301, Cout, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
+    sc, sh = 1 + 0.1 * params.normal(2302, Cout), 0.1 * params.normal(2303, Cout)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1) +
+                       sh.double().view(1, -1, 1, 1), 0.2)
+    wd = w.to(dev())
+    assert ops.winograd_ok(N, C, H, H, Cout)
+    out = ops.conv3x3_winograd(nhwc(x), ops.winograd_weight(wd), sc.to(dev()), sh.to(dev()), pool=pool)
+    direct = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(wd), sc.to(dev()), sh.to(dev()), pool=pool)
+    y, yd = (out[0], direct[0]) if pool else (out, direct)
+    assert rel_err(y, ref) < 1e-5, rel_err(y, ref)
+    assert rel_err(y, yd) < 1e-5
+    if pool:
+        assert rel_err(out[1], F.max_pool2d(ref, 2, 2)) < 1e-5
+        assert torch.equal(out[1], F.max_pool2d(out[0], 2, 2)), "the pooled output is the max of the stored outputs, bit for bit"
+    assert not ops.winograd_ok(4, 512, 8, 8, 512)     # 64 tiles: not a whole GEMM tile -> the caller keeps the direct kernel
