@@ -64,6 +64,7 @@ struct Igemm2Params {
     int nb_group;  // Cout blocks per XCD-contiguous group of the workgroup order (launch2 picks it; v2 only)
     int stage_prio;  // progress-based s_setprio in the stage loop (launch2 decides; see the stage loop)
     long w_image_stride;  // M2_GEMM: floats between the packed weights of consecutive images n
+    int gemm_ni;          // M2_GEMM: consecutive images one workgroup runs back to back (one pipeline, one epilogue per image)
 };
 
 static unsigned long long* g_clk = nullptr;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     unsigned t = tile_id;
     const int tx_i = t % p.tiles_x; t /= p.tiles_x;
     const int ty_i = t % p.tiles_y; t /= p.tiles_y;
-    const int n0 = (int)t * TI, y0 = ty_i * TH, x0 = tx_i * TW;
+    const int n0 = (int)t * (MODE == M2_GEMM ? p.gemm_ni : TI), y0 = ty_i * TH, x0 = tx_i * TW;
     const int yin0 = y0 * S - (GEMM ? 0 : 1), xin0 = x0 * S - (GEMM ? 0 : 1), nb0 = nb * BN;
     const float* const wbase = p.w + (GEMM ? (size_t)n0 * p.w_image_stride : 0);
     const int py = par >> 1, px = par & 1;
@@ -174,9 +175,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         else { th = 1 + py - (tt >> 1); tw = 1 + px - (tt & 1); }
         return (th * HW + tw) * LD;
     };
+    // M2_GEMM: image (relative to n0) whose operands the NEXT loads fetch; the stage loop moves it on at image boundaries
+    long ld_a_off = 0;
+    const float* ld_w = wbase;
     auto gload_a = [&](int c0, f32x4 (&ra)[NLA]) {
         const bool from_x = c0 < p.C1;
-        const float* src = from_x ? p.x + c0 : p.skip + (c0 - p.C1);
+        const float* src = (from_x ? p.x + c0 : p.skip + (c0 - p.C1)) + (GEMM ? ld_a_off : 0);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(src + (from_x ? offx[i] : offs[i]));
     };
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
 #pragma unroll
         for (int tt = 0; tt < GT; ++tt)
             rb[tt] = *reinterpret_cast<const f32x4*>(
-                wbase + (GEMM ? ((size_t)(chunk + tt) * p.Cout + nb0 + brow) * 16 + bq * 4
+                (GEMM ? ld_w : wbase) + (GEMM ? ((size_t)(chunk + tt) * p.Cout + nb0 + brow) * 16 + bq * 4
                               : (((size_t)chunk * C::NTAPS + tap_w(grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4));
     };
     auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
@@ -223,12 +227,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     // stores are UNCONDITIONAL.  With the loads under one runtime `if` and the stores under another, hipcc's
     // (path-insensitive) s_waitcnt insertion assumed the previous stage's loads could still be pending at the loop
     // head and emitted vmcnt(0) right after the new A loads were issued - a full memory latency exposed per stage.
-    auto stage = [&](const int chunk, auto grp_c, auto has_next_c) {
+    auto stage = [&](const int chunk, auto grp_c, auto has_next_c, const int nchunk_override = -1) {
         constexpr int grp = decltype(grp_c)::value;
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int ngrp = (grp + 1) % NG;
         constexpr bool next_a = has_next && ngrp == 0;
-        const int nchunk = chunk + (ngrp == 0 ? CPS : 0);
+        const int nchunk = nchunk_override >= 0 ? nchunk_override : chunk + (ngrp == 0 ? CPS : 0);
         if constexpr (next_a) gload_a(nchunk * C::KC, ra);
         if constexpr (has_next) gload_b(nchunk, ngrp, rb);
 
@@ -345,6 +349,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     auto set_prio = [](int) {};
 #endif
     int chunk = chunk_begin, st = 0;
+    if constexpr (GEMM) {
+        // gemm_ni images back to back in ONE software pipeline: the loads of image i+1's first stage are in flight while
+        // image i's last stage computes, and there is one prologue per workgroup instead of one per image - the Winograd
+        // GEMMs have K = 128 ... 512, i.e. only 2 ... 8 stages per image.
+        const int spi = (chunk_end - chunk_begin) / CPS;
+        const long a_img = (long)p.H * p.W * p.C1;
+        float* const yimg = p.y + (size_t)n0 * p.H * p.W * p.Cout + nb0 + wn * 32 + l31;
+        for (int img = 0; img < p.gemm_ni; ++img) {
+            for (int sg = 0; sg < spi; ++sg) {
+                const bool wrap = sg == spi - 1, last = wrap && img == p.gemm_ni - 1;
+                ld_a_off = (long)(img + (wrap ? 1 : 0)) * a_img;
+                ld_w = wbase + (size_t)(img + (wrap ? 1 : 0)) * p.w_image_stride;
+                const int nchunk = wrap ? chunk_begin : chunk_begin + (sg + 1) * CPS;
+                set_prio(st++);
+                if (last) stage(chunk_begin + sg * CPS, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+                else stage(chunk_begin + sg * CPS, integral_constant<int, 0>{}, integral_constant<bool, true>{}, nchunk);
+            }
+            float* const yb = yimg + (size_t)img * p.H * p.W * p.Cout;      // raw products: M[n0 + img][pixel][co]
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int mbase = wm * (C::BM / 2) + mt * 32;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout] = acc[mt][reg];
+                    acc[mt][reg] = 0.f;
+                }
+            }
+        }
+    } else {
     for (; chunk + CPS < chunk_end; chunk += CPS) {
         set_prio(st++);
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
@@ -360,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, false>{});
     } else {
         stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    }
     }
 #if DVG_STAGE_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -378,6 +413,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         }
     };
 
+    if constexpr (GEMM) {     // every image's products were stored inside the loop
+        clk_exit();
+        return;
+    }
     // ---- epilogue (identical math to v1) --------------------------------------------------------------
     int Ho, Wo;
     if (MODE == M2_CONV3 || MODE == M2_GEMM) { Ho = p.H; Wo = p.W; }
@@ -622,6 +661,25 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.tiles_y = Hg / TH;
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
+    if (MODE == M2_GEMM) {
+        // images per workgroup: the smallest divisor of N that gives a pipeline of >= 8 stages, as long as the launch keeps
+        // >= 512 workgroups (one full round of two per CU)
+        // images per workgroup: the smallest divisor of N that gives a pipeline of >= 8 stages, as long as the launch keeps
+        // >= 512 workgroups.  (Measured against a rounds x length cost model that preferred fewer, longer workgroups - e.g.
+        // 384 x 3 images instead of 576 x 2 for the 16x16 256 -> 256 layer: 69.6 vs 56.6 us - slots left empty cost more
+        // than a short second round, whose workgroups start as soon as first-round slots free up.)
+        const int spi = ((p.C1 / 16) + C::CHUNKS_PER_STAGE - 1) / C::CHUNKS_PER_STAGE;
+        const long wgs1 = (long)p.tiles_y * p.tiles_x * p.N * (p.Cout / 64);
+        int ni = 1;
+        for (int d = 1; d <= p.N; ++d) {
+            if (p.N % d) continue;
+            if (wgs1 / d < 512 && d > 1) break;
+            ni = d;
+            if (d * spi >= 8) break;
+        }
+        p.gemm_ni = ni;
+        p.tiles_n = p.N / ni;
+    }
     p.nblk_n = p.Cout / 64;
     p.clk = g_clk;
     p.clk_cap = g_clk_cap;
@@ -698,6 +756,12 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
     if (mode != M2_CONV4S2 && Wg % 16 == 0) {
         const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
         if (wgs >= 512) *tw = 16;
+        if (mode == M2_GEMM && *tw == 16) {
+            // batched GEMM: a launch is rounds of 512 resident workgroups; 576 big tiles are 2 rounds for 1.1 rounds of work -
+            // take the half-size tile when its round count x size is smaller (the 8x8-map Winograd GEMMs at B = 64)
+            const long r16 = (wgs + 511) / 512, r8 = (2 * wgs + 511) / 512;
+            if (r8 * 64 < r16 * 128) *tw = 8;
+        }
     }
     return 0;
 }

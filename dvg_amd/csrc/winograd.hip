@@ -134,6 +134,140 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     }
 }
 
+// ---- F(4x4, 3x3): 36 transform positions per 4x4 output tile (2.25 multiplies per output instead of 4; transformed
+// tensors 2.25x the activation instead of 4x).  Lavin's matrices; fp32 error ~1e-5 of the layer's max output (F(2x2): 2e-6).
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void bt4(const f32x4 (&d)[6], f32x4 (&e)[6]) {
+    e[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    e[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    e[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    e[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    e[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    e[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+__device__ __forceinline__ void at4(const f32x4 (&q)[6], f32x4 (&o)[4]) {
+    const f32x4 a = q[1] + q[2], b = q[1] - q[2], c = q[3] + q[4], d = q[3] - q[4];
+    o[0] = q[0] + a + c;
+    o[1] = b + 2.f * d;
+    o[2] = a + 4.f * c;
+    o[3] = b + 8.f * d + q[5];
+}
+
+__global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const long total = (long)cout * cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin), co = (int)(i / cin);
+        const float* g = w + ((size_t)co * cin + ci) * 9;
+        float t[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) t[a][s2] = G[a][0] * g[s2] + G[a][1] * g[3 + s2] + G[a][2] * g[6 + s2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                u[(((size_t)(a * 6 + b) * (cin / 16) + ci / 16) * cout + co) * 16 + (ci & 15)] =
+                    t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+    }
+}
+
+__global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
+                                                              int H, int W, int C4) {
+    const int Ht = H >> 2, Wt = W >> 2;
+    const long T = (long)N * Ht * Wt, total = T * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % Wt);
+        const long r = t / Wt;
+        const int ty = (int)(r % Ht), n = (int)(r / Ht);
+        f32x4 e[6][6];   // B^T d (rows transformed), column b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int xx = 4 * tx - 1 + b;
+            f32x4 d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int yy = 4 * ty - 1 + a;
+                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                d[a] = ok ? reinterpret_cast<const f32x4*>(x)[(((size_t)n * H + yy) * W + xx) * C4 + c4]
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 col[6];
+            bt4(d, col);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) e[a][b] = col[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            f32x4 o[6];
+            bt4(e[a], o);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) reinterpret_cast<f32x4*>(v)[((size_t)(a * 6 + b) * T + t) * C4 + c4] = o[b];
+        }
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               float* __restrict__ y_pool, int N, int H, int W, int C4,
+                                                               int act, float slope) {
+    const int Ht = H >> 2, Wt = W >> 2;
+    const long T = (long)N * Ht * Wt, total = T * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % Wt);
+        const long r = t / Wt;
+        const int ty = (int)(r % Ht), n = (int)(r / Ht);
+        f32x4 s[4][6];   // A^T q (rows), column b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            f32x4 q[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const f32x4*>(m)[((size_t)(a * 6 + b) * T + t) * C4 + c4];
+            f32x4 col[4];
+            at4(q, col);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) s[pp][b] = col[pp];
+        }
+        const f32x4 sc = scale ? reinterpret_cast<const f32x4*>(scale)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sf = shift ? reinterpret_cast<const f32x4*>(shift)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 val[4][4];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            f32x4 o[4];
+            at4(s[pp], o);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[pp][qq][k] = apply_act(o[qq][k] * sc[k] + sf[k], act, slope);
+                reinterpret_cast<f32x4*>(y)[(((size_t)n * H + 4 * ty + pp) * W + 4 * tx + qq) * C4 + c4] = val[pp][qq];
+            }
+        }
+        if (POOL) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    f32x4 mx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        mx[k] = fmaxf(fmaxf(val[2 * pp][2 * qq][k], val[2 * pp][2 * qq + 1][k]),
+                                      fmaxf(val[2 * pp + 1][2 * qq][k], val[2 * pp + 1][2 * qq + 1][k]));
+                    reinterpret_cast<f32x4*>(y_pool)[(((size_t)n * (H >> 1) + 2 * ty + pp) * (W >> 1) + 2 * tx + qq) * C4 + c4] = mx;
+                }
+        }
+    }
+}
+
 static inline unsigned wgrid(long n) {
     long g = (n + 255) / 256;
     return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -143,38 +277,49 @@ static inline unsigned wgrid(long n) {
 
 using namespace dvg;
 
-extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, void* stream) {
+extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, int m, void* stream) {
     DVG_REQUIRE(w_oihw && u_k16, DVG_ERR_NULL, "dvg_winograd_weight: NULL pointer");
-    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0, DVG_ERR_SHAPE, "dvg_winograd_weight: Cin must be a multiple of 16");
-    hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, u_k16,
-                       cout, cin);
+    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0 && (m == 2 || m == 4), DVG_ERR_SHAPE,
+                "dvg_winograd_weight: Cin must be a multiple of 16, m 2 or 4");
+    if (m == 2)
+        hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           u_k16, cout, cin);
+    else
+        hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           u_k16, cout, cin);
     return check_launch("dvg_winograd_weight");
 }
 
-extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, void* stream) {
+extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, void* stream) {
     DVG_REQUIRE(x && v, DVG_ERR_NULL, "dvg_winograd_input: NULL pointer");
-    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, DVG_ERR_SHAPE,
-                "dvg_winograd_input: even H, W and C %% 4 == 0 needed");
+    DVG_REQUIRE((m == 2 || m == 4) && N > 0 && H > 0 && W > 0 && H % m == 0 && W % m == 0 && C > 0 && C % 4 == 0,
+                DVG_ERR_SHAPE, "dvg_winograd_input: m 2 or 4, H and W multiples of m, C %% 4 == 0 needed");
     DVG_REQUIRE(aligned16(x) && aligned16(v), DVG_ERR_ALIGN, "dvg_winograd_input: alignment");
-    hipLaunchKernelGGL(winograd_input_kernel, dim3(wgrid((long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, x, v, N, H, W, C / 4);
+    const unsigned g = wgrid((long)N * (H / m) * (W / m) * (C / 4));
+    if (m == 2)
+        hipLaunchKernelGGL(winograd_input_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, v, N, H, W, C / 4);
+    else
+        hipLaunchKernelGGL(winograd4_input_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, v, N, H, W, C / 4);
     return check_launch("dvg_winograd_input");
 }
 
 extern "C" int dvg_winograd_output(const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
-                                   int H, int W, int C, int act, float slope, void* stream) {
+                                   int H, int W, int C, int act, float slope, int mt, void* stream) {
     DVG_REQUIRE(m && y, DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
-    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, DVG_ERR_SHAPE,
-                "dvg_winograd_output: even H, W and C %% 4 == 0 needed");
+    DVG_REQUIRE((mt == 2 || mt == 4) && N > 0 && H > 0 && W > 0 && H % mt == 0 && W % mt == 0 && C > 0 && C % 4 == 0,
+                DVG_ERR_SHAPE, "dvg_winograd_output: m 2 or 4, H and W multiples of m, C %% 4 == 0 needed");
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output: bad act");
     DVG_REQUIRE(aligned16(m) && aligned16(y) && aligned16(y_pool) && aligned16(scale) && aligned16(shift), DVG_ERR_ALIGN,
                 "dvg_winograd_output: alignment");
-    const unsigned g = wgrid((long)N * (H / 2) * (W / 2) * (C / 4));
-    if (y_pool)
-        hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, m, scale, shift, y, y_pool,
-                           N, H, W, C / 4, act, slope);
+    const unsigned g = wgrid((long)N * (H / mt) * (W / mt) * (C / 4));
+    const hipStream_t st = (hipStream_t)stream;
+    if (mt == 2 && y_pool)
+        hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+    else if (mt == 2)
+        hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+    else if (y_pool)
+        hipLaunchKernelGGL(winograd4_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, m, scale, shift, y,
-                           y_pool, N, H, W, C / 4, act, slope);
+        hipLaunchKernelGGL(winograd4_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
     return check_launch("dvg_winograd_output");
 }

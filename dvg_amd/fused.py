@@ -50,28 +50,37 @@ def packed_weight(conv: nn.Module) -> torch.Tensor:
     return wp
 
 
-# Winograd F(2x2,3x3) for the deep eval-mode layers (ops.conv3x3_winograd): 2.25x fewer multiply-adds, exact fp32.  Taken
-# where it measured faster than the direct implicit GEMM at B = 64 and B = 576 (tools/bench_winograd.py): 8x8 maps with
-# >= 256 input channels (x1.24-1.52) and 16x16 256 -> 256 (x1.15); at 32x32 / 64x64 the transform passes (4x the
-# activation, HBM-bound) cost more than the GEMM saves.  DVG_WINOGRAD=0 keeps the direct kernel everywhere.
-WINOGRAD = os.environ.get("DVG_WINOGRAD", "1") != "0"
+# Winograd F(m x m, 3x3) for the eval-mode 3x3 layers (ops.conv3x3_winograd): 4x (m = 4) / 2.25x (m = 2) fewer
+# multiply-adds, fp32 throughout.  Taken where it measured faster than the direct implicit GEMM at B = 64 and B = 576
+# (tools/bench_winograd.py): F(4x4) on maps up to 32x32 with >= 128 input channels (x1.22-1.78 at B = 64, x1.9-2.6 at B = 576),
+# F(2x2) where only its tile count fits (8x8 maps at small batch, >= 256 channels: x1.2-1.5); at 64x64 the transform passes
+# (HBM-bound, 2.25-4x the activation) cost more than the GEMM saves.  Rounding: F(4x4) ~1e-5 of a layer's largest output
+# (F(2x2) 2e-6, direct 3e-6), checked end to end against the oracle at the 1e-4 bar (tests/test_gpu_parity.py).
+# DVG_WINOGRAD = 0: direct kernel everywhere; 2: F(2x2) only; 4 (default): both.
+WINOGRAD = int(os.environ.get("DVG_WINOGRAD", "4"))
+if WINOGRAD not in (0, 2, 4):
+    raise RuntimeError("DVG_WINOGRAD must be 0, 2 or 4")
 
 
-def winograd_applies(n, c, h, w, cout) -> bool:
-    if not WINOGRAD or not ops.winograd_ok(n, c, h, w, cout) or c < 256:
-        return False
-    return (h <= 8 and w <= 8) or (h <= 16 and w <= 16 and cout >= 256)
+def winograd_tile(n, c, h, w, cout) -> int:
+    """Winograd output-tile size (4, 2) for this eval-mode 3x3 layer, or 0 for the direct implicit GEMM."""
+    if WINOGRAD >= 4 and c >= 128 and h <= 32 and w <= 32 and ops.winograd_ok(n, c, h, w, cout, 4):
+        return 4
+    if WINOGRAD >= 2 and c >= 256 and ops.winograd_ok(n, c, h, w, cout, 2) and \
+            ((h <= 8 and w <= 8) or (h <= 16 and w <= 16 and cout >= 256)):
+        return 2
+    return 0
 
 
-def winograd_weight(conv: nn.Module) -> torch.Tensor:
-    """U = G g G^T in the batched-GEMM layout, cached per parameter version."""
+def winograd_weight(conv: nn.Module, m: int) -> torch.Tensor:
+    """U = G g G^T in the batched-GEMM layout, cached per parameter version and tile size."""
     slot = _slot(conv)
     key = _ver(conv.weight)
-    hit = slot.get("wino")
+    hit = slot.get(("wino", m))
     if hit is not None and hit[0] == key:
         return hit[1]
-    u = ops.winograd_weight(conv.weight)
-    slot["wino"] = (key, u)
+    u = ops.winograd_weight(conv.weight, m)
+    slot[("wino", m)] = (key, u)
     return u
 
 
@@ -356,9 +365,10 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
                     return ops.convT4x4s2(x, None, _upconv_packed(conv, x.shape[1]), sc, sh, act=act, slope=slope,
                                           addend=hs[1])
                 return ops.conv3x3(x, None, hs[0], sc, sh, upsample=upsample, act=act, slope=slope, addend=hs[1])
-        if skip is None and not upsample and winograd_applies(x.shape[0], x.shape[1], x.shape[2], x.shape[3],
-                                                              conv.weight.shape[0]):
-            return ops.conv3x3_winograd(x, winograd_weight(conv), sc, sh, act=act, slope=slope, pool=pool)
+        if skip is None and not upsample:
+            m = winograd_tile(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.weight.shape[0])
+            if m:
+                return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool)
         return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
     wp = packed_weight(conv)
     u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,

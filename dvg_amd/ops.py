@@ -226,41 +226,45 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
 # ----------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) form of the 3x3 block (eval-mode deep layers; dvg_amd/csrc/winograd.hip)
 # ----------------------------------------------------------------------------------
-def winograd_weight(w: torch.Tensor) -> torch.Tensor:
-    """U = G g G^T of a Conv2d weight (Cout,Cin,3,3), in the k16 layout of the 16 batched GEMMs: (16, Cin/16, 1, Cout, 16)."""
+def winograd_weight(w: torch.Tensor, m: int = 2) -> torch.Tensor:
+    """U = G g G^T of a Conv2d weight (Cout,Cin,3,3) for F(m x m, 3x3), in the k16 layout of the (m+2)^2 batched GEMMs:
+    ((m+2)^2, Cin/16, 1, Cout, 16)."""
     _dev_f32(w, "winograd_weight")
     w = w.detach().contiguous()
     co, ci, kh, kw = w.shape
-    if (kh, kw) != (3, 3) or ci % 16:
-        raise RuntimeError("winograd_weight: (Cout, Cin % 16 == 0, 3, 3) expected")
-    u = torch.empty((16, ci // 16, 1, co, 16), device=w.device, dtype=torch.float32)
-    check(lib().dvg_winograd_weight(_p(w), _p(u), co, ci, _stream()), "winograd_weight")
+    if (kh, kw) != (3, 3) or ci % 16 or m not in (2, 4):
+        raise RuntimeError("winograd_weight: (Cout, Cin % 16 == 0, 3, 3) and m in (2, 4) expected")
+    u = torch.empty(((m + 2) ** 2, ci // 16, 1, co, 16), device=w.device, dtype=torch.float32)
+    check(lib().dvg_winograd_weight(_p(w), _p(u), co, ci, m, _stream()), "winograd_weight")
     return u
 
 
-def winograd_ok(n, c, h, w, cout) -> bool:
+def winograd_ok(n, c, h, w, cout, m: int = 2) -> bool:
     """Shapes the Winograd path takes: whole 128-row GEMM tiles and 64-channel blocks."""
-    return h % 2 == 0 and w % 2 == 0 and c % 64 == 0 and cout % 64 == 0 and (n * (h // 2) * (w // 2)) % 128 == 0
+    return h % m == 0 and w % m == 0 and c % 64 == 0 and cout % 64 == 0 and (n * (h // m) * (w // m)) % 128 == 0
 
 
 def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False):
-    """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> 16 batched GEMMs -> output transform."""
+    """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
+    transform; m (2 or 4) follows from u's leading dimension (16 or 36)."""
     _dev_f32(x, "conv3x3_winograd.x")
     assert is_nhwc(x), "conv3x3_winograd: x must be NHWC in memory"
     n, c, h, w = x.shape
-    cout = u.shape[3]
-    if tuple(u.shape) != (16, c // 16, 1, cout, 16) or not winograd_ok(n, c, h, w, cout):
+    cout, npos = u.shape[3], u.shape[0]
+    mt = {16: 2, 36: 4}.get(npos, 0)
+    if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, 16) or not winograd_ok(n, c, h, w, cout, mt):
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
-    t = n * (h // 2) * (w // 2)
-    v = torch.empty((16, t, c), device=x.device, dtype=torch.float32)
-    m = torch.empty((16, t, cout), device=x.device, dtype=torch.float32)
+    t = n * (h // mt) * (w // mt)
+    v = torch.empty((npos, t, c), device=x.device, dtype=torch.float32)
+    m = torch.empty((npos, t, cout), device=x.device, dtype=torch.float32)
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, _stream())
-    _run("winograd_gemm", 2.0 * 16 * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
-         _p(v), _p(u), _p(m), 16, t // 16, 16, c, cout, _stream())
+    _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, mt,
+         _stream())
+    _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
+         _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream())
     _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
-         _p(y), _p(yp), n, h, w, cout, act, slope, _stream())
+         _p(y), _p(yp), n, h, w, cout, act, slope, mt, _stream())
     return (y, yp) if pool else y
 
 

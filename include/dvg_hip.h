@@ -143,19 +143,20 @@ int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k
                              int N, int H, int W, int C1, int C2, int Cout, int act, float slope,
                              float* workspace, long workspace_floats, const float* addend, void* stream);
 
-/* Winograd F(2x2,3x3) form of vgg_layer for the deep eval-mode layers (vgg_64.py:5-15 at 16x16 / 8x8 maps with 256-512
- * channels): exact fp32, 2.25x fewer multiply-adds.  y = act(scale * A^T[(G g G^T) .* (B^T d B)]A + shift):
- *   dvg_winograd_weight   U (16, Cin/16, 1, Cout, 16) from the Conv2d weight (Cout,Cin,3,3)          once per weight version
- *   dvg_winograd_input    V (16, T, C)  from x NHWC (N,H,W,C), T = N*(H/2)*(W/2) tiles, zero padding 1
- *   dvg_gemm_batched_k16  M (16, T, Cout) = V x U: 16 GEMMs; the tensors are passed as 16 "images" of (T/16) x 16 pixels
- *   dvg_winograd_output   y NHWC (N,H,W,Cout) (+ y_pool, MaxPool2d(2,2) vgg_64.py:49: a Winograd tile IS a pool window)
- * H, W even; C, Cout % 64 == 0; T % 128 == 0.                                                                        */
-int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, void* stream);
-int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, void* stream);
+/* Winograd F(m x m, 3x3), m = 2 or 4, form of vgg_layer for the deep eval-mode layers (vgg_64.py:5-15 at 16x16 / 8x8 maps
+ * with 256-512 channels): fp32 throughout, 2.25x (m = 2) / 4x (m = 4) fewer multiply-adds, P = (m+2)^2 transform
+ * positions.  y = act(scale * A^T[(G g G^T) .* (B^T d B)]A + shift):
+ *   dvg_winograd_weight   U (P, Cin/16, 1, Cout, 16) from the Conv2d weight (Cout,Cin,3,3)           once per weight version
+ *   dvg_winograd_input    V (P, T, C)  from x NHWC (N,H,W,C), T = N*(H/m)*(W/m) tiles, zero padding 1
+ *   dvg_gemm_batched_k16  M (P, T, Cout) = V x U: P GEMMs; the tensors are passed as P "images" of (T/16) x 16 pixels
+ *   dvg_winograd_output   y NHWC (N,H,W,Cout) (+ y_pool, MaxPool2d(2,2) vgg_64.py:49: pool windows never straddle tiles)
+ * H, W multiples of m; C, Cout % 64 == 0; T % 128 == 0.                                                               */
+int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, int m, void* stream);
+int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, void* stream);
 int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y, int NB, int H, int W, int Cin, int Cout,
                          void* stream);
-int dvg_winograd_output(const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
-                        int W, int C, int act, float slope, void* stream);
+int dvg_winograd_output(const float* mm, const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
+                        int W, int C, int act, float slope, int m, void* stream);
 
 /* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
  * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.

@@ -19,18 +19,23 @@ def main():
         x = ops.nhwc_empty(N, C, H, H, dev).normal_()
         w = torch.randn(Cout, C, 3, 3, device=dev) * 0.02
         sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1
-        wp, u = ops.pack_igemm_weight(w), ops.winograd_weight(w)
+        wp = ops.pack_igemm_weight(w)
         td = time_fn(lambda: ops.conv3x3(x, None, wp, sc, sh))
-        tw = time_fn(lambda: ops.conv3x3_winograd(x, u, sc, sh))
-        timer = ops.KernelTimer()
-        ops.set_timer(timer)
-        for _ in range(5):
-            ops.conv3x3_winograd(x, u, sc, sh)
-        ops.set_timer(None)
-        parts = {k: round(1e3 * v["ms"] / v["launches"], 1) for k, v in timer.summary().items()}
         fl = 2.0 * N * H * H * Cout * 9 * C
-        print(f"N {N:3d} {H:2d}x{H:<2d} {C:3d}->{Cout:3d}: direct {td:7.1f} us ({fl / td / 1e6:5.1f} TF)  winograd {tw:7.1f} us "
-              f"(= {fl / tw / 1e6:5.1f} algorithmic TF, x{td / tw:.2f})  parts {parts}")
+        line = f"N {N:3d} {H:2d}x{H:<2d} {C:3d}->{Cout:3d}: direct {td:7.1f} us ({fl / td / 1e6:5.1f} TF)"
+        for m in (2, 4):
+            if not ops.winograd_ok(N, C, H, H, Cout, m):
+                continue
+            u = ops.winograd_weight(w, m)
+            tw = time_fn(lambda: ops.conv3x3_winograd(x, u, sc, sh))
+            timer = ops.KernelTimer()
+            ops.set_timer(timer)
+            for _ in range(5):
+                ops.conv3x3_winograd(x, u, sc, sh)
+            ops.set_timer(None)
+            parts = [round(1e3 * v["ms"] / v["launches"], 1) for v in timer.summary().values()]
+            line += f" | F{m}: {tw:7.1f} us x{td / tw:.2f} {parts}"
+        print(line)
 
 
 if __name__ == "__main__":
