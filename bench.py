@@ -35,6 +35,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command, committed under
 # profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
 TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r02_conv3x3_traffic.json",
+                 ("vgg", "winograd_gemm"): "r02_winograd_gemm_traffic.json",
                  ("dcgan", "conv4x4s2_igemm"): "r02_conv4x4s2_traffic.json",
                  ("dcgan", "convT4x4s2_igemm"): "r02_convT4x4s2_traffic.json"}
 
@@ -260,11 +261,26 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                        "traffic_source": tsrc,
+                       "achieved_is": "EXECUTED flops of the kernel / its HIP-event time (kernel quality against the fp32 MFMA roof)",
                        "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
-                       "algorithmic_flops_per_launch": round(a["flops"] / a["launches"]),
+                       "executed_flops_per_launch": round(a["flops"] / a["launches"]),
+                       "algorithmic_flops_per_launch": round(a["alg_flops"] / a["launches"]),
                        "launches_per_step": a["launches"] // 3,
                        "avg_launch_us": round(1000 * a["ms"] / a["launches"], 2),
                        "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
+    # The 3x3 layers as a whole (SURVEY 8(d) counts a layer's direct-form FLOPs): direct implicit-GEMM launches plus, for the
+    # layers that run as Winograd F(4x4) / F(2x2), their transform + batched-GEMM launches.  Can exceed the fp32 MFMA peak:
+    # Winograd executes 1/4 (1/2.25) of the direct form's multiplies.
+    fam = [k for k in agg if k in ("conv3x3_igemm", "winograd_input", "winograd_gemm", "winograd_output")]
+    if any(k.startswith("winograd") for k in fam):
+        ms = sum(agg[k]["ms"] for k in fam)
+        alg = sum(agg[k]["alg_flops"] for k in ("conv3x3_igemm", "winograd_gemm") if k in agg)
+        exe = sum(agg[k]["flops"] for k in ("conv3x3_igemm", "winograd_gemm") if k in agg)
+        res["roofline"]["conv3x3_layers"] = {
+            "launches_per_step": sum(agg[k]["launches"] for k in fam) // 3, "ms_per_step": round(ms / 3, 3),
+            "algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 2), "executed_tflops": round(exe / (ms * 1e-3) / 1e12, 2),
+            "algorithmic_frac_of_fp32_mfma_peak": round(alg / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "share_of_kernel_time": round(ms / total_ms, 4)}
     res["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
                           "avg_us": round(1000 * v["ms"] / v["launches"], 2),
                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
@@ -396,7 +412,11 @@ def main():
                    # nearest-x2 upsample + conv3x3 == 4x4 stride-2 transposed conv with K4 = W (*) ones(2x2): the x half of
                    # the decoder blocks' first convs runs with 4/9 of the MACs (DVG_UPCONV_AS_CONVT=0: 9-tap form)
                    "upsample_conv3x3": "as transposed 4x4/s2 conv" if (fused_mod.SKIP_HOIST and fused_mod.UPCONV_AS_CONVT)
-                   else "9-tap conv on the upsampled grid"},
+                   else "9-tap conv on the upsampled grid",
+                   # eval-mode 3x3 layers on maps up to 32x32 with >= 128 channels run as Winograd F(4x4,3x3) (F(2x2) where only
+                   # its tile count fits): fp32 throughout, 4x / 2.25x fewer multiplies (DVG_WINOGRAD=0: direct form everywhere)
+                   "conv3x3_deep_layers": {0: "direct implicit GEMM", 2: "Winograd F(2x2,3x3)", 4: "Winograd F(4x4,3x3) / F(2x2,3x3)"}[
+                       fused_mod.WINOGRAD]},
     }
     for k in ("roofline", "kernels"):
         if k in main_res:

@@ -139,7 +139,16 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ void bt4(const f32x4 (&d)[6], f32x4 (&e)[6]) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename V> struct VecN { static constexpr int N = sizeof(V) / 4; };
+template <typename V> __device__ __forceinline__ float vget(const V& v, int k) { return v[k]; }
+template <> __device__ __forceinline__ float vget<float>(const float& v, int) { return v; }
+template <typename V> __device__ __forceinline__ void vset(V& v, int k, float x) { v[k] = x; }
+template <> __device__ __forceinline__ void vset<float>(float& v, int, float x) { v = x; }
+template <typename V> __device__ __forceinline__ V vzero() { V z; for (int k = 0; k < VecN<V>::N; ++k) vset(z, k, 0.f); return z; }
+
+template <typename V>
+__device__ __forceinline__ void bt4(const V (&d)[6], V (&e)[6]) {
     e[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     e[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
     e[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
@@ -148,8 +157,9 @@ __device__ __forceinline__ void bt4(const f32x4 (&d)[6], f32x4 (&e)[6]) {
     e[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
 
-__device__ __forceinline__ void at4(const f32x4 (&q)[6], f32x4 (&o)[4]) {
-    const f32x4 a = q[1] + q[2], b = q[1] - q[2], c = q[3] + q[4], d = q[3] - q[4];
+template <typename V>
+__device__ __forceinline__ void at4(const V (&q)[6], V (&o)[4]) {
+    const V a = q[1] + q[2], b = q[1] - q[2], c = q[3] + q[4], d = q[3] - q[4];
     o[0] = q[0] + a + c;
     o[1] = b + 2.f * d;
     o[2] = a + 4.f * c;
@@ -177,6 +187,10 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// V = f32x4 / f32x2 / float: channels per thread.  A thread owns a whole 6x6 patch (36 loads, 36 stores), so the grid is
+// tiles x C / width threads: at 8x8 maps and B = 64 that is 128 workgroups with float4 - the narrower forms fill the chip
+// (accesses stay coalesced: consecutive lanes take consecutive channels) and need a quarter of the registers.
+template <typename V>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
                                                               int H, int W, int C4) {
     const int Ht = H >> 2, Wt = W >> 2;
@@ -187,38 +201,38 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __res
         const int tx = (int)(t % Wt);
         const long r = t / Wt;
         const int ty = (int)(r % Ht), n = (int)(r / Ht);
-        f32x4 e[6][6];   // B^T d (rows transformed), column b
+        V e[6][6];   // B^T d (rows transformed), column b
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int xx = 4 * tx - 1 + b;
-            f32x4 d[6];
+            V d[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const int yy = 4 * ty - 1 + a;
                 const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-                d[a] = ok ? reinterpret_cast<const f32x4*>(x)[(((size_t)n * H + yy) * W + xx) * C4 + c4]
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
+                d[a] = ok ? reinterpret_cast<const V*>(x)[(((size_t)n * H + yy) * W + xx) * C4 + c4] : vzero<V>();
             }
-            f32x4 col[6];
+            V col[6];
             bt4(d, col);
 #pragma unroll
             for (int a = 0; a < 6; ++a) e[a][b] = col[a];
         }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            f32x4 o[6];
+            V o[6];
             bt4(e[a], o);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) reinterpret_cast<f32x4*>(v)[((size_t)(a * 6 + b) * T + t) * C4 + c4] = o[b];
+            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(v)[((size_t)(a * 6 + b) * T + t) * C4 + c4] = o[b];
         }
     }
 }
 
-template <bool POOL>
+template <bool POOL, typename V>
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                float* __restrict__ y_pool, int N, int H, int W, int C4,
                                                                int act, float slope) {
+    constexpr int VN = VecN<V>::N;
     const int Ht = H >> 2, Wt = W >> 2;
     const long T = (long)N * Ht * Wt, total = T * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -227,29 +241,33 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
         const int tx = (int)(t % Wt);
         const long r = t / Wt;
         const int ty = (int)(r % Ht), n = (int)(r / Ht);
-        f32x4 s[4][6];   // A^T q (rows), column b
+        V s[4][6];   // A^T q (rows), column b
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            f32x4 q[6];
+            V q[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const f32x4*>(m)[((size_t)(a * 6 + b) * T + t) * C4 + c4];
-            f32x4 col[4];
+            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const V*>(m)[((size_t)(a * 6 + b) * T + t) * C4 + c4];
+            V col[4];
             at4(q, col);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) s[pp][b] = col[pp];
         }
-        const f32x4 sc = scale ? reinterpret_cast<const f32x4*>(scale)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 sf = shift ? reinterpret_cast<const f32x4*>(shift)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 val[4][4];
+        V sc, sf;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            vset(sc, k, scale ? scale[c4 * VN + k] : 1.f);
+            vset(sf, k, shift ? shift[c4 * VN + k] : 0.f);
+        }
+        V val[4][4];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            f32x4 o[4];
+            V o[4];
             at4(s[pp], o);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) val[pp][qq][k] = apply_act(o[qq][k] * sc[k] + sf[k], act, slope);
-                reinterpret_cast<f32x4*>(y)[(((size_t)n * H + 4 * ty + pp) * W + 4 * tx + qq) * C4 + c4] = val[pp][qq];
+                for (int k = 0; k < VN; ++k) vset(val[pp][qq], k, apply_act(vget(o[qq], k) * vget(sc, k) + vget(sf, k), act, slope));
+                reinterpret_cast<V*>(y)[(((size_t)n * H + 4 * ty + pp) * W + 4 * tx + qq) * C4 + c4] = val[pp][qq];
             }
         }
         if (POOL) {
@@ -257,12 +275,12 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
             for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    f32x4 mx;
+                    V mx;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        mx[k] = fmaxf(fmaxf(val[2 * pp][2 * qq][k], val[2 * pp][2 * qq + 1][k]),
-                                      fmaxf(val[2 * pp + 1][2 * qq][k], val[2 * pp + 1][2 * qq + 1][k]));
-                    reinterpret_cast<f32x4*>(y_pool)[(((size_t)n * (H >> 1) + 2 * ty + pp) * (W >> 1) + 2 * tx + qq) * C4 + c4] = mx;
+                    for (int k = 0; k < VN; ++k)
+                        vset(mx, k, fmaxf(fmaxf(vget(val[2 * pp][2 * qq], k), vget(val[2 * pp][2 * qq + 1], k)),
+                                          fmaxf(vget(val[2 * pp + 1][2 * qq], k), vget(val[2 * pp + 1][2 * qq + 1], k))));
+                    reinterpret_cast<V*>(y_pool)[(((size_t)n * (H >> 1) + 2 * ty + pp) * (W >> 1) + 2 * tx + qq) * C4 + c4] = mx;
                 }
         }
     }
@@ -295,11 +313,19 @@ extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W,
     DVG_REQUIRE((m == 2 || m == 4) && N > 0 && H > 0 && W > 0 && H % m == 0 && W % m == 0 && C > 0 && C % 4 == 0,
                 DVG_ERR_SHAPE, "dvg_winograd_input: m 2 or 4, H and W multiples of m, C %% 4 == 0 needed");
     DVG_REQUIRE(aligned16(x) && aligned16(v), DVG_ERR_ALIGN, "dvg_winograd_input: alignment");
-    const unsigned g = wgrid((long)N * (H / m) * (W / m) * (C / 4));
-    if (m == 2)
-        hipLaunchKernelGGL(winograd_input_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, v, N, H, W, C / 4);
-    else
-        hipLaunchKernelGGL(winograd4_input_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, v, N, H, W, C / 4);
+    const long tiles = (long)N * (H / m) * (W / m);
+    const hipStream_t st = (hipStream_t)stream;
+    if (m == 2) {
+        hipLaunchKernelGGL(winograd_input_kernel, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4);
+    } else {
+        // channels per thread: the widest form that still gives >= 1024 workgroups (see the kernel)
+        if (tiles * (C / 4) >= 1024L * 256)
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x4>, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4);
+        else if (tiles * (C / 2) >= 1024L * 256)
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x2>, dim3(wgrid(tiles * (C / 2))), dim3(256), 0, st, x, v, N, H, W, C / 2);
+        else
+            hipLaunchKernelGGL(winograd4_input_kernel<float>, dim3(wgrid(tiles * C)), dim3(256), 0, st, x, v, N, H, W, C);
+    }
     return check_launch("dvg_winograd_input");
 }
 
@@ -317,9 +343,15 @@ extern "C" int dvg_winograd_output(const float* m, const float* scale, const flo
         hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
     else if (mt == 2)
         hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
-    else if (y_pool)
-        hipLaunchKernelGGL(winograd4_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
-    else
-        hipLaunchKernelGGL(winograd4_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+    else {
+        const long tiles = (long)N * (H / 4) * (W / 4);
+#define W4OUT(POOL_, V_, CW_)                                                                                             \
+    hipLaunchKernelGGL((winograd4_output_kernel<POOL_, V_>), dim3(wgrid(tiles * (C / CW_))), dim3(256), 0, st, m, scale, shift, \
+                       y, y_pool, N, H, W, C / CW_, act, slope)
+        if (tiles * (C / 4) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x4, 4); else W4OUT(false, f32x4, 4); }
+        else if (tiles * (C / 2) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x2, 2); else W4OUT(false, f32x2, 2); }
+        else { if (y_pool) W4OUT(true, float, 1); else W4OUT(false, float, 1); }
+#undef W4OUT
+    }
     return check_launch("dvg_winograd_output");
 }

@@ -26,14 +26,17 @@ class KernelTimer:
         self.records = []  # (name, flops, bytes, ev0, ev1)
 
     def summary(self):
+        """Per kernel name: launches, ms, EXECUTED flops, algorithmic bytes, and `alg_flops` = the direct-form FLOPs of the
+        layer a launch belongs to (differs from `flops` only for the Winograd GEMMs, which execute 1/2.25 or 1/4 of them)."""
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, by, e0, e1 in self.records:
-            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, fl, by, e0, e1, alg in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "alg_flops": 0.0})
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += fl
             a["bytes"] += by
+            a["alg_flops"] += fl if alg is None else alg
         return agg
 
 
@@ -45,7 +48,7 @@ def set_timer(t):
     _timer = t
 
 
-def _run(name, flops, nbytes, fn, *args):
+def _run(name, flops, nbytes, fn, *args, alg_flops=None):
     """Launch through the C ABI; with a KernelTimer installed, bracket the launch with events."""
     if _timer is None:
         check(fn(*args), name)
@@ -54,7 +57,7 @@ def _run(name, flops, nbytes, fn, *args):
     e0.record()
     check(fn(*args), name)
     e1.record()
-    _timer.records.append((name, flops, nbytes, e0, e1))
+    _timer.records.append((name, flops, nbytes, e0, e1, alg_flops))
 
 
 def _p(t):
@@ -262,7 +265,7 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
     _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, mt,
          _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
-         _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream())
+         _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
     _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
          _p(y), _p(yp), n, h, w, cout, act, slope, mt, _stream())
     return (y, yp) if pool else y

@@ -48,6 +48,7 @@ def main():
     # HBM traffic of the dominant kernels per launch: FETCH_SIZE (KB; x2 on gfx950 for wide streaming reads, the
     # MI355X_MICROARCH.md correction) + WRITE_SIZE (KB), launch-weighted over the instantiations of a family
     fams = {"conv3x3": ("vgg", [k for k in out["vgg"] if k.startswith("conv_igemm2<0")]),
+            "winograd_gemm": ("vgg", [k for k in out["vgg"] if k.startswith("conv_igemm2<3")]),
             "conv4x4s2": ("dcgan", [k for k in out["dcgan"] if k.startswith("conv_igemm2<1")]),
             "convT4x4s2": ("dcgan", [k for k in out["dcgan"] if k.startswith("conv_igemm2<2")])}
     for name, (m, keys) in fams.items():
@@ -61,7 +62,7 @@ def main():
             fetch += c["FETCH_SIZE"]["avg"] * d
             write += c["WRITE_SIZE"]["avg"] * d
         if n:
-            json.dump({"kernel": f"{name}_igemm", "family": m, "dispatches": int(n),
+            json.dump({"kernel": name if name.startswith("winograd") else f"{name}_igemm", "family": m, "dispatches": int(n),
                        "fetch_kb_per_launch_raw": fetch / n, "write_kb_per_launch": write / n,
                        "traffic_bytes_per_launch": int((2.0 * fetch / n + write / n) * 1024),
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --model %s --steps 2 "
