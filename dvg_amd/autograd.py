@@ -116,6 +116,49 @@ def _packed(weight, transposed=False, lo=None, hi=None, dim=0):
     return wp
 
 
+def _wino(weight, m, lo=None, hi=None, dgrad=False):
+    """Winograd-domain weights U (ops.winograd_weight) of a Conv2d weight for F(m x m, 3x3), cached per parameter version:
+    forward form, or - dgrad - of the flipped / transposed kernel (optionally of the input-channel slice [lo, hi)) whose
+    3x3 correlation with d(out) is the data gradient."""
+    key = (id(weight), "wino", m, lo, hi, dgrad)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    w = weight.detach()
+    if lo is not None:
+        w = w[:, lo:hi]
+    if dgrad:
+        w = w.transpose(0, 1).flip(2, 3)
+    u = ops.winograd_weight(w.contiguous(), m)
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), u)
+    return u
+
+
+def _conv3_raw(x, weight, b, need_stats, lo=None, hi=None):
+    """Raw 3x3 conv (+ bias) of x with weight[:, lo:hi] and, for train-mode BatchNorm, its per-channel statistics: Winograd
+    where fused.winograd_tile says so (statistics by one dvg_channel_stats pass over the output), else the implicit GEMM."""
+    n, c, h, w = x.shape
+    cout = weight.shape[0]
+    m = fused.winograd_tile(n, c, h, w, cout)
+    if m:
+        u = ops.conv3x3_winograd(x, _wino(weight, m, lo, hi), None, b, act=ACT_NONE)
+        return (u, ops.channel_stats(u.permute(0, 2, 3, 1).reshape(-1, cout))) if need_stats else u
+    wp = _packed(weight) if lo is None else _packed(weight, False, lo, hi, 1)
+    return ops.conv3x3(x, None, wp, None, b, act=ACT_NONE, stats=need_stats)
+
+
+def _dgrad3(du, weight, lo, hi):
+    """Data gradient of a 3x3 conv w.r.t. its input channels [lo, hi): a 3x3 conv of d(out) with the flipped /
+    transposed kernel - Winograd when the shape qualifies."""
+    n, c, h, w = du.shape
+    m = fused.winograd_tile(n, c, h, w, hi - lo)
+    if m:
+        return ops.conv3x3_winograd(du, _wino(weight, m, lo, hi, dgrad=True), None, None, act=ACT_NONE)
+    return ops.conv3x3(du, None, _packed(weight, True, lo, hi, 1), None, None, act=ACT_NONE)
+
+
 def _bn_forward(bn, u, stats, count, act, slope, pool):
     """Shared forward tail: batch (train) or running (eval) statistics -> y (, y_pool), mean, invstd."""
     if bn.training:
@@ -177,6 +220,8 @@ class _ConvBlock(torch.autograd.Function):
                                    addend=addend)
             else:
                 raise RuntimeError(kind)
+        elif kind == "conv3" and skip is None and not up:
+            r = _conv3_raw(x, weight, b, need_stats)
         elif kind == "conv3":
             wp = _packed(weight)
             r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
@@ -260,7 +305,7 @@ class _ConvBlock(torch.autograd.Function):
                            lambda part, s_w=s_w, beta_w=beta_w, ct=weight.shape[1]: ops.wgrad_finish(
                                part, s_w, 0, 3, 3, ctot=ct, c_lo=0, beta=beta_w), "xh")
                 if need_x:
-                    dxu = ops.conv3x3(du, None, _packed(weight, True, 0, c1, 1), None, None, act=ACT_NONE)
+                    dxu = _dgrad3(du, weight, 0, c1)
                     dx = ops.upsample2x_bwd(dxu) if up else dxu
             else:
                 if s_w is not None:
@@ -274,13 +319,11 @@ class _ConvBlock(torch.autograd.Function):
             if s_w is not None:
                 _wgrad(MODE_CONV3, x, skip, du, up, q_w,
                        lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 0, 3, 3, beta=beta_w), "full")
-            if need_x:  # dgrad = the same igemm with the flipped / transposed weights
-                wd = _packed(weight, True, 0, c1, 1)
-                dxu = ops.conv3x3(du, None, wd, None, None, act=ACT_NONE)
+            if need_x:  # dgrad = a 3x3 conv with the flipped / transposed weights (igemm or Winograd)
+                dxu = _dgrad3(du, weight, 0, c1)
                 dx = ops.upsample2x_bwd(dxu) if up else dxu
             if need_skip:
-                dskip = ops.conv3x3(du, None, _packed(weight, True, c1, weight.shape[1], 1), None, None,
-                                    act=ACT_NONE)
+                dskip = _dgrad3(du, weight, c1, weight.shape[1])
         elif kind == "conv4s2":
             if s_w is not None:
                 _wgrad(MODE_CONV4S2, x, None, du, False, q_w,
@@ -315,7 +358,7 @@ class _SkipHalf(torch.autograd.Function):
     def forward(ctx, skip, weight, cfg):
         kind, c1 = cfg["kind"], cfg["c1"]
         if kind == "conv3":
-            s = ops.conv3x3(skip, None, _packed(weight, False, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
+            s = _conv3_raw(skip, weight, None, False, c1, weight.shape[1])
         else:
             s = ops.convT4x4s2(skip, None, _packed(weight, True, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         ctx.save_for_backward(skip, weight)
@@ -345,7 +388,7 @@ class _SkipHalf(torch.autograd.Function):
                        lambda part, s_w=s_w, ct=weight.shape[1]: ops.wgrad_finish(part, s_w, 0, 3, 3, ctot=ct, c_lo=c1,
                                                                                   beta=1.0), "sk")
             if ctx.needs_input_grad[0]:
-                dskip = ops.conv3x3(ds, None, _packed(weight, True, c1, weight.shape[1], 1), None, None, act=ACT_NONE)
+                dskip = _dgrad3(ds, weight, c1, weight.shape[1])
         else:
             if s_w is not None:
                 _wgrad(MODE_CONVT4S2, skip, None, ds, False, q_w,
