@@ -79,7 +79,12 @@ struct Cfg2 {
     static constexpr int HP = TI * HH * HW;
     static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64;
     static constexpr int NTAPS = GEMM ? 1 : ((MODE == M2_CONV3) ? 9 : 16);
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : 4);  // taps (GEMM: 16-channel slabs) per stage
+    // DVG_GEMM_GT: 16-channel slabs per stage of the GEMM modes.  4 (K = 64, 60 KB of LDS with the 128-row tile); 8 was
+    // measured 10-25 % slower on every Winograd shape (80 KB per workgroup: the second workgroup no longer fits the CU).
+#ifndef DVG_GEMM_GT
+#define DVG_GEMM_GT 4
+#endif
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : (GEMM ? DVG_GEMM_GT : 4));  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr int KC = 16, LD = 20;  // 80-B LDS rows: b128 lane groups land on distinct 16-B slots
@@ -914,8 +919,8 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     Igemm2Params p{x, nullptr, w_k16, nullptr, nullptr, y, nullptr, nullptr, NB, H, W, Cin, 0, Cout, 0, DVG_ACT_NONE, 0.f,
                    0, 0, 0, 0, 0, 1, 0, nullptr};
     if (int e = checks2(p, "dvg_gemm_batched_k16")) return e;
-    DVG_REQUIRE(Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE,
-                "dvg_gemm_batched_k16: Cin=%d must be a multiple of 64, H=%d W=%d multiples of 8", Cin, H, W);
+    DVG_REQUIRE(Cin % (16 * DVG_GEMM_GT) == 0 && H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE,
+                "dvg_gemm_batched_k16: Cin=%d must be a multiple of %d, H=%d W=%d multiples of 8", Cin, 16 * DVG_GEMM_GT, H, W);
     p.w_image_stride = (long)Cin * Cout;
     float* workspace = nullptr;
     const long workspace_floats = 0;

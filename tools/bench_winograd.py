@@ -16,6 +16,8 @@ SHAPES = [(64, 64, 64, 64), (64, 32, 128, 128), (64, 16, 128, 256), (64, 16, 256
 def main():
     dev = torch.device("cuda:0")
     for (N, H, C, Cout) in SHAPES:
+        if C < int(os.environ.get("BENCH_MIN_C", "0")):
+            continue
         x = ops.nhwc_empty(N, C, H, H, dev).normal_()
         w = torch.randn(Cout, C, 3, 3, device=dev) * 0.02
         sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1
