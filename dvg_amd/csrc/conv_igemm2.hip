@@ -14,6 +14,7 @@
 //     run (fully coalesced 16-B loads).
 // BN is fixed at 64 (2 waves along N) so that two workgroups share a CU (<= 67 KB LDS each) and
 // cover each other's stage hand-offs.
+#include <cstdlib>
 #include <type_traits>
 
 #include "dvg_common.h"
@@ -34,6 +35,11 @@
 //  DVG_STAGE_PRIO 1: s_setprio(3 - (stage & 3)) at every stage start (see the stage loop)
 #ifndef DVG_STAGE_PRIO
 #define DVG_STAGE_PRIO 1
+#endif
+
+//  DVG_GEMM_WGS_PER_CU: workgroups per CU the 64-row GEMM-mode tile is compiled for (register budget 512 / this per lane)
+#ifndef DVG_GEMM_WGS_PER_CU
+#define DVG_GEMM_WGS_PER_CU 4
 #endif
 
 namespace dvg {
@@ -98,7 +104,7 @@ struct Cfg2 {
 };
 
 template <int MODE, int TI, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params p) {
+__global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : 2) void conv_igemm2_kernel(const Igemm2Params p) {
     using C = Cfg2<MODE, TI, TH, TW>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
                   BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1;
@@ -151,11 +157,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     // element offsets of this thread's halo float4s in x / skip.  Halo / out-of-image slots read offset 0 (a
     // valid address) and are zeroed at the LDS write (okmask): no divergent branch, and no per-path wait
     // bookkeeping, around the loads.
-    long offx[NLA], offs[NLA];
+    // GEMM mode: the GT slabs of a stage share their row offsets (slab s = + 16 s floats): NLA1 offsets, no skip operand
+    constexpr int NOFF = GEMM ? NLA1 : NLA;
+    using aoff_t = typename std::conditional<GEMM, int, long>::type;   // GEMM: offsets inside one image (host checks < 2^31)
+    aoff_t offx[NOFF], offs[GEMM ? 1 : NLA];
     unsigned okmask = 0;
+    if (GEMM) offs[0] = 0;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-        const int slab = i / NLA1;                      // GEMM mode: 16-channel slab of the stage this load belongs to
         const int idx = tid + (i % NLA1) * 256;
         const int hp = idx >> 2, q = idx & 3;
         const int ti = hp / (HH * HW), r = hp % (HH * HW);
@@ -163,8 +172,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         const int sh = p.upsample;
         okmask |= ok ? (1u << i) : 0u;
-        offx[i] = ok ? ((((long)n * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4 + slab * 16) : 0;
-        offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
+        if (!GEMM || i < NLA1)
+            offx[GEMM ? i % NLA1 : i] = (aoff_t)(ok ? ((((long)(GEMM ? 0 : n) * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : 0);
+        if (!GEMM) offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
     }
     const int brow = tid >> 2, bq = tid & 3;  // weight tile: one float4 per thread per tap
 
@@ -181,13 +191,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         return (th * HW + tw) * LD;
     };
     // M2_GEMM: image (relative to n0) whose operands the NEXT loads fetch; the stage loop moves it on at image boundaries
-    long ld_a_off = 0;
+    long ld_a_off = GEMM ? (long)n0 * p.H * p.W * p.C1 : 0;
     const float* ld_w = wbase;
     auto gload_a = [&](int c0, f32x4 (&ra)[NLA]) {
-        const bool from_x = c0 < p.C1;
+        const bool from_x = GEMM || c0 < p.C1;
         const float* src = (from_x ? p.x + c0 : p.skip + (c0 - p.C1)) + (GEMM ? ld_a_off : 0);
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(src + (from_x ? offx[i] : offs[i]));
+        for (int i = 0; i < NLA; ++i)
+            ra[i] = *reinterpret_cast<const f32x4*>(src + (GEMM ? offx[i % NLA1] + (i / NLA1) * 16
+                                                                : (from_x ? offx[GEMM ? 0 : i] : offs[GEMM ? 0 : i])));
     };
     auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[GT]) {
 #pragma unroll
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     const int chunk_end = min(Cin / C::KC, chunk_begin + p.cps);
     f32x4 ra[NLA], rb[GT];
     unsigned long long clk0 = 0, wclk0 = 0;
-    if (p.clk && threadIdx.x == 0) {
+    if (p.clk) {   // wave-uniform condition: the stamps live in SGPRs (under `threadIdx.x == 0` they cost 8 VGPRs kernel-wide)
         clk0 = clock64();
         wclk0 = wall_clock64();
     }
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     lds_store_b(rb);
     __syncthreads();
     unsigned long long clk1 = 0;
-    if (p.clk && threadIdx.x == 0) clk1 = clock64();
+    if (p.clk) clk1 = clock64();
 
     // One stage = all resident taps of one 16-channel chunk from LDS.  GRP (stage within the chunk) and HAS_NEXT
     // are compile-time: the loop below is peeled so that inside it the next stage's global loads and their LDS
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
         for (int img = 0; img < p.gemm_ni; ++img) {
             for (int sg = 0; sg < spi; ++sg) {
                 const bool wrap = sg == spi - 1, last = wrap && img == p.gemm_ni - 1;
-                ld_a_off = (long)(img + (wrap ? 1 : 0)) * a_img;
+                ld_a_off = (long)(n0 + img + (wrap ? 1 : 0)) * a_img;
                 ld_w = wbase + (size_t)(img + (wrap ? 1 : 0)) * p.w_image_stride;
                 const int nchunk = wrap ? chunk_begin : chunk_begin + (sg + 1) * CPS;
                 set_prio(st++);
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(const Igemm2Params 
     __builtin_amdgcn_s_setprio(0);
 #endif
     unsigned long long clk_loop = 0;
-    if (p.clk && threadIdx.x == 0) clk_loop = clock64();
+    if (p.clk) clk_loop = clock64();
     auto clk_exit = [&]() {
         if (p.clk && threadIdx.x == 0 && blockIdx.x < p.clk_cap) {
             unsigned long long* d = p.clk + (size_t)blockIdx.x * 8;
@@ -667,21 +679,14 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
     if (MODE == M2_GEMM) {
-        // images per workgroup: the smallest divisor of N that gives a pipeline of >= 8 stages, as long as the launch keeps
-        // >= 512 workgroups (one full round of two per CU)
-        // images per workgroup: the smallest divisor of N that gives a pipeline of >= 8 stages, as long as the launch keeps
-        // >= 512 workgroups.  (Measured against a rounds x length cost model that preferred fewer, longer workgroups - e.g.
-        // 384 x 3 images instead of 576 x 2 for the 16x16 256 -> 256 layer: 69.6 vs 56.6 us - slots left empty cost more
-        // than a short second round, whose workgroups start as soon as first-round slots free up.)
-        const int spi = ((p.C1 / 16) + C::CHUNKS_PER_STAGE - 1) / C::CHUNKS_PER_STAGE;
-        const long wgs1 = (long)p.tiles_y * p.tiles_x * p.N * (p.Cout / 64);
+        // images per workgroup: ONE.  The kernel can run gemm_ni images back to back in one software pipeline (one prologue
+        // per workgroup instead of one per image) and with 3 workgroups per CU (138 VGPRs) 2-4 images per workgroup measured
+        // a few % faster on the K <= 256 shapes; at 4 per CU (127 VGPRs, __launch_bounds__ above) the extra wave hides the
+        // prologues and the finer-grained workgroups balance the CUs better: 1 image is fastest or tied on every vgg_64
+        // shape (tools/ab_gemm_ni.sh: e.g. 16x16 256->256 48.4 us vs 52.0 (2) / 59.0 (4); 8x8 512->256 31.7 vs 41.7 / 57.6).
         int ni = 1;
-        for (int d = 1; d <= p.N; ++d) {
-            if (p.N % d) continue;
-            if (wgs1 / d < 512 && d > 1) break;
-            ni = d;
-            if (d * spi >= 8) break;
-        }
+        static const char* force_ni = getenv("DVG_GEMM_NI");   // A/B runs only
+        if (force_ni && p.N % atoi(force_ni) == 0) ni = atoi(force_ni);
         p.gemm_ni = ni;
         p.tiles_n = p.N / ni;
     }
@@ -764,8 +769,11 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
         if (mode == M2_GEMM && *tw == 16) {
             // batched GEMM: a launch is rounds of 512 resident workgroups; 576 big tiles are 2 rounds for 1.1 rounds of work -
             // take the half-size tile when its round count x size is smaller (the 8x8-map Winograd GEMMs at B = 64)
-            const long r16 = (wgs + 511) / 512, r8 = (2 * wgs + 511) / 512;
+            // (the 128-row tile runs 2 per CU - 219 VGPRs, 60 KB of LDS -, the 64-row tile 4 per CU)
+            const long r16 = (wgs + 511) / 512, r8 = (2 * wgs + 1023) / 1024;
             if (r8 * 64 < r16 * 128) *tw = 8;
+            static const char* force = getenv("DVG_GEMM_TW");   // A/B runs only
+            if (force) *tw = atoi(force);
         }
     }
     return 0;
@@ -921,6 +929,7 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     if (int e = checks2(p, "dvg_gemm_batched_k16")) return e;
     DVG_REQUIRE(Cin % (16 * DVG_GEMM_GT) == 0 && H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE,
                 "dvg_gemm_batched_k16: Cin=%d must be a multiple of %d, H=%d W=%d multiples of 8", Cin, 16 * DVG_GEMM_GT, H, W);
+    DVG_REQUIRE((long)H * W * Cin < (1L << 31), DVG_ERR_SHAPE, "dvg_gemm_batched_k16: image of %d x %d x %d floats too large", H, W, Cin);
     p.w_image_stride = (long)Cin * Cout;
     float* workspace = nullptr;
     const long workspace_floats = 0;
