@@ -75,6 +75,10 @@ SIGNATURES = {
     "dvg_conv_wgrad": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_conv_wgrad_splits_multi": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "dvg_conv_wgrad_multi": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_winograd_wgrad_operands": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p]),
+    "dvg_winograd_wgrad_splits": (_i, [_l, _i, _i]),
+    "dvg_winograd_wgrad_gemm": (_i, [_p, _p, _p, _l, _i, _i, _p]),
+    "dvg_winograd_wgrad_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "dvg_wgrad_thin_rows": (_i, [_i, _i, _i, _i]),
     "dvg_wgrad_thin": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_lstm_gates_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -46,14 +46,27 @@ _wgrad_queues = {}
 _wgrad_flush_queued = False
 
 
+# Weight gradients of the 3x3 / stride-1 layers on maps up to 32x32 with channel counts that are multiples of 128 in
+# Winograd F(4x4,3x3) form (ops.winograd_wgrad_partial_multi: a quarter of the multiply-adds; DVG_WINOGRAD_WGRAD=0: always
+# the direct kernel).  Both produce the same packed slab, so the finish closures do not care.
+WINOGRAD_WGRAD = os.environ.get("DVG_WINOGRAD_WGRAD", "1") != "0"
+
+
+def _wgrad_partial(mode, xs, skips, dus, up):
+    n, c, h, w = xs[0].shape
+    if WINOGRAD_WGRAD and fused.WINOGRAD and mode == MODE_CONV3 and skips is None and not up and \
+            ops.winograd_wgrad_ok(n, c, h, w, dus[0].shape[1]):
+        return ops.winograd_wgrad_partial_multi(xs, dus)
+    return ops.conv_wgrad_partial_multi(mode, xs, skips, dus, upsample=up)
+
+
 def _flush_one(key):
     q = _wgrad_queues.pop(key, None)
     if not q:
         return
     mode, up, finish = q[0][0], q[0][1], q[0][2]
     xs, skips, dus = [e[3] for e in q], [e[4] for e in q], [e[5] for e in q]
-    part = ops.conv_wgrad_partial_multi(mode, xs, None if skips[0] is None else skips, dus, upsample=up)
-    finish(part)
+    finish(_wgrad_partial(mode, xs, None if skips[0] is None else skips, dus, up))
 
 
 def flush_wgrads():
@@ -68,7 +81,7 @@ def _wgrad(mode, x, skip, du, up, sink, finish, tag):
     otherwise.  finish(partial) reduces the partial slabs into the destination."""
     global _wgrad_flush_queued
     if WGRAD_BATCH <= 1 or sink is None or not DIRECT_PARAM_GRADS:
-        finish(ops.conv_wgrad_partial(mode, x, skip, du, upsample=up))
+        finish(_wgrad_partial(mode, [x], None if skip is None else [skip], [du], up))
         return
     key = (sink.data_ptr(), tag, mode, up, tuple(x.shape), tuple(du.shape), None if skip is None else tuple(skip.shape))
     q = _wgrad_queues.setdefault(key, [])

@@ -192,7 +192,9 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
 // (accesses stay coalesced: consecutive lanes take consecutive channels) and need a quarter of the registers.
 template <typename V>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
-                                                              int H, int W, int C4) {
+                                                              int H, int W, int C4, long Tt, long t_off) {
+    // Tt / t_off: tiles per position of the destination and this call's first tile (the weight-gradient path concatenates
+    // the tiles of several uses of a layer; Tt = N * tiles per image, t_off = 0 otherwise)
     const int Ht = H >> 2, Wt = W >> 2;
     const long T = (long)N * Ht * Wt, total = T * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -222,12 +224,60 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __res
             V o[6];
             bt4(e[a], o);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(v)[((size_t)(a * 6 + b) * T + t) * C4 + c4] = o[b];
+            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(v)[((size_t)(a * 6 + b) * Tt + t_off + t) * C4 + c4] = o[b];
+        }
+    }
+}
+
+// A d for a 4-vector d (A = (A^T)^T, 6x4): the adjoint of at4
+template <typename V>
+__device__ __forceinline__ void a4(const V (&d)[4], V (&o)[6]) {
+    const V s02 = d[0] + d[2], s13 = d[1] + d[3], t = d[0] + 4.f * d[2], u = 2.f * d[1] + 8.f * d[3];
+    o[0] = d[0];
+    o[1] = s02 + s13;
+    o[2] = s02 - s13;
+    o[3] = t + u;
+    o[4] = t - u;
+    o[5] = d[3];
+}
+
+// dM = A dY A^T per 4x4 tile of d(out) (the weight gradient's second operand, wino_wgrad.hip): 16 loads, 36 stores per
+// thread; same tile order and destination layout [position][tile][channel] as the input transform.
+template <typename V>
+__global__ __launch_bounds__(256) void winograd4_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, int N, int H,
+                                                           int W, int C4, long Tt, long t_off) {
+    const int Ht = H >> 2, Wt = W >> 2;
+    const long T = (long)N * Ht * Wt, total = T * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % Wt);
+        const long r = t / Wt;
+        const int ty = (int)(r % Ht), n = (int)(r / Ht);
+        V e[6][4];   // A d over the rows, column b
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            V d[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                d[a] = reinterpret_cast<const V*>(dy)[(((size_t)n * H + 4 * ty + a) * W + 4 * tx + b) * C4 + c4];
+            V col[6];
+            a4(d, col);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) e[a][b] = col[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            V o[6];
+            a4(e[a], o);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(dm)[((size_t)(a * 6 + b) * Tt + t_off + t) * C4 + c4] = o[b];
         }
     }
 }
 
 template <bool POOL, typename V>
+
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                float* __restrict__ y_pool, int N, int H, int W, int C4,
@@ -320,16 +370,53 @@ extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W,
     } else {
         // channels per thread: the widest form that still gives >= 1024 workgroups (see the kernel)
         if (tiles * (C / 4) >= 1024L * 256)
-            hipLaunchKernelGGL(winograd4_input_kernel<f32x4>, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4);
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x4>, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4, tiles, 0L);
         else if (tiles * (C / 2) >= 1024L * 256)
-            hipLaunchKernelGGL(winograd4_input_kernel<f32x2>, dim3(wgrid(tiles * (C / 2))), dim3(256), 0, st, x, v, N, H, W, C / 2);
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x2>, dim3(wgrid(tiles * (C / 2))), dim3(256), 0, st, x, v, N, H, W, C / 2, tiles, 0L);
         else
-            hipLaunchKernelGGL(winograd4_input_kernel<float>, dim3(wgrid(tiles * C)), dim3(256), 0, st, x, v, N, H, W, C);
+            hipLaunchKernelGGL(winograd4_input_kernel<float>, dim3(wgrid(tiles * C)), dim3(256), 0, st, x, v, N, H, W, C, tiles, 0L);
     }
     return check_launch("dvg_winograd_input");
 }
 
-extern "C" int dvg_winograd_output(const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
+// Operands of the Winograd-form weight gradient (wino_wgrad.hip) for ONE use of a layer: V = B^T x B of the layer input
+// x (N,H,W,Cin) and dM = A dY A^T of d(out) (N,H,W,Cout), written at tile offset t_off of buffers that hold t_total tiles
+// per position ([36][t_total][C]; several uses of a layer are concatenated along the tile axis).  x or dy may be NULL to
+// skip that operand.  F(4x4,3x3) only.
+extern "C" int dvg_winograd_wgrad_operands(const float* x, const float* dy, float* v, float* dm, int N, int H, int W, int Cin,
+                                           int Cout, long t_total, long t_off, void* stream) {
+    DVG_REQUIRE((x && v) || (dy && dm), DVG_ERR_NULL, "dvg_winograd_wgrad_operands: nothing to do");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0,
+                DVG_ERR_SHAPE, "dvg_winograd_wgrad_operands: H and W multiples of 4, channels multiples of 4 needed");
+    const long tiles = (long)N * (H / 4) * (W / 4);
+    DVG_REQUIRE(t_off >= 0 && t_off + tiles <= t_total, DVG_ERR_SHAPE,
+                "dvg_winograd_wgrad_operands: tiles [%ld, %ld) outside the buffer of %ld", t_off, t_off + tiles, t_total);
+    DVG_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(v) && aligned16(dm), DVG_ERR_ALIGN,
+                "dvg_winograd_wgrad_operands: alignment");
+    const hipStream_t st = (hipStream_t)stream;
+#define WOPS(KERNEL_, SRC_, DST_, C_)                                                                                          \
+    do {                                                                                                                       \
+        if (tiles * ((C_) / 4) >= 1024L * 256)                                                                                 \
+            hipLaunchKernelGGL(KERNEL_<f32x4>, dim3(wgrid(tiles * ((C_) / 4))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 4, t_total, t_off); \
+        else if (tiles * ((C_) / 2) >= 1024L * 256)                                                                            \
+            hipLaunchKernelGGL(KERNEL_<f32x2>, dim3(wgrid(tiles * ((C_) / 2))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 2, t_total, t_off); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL(KERNEL_<float>, dim3(wgrid(tiles * (C_))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_), t_total, t_off);           \
+    } while (0)
+    if (x && v) {
+        WOPS(winograd4_input_kernel, x, v, Cin);
+        if (int e = check_launch("dvg_winograd_wgrad_operands (input)")) return e;
+    }
+    if (dy && dm) {
+        WOPS(winograd4_dy_kernel, dy, dm, Cout);
+        if (int e = check_launch("dvg_winograd_wgrad_operands (dy)")) return e;
+    }
+#undef WOPS
+    return DVG_OK;
+}
+
+extern "C" int dvg_winograd_output(
+const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
                                    int H, int W, int C, int act, float slope, int mt, void* stream) {
     DVG_REQUIRE(m && y, DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
     DVG_REQUIRE((mt == 2 || mt == 4) && N > 0 && H > 0 && W > 0 && H % mt == 0 && W % mt == 0 && C > 0 && C % 4 == 0,

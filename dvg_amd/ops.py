@@ -622,6 +622,54 @@ def conv_wgrad_partial_multi(mode, xs, skips, dus, *, upsample=False):
     return partial
 
 
+def winograd_wgrad_ok(n, cin, h, w, cout):
+    """Shapes the Winograd-form weight gradient takes: 3x3 / stride 1, maps up to 32x32 in whole 4x4 tiles, channel counts
+    multiples of 128 on both sides."""
+    return h % 4 == 0 and w % 4 == 0 and h <= 32 and w <= 32 and cin % 128 == 0 and cout % 128 == 0 and n > 0
+
+
+def winograd_wgrad_partial_multi(xs, dus):
+    """The packed (1, 9, Cout, Cin) weight-gradient slab of a 3x3 conv, sum_i dOut_i (x) In_i over 1..n same-shape uses, in
+    Winograd F(4x4,3x3) form (dvg_winograd_wgrad_*): interchangeable with conv_wgrad_partial_multi(MODE_CONV3, ...)."""
+    items = len(xs)
+    x, du = xs[0], dus[0]
+    n, cin, h, w = x.shape
+    cout = du.shape[1]
+    if not winograd_wgrad_ok(n, cin, h, w, cout) or tuple(du.shape) != (n, cout, h, w):
+        raise RuntimeError(f"winograd_wgrad: unsupported shape x {tuple(x.shape)} dout {tuple(du.shape)}")
+    for i in range(items):
+        if xs[i].shape != x.shape or dus[i].shape != du.shape or not is_nhwc(xs[i]) or not is_nhwc(dus[i]):
+            raise RuntimeError("winograd_wgrad_partial_multi: items must share one NHWC shape")
+        _dev_f32(xs[i], "winograd_wgrad.x")
+        _dev_f32(dus[i], "winograd_wgrad.dout")
+    t = n * (h // 4) * (w // 4)
+    tp = (items * t + 63) // 64 * 64
+    alloc = torch.empty if tp == items * t else torch.zeros      # padding rows must be zero
+    v = alloc((36, tp, cin), device=x.device, dtype=torch.float32)
+    dm = alloc((36, tp, cout), device=x.device, dtype=torch.float32)
+    for i in range(items):
+        _run("winograd_wgrad_operands", 0.0, 4.0 * 3.25 * (x.numel() + du.numel()), lib().dvg_winograd_wgrad_operands,
+             _p(xs[i]), _p(dus[i]), _p(v), _p(dm), n, h, w, cin, cout, tp, i * t, _stream())
+    s = lib().dvg_winograd_wgrad_splits(tp, cin, cout)
+    if s <= 0:
+        raise RuntimeError(f"winograd_wgrad: unsupported shape tiles={tp} Cin={cin} Cout={cout}")
+    part = torch.empty((s, 36, cout, cin), device=x.device, dtype=torch.float32)
+    _run("winograd_wgrad_gemm", 2.0 * 36 * tp * cin * cout, 4.0 * (v.numel() + dm.numel() + part.numel()),
+         lib().dvg_winograd_wgrad_gemm, _p(dm), _p(v), _p(part), tp, cin, cout, _stream(),
+         alg_flops=items * 2.0 * du.numel() * 9 * cin)
+    packed = torch.empty((1, 9, cout, cin), device=x.device, dtype=torch.float32)
+    if s > 2:
+        # many thin slabs (the 128-channel layers: one output block per position, K split ~30 ways): sum them with the wide
+        # slab reduction first - the transform kernel's one thread per (co, ci) would walk 36 * S loads serially
+        summed = torch.empty((36, cout, cin), device=x.device, dtype=torch.float32)
+        _run("reduce_partials", 0.0, 4.0 * (part.numel() + summed.numel()), lib().dvg_reduce_partials, _p(part), _p(summed),
+             s, summed.numel(), _stream())
+        part, s = summed, 1
+    _run("winograd_wgrad_reduce", 0.0, 4.0 * (part.numel() + packed.numel()), lib().dvg_winograd_wgrad_reduce, _p(part), s,
+         _p(packed), cin, cout, _stream())
+    return packed
+
+
 def wgrad_finish(partial, dst, kind, kh, kw, *, ctot=None, c_lo=0, beta=0.0):
     """dst = beta * dst + sum of the partial slabs (S, kh*kw, Cout, Cin), addressed as kind 0: Conv2d weight
     (Cout, Ctot, kh, kw)[:, c_lo:c_lo+Cin]; 1: ConvTranspose2d weight (Ctot, Cout, kh, kw)[c_lo:c_lo+Cin] (flipped);

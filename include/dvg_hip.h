@@ -358,6 +358,24 @@ int dvg_conv_wgrad_multi(int mode, int items, const float* const* x, const float
                          const float* const* dout, float* partial, int N, int H, int W, int C1, int C2,
                          int Cout, int upsample_x, void* stream);
 
+/* The weight gradient of a 3x3 / stride-1 Conv2d in Winograd F(4x4,3x3) form (vgg_layer, vgg_64.py:5-15, under
+ * train.py:240 `loss.backward()`; maps up to 32x32, Cin and Cout multiples of 128): a quarter of the direct form's
+ * multiply-adds.   dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G:
+ *   dvg_winograd_wgrad_operands  V (36, t_total, Cin) = B^T x B of the layer input x NHWC (N,H,W,Cin) and
+ *                                dM (36, t_total, Cout) = A dY A^T of d(out) NHWC (N,H,W,Cout), written at tile offset
+ *                                t_off: the N*(H/4)*(W/4) tiles of several uses of ONE layer are concatenated along the
+ *                                tile axis (x or dy may be NULL to skip that operand); t_total % 64 == 0, rows no use
+ *                                wrote must be zero
+ *   dvg_winograd_wgrad_gemm      partial (S, 36, Cout, Cin): per position the product dM^T V over the tiles, K-split into
+ *                                S = dvg_winograd_wgrad_splits(t_total, Cin, Cout) slabs (0 = unsupported shape)
+ *   dvg_winograd_wgrad_reduce    packed (9, Cout, Cin) = G^T (sum_s partial[s]) G: ONE slab in dvg_conv_wgrad's layout,
+ *                                which dvg_wgrad_finish places into the parameter's gradient                              */
+int dvg_winograd_wgrad_operands(const float* x, const float* dy, float* v, float* dm, int N, int H, int W, int Cin,
+                                int Cout, long t_total, long t_off, void* stream);
+int dvg_winograd_wgrad_splits(long t_total, int Cin, int Cout);
+int dvg_winograd_wgrad_gemm(const float* dm, const float* v, float* partial, long t_total, int Cin, int Cout, void* stream);
+int dvg_winograd_wgrad_reduce(const float* partial, int S, float* packed, int Cin, int Cout, void* stream);
+
 /* Finish of a weight gradient IN PLACE in the parameter's gradient buffer (train.py:240 `loss.backward()` accumulates
  * into .grad; here the kernel that finishes the gradient does it, so no per-use gradient tensor and no accumulation
  * launch exist):  dst = beta * dst + sum_s partial[s],  partial = the S packed [KH*KW][Cout][Cin] slabs of dvg_conv_wgrad,

@@ -80,6 +80,29 @@ def test_conv3_block_backward(N, H, C1, C2, Cout, up, pool):
     assert float(conv.bias.grad.abs().max()) < 1e-3 * float(ps["w"].grad.abs().max()) + 1e-6  # ~0 under batch stats
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,items", [(8, 8, 128, 128, 1), (3, 8, 128, 256, 2), (4, 16, 256, 128, 3),
+                                                 (2, 32, 128, 128, 1), (8, 8, 512, 512, 8)])
+def test_winograd_weight_gradient_matches_direct_and_fp64(N, H, Cin, Cout, items):
+    """dvg_winograd_wgrad_* (F(4x4,3x3) form, several uses of a layer in one product) against the direct kernel's slabs and
+    against the fp64 weight gradient of F.conv2d; the (3, 8, ...) case has 24 tiles: the zero-padded K tail."""
+    from dvg_amd import ops
+    xs = [ops.to_nhwc(params.normal(20 + i, N, Cin, H, H).to(dev())) for i in range(items)]
+    dus = [ops.to_nhwc(params.normal(40 + i, N, Cout, H, H).to(dev())) for i in range(items)]
+    assert ops.winograd_wgrad_ok(N, Cin, H, H, Cout)
+    packed = ops.winograd_wgrad_partial_multi(xs, dus)
+    assert tuple(packed.shape) == (1, 9, Cout, Cin)
+    direct = ops.conv_wgrad_partial_multi(ops.MODE_CONV3, xs, None, dus).sum(0, keepdim=True)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    sum((F.conv2d(x.double().cpu(), w, None, 1, 1) * du.double().cpu()).sum() for x, du in zip(xs, dus)).backward()
+    ref = w.grad.permute(2, 3, 0, 1).reshape(1, 9, Cout, Cin)
+    assert rel_err(direct, ref) < 2e-5
+    assert rel_err(packed, ref) < 2e-4            # F(4x4,3x3)'s transform constants cost ~1 digit in fp32
+    # through the in-place finish: beta accumulates
+    dst = torch.ones(Cout, Cin, 3, 3, device=dev())
+    ops.wgrad_finish(packed, dst, 0, 3, 3, beta=1.0)
+    assert rel_err(dst - 1.0, w.grad) < 2e-4
+
+
 def _reference_case(family, seed):
     """The B=16 train-mode case of tests/golden/make_golden.py:run_backbone_grads, rebuilt from its seeds."""
     mod = our_module(family, 64)
