@@ -25,8 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WW_BM = 128;                // Cout rows / Cin columns of a workgroup's output block
-// Variants (template parameters; the host picks WW_DEFAULT_*, DVG_WW_DB / DVG_WW_KS override for A/B runs):
-//   KS  tiles (K rows) per stage: 32 or 64
+// Variants (template parameters; the host picks WW_DEFAULT_*, DVG_WW_DB overrides for A/B runs):
+//   KS  tiles (K rows) per stage: 32 (64 measured 2-4 % slower in the single-buffer form and is not instantiated)
 //   DB  true: two LDS stages, one barrier per stage; false: one LDS stage, the next stage's ds_writes behind a barrier
 //       under the last k group's MFMAs (as the forward igemm does)
 constexpr bool WW_DEFAULT_DB = false;
@@ -183,24 +183,20 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(const WwParams 
     stage(st1 - 1, std::integral_constant<bool, false>{});
 
     const size_t slab = (size_t)36 * p.Cout * p.Cin;
-    // One running pointer, advanced by wave-uniform strides: with 32 independent row offsets (row * Cin) hipcc hoisted them
-    // all out of the segment loop as invariants - 64 VGPRs live through the whole kernel.
-    size_t out_off = (size_t)seg * slab + (((size_t)xi * p.Cout + bi * WW_BM + wr * 64 + 4 * hh) * p.Cin + bj * WW_BM + wc * 64 + l31);
-    asm volatile("" : "+v"(out_off));   // opaque: not an invariant to precompute per row (the offset, so that `out` stays a global pointer)
-    float* out = p.part + out_off;
     const int nzero = st1 == p.nst ? p.S - 1 - seg : 0;   // the block's last segment: zero the slabs it did not use
+    float* out = p.part + (size_t)seg * slab + (((size_t)xi * p.Cout + bi * WW_BM + wr * 64) * p.Cin + bj * WW_BM + wc * 64 + l31);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {       // accumulator registers 4g .. 4g+3 = rows 32 m + 8 g + 4 hh + (0..3)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[0] = acc[m][0][4 * g + r];
-                out[32] = acc[m][1][4 * g + r];
-                out += p.Cin;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                out[(size_t)row * p.Cin + n * 32] = acc[m][n][reg];
             }
-            out += 4 * p.Cin;
-        }
+    // (hipcc hoists the 32 row offsets of these stores out of the segment loop - 64 VGPRs live through the kernel, 238 in
+    // all; a running pointer with wave-uniform strides brought that to 174 and measured 4-6 % SLOWER at the same two waves
+    // per SIMD, so the offsets stay)
     // rolled, cooperative and coalesced: with the accumulator stores' 64 row addresses reused for the zero stores hipcc kept
     // them all live across the kernel (256 VGPRs + spills)
     float* zbase = p.part + (size_t)(seg + 1) * slab + ((size_t)xi * p.Cout + bi * WW_BM) * p.Cin + bj * WW_BM;
@@ -243,10 +239,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
 }
 
-static int ww_ks() {
-    static const char* env = getenv("DVG_WW_KS");   // A/B runs only
-    return env && atoi(env) == 64 ? 64 : (env && atoi(env) == 32 ? 32 : WW_DEFAULT_KS);
-}
+static int ww_ks() { return WW_DEFAULT_KS; }   // (64-row stages in the single-buffer form: 237+ VGPRs, 2-4 % slower)
 
 // q = stages per workgroup, W = workgroups, S = slabs (the most segments any output block is cut into)
 static void ww_plan(long Tp, int Cin, int Cout, long* q_out, long* w_out, int* s_out) {
@@ -314,9 +307,7 @@ extern "C" int dvg_winograd_wgrad_gemm(const float* dm, const float* v, float* p
     static const char* env = getenv("DVG_WW_DB");   // A/B runs only
     const bool db = env ? atoi(env) != 0 : WW_DEFAULT_DB;
     const hipStream_t st = (hipStream_t)stream;
-    if (ks == 32) return db ? ww_launch<true, 32>(p, st) : ww_launch<false, 32>(p, st);
-    return db ? fail(DVG_ERR_SHAPE, "dvg_winograd_wgrad_gemm: 64-row stages need the single-buffer variant")
-              : ww_launch<false, 64>(p, st);
+    return db ? ww_launch<true, 32>(p, st) : ww_launch<false, 32>(p, st);
 }
 
 extern "C" int dvg_winograd_wgrad_reduce(const float* partial, int S, float* packed, int Cin, int Cout, void* stream) {
