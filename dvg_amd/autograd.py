@@ -42,6 +42,7 @@ def _c(t):
 # autograd engine's end-of-backward callback, when the backward pass that queued them completes - `.grad` is final when
 # `loss.backward()` returns, as always.  Only with in-place gradients (the finish kernel accumulates into `.grad`).
 WGRAD_BATCH = int(os.environ.get("DVG_WGRAD_BATCH", "8"))
+DENSE_BATCH = int(os.environ.get("DVG_DENSE_BATCH", "64"))   # uses of a Linear / LSTMCell per batched dW GEMM (1: per use)
 _wgrad_queues = {}
 _wgrad_flush_queued = False
 
@@ -69,11 +70,53 @@ def _flush_one(key):
     finish(_wgrad_partial(mode, xs, None if skips[0] is None else skips, dus, up))
 
 
+# Dense layers (Linear, LSTMCell) under BPTT: dW = sum_t dY_t^T X_t is ONE GEMM over the concatenated time steps
+# (K = steps x batch) instead of two transposes, a GEMM and a column sum per step; queued like the conv weight gradients and
+# flushed by the same end-of-backward callback.  Entries: (dY, [inputs...]) per use; sinks: (weight sinks..., bias sinks...).
+_dense_queues = {}
+
+
+def _flush_dense(key):
+    ent = _dense_queues.pop(key, None)
+    if not ent:
+        return
+    w_sinks, b_sinks, uses = ent["w"], ent["b"], ent["uses"]
+    dys = [u[0] for u in uses]
+    dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
+    dyt = ops.transpose2d(dy)
+    for i, s_w in enumerate(w_sinks):
+        if s_w is None:
+            continue
+        xs = [u[1][i] for u in uses]
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+        ops.gemm_nt(dyt, ops.transpose2d(x), None, None, out=s_w, accumulate=True)
+    for s_b in b_sinks:
+        if s_b is not None:
+            ops.colsum(dy, out=s_b, accumulate=True)
+
+
+def _dense_wgrad(w_sinks, b_sinks, dy, inputs):
+    """Queue one use of a dense layer's parameter gradients (all sinks are in-place `.grad` buffers)."""
+    global _wgrad_flush_queued
+    key = tuple(None if t is None else t.data_ptr() for t in list(w_sinks) + list(b_sinks)) + (tuple(dy.shape),)
+    ent = _dense_queues.get(key)
+    if ent is None:
+        ent = _dense_queues[key] = {"w": w_sinks, "b": b_sinks, "uses": []}
+    ent["uses"].append((dy, inputs))
+    if len(ent["uses"]) >= DENSE_BATCH:
+        _flush_dense(key)
+    elif len(ent["uses"]) == 1 or not _wgrad_flush_queued:   # as in _wgrad: every fresh queue asks for the flush
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        _wgrad_flush_queued = True
+
+
 def flush_wgrads():
     global _wgrad_flush_queued
     _wgrad_flush_queued = False
     for key in list(_wgrad_queues):
         _flush_one(key)
+    for key in list(_dense_queues):
+        _flush_dense(key)
 
 
 def _wgrad(mode, x, skip, du, up, sink, finish, tag):
@@ -127,6 +170,20 @@ def _packed(weight, transposed=False, lo=None, hi=None, dim=0):
         _pack_cache.clear()
     _pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), wp)
     return wp
+
+
+def _transposed(weight):
+    """Contiguous transpose of a 2-D parameter, cached per parameter version: the data gradients of Linear / LSTMCell are
+    NT GEMMs against W^T, and BPTT asked for the same transpose once per time step."""
+    key = (id(weight), "T")
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    wt = ops.transpose2d(weight.detach())
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), wt)
+    return wt
 
 
 def _wino(weight, m, lo=None, hi=None, dgrad=False):
@@ -569,8 +626,12 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act != ACT_NONE else _c(dy)
-        dx = ops.gemm_nt(dpre, ops.transpose2d(weight.detach()), None, None) if ctx.needs_input_grad[0] else None
+        dx = ops.gemm_nt(dpre, _transposed(ctx.params[0]), None, None) if ctx.needs_input_grad[0] else None
         s_w = _sink(ctx.params[0], ctx.needs_input_grad[1])
+        s_b0 = _sink(ctx.params[1], ctx.needs_input_grad[2]) if ctx.has_bias else None
+        if DENSE_BATCH > 1 and s_w is not None and (s_b0 is not None or not ctx.has_bias):
+            _dense_wgrad((s_w,), (s_b0,), dpre, (x,))
+            return dx, None, None, None
         dW = ops.gemm_nt(ops.transpose2d(dpre), ops.transpose2d(x), None, None, out=s_w, accumulate=s_w is not None)
         db = None
         if ctx.has_bias:
@@ -597,11 +658,14 @@ class _LSTMCell(torch.autograd.Function):
     def backward(ctx, dh2, dc2):
         x, h, c, w_ih, w_hh, gates, c2 = ctx.saved_tensors
         dG, dc = ops.lstm_gates_bwd(dh2, dc2, gates, c, c2)
-        dGt = ops.transpose2d(dG)
-        dx = ops.gemm_nt(dG, ops.transpose2d(w_ih.detach()), None, None) if ctx.needs_input_grad[0] else None
-        dh = ops.gemm_nt(dG, ops.transpose2d(w_hh.detach()), None, None) if ctx.needs_input_grad[1] else None
+        dx = ops.gemm_nt(dG, _transposed(ctx.params[0]), None, None) if ctx.needs_input_grad[0] else None
+        dh = ops.gemm_nt(dG, _transposed(ctx.params[1]), None, None) if ctx.needs_input_grad[1] else None
         ng = ctx.needs_input_grad
         sinks = [_sink(p, n) for p, n in zip(ctx.params, ng[3:7])]
+        if DENSE_BATCH > 1 and all(t is not None for t in sinks):
+            _dense_wgrad((sinks[0], sinks[1]), (sinks[2], sinks[3]), dG, (x, h))
+            return dx, dh, (dc if ng[2] else None), None, None, None, None
+        dGt = ops.transpose2d(dG)
         dw_ih = ops.gemm_nt(dGt, ops.transpose2d(x), None, None, out=sinks[0], accumulate=sinks[0] is not None)
         dw_hh = ops.gemm_nt(dGt, ops.transpose2d(h), None, None, out=sinks[1], accumulate=sinks[1] is not None)
         dbs = []

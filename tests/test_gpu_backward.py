@@ -300,7 +300,7 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(family):
                 ((y * gy).sum() + h.sum()).backward()
             res[direct] = {k: p.grad.detach().clone() for m_ in (enc, dec) for k, p in m_.named_parameters()}
             assert all(p.grad is not None for m_ in (enc, dec) for p in m_.parameters())
-            assert not ag._wgrad_queues, "every queued weight gradient is flushed when backward() returns"
+            assert not ag._wgrad_queues and not ag._dense_queues, "every queued weight gradient is flushed when backward() returns"
         finally:
             ag.DIRECT_PARAM_GRADS, ag.WGRAD_BATCH = True, old_batch
     for k, g in res[False].items():
@@ -313,8 +313,10 @@ def test_in_place_gradients_lstm_linear():
     from dvg_amd import autograd as ag
     import dvg_amd.models.lstm as ours
     res = {}
-    for direct in (True, False):
-        ag.DIRECT_PARAM_GRADS = direct
+    old_dense = ag.DENSE_BATCH
+    for direct in (True, False, "per_use", "batch2"):   # default: one dW GEMM over all time steps of a backward pass
+        ag.DIRECT_PARAM_GRADS = direct is not False
+        ag.DENSE_BATCH = {"per_use": 1, "batch2": 2}.get(direct, old_dense)
         try:
             net = ours.lstm(90, 90, 256, 2, 6)
             net.load_state_dict(params.fill_state_dict(net.state_dict(), 2200))
@@ -324,7 +326,9 @@ def test_in_place_gradients_lstm_linear():
                 loss = sum((net(params.normal(2210 + t, 6, 90, scale=0.5).to(dev())) ** 2).sum() for t in range(3))
                 loss.backward()
             res[direct] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+            assert not ag._dense_queues
         finally:
-            ag.DIRECT_PARAM_GRADS = True
+            ag.DIRECT_PARAM_GRADS, ag.DENSE_BATCH = True, old_dense
     for k, g in res[False].items():
-        assert float((res[True][k] - g).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-20) + 1e-9, k
+        for mode in (True, "per_use", "batch2"):
+            assert float((res[mode][k] - g).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-20) + 1e-9, (k, mode)
