@@ -78,6 +78,7 @@ SIGNATURES = {
     "dvg_winograd_wgrad_operands": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p]),
     "dvg_winograd_wgrad_splits": (_i, [_l, _i, _i]),
     "dvg_winograd_wgrad_gemm": (_i, [_p, _p, _p, _l, _i, _i, _p]),
+    "dvg_winograd_wgrad_gemm_items": (_i, [_p, _p, _i, _l, _p, _i, _i, _p]),
     "dvg_winograd_wgrad_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "dvg_wgrad_thin_rows": (_i, [_i, _i, _i, _i]),
     "dvg_wgrad_thin": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

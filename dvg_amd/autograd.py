@@ -53,11 +53,15 @@ _wgrad_flush_queued = False
 WINOGRAD_WGRAD = os.environ.get("DVG_WINOGRAD_WGRAD", "1") != "0"
 
 
-def _wgrad_partial(mode, xs, skips, dus, up):
-    n, c, h, w = xs[0].shape
-    if WINOGRAD_WGRAD and fused.WINOGRAD and mode == MODE_CONV3 and skips is None and not up and \
-            ops.winograd_wgrad_ok(n, c, h, w, dus[0].shape[1]):
-        return ops.winograd_wgrad_partial_multi(xs, dus)
+def _wino_wgrad_applies(mode, x, skip, cout, up):
+    n, c, h, w = x.shape
+    return bool(WINOGRAD_WGRAD and fused.WINOGRAD and mode == MODE_CONV3 and skip is None and not up
+                and ops.winograd_wgrad_ok(n, c, h, w, cout))
+
+
+def _wgrad_partial(mode, xs, skips, dus, up, vs=None):
+    if _wino_wgrad_applies(mode, xs[0], None if skips is None else skips[0], dus[0].shape[1], up):
+        return ops.winograd_wgrad_partial_multi(xs, dus, vs)
     return ops.conv_wgrad_partial_multi(mode, xs, skips, dus, upsample=up)
 
 
@@ -66,8 +70,8 @@ def _flush_one(key):
     if not q:
         return
     mode, up, finish = q[0][0], q[0][1], q[0][2]
-    xs, skips, dus = [e[3] for e in q], [e[4] for e in q], [e[5] for e in q]
-    finish(_wgrad_partial(mode, xs, None if skips[0] is None else skips, dus, up))
+    xs, skips, dus, vs = [e[3] for e in q], [e[4] for e in q], [e[5] for e in q], [e[6] for e in q]
+    finish(_wgrad_partial(mode, xs, None if skips[0] is None else skips, dus, up, vs))
 
 
 # Dense layers (Linear, LSTMCell) under BPTT: dW = sum_t dY_t^T X_t is ONE GEMM over the concatenated time steps
@@ -119,16 +123,17 @@ def flush_wgrads():
         _flush_dense(key)
 
 
-def _wgrad(mode, x, skip, du, up, sink, finish, tag):
+def _wgrad(mode, x, skip, du, up, sink, finish, tag, v=None):
     """Weight gradient of one use: queued for a batched launch when it accumulates in place into `sink`, immediate
-    otherwise.  finish(partial) reduces the partial slabs into the destination."""
+    otherwise.  finish(partial) reduces the partial slabs into the destination.  v: the forward's Winograd input transform of
+    x when it kept one (SAVE_WINO_V)."""
     global _wgrad_flush_queued
     if WGRAD_BATCH <= 1 or sink is None or not DIRECT_PARAM_GRADS:
-        finish(_wgrad_partial(mode, [x], None if skip is None else [skip], [du], up))
+        finish(_wgrad_partial(mode, [x], None if skip is None else [skip], [du], up, [v]))
         return
     key = (sink.data_ptr(), tag, mode, up, tuple(x.shape), tuple(du.shape), None if skip is None else tuple(skip.shape))
     q = _wgrad_queues.setdefault(key, [])
-    q.append((mode, up, finish, x, skip, du))
+    q.append((mode, up, finish, x, skip, du, v))
     if len(q) >= WGRAD_BATCH:
         _flush_one(key)
     elif len(q) == 1 or not _wgrad_flush_queued:
@@ -206,14 +211,24 @@ def _wino(weight, m, lo=None, hi=None, dgrad=False):
     return u
 
 
-def _conv3_raw(x, weight, b, need_stats, lo=None, hi=None):
+# Keep the forward's Winograd input transform V (2.25 x the layer input) for the weight gradient instead of recomputing it in
+# the backward pass: ~17 GB more live memory in a vgg_64 iteration at B = 64 (of 288), half of the weight gradient's operand
+# passes gone.  DVG_SAVE_WINO_V=0: recompute.
+SAVE_WINO_V = os.environ.get("DVG_SAVE_WINO_V", "1") != "0"
+
+
+def _conv3_raw(x, weight, b, need_stats, lo=None, hi=None, keep_v=None):
     """Raw 3x3 conv (+ bias) of x with weight[:, lo:hi] and, for train-mode BatchNorm, its per-channel statistics: Winograd
     where fused.winograd_tile says so (statistics by one dvg_channel_stats pass over the output), else the implicit GEMM."""
     n, c, h, w = x.shape
     cout = weight.shape[0]
     m = fused.winograd_tile(n, c, h, w, cout)
     if m:
-        u = ops.conv3x3_winograd(x, _wino(weight, m, lo, hi), None, b, act=ACT_NONE)
+        # keep_v: a dict from a caller whose backward will take the weight gradient of this conv
+        want_v = keep_v is not None and m == 4 and SAVE_WINO_V and _wino_wgrad_applies(MODE_CONV3, x, None, cout, False)
+        u = ops.conv3x3_winograd(x, _wino(weight, m, lo, hi), None, b, act=ACT_NONE, return_v=want_v)
+        if want_v:
+            u, keep_v["v"] = u
         return (u, ops.channel_stats(u.permute(0, 2, 3, 1).reshape(-1, cout))) if need_stats else u
     wp = _packed(weight) if lo is None else _packed(weight, False, lo, hi, 1)
     return ops.conv3x3(x, None, wp, None, b, act=ACT_NONE, stats=need_stats)
@@ -276,6 +291,7 @@ class _ConvBlock(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         need_stats = bn.training
         c1 = x.shape[1]
+        keep = {}
         if addend is not None:
             # x half of a concat conv; `addend` = conv(skip, W_skip) shared by the decoder calls of a step (_SkipHalf)
             if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
@@ -291,7 +307,7 @@ class _ConvBlock(torch.autograd.Function):
             else:
                 raise RuntimeError(kind)
         elif kind == "conv3" and skip is None and not up:
-            r = _conv3_raw(x, weight, b, need_stats)
+            r = _conv3_raw(x, weight, b, need_stats, keep_v=keep if ctx.needs_input_grad[2] else None)
         elif kind == "conv3":
             wp = _packed(weight)
             r = ops.conv3x3(x, skip, wp, None, b, upsample=up, act=ACT_NONE, stats=need_stats)
@@ -312,6 +328,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.save_for_backward(x, skip, weight, gamma, u, y, mean, invstd)
         ctx.params = (weight, bias, gamma, beta)     # the Parameter objects: backward accumulates into their .grad
         ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None, x_half=addend is not None)
+        ctx.wino_v = keep.get("v")                   # the forward's Winograd input transform, for the weight gradient
         return out if pool else y
 
     @staticmethod
@@ -388,7 +405,9 @@ class _ConvBlock(torch.autograd.Function):
         if kind == "conv3":
             if s_w is not None:
                 _wgrad(MODE_CONV3, x, skip, du, up, q_w,
-                       lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 0, 3, 3, beta=beta_w), "full")
+                       lambda part, s_w=s_w, beta_w=beta_w: ops.wgrad_finish(part, s_w, 0, 3, 3, beta=beta_w), "full",
+                       v=ctx.wino_v)
+                ctx.wino_v = None
             if need_x:  # dgrad = a 3x3 conv with the flipped / transposed weights (igemm or Winograd)
                 dxu = _dgrad3(du, weight, 0, c1)
                 dx = ops.upsample2x_bwd(dxu) if up else dxu
@@ -427,13 +446,15 @@ class _SkipHalf(torch.autograd.Function):
     @staticmethod
     def forward(ctx, skip, weight, cfg):
         kind, c1 = cfg["kind"], cfg["c1"]
+        keep = {}
         if kind == "conv3":
-            s = _conv3_raw(skip, weight, None, False, c1, weight.shape[1])
+            s = _conv3_raw(skip, weight, None, False, c1, weight.shape[1], keep_v=keep if ctx.needs_input_grad[1] else None)
         else:
             s = ops.convT4x4s2(skip, None, _packed(weight, True, c1, weight.shape[0], 0), None, None, act=ACT_NONE)
         ctx.save_for_backward(skip, weight)
         ctx.param = weight
         ctx.cfg = cfg
+        ctx.wino_v = keep.get("v")
         ctx.set_materialize_grads(False)     # d S arrives through cfg["ds_holder"] (summed in-kernel), not through autograd
         return s
 
@@ -456,7 +477,8 @@ class _SkipHalf(torch.autograd.Function):
             if s_w is not None:
                 _wgrad(MODE_CONV3, skip, None, ds, False, q_w,
                        lambda part, s_w=s_w, ct=weight.shape[1]: ops.wgrad_finish(part, s_w, 0, 3, 3, ctot=ct, c_lo=c1,
-                                                                                  beta=1.0), "sk")
+                                                                                  beta=1.0), "sk", v=ctx.wino_v)
+                ctx.wino_v = None
             if ctx.needs_input_grad[0]:
                 dskip = _dgrad3(ds, weight, c1, weight.shape[1])
         else:

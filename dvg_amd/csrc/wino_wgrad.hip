@@ -36,7 +36,8 @@ constexpr int ww_lds_bytes(bool db, int ks) { return (db ? 2 : 1) * 2 * ww_opf(k
 
 struct WwParams {
     const float* dm;   // [36][Tp][Cout]
-    const float* v;    // [36][Tp][Cin]
+    const float* v[8]; // per use: [36][t_item][Cin] (the forward's saved input transforms), or ONE buffer [36][Tp][Cin]
+    int t_item;        // tiles per V buffer (Tp when there is one); a multiple of the stage length
     float* part;       // [S][36][Cout][Cin]
     long Tp;           // tiles (padded to a multiple of 64; padding rows are zero)
     int Cin, Cout, S, nst, nbi, nbj;   // S slabs, nst = Tp / KS stages per output block
@@ -62,14 +63,17 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(const WwParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hh = lane >> 5;
     const int w = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int rq = tid >> 5, cg = tid & 31;
-    const float *A = nullptr, *B = nullptr;
+    const float* A = nullptr;
+    int xi = 0;
+    long b_thread = 0;   // this thread's offset inside a V row block: (k quad rows) * Cin + Cin block + column
 
     float ra[NQ][16], rb[NQ][16];
     auto gload = [&](int st) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const float* a = A + ((size_t)st * KS + q * 32) * p.Cout;
-            const float* b = B + ((size_t)st * KS + q * 32) * p.Cin;
+            const int row = st * KS + q * 32, item = row / p.t_item;     // wave-uniform: which use's V this stage reads
+            const float* b = p.v[item] + ((size_t)xi * p.t_item + (row - item * p.t_item)) * p.Cin + b_thread;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -102,9 +106,10 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(const WwParams 
     const int blk = u / p.nst;
     const int st0 = u - blk * p.nst, st1 = min(p.nst, st0 + (u_end - u));
     const int seg = w - blk * p.nst / p.q;
-    const int bj = blk % p.nbj, bi = (blk / p.nbj) % p.nbi, xi = blk / (p.nbj * p.nbi);
+    const int bj = blk % p.nbj, bi = (blk / p.nbj) % p.nbi;
+    xi = blk / (p.nbj * p.nbi);
     A = p.dm + ((size_t)xi * p.Tp + rq * 4) * p.Cout + bi * WW_BM + cg;
-    B = p.v + ((size_t)xi * p.Tp + rq * 4) * p.Cin + bj * WW_BM + cg;
+    b_thread = (long)rq * 4 * p.Cin + bj * WW_BM + cg;
     u += st1 - st0;
     f32x16 acc[2][2];
 #pragma unroll
@@ -290,15 +295,35 @@ extern "C" int dvg_winograd_wgrad_splits(long tiles_padded, int Cin, int Cout) {
     return q > 0 ? S : 0;
 }
 
+static int ww_gemm(const float* dm, const float* const* v, int items, long t_item, float* partial, long tiles_padded, int Cin,
+                   int Cout, void* stream);
+
 extern "C" int dvg_winograd_wgrad_gemm(const float* dm, const float* v, float* partial, long tiles_padded, int Cin, int Cout,
                                        void* stream) {
-    DVG_REQUIRE(dm && v && partial, DVG_ERR_NULL, "dvg_winograd_wgrad_gemm: NULL pointer");
+    return ww_gemm(dm, &v, 1, tiles_padded, partial, tiles_padded, Cin, Cout, stream);
+}
+
+extern "C" int dvg_winograd_wgrad_gemm_items(const float* dm, const float* const* v_items, int items, long tiles_per_item,
+                                             float* partial, int Cin, int Cout, void* stream) {
+    DVG_REQUIRE(v_items && items >= 1 && items <= 8, DVG_ERR_SHAPE, "dvg_winograd_wgrad_gemm_items: 1..8 items");
+    DVG_REQUIRE(tiles_per_item > 0 && tiles_per_item % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_wgrad_gemm_items: tiles per item (%ld) must be a multiple of 64", tiles_per_item);
+    return ww_gemm(dm, v_items, items, tiles_per_item, partial, (long)items * tiles_per_item, Cin, Cout, stream);
+}
+
+static int ww_gemm(const float* dm, const float* const* v_items, int items, long t_item, float* partial, long tiles_padded,
+                   int Cin, int Cout, void* stream) {
+    DVG_REQUIRE(dm && v_items && partial, DVG_ERR_NULL, "dvg_winograd_wgrad_gemm: NULL pointer");
+    for (int i = 0; i < items; ++i)
+        DVG_REQUIRE(v_items[i] && aligned16(v_items[i]), DVG_ERR_NULL, "dvg_winograd_wgrad_gemm: V of item %d NULL / unaligned", i);
+    const float* v = v_items[0];
     DVG_REQUIRE(tiles_padded > 0 && tiles_padded % 64 == 0 && Cin > 0 && Cout > 0 && Cin % WW_BM == 0 && Cout % WW_BM == 0,
                 DVG_ERR_SHAPE, "dvg_winograd_wgrad_gemm: tiles=%ld must be a multiple of 64, Cin=%d / Cout=%d multiples of 128",
                 tiles_padded, Cin, Cout);
     DVG_REQUIRE(aligned16(dm) && aligned16(v) && aligned16(partial), DVG_ERR_ALIGN, "dvg_winograd_wgrad_gemm: alignment");
     const int ks = ww_ks();
-    WwParams p{dm, v, partial, tiles_padded, Cin, Cout, 1, (int)(tiles_padded / ks), Cout / WW_BM, Cin / WW_BM, 0, 0};
+    WwParams p{dm, {}, (int)t_item, partial, tiles_padded, Cin, Cout, 1, (int)(tiles_padded / ks), Cout / WW_BM, Cin / WW_BM, 0, 0};
+    for (int i = 0; i < 8; ++i) p.v[i] = v_items[i < items ? i : 0];
     long wgs, q;
     ww_plan(tiles_padded, Cin, Cout, &q, &wgs, &p.S);
     DVG_REQUIRE(q > 0, DVG_ERR_SHAPE, "dvg_winograd_wgrad_gemm: too many tiles (%ld)", tiles_padded);

@@ -247,7 +247,7 @@ def winograd_ok(n, c, h, w, cout, m: int = 2) -> bool:
     return h % m == 0 and w % m == 0 and c % 64 == 0 and cout % 64 == 0 and (n * (h // m) * (w // m)) % 128 == 0
 
 
-def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False):
+def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False):
     """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
     transform; m (2 or 4) follows from u's leading dimension (16 or 36)."""
     _dev_f32(x, "conv3x3_winograd.x")
@@ -268,6 +268,8 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
     _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
          _p(y), _p(yp), n, h, w, cout, act, slope, mt, _stream())
+    if return_v:   # the input transform (P, T, C): the Winograd-form weight gradient's second operand (training)
+        return ((y, yp) if pool else y), v
     return (y, yp) if pool else y
 
 
@@ -628,9 +630,12 @@ def winograd_wgrad_ok(n, cin, h, w, cout):
     return h % 4 == 0 and w % 4 == 0 and h <= 32 and w <= 32 and cin % 128 == 0 and cout % 128 == 0 and n > 0
 
 
-def winograd_wgrad_partial_multi(xs, dus):
+def winograd_wgrad_partial_multi(xs, dus, vs=None):
     """The packed (1, 9, Cout, Cin) weight-gradient slab of a 3x3 conv, sum_i dOut_i (x) In_i over 1..n same-shape uses, in
-    Winograd F(4x4,3x3) form (dvg_winograd_wgrad_*): interchangeable with conv_wgrad_partial_multi(MODE_CONV3, ...)."""
+    Winograd F(4x4,3x3) form (dvg_winograd_wgrad_*): interchangeable with conv_wgrad_partial_multi(MODE_CONV3, ...).
+    vs: the uses' input transforms (36, T, Cin) as the forward pass computed them (conv3x3_winograd(return_v=True)); given
+    for every use (and T % 64 == 0) they are read in place instead of recomputed from xs."""
+    import ctypes as C
     items = len(xs)
     x, du = xs[0], dus[0]
     n, cin, h, w = x.shape
@@ -644,19 +649,28 @@ def winograd_wgrad_partial_multi(xs, dus):
         _dev_f32(dus[i], "winograd_wgrad.dout")
     t = n * (h // 4) * (w // 4)
     tp = (items * t + 63) // 64 * 64
+    saved = vs is not None and t % 64 == 0 and all(
+        v is not None and tuple(v.shape) == (36, t, cin) and v.is_contiguous() and v.dtype == torch.float32 and v.device == x.device
+        for v in vs)
     alloc = torch.empty if tp == items * t else torch.zeros      # padding rows must be zero
-    v = alloc((36, tp, cin), device=x.device, dtype=torch.float32)
+    v = None if saved else alloc((36, tp, cin), device=x.device, dtype=torch.float32)
     dm = alloc((36, tp, cout), device=x.device, dtype=torch.float32)
     for i in range(items):
-        _run("winograd_wgrad_operands", 0.0, 4.0 * 3.25 * (x.numel() + du.numel()), lib().dvg_winograd_wgrad_operands,
-             _p(xs[i]), _p(dus[i]), _p(v), _p(dm), n, h, w, cin, cout, tp, i * t, _stream())
+        _run("winograd_wgrad_operands", 0.0, 4.0 * 3.25 * ((0 if saved else x.numel()) + du.numel()),
+             lib().dvg_winograd_wgrad_operands, None if saved else _p(xs[i]), _p(dus[i]), _p(v), _p(dm), n, h, w, cin, cout,
+             tp, i * t, _stream())
     s = lib().dvg_winograd_wgrad_splits(tp, cin, cout)
     if s <= 0:
         raise RuntimeError(f"winograd_wgrad: unsupported shape tiles={tp} Cin={cin} Cout={cout}")
     part = torch.empty((s, 36, cout, cin), device=x.device, dtype=torch.float32)
-    _run("winograd_wgrad_gemm", 2.0 * 36 * tp * cin * cout, 4.0 * (v.numel() + dm.numel() + part.numel()),
-         lib().dvg_winograd_wgrad_gemm, _p(dm), _p(v), _p(part), tp, cin, cout, _stream(),
-         alg_flops=items * 2.0 * du.numel() * 9 * cin)
+    gemm_bytes = 4.0 * (36.0 * tp * cin + dm.numel() + part.numel())
+    if saved:
+        pv = (C.c_void_p * items)(*[t_.data_ptr() for t_ in vs])
+        _run("winograd_wgrad_gemm", 2.0 * 36 * tp * cin * cout, gemm_bytes, lib().dvg_winograd_wgrad_gemm_items, _p(dm), pv,
+             items, t, _p(part), cin, cout, _stream(), alg_flops=items * 2.0 * du.numel() * 9 * cin)
+    else:
+        _run("winograd_wgrad_gemm", 2.0 * 36 * tp * cin * cout, gemm_bytes, lib().dvg_winograd_wgrad_gemm, _p(dm), _p(v),
+             _p(part), tp, cin, cout, _stream(), alg_flops=items * 2.0 * du.numel() * 9 * cin)
     packed = torch.empty((1, 9, cout, cin), device=x.device, dtype=torch.float32)
     if s > 2:
         # many thin slabs (the 128-channel layers: one output block per position, K split ~30 ways): sum them with the wide

@@ -374,6 +374,11 @@ int dvg_winograd_wgrad_operands(const float* x, const float* dy, float* v, float
                                 int Cout, long t_total, long t_off, void* stream);
 int dvg_winograd_wgrad_splits(long t_total, int Cin, int Cout);
 int dvg_winograd_wgrad_gemm(const float* dm, const float* v, float* partial, long t_total, int Cin, int Cout, void* stream);
+/* The same with V given per use: `v_items` is a HOST array of `items` (1..8) device pointers to (36, tiles_per_item, Cin)
+ * buffers - the input transforms the forward pass computed for the layer (dvg_winograd_input, m = 4), kept instead of
+ * recomputed; dM is still one concatenated (36, items * tiles_per_item, Cout) buffer.  tiles_per_item % 64 == 0.          */
+int dvg_winograd_wgrad_gemm_items(const float* dm, const float* const* v_items, int items, long tiles_per_item,
+                                  float* partial, int Cin, int Cout, void* stream);
 int dvg_winograd_wgrad_reduce(const float* partial, int S, float* packed, int Cin, int Cout, void* stream);
 
 /* Finish of a weight gradient IN PLACE in the parameter's gradient buffer (train.py:240 `loss.backward()` accumulates

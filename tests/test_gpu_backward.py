@@ -103,6 +103,24 @@ def test_winograd_weight_gradient_matches_direct_and_fp64(N, H, Cin, Cout, items
     assert rel_err(dst - 1.0, w.grad) < 2e-4
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,items", [(32, 8, 128, 128, 3), (8, 16, 256, 128, 2)])
+def test_winograd_weight_gradient_from_saved_input_transforms(N, H, Cin, Cout, items):
+    """The forward's input transforms (conv3x3_winograd(return_v=True)) read in place, one buffer per use, give the same slab
+    as recomputing them from the layer inputs."""
+    from dvg_amd import ops
+    xs = [ops.to_nhwc(params.normal(60 + i, N, Cin, H, H).to(dev())) for i in range(items)]
+    dus = [ops.to_nhwc(params.normal(70 + i, N, Cout, H, H).to(dev())) for i in range(items)]
+    u = ops.winograd_weight(params.normal(80, Cout, Cin, 3, 3, scale=0.05).to(dev()), 4)
+    vs = [ops.conv3x3_winograd(x, u, None, None, act=ops.ACT_NONE, return_v=True)[1] for x in xs]
+    assert tuple(vs[0].shape) == (36, N * (H // 4) ** 2, Cin)
+    a = ops.winograd_wgrad_partial_multi(xs, dus)
+    b = ops.winograd_wgrad_partial_multi(xs, dus, vs)
+    assert torch.equal(a, b)        # same operands, same kernel, same order of operations
+    # a V that does not fit (wrong shape) falls back to recomputation
+    c = ops.winograd_wgrad_partial_multi(xs, dus, [v[:, :64] for v in vs])
+    assert torch.equal(a, c)
+
+
 def _reference_case(family, seed):
     """The B=16 train-mode case of tests/golden/make_golden.py:run_backbone_grads, rebuilt from its seeds."""
     mod = our_module(family, 64)
