@@ -271,7 +271,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     # The 3x3 layers as a whole (SURVEY 8(d) counts a layer's direct-form FLOPs): direct implicit-GEMM launches plus, for the
     # layers that run as Winograd F(4x4) / F(2x2), their transform + batched-GEMM launches.  Can exceed the fp32 MFMA peak:
     # Winograd executes 1/4 (1/2.25) of the direct form's multiplies.
-    fam = [k for k in agg if k in ("conv3x3_igemm", "winograd_input", "winograd_gemm", "winograd_output")]
+    fam = [k for k in agg if k in ("conv3x3_igemm", "winograd_input", "winograd_gemm", "winograd_output", "winograd_output_input")]
     if any(k.startswith("winograd") for k in fam):
         ms = sum(agg[k]["ms"] for k in fam)
         alg = sum(agg[k]["alg_flops"] for k in ("conv3x3_igemm", "winograd_gemm") if k in agg)

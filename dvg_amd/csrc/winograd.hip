@@ -336,6 +336,68 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
     }
 }
 
+// Output transform of layer L + input transform of layer L + 1 in ONE pass, for two consecutive eval-mode vgg_layers at the
+// same resolution whose intermediate activation has no other consumer (the inner layers of a vgg block, vgg_64.py:24-43,
+// 70-87): y = act(scale * A^T M A + shift) is staged in LDS (one image x CS channels per workgroup: 16 KB) and leaves as
+// V' = B^T y B - the activation never travels to HBM and back (M in, V' out: 4.5 units of traffic instead of 6.5) and one
+// launch of two disappears.  HW = 8 or 16 (map side); thread = one 4x4 tile x one channel.
+template <int HW>
+__global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ v, int N,
+                                                               int C, int act, float slope) {
+    constexpr int WT = HW / 4, TI = WT * WT, CS = 256 / TI;    // tiles per image side / per image, channels per workgroup
+    __shared__ float ys[HW * HW * CS];
+    const int tid = threadIdx.x, cl = tid % CS, t_img = tid / CS, ty = t_img / WT, tx = t_img % WT;
+    const int cblocks = C / CS;
+    const int n = blockIdx.x / cblocks, c = (blockIdx.x % cblocks) * CS + cl;
+    const long T = (long)N * TI, t = (long)n * TI + t_img;
+    {
+        float sq[4][6];   // A^T q (rows), column b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float q[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q[a] = m[((size_t)(a * 6 + b) * T + t) * C + c];
+            float col[4];
+            at4(q, col);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) sq[pp][b] = col[pp];
+        }
+        const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            float o[4];
+            at4(sq[pp], o);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                ys[((4 * ty + pp) * HW + 4 * tx + qq) * CS + cl] = apply_act(o[qq] * sc + sf, act, slope);
+        }
+    }
+    __syncthreads();
+    float e[6][6];   // B^T d (rows transformed), column b
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const int xx = 4 * tx - 1 + b;
+        float d[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const int yy = 4 * ty - 1 + a;
+            d[a] = ((unsigned)yy < (unsigned)HW && (unsigned)xx < (unsigned)HW) ? ys[(yy * HW + xx) * CS + cl] : 0.f;
+        }
+        float col[6];
+        bt4(d, col);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) e[a][b] = col[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float o[6];
+        bt4(e[a], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) v[((size_t)(a * 6 + b) * T + t) * C + c] = o[b];
+    }
+}
+
 static inline unsigned wgrid(long n) {
     long g = (n + 255) / 256;
     return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -413,6 +475,24 @@ extern "C" int dvg_winograd_wgrad_operands(const float* x, const float* dy, floa
     }
 #undef WOPS
     return DVG_OK;
+}
+
+// M (36, T, C) of layer L -> V (36, T, C) of layer L + 1 (see winograd4_out_in_kernel): H == W in {8, 16}, F(4x4,3x3),
+// C % 64 == 0.  The activation y = act(scale * A^T M A + shift) itself is not written.
+extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H,
+                                         int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(mm && v_next, DVG_ERR_NULL, "dvg_winograd_output_input: NULL pointer");
+    DVG_REQUIRE(N > 0 && H == W && (H == 8 || H == 16) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_output_input: 8x8 or 16x16 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_input: bad act");
+    const hipStream_t st = (hipStream_t)stream;
+    if (H == 8)
+        hipLaunchKernelGGL(winograd4_out_in_kernel<8>, dim3((unsigned)((long)N * (C / 64))), dim3(256), 0, st, mm, scale, shift,
+                           v_next, N, C, act, slope);
+    else
+        hipLaunchKernelGGL(winograd4_out_in_kernel<16>, dim3((unsigned)((long)N * (C / 16))), dim3(256), 0, st, mm, scale, shift,
+                           v_next, N, C, act, slope);
+    return check_launch("dvg_winograd_output_input");
 }
 
 extern "C" int dvg_winograd_output(

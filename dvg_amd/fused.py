@@ -350,9 +350,33 @@ def _hoisted_skip(conv, x, skip, partial_fn):
     return px, ent[4]
 
 
-def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2):
+# Eval mode: two consecutive Winograd layers at 8x8 / 16x16 hand over the next layer's input transform instead of the
+# activation (ops.WinoV, dvg_winograd_output_input).  DVG_WINOGRAD_CHAIN=0: every layer writes its activation.
+WINOGRAD_CHAIN = os.environ.get("DVG_WINOGRAD_CHAIN", "1") != "0"
+
+
+def _chain_to(conv_next, n, c, h, w):
+    """True when the layer after this one (conv_next, fed by this layer's (n,c,h,w) output and nothing else) can take a WinoV."""
+    return (WINOGRAD_CHAIN and WINOGRAD >= 4 and conv_next is not None and not conv_next.training
+            and conv_next.weight.shape[1] == c and tuple(conv_next.kernel_size) == (3, 3)
+            and winograd_tile(n, c, h, w, conv_next.weight.shape[0]) == 4 and ops.winograd_chain_ok(n, c, h, w))
+
+
+def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2, next_conv=None):
     """vgg_layer (vgg_64.py:5-15) with optional fused cat/upsample on the input and
-    fused 2x2 max-pool on the output."""
+    fused 2x2 max-pool on the output.  next_conv: the Conv2d of the vgg_layer that consumes this layer's output and is its
+    ONLY consumer - in eval mode the result may then be an ops.WinoV (that layer's Winograd input transform) instead of the
+    activation; pass it on as `x` unchanged."""
+    if isinstance(x, ops.WinoV):
+        if bn.training or skip is not None or upsample:
+            raise RuntimeError("conv3_bn_act: a WinoV input needs an eval-mode plain 3x3 layer")
+        sc, sh = folded_affine(conv, bn)
+        n, c, h, w = x.shape
+        cout = conv.weight.shape[0]
+        if winograd_tile(n, c, h, w, cout) != 4:
+            raise RuntimeError("conv3_bn_act: WinoV handed to a layer that is not F(4x4,3x3)")
+        to_v = (not pool) and _chain_to(next_conv, n, cout, h, w)
+        return ops.conv3x3_winograd(x, winograd_weight(conv, 4), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("conv3", conv, bn, x, skip, upsample=upsample, pool=pool, act=act, slope=slope)
@@ -368,7 +392,9 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         if skip is None and not upsample:
             m = winograd_tile(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.weight.shape[0])
             if m:
-                return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool)
+                to_v = m == 4 and (not pool) and not torch.is_grad_enabled() and \
+                    _chain_to(next_conv, x.shape[0], conv.weight.shape[0], x.shape[2], x.shape[3])
+                return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
         return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
     wp = packed_weight(conv)
     u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,

@@ -133,8 +133,8 @@ class VggEncoder(nn.Module):
                 elif last:  # stage output = skip tensor; its 2x2 max-pool feeds the next stage
                     full, h = fused.conv3_bn_act(conv, bn, h, pool=True)
                     skips.append(full)
-                else:
-                    h = fused.conv3_bn_act(conv, bn, h)
+                else:       # inner layer: its output has one consumer, the next layer (eval: may hand over an ops.WinoV)
+                    h = fused.conv3_bn_act(conv, bn, h, next_conv=layers[li + 1].main[0])
         return fused.head_bn_tanh(head[0], head[1], h), skips
 
     def forward(self, input):
@@ -168,13 +168,16 @@ class VggDecoder(nn.Module):
         for s in range(2, n + 1):
             sk = ops.to_nhwc(skip[n - s])
             first = True
-            for layer in getattr(self, f"upc{s}"):
+            mods = list(getattr(self, f"upc{s}"))
+            for li, layer in enumerate(mods):
                 if isinstance(layer, vgg_layer):
                     if first:  # nearest x2 + cat(skip) fused into the tile loader
                         d = fused.conv3_bn_act(layer.main[0], layer.main[1], d, sk, upsample=True)
                         first = False
-                    else:
-                        d = fused.conv3_bn_act(layer.main[0], layer.main[1], d)
+                    else:      # an inner layer followed by another vgg_layer of the block may hand over an ops.WinoV
+                        nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None
+                        d = fused.conv3_bn_act(layer.main[0], layer.main[1], d,
+                                               next_conv=None if nxt is None else nxt.main[0])
                 elif isinstance(layer, nn.ConvTranspose2d):
                     d = fused.convT3_last(layer, d, act=ACT_SIGMOID)
         return d

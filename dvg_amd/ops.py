@@ -247,25 +247,68 @@ def winograd_ok(n, c, h, w, cout, m: int = 2) -> bool:
     return h % m == 0 and w % m == 0 and c % 64 == 0 and cout % 64 == 0 and (n * (h // m) * (w // m)) % 128 == 0
 
 
-def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False):
+class WinoV:
+    """The Winograd F(4x4,3x3) input transform V (36, T, C) of an activation (N,C,H,W) that was never materialised: what
+    conv3x3_winograd(..., to_v=True) hands to the next layer's conv3x3_winograd instead of y."""
+    __slots__ = ("v", "shape")
+
+    def __init__(self, v, shape):
+        self.v, self.shape = v, tuple(shape)
+
+    @property
+    def device(self):
+        return self.v.device
+
+    @property
+    def requires_grad(self):
+        return False
+
+
+def winograd_chain_ok(n, c, h, w):
+    """Shapes dvg_winograd_output_input takes (the fused output -> input transform between two F(4x4,3x3) layers)."""
+    return h == w and h in (8, 16) and c % 64 == 0 and n > 0
+
+
+def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False, to_v=False):
     """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
-    transform; m (2 or 4) follows from u's leading dimension (16 or 36)."""
-    _dev_f32(x, "conv3x3_winograd.x")
-    assert is_nhwc(x), "conv3x3_winograd: x must be NHWC in memory"
-    n, c, h, w = x.shape
+    transform; m (2 or 4) follows from u's leading dimension (16 or 36).  x may be a WinoV (the previous layer's to_v=True
+    result: no input transform); to_v=True returns the NEXT layer's input transform as a WinoV instead of y (m = 4, no pool,
+    winograd_chain_ok shapes: dvg_winograd_output_input)."""
+    from_v = isinstance(x, WinoV)
+    if from_v:
+        n, c, h, w = x.shape
+    else:
+        _dev_f32(x, "conv3x3_winograd.x")
+        assert is_nhwc(x), "conv3x3_winograd: x must be NHWC in memory"
+        n, c, h, w = x.shape
     cout, npos = u.shape[3], u.shape[0]
     mt = {16: 2, 36: 4}.get(npos, 0)
     if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, 16) or not winograd_ok(n, c, h, w, cout, mt):
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
+    if (from_v or to_v) and (mt != 4 or return_v):
+        raise RuntimeError("conv3x3_winograd: WinoV hand-over needs F(4x4,3x3) and no return_v")
+    if to_v and (pool or not winograd_chain_ok(n, cout, h, w)):
+        raise RuntimeError(f"conv3x3_winograd: to_v unsupported for output {(n, cout, h, w)} pool={pool}")
     t = n * (h // mt) * (w // mt)
-    v = torch.empty((npos, t, c), device=x.device, dtype=torch.float32)
-    m = torch.empty((npos, t, cout), device=x.device, dtype=torch.float32)
-    y = nhwc_empty(n, cout, h, w, x.device)
-    yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, mt,
-         _stream())
+    dev = x.device
+    m = torch.empty((npos, t, cout), device=dev, dtype=torch.float32)
+    if from_v:
+        v = x.v
+        if tuple(v.shape) != (npos, t, c):
+            raise RuntimeError("conv3x3_winograd: WinoV does not match its shape")
+    else:
+        v = torch.empty((npos, t, c), device=dev, dtype=torch.float32)
+        _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, mt,
+             _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
+    if to_v:
+        vn = torch.empty((npos, t, cout), device=dev, dtype=torch.float32)
+        _run("winograd_output_input", 0.0, 4.0 * (m.numel() + vn.numel()), lib().dvg_winograd_output_input, _p(m), _p(scale),
+             _p(shift), _p(vn), n, h, w, cout, act, slope, _stream())
+        return WinoV(vn, (n, cout, h, w))
+    y = nhwc_empty(n, cout, h, w, dev)
+    yp = nhwc_empty(n, cout, h // 2, w // 2, dev) if pool else None
     _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
          _p(y), _p(yp), n, h, w, cout, act, slope, mt, _stream())
     if return_v:   # the input transform (P, T, C): the Winograd-form weight gradient's second operand (training)

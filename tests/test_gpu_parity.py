@@ -602,3 +602,62 @@ def test_eval_backbone_at_winograd_batch_matches_oracle(family, B):
     assert e_h < 1e-4 and e_y < 1e-4
     for a, b in zip(skips, skips_ref):
         assert rel_err(a, b) < 1e-4
+
+
+@pytest.mark.parametrize("N,H,C,Cmid,Cout", [(32, 8, 256, 512, 512), (8, 16, 128, 256, 256), (32, 8, 512, 512, 256)])
+def test_winograd_chain_hands_over_the_input_transform(N, H, C, Cmid, Cout):
+    """dvg_winograd_output_input: two consecutive F(4x4,3x3) layers with the first layer's activation never written - the
+    second layer's result equals (bit for bit: same kernels around it, same arithmetic inside) the unchained pair's, and both
+    match the fp64 reference."""
+    from dvg_amd import ops
+    x = params.normal(2500, N, C, H, H)
+    w1 = params.normal(2501, Cmid, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
+    w2 = params.normal(2502, Cout, Cmid, 3, 3, scale=1.2 / (3 * Cmid ** 0.5))
+    s1, b1 = 1 + 0.1 * params.normal(2503, Cmid), 0.1 * params.normal(2504, Cmid)
+    s2, b2 = 1 + 0.1 * params.normal(2505, Cout), 0.1 * params.normal(2506, Cout)
+    mid = F.leaky_relu(F.conv2d(x.double(), w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1), 0.2)
+    ref = F.leaky_relu(F.conv2d(mid, w2.double(), padding=1) * s2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1), 0.2)
+    u1, u2 = ops.winograd_weight(w1.to(dev()), 4), ops.winograd_weight(w2.to(dev()), 4)
+    d = lambda t: t.to(dev())   # noqa: E731
+    y1 = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1))
+    y2 = ops.conv3x3_winograd(y1, u2, d(s2), d(b2))
+    assert ops.winograd_chain_ok(N, Cmid, H, H)
+    v = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1), to_v=True)
+    assert isinstance(v, ops.WinoV) and v.shape == (N, Cmid, H, H)
+    y2c = ops.conv3x3_winograd(v, u2, d(s2), d(b2))
+    assert torch.equal(y2c, y2)
+    assert rel_err(y2c, ref) < 1e-4
+    # three in a row, the last one pooled
+    v2 = ops.conv3x3_winograd(v, u2, d(s2), d(b2), to_v=True) if Cout == Cmid else None
+    if v2 is not None:
+        a = ops.conv3x3_winograd(v2, u2, d(s2), d(b2), pool=True)
+        b = ops.conv3x3_winograd(y2, u2, d(s2), d(b2), pool=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_eval_rollout_modules_chain_equals_unchained():
+    """vgg_64 encoder -> decoder in eval mode at a Winograd batch with and without the WinoV hand-over (fused.WINOGRAD_CHAIN):
+    identical outputs, and the chained run launches dvg_winograd_output_input."""
+    from dvg_amd import fused, ops
+    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
+    x = params.frames(2600, 32, 1, 64).to(dev())
+    enc.to(dev()).eval(), dec.to(dev()).eval()
+    out = {}
+    for chain in (True, False):
+        old = fused.WINOGRAD_CHAIN
+        fused.WINOGRAD_CHAIN = chain
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        try:
+            with torch.no_grad():
+                h, skips = enc(x)
+                y = dec([h, skips])
+        finally:
+            ops.set_timer(None)
+            fused.WINOGRAD_CHAIN = old
+        out[chain] = (h, skips, y, timer.summary())
+    n_fused = out[True][3].get("winograd_output_input", {}).get("launches", 0)
+    assert n_fused >= 5 and "winograd_output_input" not in out[False][3], (n_fused, list(out[False][3]))
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.equal(a, b)
