@@ -594,9 +594,10 @@ def test_eval_backbone_at_winograd_batch_matches_oracle(family, B):
             y = dec([h, skips])
     finally:
         ops.conv3x3_winograd = real
-    assert len(used) >= 8 and (36 in {u for u, _ in used}), used
-    if B == 8:
-        assert 16 in {u for u, _ in used}, "8x8 maps at B = 8 have 128 F(2x2) tiles but only 32 F(4x4) tiles"
+    if fused.WINOGRAD == 4:      # (under DVG_WINOGRAD=0 / 2 the same parity bars apply to whatever path runs)
+        assert len(used) >= 8 and (36 in {u for u, _ in used}), used
+        if B == 8:
+            assert 16 in {u for u, _ in used}, "8x8 maps at B = 8 have 128 F(2x2) tiles but only 32 F(4x4) tiles"
     e_h, e_y = rel_err(h, h_ref), rel_err(y, y_ref)
     print(f"winograd backbone B={B}: rel err latent {e_h:.2e} frame {e_y:.2e} ({len(used)} winograd layers)")
     assert e_h < 1e-4 and e_y < 1e-4
@@ -657,7 +658,9 @@ def test_eval_rollout_modules_chain_equals_unchained():
             fused.WINOGRAD_CHAIN = old
         out[chain] = (h, skips, y, timer.summary())
     n_fused = out[True][3].get("winograd_output_input", {}).get("launches", 0)
-    assert n_fused >= 5 and "winograd_output_input" not in out[False][3], (n_fused, list(out[False][3]))
+    assert "winograd_output_input" not in out[False][3], list(out[False][3])
+    if fused.WINOGRAD == 4:
+        assert n_fused >= 5, n_fused
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
     for a, b in zip(out[True][1], out[False][1]):
         assert torch.equal(a, b)
