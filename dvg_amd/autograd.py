@@ -114,9 +114,18 @@ def _dense_wgrad(w_sinks, b_sinks, dy, inputs):
         _wgrad_flush_queued = True
 
 
+# Streams other than the current one on which backward nodes may have queued weight-gradient operands (train.Trainer's
+# latent-path stream): the flush, which runs on the stream that called backward(), waits for them first.
+JOIN_STREAMS = []
+
+
 def flush_wgrads():
     global _wgrad_flush_queued
     _wgrad_flush_queued = False
+    if JOIN_STREAMS and (_wgrad_queues or _dense_queues):
+        cur = torch.cuda.current_stream()
+        for s_ in JOIN_STREAMS:
+            cur.wait_stream(s_)
     for key in list(_wgrad_queues):
         _flush_one(key)
     for key in list(_dense_queues):

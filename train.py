@@ -121,6 +121,9 @@ class Trainer:
         self.share_skip_halves = True
         # True = the GP fine-tuning closure reuses the encodings of the LSTM fine-tuning closure that precedes it
         self.share_closure_encodings = True
+        # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
+        self.latent_stream = os.environ.get("DVG_LATENT_STREAM", "1") != "0"
+        self._side_stream = None
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group.  All groups live in ONE
         # flat arena in the order [GP | likelihood | LSTM | decoder | encoder]: parameters, gradients (p.grad are views)
         # and both moments; the data-parallel all-reduce works on ranges of arena.g in place.
@@ -182,6 +185,13 @@ class Trainer:
     def train_mode(self):
         for m in self.modules:
             m.train()
+
+    def _latent_stream(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+            from dvg_amd import autograd as _ag
+            _ag.JOIN_STREAMS.append(self._side_stream)   # the end-of-backward weight-gradient flush waits for it
+        return self._side_stream
 
     def _gp_in(self, h):
         return h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)
@@ -306,22 +316,40 @@ class Trainer:
             enc_out = enc_all
             enc_all = [(h.detach().requires_grad_(True), [s.detach().requires_grad_(True) for s in sk])
                        for h, sk in enc_out]
+        # The latent path (LSTM step, GP posterior + ELBO term, latent MSE: a few dozen small latency-bound kernels per
+        # step) runs on a second stream, ahead of the decoder calls it feeds: the decoders' MFMA-bound kernels hide it.
+        # autograd replays the stream assignment in the backward pass (a node runs on its forward stream, with event
+        # dependencies); the end-of-backward weight-gradient flush and this function join the streams explicitly.
+        cur = torch.cuda.current_stream()
+        # (eager iterations only: replayed as a hipGraph the two-stream DAG measured 3-5 ms SLOWER per iteration - the
+        # cross-stream dependency edges cost more than the overlap of kernels that no longer wait for the CPU gives)
+        side = self._latent_stream() if self.latent_stream and not torch.cuda.is_current_stream_capturing() else None
         for i in range(1, opt.n_past + opt.n_future):
             h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1), skip)
             h_target = self._enc(enc_all, x, i)[0]
-            h_pred = self.frame_predictor(h)
-            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
-            gp_pred = self.gp_layer(self._gp_in(h))
-            max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
+            if side is not None:
+                side.wait_stream(cur)          # this step's encodings (already there when the frames were encoded up front)
+            with torch.cuda.stream(side if side is not None else cur):
+                h_pred = self.frame_predictor(h)
+                mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+                gp_pred = self.gp_layer(self._gp_in(h))
+                max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
+                gp_mean = gp_pred.mean.transpose(0, 1)
+            if side is not None:
+                cur.wait_event(side.record_event())
             with self._share_scope():   # the three decoder calls of a step share the skip halves of their concat convs
                 x_pred = self.decoder([h_pred, skip])
                 x_target_pred = self.decoder([h_target, skip])
-                x_pred_gp = self.decoder([gp_pred.mean.transpose(0, 1), skip])
+                x_pred_gp = self.decoder([gp_mean, skip])
             ae_mse = ae_mse + self.mse_latent_criterion(x_target_pred, x[i])
             mse = mse + self.mse_criterion(x_pred, x[i])
             mse_gp = mse_gp + self.mse_latent_criterion(x_pred_gp, x[i])
+        if side is not None:
+            cur.wait_stream(side)
         loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
         loss.backward()
+        if side is not None:
+            cur.wait_stream(side)              # the latent path's backward kernels
         if staged:
             # gradients of GP, likelihood, LSTM and decoder are final: their all-reduce runs under the encoder phase
             pending = self.reducer.start(self.rng_gp[0], self.rng_dec[1])
