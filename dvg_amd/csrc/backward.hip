@@ -270,12 +270,33 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dxu, float* __re
 }
 
 // out[c] = sum_r a[r][c]   (bias gradients; rows = batch)
-__global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += a[(size_t)r * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+// Workgroup = 16 columns x 16 row lanes; a lane walks rows rl, rl + 16, ... with four independent partial sums (loads in
+// flight), the lanes combine through LDS in a fixed order (deterministic).  One thread per column walking all rows serially
+// took 226 us for the (1216, 1024) gate gradients of a whole BPTT pass (autograd._dense_wgrad).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int C,
+                                                     int accumulate) {
+    __shared__ float red[16 * 16];
+    const int lc = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lc;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        int r = rl;
+        for (; r + 48 < rows; r += 64) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = a[(size_t)(r + 16 * k) * C + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += v[k];
+        }
+        for (; r < rows; r += 16) s[0] += a[(size_t)r * C + c];
+    }
+    red[rl * 16 + lc] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    float t = red[lc];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k * 16 + lc];
+    out[c] = accumulate ? out[c] + t : t;
 }
 
 // Weight-gradient finish: dW (nn layout, possibly a channel slice of a wider weight) = beta * dW + sum_s partial[s], with
@@ -655,7 +676,7 @@ extern "C" int dvg_upsample2x_bwd(const float* dxu, float* dx, int N, int H, int
 extern "C" int dvg_colsum(const float* a, float* out, int rows, int C, int accumulate, void* stream) {
     DVG_REQUIRE(a && out, DVG_ERR_NULL, "dvg_colsum: NULL pointer");
     DVG_REQUIRE(rows > 0 && C > 0, DVG_ERR_SHAPE, "dvg_colsum: bad shape");
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, out, rows, C, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, out, rows, C, accumulate);
     return check_launch("dvg_colsum");
 }
 

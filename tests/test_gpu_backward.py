@@ -121,6 +121,19 @@ def test_winograd_weight_gradient_from_saved_input_transforms(N, H, Cin, Cout, i
     assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("rows,C", [(64, 90), (1216, 1024), (7, 33), (100, 16)])
+def test_colsum_matches_torch(rows, C):
+    """dvg_colsum (bias gradients; rows = batch x time steps when a BPTT pass is reduced in one launch), plain and accumulating."""
+    from dvg_amd import ops
+    a = params.normal(90, rows, C).to(dev())
+    ref = a.double().sum(0)
+    out = ops.colsum(a)
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    acc = torch.full((C,), 2.0, device=dev())
+    ops.colsum(a, out=acc, accumulate=True)
+    assert float((acc.double() - 2.0 - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 def _reference_case(family, seed):
     """The B=16 train-mode case of tests/golden/make_golden.py:run_backbone_grads, rebuilt from its seeds."""
     mod = our_module(family, 64)
