@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="complete rollouts in flight at once (independent samples of the make_gifs loop, one hipGraph and one "
+                         "stream each); 1 = one serial chain of launches")
     ap.add_argument("--no-families", action="store_true", help="skip the other model family")
     ap.add_argument("--no-roofline", action="store_true", help="skip the eager HIP-event leg (timeline profiling runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training leg")
@@ -218,7 +221,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     import torch
     from dvg_amd import ops
     from dvg_amd.data import SyntheticMovingMNIST
-    from dvg_amd.rollout import GraphedRollout, sample_rollout
+    from dvg_amd.rollout import ConcurrentRollouts, sample_rollout
     n_eval = args.n_past + args.n_future
     enc, dec, fp, gp, lik = build_models(model, args.batch, 1, ctx.dev, args.seed + ctx.rank)
     # inputs resident in HBM before the timed region; composited on the GPU (identical to normalize_data(host batch))
@@ -228,18 +231,35 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     def eager_step():
         return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
 
-    step = eager_step if args.no_graph else GraphedRollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
-    for _ in range(warmup):
-        step()
+    # A step = one COMPLETE rollout (conditioning + prediction, B clips).  The rollouts of the make_gifs sample loop are
+    # independent: `inflight` of them run at once, each as its own hipGraph on its own stream (rollout.ConcurrentRollouts);
+    # K steps = K rollouts issued round-robin, per-rollout work and results unchanged.
+    inflight = 1 if args.no_graph else max(1, args.inflight)
+    cr = None if args.no_graph else ConcurrentRollouts(enc, dec, fp, gp, lik, x, args.n_past, n_eval, inflight=inflight)
+
+    def run(n, chains=None):
+        if cr is None:
+            for _ in range(n):
+                last = eager_step()
+            return last
+        return cr.run(n, chains=chains)[0]
+
+    run(warmup)
     ctx.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = step()
+    out = run(steps)
     ctx.barrier()
     dt = ctx.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(out[-1]).all())
     frames = args.batch * args.n_future * steps * ctx.world
-    res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3)}
+    res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3), "rollouts_in_flight": inflight}
+    if inflight > 1:   # the same K rollouts as ONE serial chain of launches (one graph, one stream), for comparison
+        ctx.barrier()
+        t0 = time.perf_counter()
+        run(steps, chains=1)
+        ctx.barrier()
+        dt1 = ctx.max_over_ranks(time.perf_counter() - t0)
+        res["single_chain"] = {"value": round(frames / dt1, 1), "ms_per_step": round(1000 * dt1 / steps, 3)}
     if ctx.rank != 0 or args.no_roofline:
         return res
     # roofline leg: the same rollout with every launch bracketed by HIP events on the launch stream
@@ -399,6 +419,7 @@ def main():
         "metric": "predicted frames/sec at 64x64, batch 64, 10-in/10-out",
         "value": main_res["value"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+        "single_chain": main_res.get("single_chain"),
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Moving-MNIST 64x64 rollout (generate_frames.py make_gifs sample loop), "
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "
@@ -406,6 +427,9 @@ def main():
                    "batch_per_gpu": args.batch, "n_past": args.n_past, "n_future": args.n_future,
                    "parallelism": f"replicas x{ctx.world} (no data-path collective)",
                    "launch": "eager" if args.no_graph else "hipGraph replay",
+                   # independent rollouts (samples of the make_gifs loop) in flight at once, one hipGraph + stream each; every
+                   # step is a complete rollout, ms_per_step = wall time / steps; `single_chain` = the same steps back to back
+                   "rollouts_in_flight": main_res["rollouts_in_flight"],
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's
                    # first conv is computed once per rollout and added in the epilogue (DVG_SKIP_HOIST=0: recompute)
                    "loop_invariant_skip_halves": "hoisted" if fused_mod.SKIP_HOIST else "recomputed every step",

@@ -228,3 +228,39 @@ class GraphedRollout:
                     dst.copy_(src)
         self.graph.replay()
         return self.frames
+
+
+class ConcurrentRollouts:
+    """`inflight` complete rollouts of ONE batch in flight at once: the rollouts of make_gifs' `for s in range(nsample)`
+    loop (generate_frames.py:143-177) are independent of each other, so each gets its own hipGraph (own static buffers, own
+    private pool: no buffer is shared between two graphs; weights, packed weights and BatchNorm folds are read-only) and its
+    own stream.  A rollout is a serial chain of ~500 launches, many of them small (LSTM cells, GEMV-shaped ends, the GP
+    sample, the 8x8 / 4x4 layers): with several chains in flight the tail of one launch and the latency-bound phases of one
+    rollout fill with another rollout's work.  Per-rollout arithmetic is unchanged (every rollout is a full
+    `sample_rollout`: conditioning included, nothing shared or amortised across rollouts) and so are its results.
+    `run(n)` issues n rollouts round-robin over the graphs and returns the static frame lists of the `inflight` most
+    recent ones; the caller synchronises (or records events) before reading them."""
+
+    def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval, inflight=2,
+                 last_frame_skip=False, period=15):
+        if inflight < 1:
+            raise ValueError("inflight must be >= 1")
+        self.rollouts = [GraphedRollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
+                                        last_frame_skip, period) for _ in range(inflight)]
+        self.streams = [torch.cuda.Stream() for _ in range(inflight)]
+        self._next = 0
+
+    def run(self, n: int, x: Optional[Sequence[torch.Tensor]] = None, chains: Optional[int] = None) -> List[List[torch.Tensor]]:
+        """`chains`: use only the first `chains` graphs (1 = the rollouts back to back as one serial chain)."""
+        nc = len(self.rollouts) if chains is None else max(1, min(chains, len(self.rollouts)))
+        cur = torch.cuda.current_stream()
+        for s in self.streams[:nc]:
+            s.wait_stream(cur)            # inputs written on the caller's stream are visible to every chain
+        for _ in range(n):
+            k = self._next % nc
+            self._next = (k + 1) % nc
+            with torch.cuda.stream(self.streams[k]):
+                self.rollouts[k](x)       # a stream runs its replays in order: a graph never overlaps itself
+        for s in self.streams[:nc]:
+            cur.wait_stream(s)
+        return [r.frames for r in self.rollouts[:nc]]

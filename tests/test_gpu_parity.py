@@ -544,6 +544,38 @@ def test_rollout_precomputes_frozen_skip_halves_on_a_second_stream():
             assert rel_err(hoisted[t], plain[t]) < 2e-5 and rel_err(replay[t], plain[t]) < 2e-5, (family, t)
 
 
+def test_concurrent_rollouts_equal_the_serial_chain():
+    """rollout.ConcurrentRollouts: three complete rollouts in flight (one hipGraph + one stream each) must each reproduce the
+    eager rollout bit for bit - no buffer may be shared between two graphs - also when replays of different graphs overlap
+    many times over and new inputs are handed in between runs."""
+    from dvg_amd.rollout import ConcurrentRollouts, sample_rollout
+    from tests.test_gpu_configs import _build
+    B, n_past, n_eval = 8, 4, 9
+    for family in ("dcgan", "vgg"):
+        mods, _ = _build(family, 64, 1, B, 2900)
+        for m in mods:
+            m.to(dev()).eval()
+        xs = [params.frames(2910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
+        xs2 = [params.frames(2950 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
+        ref = sample_rollout(*mods, xs, n_past, n_eval, period=0)
+        ref2 = sample_rollout(*mods, xs2, n_past, n_eval, period=0)
+        cr = ConcurrentRollouts(*mods, xs, n_past, n_eval, inflight=3, period=0)
+        outs = cr.run(11)
+        torch.cuda.synchronize()
+        assert len(outs) == 3
+        for frames in outs:
+            for t in range(n_eval):
+                assert torch.equal(frames[t], ref[t]), (family, t)
+        outs = cr.run(7, xs2)
+        torch.cuda.synchronize()
+        for frames in outs:
+            for t in range(n_eval):
+                assert torch.equal(frames[t], ref2[t]), (family, t)
+        one = cr.run(2, xs, chains=1)
+        torch.cuda.synchronize()
+        assert len(one) == 1 and all(torch.equal(one[0][t], ref[t]) for t in range(n_eval))
+
+
 @pytest.mark.parametrize("N,H,C,Cout,pool", [(8, 8, 64, 64, False), (8, 8, 512, 256, True), (8, 16, 256, 256, False),
                                              (64, 8, 256, 512, True), (2, 32, 128, 64, False), (32, 8, 512, 512, True)])
 def test_winograd_conv3x3_matches_direct_and_fp64(N, H, C, Cout, pool):
