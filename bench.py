@@ -34,6 +34,8 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command, committed under
 # profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
+# direct-form FLOPs of one B = 64, 10-in/10-out rollout (19 encoder + 10 decoder passes + 19 LSTM steps)
+SURVEY_FLOPS_PER_ROLLOUT = {"vgg": 4.99e12, "dcgan": 0.51e12}
 TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r02_conv3x3_traffic.json",
                  ("vgg", "winograd_gemm"): "r02_winograd_gemm_traffic.json",
                  ("dcgan", "conv4x4s2_igemm"): "r02_conv4x4s2_traffic.json",
@@ -301,6 +303,18 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
             "algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 2), "executed_tflops": round(exe / (ms * 1e-3) / 1e12, 2),
             "algorithmic_frac_of_fp32_mfma_peak": round(alg / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "share_of_kernel_time": round(ms / total_ms, 4)}
+    # the rollout as a whole against the fp32 MFMA roof: FLOPs its launches EXECUTE per step, and the step's direct-form
+    # ("algorithmic", SURVEY.md 8(d): 2 x MACs of every conv / convT / linear as the reference runs them, skip halves
+    # recomputed every step, 9-tap upsample convs) FLOPs, both over the timed wall time per step
+    exe_step = sum(v["flops"] for v in agg.values()) / 3
+    alg_step = SURVEY_FLOPS_PER_ROLLOUT.get(model) if (args.batch, args.n_past, args.n_future) == (64, 10, 10) else None
+    sec = res["ms_per_step"] * 1e-3
+    res["rollout_flops"] = {"executed_per_step": round(exe_step), "executed_tflops": round(exe_step / sec / 1e12, 2),
+                            "executed_frac_of_fp32_mfma_peak": round(exe_step / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "algorithmic_per_step": alg_step,
+                            "algorithmic_tflops": None if alg_step is None else round(alg_step / sec / 1e12, 2),
+                            "algorithmic_frac_of_fp32_mfma_peak": None if alg_step is None else
+                            round(alg_step / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     res["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
                           "avg_us": round(1000 * v["ms"] / v["launches"], 2),
                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
@@ -442,7 +456,7 @@ def main():
                    "conv3x3_deep_layers": {0: "direct implicit GEMM", 2: "Winograd F(2x2,3x3)", 4: "Winograd F(4x4,3x3) / F(2x2,3x3)"}[
                        fused_mod.WINOGRAD]},
     }
-    for k in ("roofline", "kernels"):
+    for k in ("roofline", "rollout_flops", "kernels"):
         if k in main_res:
             result[k] = main_res[k]
 
