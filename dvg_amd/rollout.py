@@ -264,3 +264,84 @@ class ConcurrentRollouts:
         for s in self.streams[:nc]:
             cur.wait_stream(s)
         return [r.frames for r in self.rollouts[:nc]]
+
+
+class GraphedSampler:
+    """The `for s in range(nsample)` body of make_gifs (generate_frames.py:163-178: the prediction phase of one sample from
+    the state the conditioning frames left behind, then utils.eval_seq's SSIM / PSNR per predicted frame) captured as
+    hipGraphs and replayed once per sample, `inflight` samples at a time (one graph + one stream each, see
+    ConcurrentRollouts).  The conditioning state (LSTM state, frozen skip tensors, last conditioning frame) and the ground
+    truth live in static buffers shared by all chains (read-only during replays); GP base samples eps (D,B) per trigger step,
+    predicted frames and metrics are per chain.  `set_batch()` installs a new batch, `run()` draws the samples."""
+
+    def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, state: dict, x, n_past, n_eval,
+                 last_frame_skip=False, period=15, inflight=3):
+        self._mods = (encoder, decoder, frame_predictor, gp_layer, likelihood)
+        self.n_past, self.n_eval, self.period = n_past, n_eval, period
+        self._kw = dict(n_past=n_past, n_eval=n_eval, last_frame_skip=last_frame_skip, period=period)
+        dev = x[0].device
+        B, D = x[0].shape[0], gp_layer.num_dims
+        # static state shared by all chains
+        self.hidden = [(h.clone(), c.clone()) for h, c in state["hidden"]]
+        self.skip = None if state["skip"] is None else [s.clone(memory_format=torch.preserve_format) for s in state["skip"]]
+        self.x = torch.stack([t.contiguous() for t in x])            # conditioning frames + ground truth of the metrics
+        self.steps = [i for i in range(n_past, n_eval) if period and i % period == 0]
+        self.chains = []
+        for _ in range(max(1, inflight)):
+            self.chains.append({"eps": {i: torch.zeros(D, B, device=dev) for i in self.steps},
+                                "stream": torch.cuda.Stream()})
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
+            self._body(self.chains[0])
+        torch.cuda.current_stream().wait_stream(side)
+        for ch in self.chains:
+            ch["graph"] = torch.cuda.CUDAGraph()
+            ops.clear_skip_proj_cache()
+            fused.clear_skip_hoist_cache()
+            with torch.cuda.graph(ch["graph"]):
+                ch["frames"], ch["ssim"], ch["psnr"] = self._body(ch)
+            ops.clear_skip_proj_cache()
+            fused.clear_skip_hoist_cache()
+
+    def _state(self):
+        return {"hidden": list(self.hidden), "skip": self.skip, "frames": [self.x[i] for i in range(self.n_past)]}
+
+    def _body(self, ch):
+        frames = sample_from(self._state(), *self._mods, eps_by_step=ch["eps"], **self._kw)
+        T = self.n_eval - self.n_past
+        m = [ops.eval_frames(self.x[self.n_past + t], frames[self.n_past + t]) for t in range(T)]
+        return torch.stack(frames), torch.stack([a for a, _ in m], 1), torch.stack([b for _, b in m], 1)
+
+    def set_batch(self, state: dict, x) -> None:
+        """New conditioning state (rollout.condition) and frames, copied into the static buffers on the current stream."""
+        for (h, c), (h2, c2) in zip(self.hidden, state["hidden"]):
+            h.copy_(h2)
+            c.copy_(c2)
+        if self.skip is not None:
+            for s, s2 in zip(self.skip, state["skip"]):
+                s.copy_(s2)
+        for i, t in enumerate(x):
+            self.x[i].copy_(t)
+
+    def run(self, nsample: int, samples: torch.Tensor, ssim: torch.Tensor, psnr: torch.Tensor,
+            eps_by_sample: Optional[Sequence[Dict[int, torch.Tensor]]] = None) -> None:
+        """Draws `nsample` samples: samples[s] <- the n_eval frames (n_eval,B,C,H,W), ssim[:, s] / psnr[:, s] <- (B,T).
+        eps_by_sample[s][i]: base sample of sample s at trigger step i (parity runs); None = torch's generator."""
+        cur = torch.cuda.current_stream()
+        for ch in self.chains:
+            ch["stream"].wait_stream(cur)
+        for s in range(nsample):
+            ch = self.chains[s % len(self.chains)]
+            with torch.cuda.stream(ch["stream"]):
+                for i in self.steps:
+                    if eps_by_sample is None:
+                        ch["eps"][i].normal_()
+                    else:
+                        ch["eps"][i].copy_(eps_by_sample[s][i])
+                ch["graph"].replay()
+                samples[s].copy_(ch["frames"])
+                ssim[:, s].copy_(ch["ssim"])
+                psnr[:, s].copy_(ch["psnr"])
+        for ch in self.chains:
+            cur.wait_stream(ch["stream"])

@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import utils  # noqa: E402
 from dvg_amd import ops  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
-from dvg_amd.rollout import condition, posterior_rollout, sample_from, sample_rollout  # noqa: E402
+from dvg_amd.rollout import GraphedSampler, condition, posterior_rollout, sample_from, sample_rollout  # noqa: E402
 from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
 
 
@@ -60,6 +60,8 @@ def build_parser():
     p.add_argument('--nbatches', type=int, default=5)
     p.add_argument('--trigger_indices', type=int, default=None, help='GPtrigger_gen: how many batch indices')
     p.add_argument('--synthetic_ckpt', action='store_true')
+    p.add_argument('--inflight', type=int, default=3,
+                   help='make_gifs: samples of a batch drawn at once (one hipGraph + stream each); 0 = eager loop, one at a time')
     p.add_argument('--synthetic_data', action='store_true',
                    help='datasets other than smmnist: synthetic clips of the right shape (--data_root is not read)')
     return p
@@ -77,6 +79,7 @@ class Generator:
         for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood):
             m.to(device).eval()
         self.frame_predictor.batch_size = opt.batch_size
+        self._sampler, self._sampler_key = None, None
 
     def _gp(self, h):
         return self.likelihood(self.gp_layer(h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)))
@@ -93,6 +96,20 @@ class Generator:
         all_gen = []
         # everything before the first predicted frame is the same for all nsample rollouts of this batch: once per batch
         state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip, decoder=self.decoder)
+        inflight = getattr(opt, 'inflight', 3)
+        if inflight > 0:
+            # the nsample rollouts are independent: each is a replay of the captured sample body, `inflight` at a time
+            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight)
+            if self._sampler_key != key:
+                self._sampler = GraphedSampler(self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
+                                               self.likelihood, state, x, opt.n_past, opt.n_eval, opt.last_frame_skip,
+                                               inflight=inflight)
+                self._sampler_key = key
+            self._sampler.set_batch(state, x)
+            samples = torch.empty((nsample, opt.n_eval) + tuple(x[0].shape), device=self.dev)
+            self._sampler.run(nsample, samples, ssim, psnr, eps_by_sample)
+            best = ssim.mean(2).argsort(1)[:, -1]
+            return {'posterior': torch.stack(post), 'samples': samples, 'ssim': ssim, 'psnr': psnr, 'best': best}
         for s in range(nsample):
             frames = sample_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
                                  self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip,
@@ -190,6 +207,7 @@ def main(argv=None):
         opt = ckpt['opt']
         opt.n_eval, opt.n_future, opt.batch_size = args.n_eval, args.n_future, args.batch_size
         opt.log_dir = args.log_dir
+        opt.inflight = args.inflight
     os.makedirs('%s/gen/' % opt.log_dir, exist_ok=True)
     print("Random Seed: ", opt.seed)
     random.seed(opt.seed)

@@ -144,13 +144,16 @@ def test_gp_trigger_generation_matches_oracle(depth, index):
         g.gp_trigger_gen([xs[0][:2].to(DEV)], n_index=1, total=14)
 
 
-def test_make_gifs_best_ssim_matches_oracle():
+@pytest.mark.parametrize("inflight", [0, 2])
+def test_make_gifs_best_ssim_matches_oracle(inflight):
     """generate_frames.py:143-189,207: nsample rollouts with GP samples at i % 15 == 0, SSIM / PSNR per frame
-    (utils.eval_seq), best sample per row = np.argsort(mean SSIM)[-1] - exact index match."""
+    (utils.eval_seq), best sample per row = np.argsort(mean SSIM)[-1] - exact index match.  inflight = 0: the eager sample
+    loop; 2: the sample body replayed as hipGraphs, two samples at a time (rollout.GraphedSampler)."""
     import generate_frames
     B, n_past, n_eval, S = 3, 3, 20, 3
     opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", "dcgan",
-                                                     "--n_past", str(n_past), "--n_eval", str(n_eval)])
+                                                     "--n_past", str(n_past), "--n_eval", str(n_eval),
+                                                     "--inflight", str(inflight)])
     mods, (esd, dsd, lsd, gsd, lik) = _build("dcgan", 64, 1, B, 1800)
     ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
     g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
@@ -178,6 +181,17 @@ def test_make_gifs_best_ssim_matches_oracle():
     assert len(decidable) >= 2, (gaps[:, -1] - gaps[:, -2], dev_)
     for i in decidable:
         assert int(res["best"][i]) == ref_best[i], (i, res["best"].tolist(), ref_best)
+    if inflight:
+        # the replayed sample body is the eager loop's arithmetic: same kernels on the same inputs, a second batch included
+        xs2 = [params.frames(1870 + t, B, 1, 64).to(DEV) for t in range(n_eval)]
+        eps_d = [{15: e[15].to(DEV)} for e in eps]
+        for batch in ([t.to(DEV) for t in xs], xs2):
+            a = g.make_gifs(batch, S, eps_by_sample=eps_d)
+            g.opt.inflight = 0
+            b = g.make_gifs(batch, S, eps_by_sample=eps_d)
+            g.opt.inflight = inflight
+            for k in ("samples", "ssim", "psnr", "best", "posterior"):
+                assert torch.equal(a[k], b[k]), k
 
 
 def test_gaussian_encoder_matches_reference_golden(golden):
