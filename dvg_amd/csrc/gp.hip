@@ -10,6 +10,8 @@
 // B = 64).  The factorisations are wave-synchronous (lane = matrix row, row
 // broadcasts through LDS, no workgroup barriers inside the O(n^3) loops) while the
 // other three waves assemble W = L_S^T K_Zx in parallel.
+#include <cstdlib>
+
 #include "dvg_common.h"
 
 namespace dvg {
@@ -39,65 +41,20 @@ struct GpParams {
     unsigned clk_cap;
 };
 
-// In-place lower Cholesky of the n x n matrix A (row stride ld) by ONE wave:
-// lane owns rows lane and lane+64.  Left-looking by columns: column j needs rows'
-// dot products with row j over the already finished columns.
-__device__ void wave_cholesky(float* A, int n, int ld, int lane) {
-    for (int j = 0; j < n; ++j) {
-        float s0 = 0.f, s1 = 0.f;
-        const int i0 = lane, i1 = lane + 64;
-        const bool a0 = i0 >= j && i0 < n, a1 = i1 >= j && i1 < n;
-        if (a0) s0 = A[i0 * ld + j];
-        if (a1) s1 = A[i1 * ld + j];
-        // 4 columns per trip with independent partial sums: the 8-12 LDS reads of a trip are issued together, so the
-        // ~64-cycle LDS latency is paid once per 4 columns instead of once per column
-        float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 4 <= j; k += 4) {
-            float lj[4], v0[4], v1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lj[q] = A[j * ld + k + q];
-                v0[q] = a0 ? A[i0 * ld + k + q] : 0.f;
-                v1[q] = a1 ? A[i1 * ld + k + q] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                t0[q] = fmaf(v0[q], lj[q], t0[q]);
-                t1[q] = fmaf(v1[q], lj[q], t1[q]);
-            }
-        }
-        for (; k < j; ++k) {
-            const float ljk = A[j * ld + k];
-            if (a0) t0[0] = fmaf(A[i0 * ld + k], ljk, t0[0]);
-            if (a1) t1[0] = fmaf(A[i1 * ld + k], ljk, t1[0]);
-        }
-        s0 -= (t0[0] + t0[1]) + (t0[2] + t0[3]);
-        s1 -= (t1[0] + t1[1]) + (t1[2] + t1[3]);
-        // the diagonal element lives in lane j%64, slot j/64
-        float d = __shfl((j < 64) ? s0 : s1, j & 63);
-        d = sqrtf(fmaxf(d, 1e-12f));
-        const float inv = 1.f / d;
-        if (a0) A[i0 * ld + j] = (i0 == j) ? d : s0 * inv;
-        if (a1) A[i1 * ld + j] = (i1 == j) ? d : s1 * inv;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // In-place lower Cholesky of the n x n matrix A (row stride ld, n <= 128) by the WHOLE 256-thread workgroup:
 // right-looking in panels of 8 columns.  The panel (8 columns, all rows below) is factored by wave 0 with dot
 // products of at most 7 terms; the trailing matrix gets its rank-8 update from all 256 threads (thread = one row x
 // a strided set of columns, the row's panel entries in registers, the column's broadcast from LDS; the panel
 // itself is factored in registers with uniform-lane shuffles).  The
-// wave-serial left-looking version (wave_cholesky, kept for the backward kernel's concurrent phases) spent 242 K
-// cycles on the 64x64 predictive covariance and 96 K on K_ZZ - 72 % of gp_predict.
+// wave-serial left-looking version both GP kernels started with spent 242 K cycles on the 64x64 predictive covariance
+// and 96 K on K_ZZ - 72 % of gp_predict.
 // Every thread of the workgroup must call it (it contains __syncthreads).  Only the lower triangle is written.
 // value of `v` in lane `src` (compile-time constant after unrolling): v_readlane_b32, not a ds_bpermute round trip
 __device__ __forceinline__ float read_lane(float v, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
+template <int NT>
 __device__ void block_cholesky(float* A, int n, int ld, int tid) {
     constexpr int NB = 8;
     const int lane = tid & 63, wave = tid >> 6;
@@ -141,7 +98,7 @@ __device__ void block_cholesky(float* A, int n, int ld, int tid) {
         __syncthreads();
         const int t0 = k0 + kb;
         if (t0 < n) {
-            const int RL = (n - t0 <= 64) ? 64 : 128, G = 256 / RL;
+            const int RL = (n - t0 <= 64) ? 64 : 128, G = NT / RL;
             const int i = t0 + tid % RL, g = tid / RL;
             if (i < n) {
                 float ai[NB];
@@ -171,17 +128,95 @@ __device__ void block_cholesky(float* A, int n, int ld, int tid) {
     }
 }
 
+template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
-    // 256 threads; scratch >= 4 floats
+    // NT threads; scratch >= NT / 64 floats; fixed summation order
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += scratch[w];
+    return t;
 }
 
-__global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
+// Blocked forward substitution L X = R in place (R = X [M][ncol], row stride LB; L lower, row stride LM): per block of 8
+// rows one thread per column solves the 8x8 triangle, then all 256 threads subtract the block's contribution from the
+// rows below.  One thread per column walking all M rows serially took 49 K cycles (M = 40, 65 columns).
+// Every thread of the workgroup must call it (it contains __syncthreads); ends with a barrier.
+template <int NT>
+__device__ void block_forward_subst(const float* L, int LM, float* X, int LB, int M, int ncol, int tid) {
+    constexpr int RB = 8;
+    for (int r0 = 0; r0 < M; r0 += RB) {
+        const int rb = min(RB, M - r0);
+        for (int col = tid; col < ncol; col += NT) {
+            float xv[RB];
+#pragma unroll
+            for (int a = 0; a < RB; ++a) {
+                xv[a] = 0.f;
+                if (a < rb) {
+                    float acc = X[(r0 + a) * LB + col];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (q < a) acc = fmaf(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
+                    xv[a] = acc / L[(r0 + a) * LM + r0 + a];
+                    X[(r0 + a) * LB + col] = xv[a];
+                }
+            }
+        }
+        __syncthreads();
+        const int below = M - (r0 + rb);
+        for (int e = tid; e < below * ncol; e += NT) {
+            const int i = r0 + rb + e / ncol, col = e % ncol;
+            float acc = X[i * LB + col];
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+                if (q < rb) acc = fmaf(-L[i * LM + r0 + q], X[(r0 + q) * LB + col], acc);
+            X[i * LB + col] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// Blocked backward substitution L^T X = R in place, the mirror image: row blocks from the bottom, the 8x8 triangle of a
+// block is the transpose of L's diagonal block, rows ABOVE the block get its contribution.
+template <int NT>
+__device__ void block_backward_subst(const float* L, int LM, float* X, int LB, int M, int ncol, int tid) {
+    constexpr int RB = 8;
+    for (int r1 = M; r1 > 0; r1 -= RB) {
+        const int r0 = max(0, r1 - RB), rb = r1 - r0;
+        for (int col = tid; col < ncol; col += NT) {
+            float xv[RB];
+#pragma unroll
+            for (int a = RB - 1; a >= 0; --a) {
+                xv[a] = 0.f;
+                if (a < rb) {
+                    float acc = X[(r0 + a) * LB + col];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (q > a && q < rb) acc = fmaf(-L[(r0 + q) * LM + r0 + a], xv[q], acc);
+                    xv[a] = acc / L[(r0 + a) * LM + r0 + a];
+                    X[(r0 + a) * LB + col] = xv[a];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < r0 * ncol; e += NT) {
+            const int i = e / ncol, col = e % ncol;
+            float acc = X[i * LB + col];
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+                if (q < rb) acc = fmaf(-L[(r0 + q) * LM + i], X[(r0 + q) * LB + col], acc);
+            X[i * LB + col] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B;
@@ -195,8 +230,8 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     float* zs = Wm + M * LB;       // [M]
     float* xs = zs + M;            // [B]
     float* mu = xs + B;            // [B]
-    float* red = mu + B;           // [8]
-    float* Sg = red + 8;           // [B][LS]   predictive covariance (only when needed)
+    float* red = mu + B;           // [16]
+    float* Sg = red + 16;          // [B][LS]   predictive covariance (only when needed)
 
     // torch.nn.functional.softplus (beta 1, threshold 20) of the raw parameters when the caller passes them as they are
     // (gp_models.py hyper-parameters / GaussianLikelihood noise with its GreaterThan(1e-4) floor): saves three
@@ -210,16 +245,16 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
-    for (int i = tid; i < M; i += 256) zs[i] = p.z[(size_t)d * M + i];
-    for (int b = tid; b < B; b += 256) xs[b] = p.h[(size_t)b * p.D + d];
+    for (int i = tid; i < M; i += NT) zs[i] = p.z[(size_t)d * M + i];
+    for (int b = tid; b < B; b += NT) xs[b] = p.h[(size_t)b * p.D + d];
     __syncthreads();
-    for (int i = tid; i < M * M; i += 256) {
+    for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         const float dz = zs[r] - zs[q];
         L[r * LM + q] = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
         Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
     }
-    for (int i = tid; i < M * (B + 1); i += 256) {
+    for (int i = tid; i < M * (B + 1); i += NT) {
         const int r = i / (B + 1), b = i % (B + 1);
         float v;
         if (b < B) {
@@ -234,55 +269,21 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
 
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 1] = clock64();
     // W = L_S^T K_Zx (needs the un-solved K_Zx), then chol(K_ZZ) by the whole workgroup
-    for (int i = tid; i < M * B; i += 256) {
+    for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
         float acc = 0.f;
         for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], AK[j * LB + b], acc);
         Wm[r * LB + b] = acc;
     }
-    block_cholesky(L, M, LM, tid);   // ends with __syncthreads
+    block_cholesky<NT>(L, M, LM, tid);   // ends with __syncthreads
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 2] = clock64();
 
-    // Blocked forward substitution L X = [K_Zx | m-c]: per block of 8 rows, one thread per column solves the 8x8
-    // triangle, then all threads subtract the block's contribution from the rows below (one thread per column
-    // walking all M rows serially took 49 K cycles).
-    {
-        constexpr int RB = 8;
-        const int ncol = B + 1;
-        for (int r0 = 0; r0 < M; r0 += RB) {
-            const int rb = min(RB, M - r0);
-            for (int col = tid; col < ncol; col += 256) {
-                float xv[RB];
-#pragma unroll
-                for (int a = 0; a < RB; ++a) {
-                    xv[a] = 0.f;
-                    if (a < rb) {
-                        float acc = AK[(r0 + a) * LB + col];
-#pragma unroll
-                        for (int q = 0; q < RB; ++q)
-                            if (q < a) acc = fmaf(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
-                        xv[a] = acc / L[(r0 + a) * LM + r0 + a];
-                        AK[(r0 + a) * LB + col] = xv[a];
-                    }
-                }
-            }
-            __syncthreads();
-            const int below = M - (r0 + rb);
-            for (int e = tid; e < below * ncol; e += 256) {
-                const int i = r0 + rb + e / ncol, col = e % ncol;
-                float acc = AK[i * LB + col];
-#pragma unroll
-                for (int q = 0; q < RB; ++q)
-                    if (q < rb) acc = fmaf(-L[i * LM + r0 + q], AK[(r0 + q) * LB + col], acc);
-                AK[i * LB + col] = acc;
-            }
-            __syncthreads();
-        }
-    }
+    // L X = [K_Zx | m-c]
+    block_forward_subst<NT>(L, LM, AK, LB, M, B + 1, tid);
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 3] = clock64();
 
     // predictive mean and marginal variance
-    for (int b = tid; b < B; b += 256) {
+    for (int b = tid; b < B; b += NT) {
         float m = 0.f, qa = 0.f, qw = 0.f;
         for (int i = 0; i < M; ++i) {
             const float a = AK[i * LB + b], w = Wm[i * LB + b];
@@ -304,19 +305,19 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
         // KL(q(u)||p(u)) = 0.5 [ -log|K| - log|S'| + tr(S'K) + (m-c)^T K^-1 (m-c) - M ],
         // tr(S'K) = || L^T L_S ||_F^2,  (m-c)^T K^-1 (m-c) = || L^-1 (m-c) ||^2
         float part = 0.f;
-        for (int i = tid; i < M * M; i += 256) {
+        for (int i = tid; i < M * M; i += NT) {
             const int r = i / M, q = i % M;
             float acc = 0.f;
             for (int k = (r > q ? r : q); k < M; ++k) acc = fmaf(L[k * LM + r], Ls[k * LM + q], acc);
             part = fmaf(acc, acc, part);
         }
-        for (int i = tid; i < M; i += 256) {
+        for (int i = tid; i < M; i += NT) {
             const float v = AK[i * LB + B];
             part = fmaf(v, v, part);
             part -= 2.f * logf(L[i * LM + i]);
             part -= 2.f * logf(fabsf(Ls[i * LM + i]));
         }
-        const float tot = block_sum(part, red, tid);
+        const float tot = block_sum<NT>(part, red, tid);
         if (tid == 0) p.kl[d] = 0.5f * (tot - (float)M);
     }
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
         // lower-triangular tiles only, mirrored on store
         {
             const int nt = (B + 3) / 4;
-            for (int t = tid; t < nt * nt; t += 256) {
+            for (int t = tid; t < nt * nt; t += NT) {
                 const int tr = t / nt, tq = t % nt;
                 if (tq > tr) continue;
                 float acc[4][4];
@@ -377,9 +378,9 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
         __syncthreads();
         if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 5] = clock64();
         if (p.sample != nullptr) {
-            block_cholesky(Sg, B, LS, tid);   // ends with __syncthreads
+            block_cholesky<NT>(Sg, B, LS, tid);   // ends with __syncthreads
         if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 6] = clock64();
-            for (int b = tid; b < B; b += 256) {
+            for (int b = tid; b < B; b += NT) {
                 float acc = mu[b];
 #pragma unroll 4
                 for (int j = 0; j <= b; ++j) acc = fmaf(Sg[b * LS + j], p.eps[(size_t)d * B + j], acc);
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(256) void gp_predict_kernel(const GpParams p) {
 //   G2 = dL/dKzx = alpha gm^T + 2 P diag(gq) + L_S GW
 //   GK = dL/dK   = -tau alpha^T - P diag(gq) P^T + gk/2 (-K^-1 + L_S L_S^T - alpha alpha^T)
 //   dL_S = tril( Kzx GW^T + gk (K L_S - diag(1/L_S_ii)) ),  dm = tau + gk alpha,  dc = sum gm - sum dm
-// and the RBF chain rule maps (GK, G2) onto z, x, s, ell.  K^-1 is formed explicitly from L^-1
-// (M = 40: a 40x40 triangular inverse by forward substitution, one thread per column).
+// and the RBF chain rule maps (GK, G2) onto z, x, s, ell.  K^-1 is applied by blocked triangular solves with L; the
+// explicit K^-1 of the KL trace term comes out of the same solves (identity columns appended to the right-hand sides).
 // ---------------------------------------------------------------------------------------
 struct GpBwdParams {
     const float* h; const float* z; const float* var_mean; const float* chol_var;
@@ -411,23 +412,27 @@ struct GpBwdParams {
     float* dh; float* dz; float* dm; float* dls; float* dc; float* ds; float* dell;
     int B, D, M;
     float jitter;
+    unsigned long long* clk;  // debug only (dvg_debug_set_gp_clockbuf): 12 x u64 phase stamps per workgroup
+    unsigned clk_cap;
 };
 
-__global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) {
+#define GP_STAMP(k) if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + (k)] = clock64();
+
+template <int NT>
+__global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B, LM = M + 1, LB = B + 2;
+    const int NP = B + 2 + M, LP = NP + 1;   // P = K^-1 [Kzx | m-c | Kzx gm | I]
     float* Kj = sm;               // [M][LM] K with jitter
     float* L = Kj + M * LM;       // chol(K)
-    float* Li = L + M * LM;       // L^-1
-    float* Ki = Li + M * LM;      // K^-1
-    float* Ls = Ki + M * LM;      // variational factor
+    float* Ls = L + M * LM;       // variational factor
     float* GK = Ls + M * LM;      // dL/dK
     float* Kzx = GK + M * LM;     // [M][LB]
-    float* P = Kzx + M * LB;      // K^-1 Kzx
-    float* Wm = P + M * LB;       // W, then GW
+    float* Wm = Kzx + M * LB;     // W, then GW
     float* G2 = Wm + M * LB;      // dL/dKzx
-    float* zs = G2 + M * LB;      // [M]
+    float* P = G2 + M * LB;       // [M][LP]
+    float* zs = P + M * LP;       // [M]
     float* rr = zs + M;           // m - c
     float* al = rr + M;           // alpha
     float* tt = al + M;           // Kzx gm
@@ -436,23 +441,25 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
     float* gm = xs + B;
     float* gv = gm + B;
     float* gq = gv + B;
-    float* red = gq + B;          // [8]
+    float* red = gq + B;          // [16]
+    const float* Ki = P + B + 2;  // K^-1 = the last M columns of P (row stride LP)
 
     const float s = p.outputscale[d], ell = p.lengthscale[d];
     const float ninv = -0.5f / (ell * ell), c0 = p.mean_const[d];
     const float gk = p.gkl ? p.gkl[d] : 0.f;
 
-    for (int i = tid; i < M; i += 256) {
+    GP_STAMP(0)
+    for (int i = tid; i < M; i += NT) {
         zs[i] = p.z[(size_t)d * M + i];
         rr[i] = p.var_mean[(size_t)d * M + i] - c0;
     }
-    for (int b = tid; b < B; b += 256) {
+    for (int b = tid; b < B; b += NT) {
         xs[b] = p.h[(size_t)b * p.D + d];
         gm[b] = p.gmean ? p.gmean[(size_t)d * B + b] : 0.f;
         gv[b] = p.gvar ? p.gvar[(size_t)d * B + b] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < M * M; i += 256) {
+    for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         const float dz = zs[r] - zs[q];
         const float v = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
@@ -460,101 +467,75 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
         L[r * LM + q] = v;
         Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
     }
-    for (int i = tid; i < M * B; i += 256) {
+    for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
         const float dx = zs[r] - xs[b];
         Kzx[r * LB + b] = s * expf(dx * dx * ninv);
     }
     __syncthreads();
-    if (wave == 0) {
-        wave_cholesky(L, M, LM, lane);
-    } else {
-        for (int i = tid - 64; i < M * B; i += 192) {
-            const int r = i / B, b = i % B;
-            float acc = 0.f;
-            for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], Kzx[j * LB + b], acc);
-            Wm[r * LB + b] = acc;
-        }
+    GP_STAMP(1)
+    // W = L_S^T Kzx and tt = Kzx gm by all threads, then chol(K) by the whole workgroup (8-column panels in registers,
+    // rank-8 trailing updates; the wave-serial left-looking factorisation this kernel used first took ~40 us of its 159)
+    for (int i = tid; i < M * B; i += NT) {
+        const int r = i / B, b = i % B;
+        float acc = 0.f;
+        for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], Kzx[j * LB + b], acc);
+        Wm[r * LB + b] = acc;
     }
-    __syncthreads();
-    // tt = Kzx gm (needs the chol barrier only for ordering of LDS reuse, not for its data)
-    for (int i = tid; i < M; i += 256) {
+    for (int i = tid; i < M; i += NT) {
         float acc = 0.f;
         for (int b = 0; b < B; ++b) acc = fmaf(Kzx[i * LB + b], gm[b], acc);
         tt[i] = acc;
     }
-    __syncthreads();
-    // P <- [Kzx | m-c | Kzx gm]; then K^-1 applied column-wise by two TRIANGULAR solves with L
-    // (an explicit fp32 K^-1 loses ~cond(K)*eps = 1e-3 and the c / s gradients cancel to 1e-2 of it).
-    for (int i = tid; i < M * (B + 2); i += 256) {
-        const int r = i / (B + 2), b = i % (B + 2);
-        P[r * LB + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : tt[r]);
+    GP_STAMP(2)
+    block_cholesky<NT>(L, M, LM, tid);   // ends with __syncthreads
+    GP_STAMP(3)
+    // P <- [Kzx | m-c | Kzx gm | I]; then K^-1 applied column-wise by two blocked TRIANGULAR solves with L
+    // (an explicit fp32 K^-1 from L^-1 loses ~cond(K)*eps = 1e-3 and the c / s gradients cancel to 1e-2 of it).  The
+    // identity columns give K^-1 itself, which only the KL trace term -gk/2 K^-1 needs.
+    for (int i = tid; i < M * NP; i += NT) {
+        const int r = i / NP, b = i % NP;
+        P[r * LP + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : (b == B + 1 ? tt[r] : (b - B - 2 == r ? 1.f : 0.f)));
     }
     __syncthreads();
-    if (tid < B + 2) {
-        const int col = tid;
-        for (int i = 0; i < M; ++i) {            // L y = b
-            float acc = P[i * LB + col];
-#pragma unroll 4
-            for (int j = 0; j < i; ++j) acc = fmaf(-L[i * LM + j], P[j * LB + col], acc);
-            P[i * LB + col] = acc / L[i * LM + i];
-        }
-        for (int i = M - 1; i >= 0; --i) {       // L^T x = y
-            float acc = P[i * LB + col];
-#pragma unroll 4
-            for (int k = i + 1; k < M; ++k) acc = fmaf(-L[k * LM + i], P[k * LB + col], acc);
-            P[i * LB + col] = acc / L[i * LM + i];
-        }
-    } else if (tid >= 192 && tid - 192 < M) {
-        // meanwhile: L^-1 (only the KL trace term -gk/2 K^-1 needs the explicit inverse), one thread per column
-        const int j = tid - 192;
-        for (int i = 0; i < M; ++i) {
-            float acc = (i == j) ? 1.f : 0.f;
-            if (i < j) { Li[i * LM + j] = 0.f; continue; }
-            for (int k = j; k < i; ++k) acc = fmaf(-L[i * LM + k], Li[k * LM + j], acc);
-            Li[i * LM + j] = acc / L[i * LM + i];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < M * M; i += 256) {
-        const int r = i / M, q = i % M;
-        float acc = 0.f;
-        for (int k = (r > q ? r : q); k < M; ++k) acc = fmaf(Li[k * LM + r], Li[k * LM + q], acc);
-        Ki[r * LM + q] = acc;
-    }
-    for (int i = tid; i < M; i += 256) {
-        al[i] = P[i * LB + B];
-        tau[i] = P[i * LB + B + 1];
+    block_forward_subst<NT>(L, LM, P, LP, M, NP, tid);
+    GP_STAMP(4)
+    block_backward_subst<NT>(L, LM, P, LP, M, NP, tid);
+    GP_STAMP(5)
+    for (int i = tid; i < M; i += NT) {
+        al[i] = P[i * LP + B];
+        tau[i] = P[i * LP + B + 1];
     }
     __syncthreads();
     float ds_part = 0.f;
-    for (int b = tid; b < B; b += 256) {
+    for (int b = tid; b < B; b += NT) {
         float q = 0.f;
-        for (int i = 0; i < M; ++i) q = fmaf(Kzx[i * LB + b], P[i * LB + b], q);
+        for (int i = 0; i < M; ++i) q = fmaf(Kzx[i * LB + b], P[i * LP + b], q);
         const float mask = (s - q > 0.f) ? 1.f : 0.f;
         gq[b] = -gv[b] * mask;
         ds_part += gv[b] * mask;
     }
     __syncthreads();
-    for (int i = tid; i < M * B; i += 256) {   // GW = 2 gv W (in place)
+    GP_STAMP(6)
+    for (int i = tid; i < M * B; i += NT) {   // GW = 2 gv W (in place)
         const int r = i / B, b = i % B;
         Wm[r * LB + b] *= 2.f * gv[b];
     }
     __syncthreads();
-    for (int i = tid; i < M * B; i += 256) {
+    for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        float acc = gm[b] * al[r] + 2.f * gq[b] * P[r * LB + b];
+        float acc = gm[b] * al[r] + 2.f * gq[b] * P[r * LP + b];
         for (int k = 0; k <= r; ++k) acc = fmaf(Ls[r * LM + k], Wm[k * LB + b], acc);
         G2[r * LB + b] = acc;
     }
-    for (int i = tid; i < M * M; i += 256) {
+    for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         float acc = -tau[r] * al[q];
-        for (int b = 0; b < B; ++b) acc = fmaf(-gq[b] * P[r * LB + b], P[q * LB + b], acc);
+        for (int b = 0; b < B; ++b) acc = fmaf(-gq[b] * P[r * LP + b], P[q * LP + b], acc);
         float sp = 0.f;
         const int kmax = r < q ? r : q;
         for (int k = 0; k <= kmax; ++k) sp = fmaf(Ls[r * LM + k], Ls[q * LM + k], sp);
-        acc += 0.5f * gk * (-Ki[r * LM + q] + sp - al[r] * al[q]);
+        acc += 0.5f * gk * (-Ki[r * LP + q] + sp - al[r] * al[q]);
         GK[r * LM + q] = acc;
         // dL_S (lower part)
         float g = 0.f;
@@ -567,17 +548,18 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
         p.dls[((size_t)d * M + r) * M + q] = g;
     }
     float dc_part = 0.f;
-    for (int i = tid; i < M; i += 256) {
+    for (int i = tid; i < M; i += NT) {
         const float dr = tau[i] + gk * al[i];
         p.dm[(size_t)d * M + i] = dr;
         dc_part -= dr;
     }
-    for (int b = tid; b < B; b += 256) dc_part += gm[b];
+    for (int b = tid; b < B; b += NT) dc_part += gm[b];
     __syncthreads();
+    GP_STAMP(7)
     // RBF chain rule
     float ds_acc = 0.f, dl_acc = 0.f;
     const float il2 = 1.f / (ell * ell), il3 = il2 / ell;
-    for (int i = tid; i < M * M; i += 256) {
+    for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         const float kp = Kj[r * LM + q] - (r == q ? p.jitter : 0.f);
         const float dz = zs[r] - zs[q];
@@ -585,14 +567,14 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
         ds_acc += g;
         dl_acc = fmaf(g, dz * dz, dl_acc);
     }
-    for (int i = tid; i < M * B; i += 256) {
+    for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
         const float dx = zs[r] - xs[b];
         const float g = G2[r * LB + b] * Kzx[r * LB + b];
         ds_acc += g;
         dl_acc = fmaf(g, dx * dx, dl_acc);
     }
-    for (int i = tid; i < M; i += 256) {
+    for (int i = tid; i < M; i += NT) {
         float acc = 0.f;
         for (int j = 0; j < M; ++j) {
             const float kp = Kj[i * LM + j] - (i == j ? p.jitter : 0.f);
@@ -601,28 +583,58 @@ __global__ __launch_bounds__(256) void gp_train_bwd_kernel(const GpBwdParams p) 
         for (int b = 0; b < B; ++b) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b]), acc);
         p.dz[(size_t)d * M + i] = acc * il2;
     }
-    for (int b = tid; b < B; b += 256) {
+    for (int b = tid; b < B; b += NT) {
         float acc = 0.f;
         for (int i = 0; i < M; ++i) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b], acc);
         p.dh[(size_t)b * p.D + d] = acc * il2;
     }
-    const float ds_tot = block_sum(ds_acc, red, tid);
-    const float dl_tot = block_sum(dl_acc, red, tid);
-    const float dc_tot = block_sum(dc_part, red, tid);
-    const float dsdir_tot = block_sum(ds_part, red, tid);
+    GP_STAMP(8)
+    const float ds_tot = block_sum<NT>(ds_acc, red, tid);
+    const float dl_tot = block_sum<NT>(dl_acc, red, tid);
+    const float dc_tot = block_sum<NT>(dc_part, red, tid);
+    const float dsdir_tot = block_sum<NT>(ds_part, red, tid);
     if (tid == 0) {
         p.ds[d] = ds_tot / s + dsdir_tot;
         p.dell[d] = dl_tot * il3;
         p.dc[d] = dc_tot;
     }
+    GP_STAMP(9)
 }
 
 }  // namespace dvg
 
 using namespace dvg;
 
+// Threads per workgroup (= per latent dim).  One workgroup per CU and every phase a chain of LDS round trips: more waves
+// per SIMD are the only latency hiding there is (tools/diag_gp_bwd.py, tools/bench_gp.py; DVG_GP_THREADS=256|512|1024
+// overrides both kernels for A/B runs).
+#ifndef GP_PREDICT_THREADS
+#define GP_PREDICT_THREADS 1024
+#endif
+#ifndef GP_BWD_THREADS
+#define GP_BWD_THREADS 1024
+#endif
+static int gp_threads(int dflt) {
+    static const char* e = getenv("DVG_GP_THREADS");
+    const int n = e ? atoi(e) : dflt;
+    return (n == 256 || n == 512 || n == 1024) ? n : dflt;
+}
+
+template <int NT, typename K, typename P>
+static int gp_launch(K kernel, const P& p, int D, size_t lds, void* stream, const char* who) {
+    static size_t attr_lds = 0;   // per instantiation; one-thread contract of the header
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kernel, dim3(D), dim3(NT), lds, (hipStream_t)stream, p);
+    return check_launch(who);
+}
+
 extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
-    size_t f = (size_t)2 * M * (M + 1) + (size_t)2 * M * (B + 2) + M + 2 * (size_t)B + 8;
+    size_t f = (size_t)2 * M * (M + 1) + (size_t)2 * M * (B + 2) + M + 2 * (size_t)B + 16;
     if (need_cov) f += (size_t)B * (B + 1);
     return f * 4;
 }
@@ -640,22 +652,18 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
     const int need_cov = (cov != nullptr) || (sample != nullptr);
     const size_t lds = dvg_gp_lds_bytes(B, M, need_cov);
     DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gp_predict_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_lds = lds;
-    }
     DVG_REQUIRE(train_mode >= 0 && train_mode <= 3, DVG_ERR_SHAPE, "dvg_gp_predict: train_mode flags must be 0..3");
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
                B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, g_gp_clk, g_gp_clk_cap};
-    hipLaunchKernelGGL(gp_predict_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
-    return check_launch("dvg_gp_predict");
+    switch (gp_threads(GP_PREDICT_THREADS)) {
+        case 256: return gp_launch<256>(gp_predict_kernel<256>, p, D, lds, stream, "dvg_gp_predict");
+        case 512: return gp_launch<512>(gp_predict_kernel<512>, p, D, lds, stream, "dvg_gp_predict");
+        default: return gp_launch<1024>(gp_predict_kernel<1024>, p, D, lds, stream, "dvg_gp_predict");
+    }
 }
 
 extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) {
-    return ((size_t)6 * M * (M + 1) + (size_t)4 * M * (B + 2) + 5 * (size_t)M + 4 * (size_t)B + 8) * 4;
+    return ((size_t)4 * M * (M + 1) + (size_t)3 * M * (B + 2) + (size_t)M * (B + M + 3) + 5 * (size_t)M + 4 * (size_t)B + 16) * 4;
 }
 
 extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
@@ -670,17 +678,13 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
                 "dvg_gp_train_bwd: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
     const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
     DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gp_train_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_lds = lds;
-    }
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
-                  dh, dz, dm, dls, dc, ds, dell, B, D, M, jitter};
-    hipLaunchKernelGGL(gp_train_bwd_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, p);
-    return check_launch("dvg_gp_train_bwd");
+                  dh, dz, dm, dls, dc, ds, dell, B, D, M, jitter, g_gp_clk, g_gp_clk_cap};
+    switch (gp_threads(GP_BWD_THREADS)) {
+        case 256: return gp_launch<256>(gp_train_bwd_kernel<256>, p, D, lds, stream, "dvg_gp_train_bwd");
+        case 512: return gp_launch<512>(gp_train_bwd_kernel<512>, p, D, lds, stream, "dvg_gp_train_bwd");
+        default: return gp_launch<1024>(gp_train_bwd_kernel<1024>, p, D, lds, stream, "dvg_gp_train_bwd");
+    }
 }
 
 extern "C" void dvg_debug_set_gp_clockbuf(void* buf, unsigned records) {

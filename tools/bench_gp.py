@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-call time of the GP kernels at training shapes (train-mode predict + backward), steady clocks (GPU only)."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dvg_amd import ops  # noqa: E402
+from oracle import params  # noqa: E402
+from tools.bench_small import time_fn  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    D, M = 90, 40
+    gsd, _ = params.gp_state(3, D, M)
+    g = {k: v.to(dev) for k, v in gsd.items()}
+    z = g["variational_strategy.inducing_points"]
+    m = g["variational_strategy.variational_distribution.variational_mean"]
+    ls = g["variational_strategy.variational_distribution.chol_variational_covar"]
+    s = F.softplus(g["covar_module.raw_outputscale"]).reshape(-1)
+    ell = F.softplus(g["covar_module.base_kernel.raw_lengthscale"]).reshape(-1)
+    c = g["mean_module.constant"].reshape(-1)
+    for B in (16, 64, 128):
+        h = torch.tanh(torch.randn(B, D, device=dev))
+        gm, gv, gk = torch.randn(D, B, device=dev), torch.randn(D, B, device=dev), torch.randn(D, device=dev)
+        bwd = time_fn(lambda: ops.gp_train_bwd(h, z, m, ls, c, s, ell, gm, gv, gk, 1e-3), iters=100)
+        fwd = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, train_mode=True, want_kl=True, jitter=1e-3), iters=100)
+        eps = torch.randn(D, B, device=dev)
+        smp = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, noise=s, eps=eps, jitter=1e-3), iters=100)
+        print(f"B={B:4d}  gp_train_bwd {bwd:7.1f} us   gp_predict(train, KL) {fwd:7.1f} us   gp_predict(eval, sample) {smp:7.1f} us")
+
+
+if __name__ == "__main__":
+    main()
