@@ -34,13 +34,21 @@ def main():
     rr = sys.argv[1]
     tag = f"r{rr}"
     for sub, name in (("stats_vgg", "vgg64_rollout"), ("stats_dcgan", "dcgan64_rollout"), ("stats_train", "train_vgg64"),
-                      ("stats_train_dcgan", "train_dcgan64")):
+                      ("stats_train_dcgan", "train_dcgan64"), ("stats_vgg_inflight3", "vgg64_rollout_inflight3"),
+                      ("stats_dcgan_inflight3", "dcgan64_rollout_inflight3")):
         f = glob.glob(os.path.join(SRC, sub, "**", "*kernel_stats.csv"), recursive=True)
         if f:
             shutil.copy(f[0], os.path.join(DST, f"{tag}_{name}_kernel_stats.csv"))
     for f, name in (("bench.json", "bench.json"), ("train_graph.jsonl", "train_graphed.jsonl")):
         if os.path.exists(os.path.join(SRC, f)):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"{tag}_{name}"))
+    # the bench lines printed by the profiled commands themselves (their live-event roofline legs ran under rocprofv3)
+    for m in ("vgg", "dcgan"):
+        f = os.path.join(SRC, f"bench_{m}_under_rocprof.log")
+        if os.path.exists(f):
+            lines = [ln for ln in open(f) if ln.lstrip().startswith("{") and '"metric"' in ln]
+            if lines:
+                open(os.path.join(DST, f"{tag}_{m}64_rollout_bench_under_rocprof.json"), "w").write(lines[-1])
     out = {}
     for m in ("vgg", "dcgan"):
         out[m] = pmc(f"pmc_{m}_*")
