@@ -191,9 +191,9 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        # Rehearsal of the multi-rank control flow on a ONE-GPU box (never a measurement): DVG_BENCH_SHARE_GPU=1 puts every
-        # rank on device 0 and DVG_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
-        self.rehearsal = os.environ.get("DVG_BENCH_SHARE_GPU") == "1"
+        # Rehearsal of the multi-rank control flow on a ONE-GPU box (never a measurement): DVG_DP_SHARE_GPU=1 puts every
+        # rank on device 0 and DVG_DP_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+        self.rehearsal = os.environ.get("DVG_DP_SHARE_GPU") == "1"
         if self.rehearsal:
             self.local = 0
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -204,7 +204,7 @@ class Ctx:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            backend = os.environ.get("DVG_BENCH_BACKEND", "nccl")
+            backend = os.environ.get("DVG_DP_BACKEND", "nccl")
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -431,7 +431,7 @@ def main():
     if world_env != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}", file=sys.stderr)
         sys.exit(2)
-    if os.environ.get("DVG_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
+    if os.environ.get("DVG_DP_SHARE_GPU") != "1" and torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
         print(f"bench.py: rank needs GPU {os.environ.get('LOCAL_RANK', '0')}, only {torch.cuda.device_count()} visible",
               file=sys.stderr)
         sys.exit(2)
@@ -467,7 +467,7 @@ def main():
                        fused_mod.WINOGRAD]},
     }
     if ctx.rehearsal:
-        result["rehearsal"] = ("DVG_BENCH_SHARE_GPU=1: all ranks share GPU 0 (backend %s) - a rehearsal of the multi-rank "
+        result["rehearsal"] = ("DVG_DP_SHARE_GPU=1: all ranks share GPU 0 (backend %s) - a rehearsal of the multi-rank "
                                "control flow, NOT a measurement" % getattr(ctx, "backend", "none"))
     for k in ("roofline", "rollout_flops", "kernels"):
         if k in main_res:

@@ -1,8 +1,8 @@
 """The multi-rank control flow of bench.py, rehearsed on the ONE GPU of the test box: `python bench.py --gpus 2` from a bare
 environment must start its own launcher as a child process, both ranks must run the replica rollouts and the data-parallel
 training leg (four gradient all-reduces per iteration over the flat arena) and rank 0 must print one JSON line.  RCCL refuses
-two ranks on one device, so the rehearsal switches put both ranks on GPU 0 with the gloo backend (DVG_BENCH_SHARE_GPU=1,
-DVG_BENCH_BACKEND=gloo): the numbers mean nothing and the line says so; the code path - self-launch, rendezvous, barriers,
+two ranks on one device, so the rehearsal switches put both ranks on GPU 0 with the gloo backend (DVG_DP_SHARE_GPU=1,
+DVG_DP_BACKEND=gloo): the numbers mean nothing and the line says so; the code path - self-launch, rendezvous, barriers,
 max-over-ranks timing, ArenaReducer ranges, the guarded graphed leg - is the one the 8-GPU run takes."""
 import json
 import os
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_two_ranks_rehearsal():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DVG_BENCH_SHARE_GPU="1", DVG_BENCH_BACKEND="gloo")
+    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--model", "dcgan", "--no-families", "--no-cpu-baseline", "--train-iters", "1",
                         "--train-graph-timeout", "120"],
@@ -33,3 +33,26 @@ def test_bench_two_ranks_rehearsal():
     assert t["eager"]["allreduces_per_iter"] == 4.0   # decoder / LSTM / GP range, encoder range, LSTM range, GP range
     assert t["eager"]["allreduce_MB_per_iter"] > 40
     assert "eager_no_allreduce" in t and "hipgraph" in t
+
+
+def test_train_py_two_ranks_end_with_identical_parameters():
+    """train.py under `torch.distributed.run` with two ranks (rehearsal switches: both on GPU 0, gloo): identical initial
+    parameters on both ranks, different data per rank, gradients averaged over the flat arena in place - after two
+    iterations (train_model + both fine-tuning closures each) every rank must hold bit-identical parameters, and they must
+    differ from a single-rank run on rank 0's data alone (i.e. the other rank's gradients did arrive)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", DVG_PRINT_PARAM_CHECKSUM="1", OMP_NUM_THREADS="2")
+    args = ["--model", "dcgan", "--dataset", "smmnist", "--n_past", "2", "--n_future", "3", "--n_eval", "5", "--niter", "1",
+            "--epoch_size", "2", "--no_save", "--save_every", "1000"]
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return {ln.split()[1]: ln.split()[-2:] for ln in r.stdout.splitlines() if "param checksum" in ln}
+
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29577", os.path.join(ROOT, "train.py"), "--batch_size", "8"] + args)
+    assert set(two) == {"0", "1"}, two
+    assert two["0"] == two["1"], two
+    one = run([sys.executable, os.path.join(ROOT, "train.py"), "--batch_size", "4"] + args)
+    assert one["0"] != two["0"]

@@ -571,6 +571,11 @@ def main(argv=None):
                 tr.save('%s/model.pth' % opt.output_path)
         if epoch % 10 == 0 and rank == 0:
             print('log dir: %s' % opt.log_dir)
+    if os.environ.get("DVG_PRINT_PARAM_CHECKSUM") == "1":   # tests: every rank must end with the same parameters
+        mods = (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer, tr.likelihood)
+        cs = sum(float(p.detach().double().sum()) for m in mods for p in m.parameters())
+        ab = sum(float(p.detach().double().abs().sum()) for m in mods for p in m.parameters())
+        print('rank %d param checksum %.17g %.17g' % (rank, cs, ab), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
