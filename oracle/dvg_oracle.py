@@ -22,7 +22,9 @@ Pinning:
     functions below restate the gpytorch 0.3.x WhitenedVariationalStrategy /
     GaussianLikelihood / VariationalELBO arithmetic as documented in DESIGN.md
     ("GP: equations of record") and are self-checked in fp64 against closed-form
-    identities (tests/test_oracle_gp.py).
+    identities and against PUBLISHED results they must reproduce with the optimal q(u) of Titsias 2009: the DTC
+    predictive, the collapsed bound, and - inducing points at the data - exact GP regression and its log marginal
+    likelihood (Rasmussen & Williams eq. 2.25 / 2.26 / 2.30)  (tests/test_oracle_gp.py).
   * evaluation metrics (utils.eval_seq -> skimage compare_ssim / compare_psnr): **parity unpinned** as well -
     scikit-image is neither vendored, pinned nor installed; `ssim_skimage` / `psnr_skimage` restate its published
     algorithm with the defaults the reference relies on, pinned by closed forms and a brute-force window evaluation
