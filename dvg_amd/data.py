@@ -92,17 +92,26 @@ class SyntheticMovingMNIST:
         x[x > 1] = 1.0
         return x
 
-    def batch_device(self, batch_size: int, device) -> list:
-        """The same batch as `utils.normalize_data(opt, dtype, self.batch(batch_size))` - bit for bit, given the same
-        generator state - composited on the GPU (dvg_moving_mnist_compose) straight into the T x (B,1,S,S) layout:
-        only the integer trajectories (a few KB) cross PCIe."""
-        from . import ops
+    def trajectories(self, batch_size: int):
+        """The host half of a batch: sprite ids (B, num_digits) and positions (B, num_digits, T, 2) int32, drawn in the
+        order `batch()` draws them (same generator state -> same batch)."""
         trajs = [self._trajectory() for _ in range(batch_size)]
         ids = np.stack([t[0] for t in trajs])
         pos = np.stack([t[1] for t in trajs])
         lim = self.image_size - self.digit_size
         if ids.min() < 0 or ids.max() >= self.N or pos.min() < 0 or pos.max() > lim:
             raise RuntimeError("SyntheticMovingMNIST: trajectory outside the canvas")
+        return ids, pos
+
+    def batch_device(self, batch_size: int, device) -> list:
+        """The same batch as `utils.normalize_data(opt, dtype, self.batch(batch_size))` - bit for bit, given the same
+        generator state - composited on the GPU (dvg_moving_mnist_compose) straight into the T x (B,1,S,S) layout:
+        only the integer trajectories (a few KB) cross PCIe."""
+        return self.compose_device(*self.trajectories(batch_size), device)
+
+    def compose_device(self, ids, pos, device) -> list:
+        """The device half: additive compositing + clip + normalize_data's layout in one kernel."""
+        from . import ops
         if getattr(self, "_dev_sprites", None) is None or self._dev_sprites.device != torch.device(device):
             self._dev_sprites = torch.from_numpy(self.data).to(device)
         out = ops.moving_mnist_compose(self._dev_sprites, torch.from_numpy(ids).to(device),
@@ -116,6 +125,11 @@ class SyntheticMovingMNIST:
 def synthetic_video(batch, seq_len, channels, res, seed=1) -> torch.Tensor:
     """(B,T,H,W,C) U[0,1]-textured clips with temporal coherence, for the KTH/BAIR/UCF-shaped configs."""
     rng = np.random.default_rng(seed)
-    base = rng.uniform(0, 1, (batch, 1, res, res, channels)).astype(np.float32)
-    drift = rng.normal(0, 0.05, (batch, seq_len, res, res, channels)).astype(np.float32).cumsum(1)
-    return torch.from_numpy(np.clip(base + drift, 0, 1))
+    base = rng.random((batch, 1, res, res, channels), dtype=np.float32)
+    # float32 draws, scaled / accumulated / clipped in place: the float64 form took longer on the host than a dcgan_64
+    # training iteration at this shape takes on the GPU (train.py draws batches on a background thread)
+    drift = rng.standard_normal((batch, seq_len, res, res, channels), dtype=np.float32)
+    drift *= np.float32(0.05)
+    np.cumsum(drift, axis=1, out=drift)
+    drift += base
+    return torch.from_numpy(np.clip(drift, 0, 1, out=drift))
