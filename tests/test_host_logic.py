@@ -181,3 +181,23 @@ def test_init_weights_matches_reference_distribution():
     assert abs(float(w.std()) - 0.02) < 2e-3 and abs(float(w.mean())) < 1e-3
     assert float(e.c3[1].main[0].bias.abs().max()) == 0.0
     assert abs(float(e.c3[1].main[1].weight.mean()) - 1.0) < 0.01
+
+
+def test_batch_prefetcher_keeps_order_propagates_errors_and_ends():
+    """train.BatchPrefetcher: the generator's items in its order from a background thread, its exception re-raised at the
+    consumer, exhaustion as StopIteration (repeatably)."""
+    import train
+    assert list(train.BatchPrefetcher(iter(range(9)), depth=2)) == list(range(9))
+    pf = train.BatchPrefetcher(iter([1]))
+    assert next(pf) == 1
+    for _ in range(2):
+        with pytest.raises(StopIteration):
+            next(pf)
+
+    def bad():
+        yield "a"
+        raise ValueError("boom")
+    pf = train.BatchPrefetcher(bad())
+    assert next(pf) == "a"
+    with pytest.raises(ValueError):
+        next(pf)

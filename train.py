@@ -506,10 +506,13 @@ class BatchPrefetcher:
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
+    _END = object()
+
     def _run(self):
         try:
             for item in self.gen:
                 self.q.put(item)
+            self.q.put(self._END)
         except BaseException as e:   # noqa: BLE001 - handed to the consumer
             self.q.put(e)
 
@@ -518,6 +521,9 @@ class BatchPrefetcher:
 
     def __next__(self):
         item = self.q.get()
+        if item is self._END:
+            self.q.put(item)         # stay exhausted
+            raise StopIteration
         if isinstance(item, BaseException):
             raise item
         return item
