@@ -61,6 +61,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true", help="skip the eager HIP-event leg (timeline profiling runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training leg")
     ap.add_argument("--train-iters", type=int, default=6)
+    ap.add_argument("--train-full-graph", action="store_true",
+                    help="with several ranks, also try the iteration as ONE hipGraph with the RCCL all-reduces captured "
+                         "inside.  Off by default: on this stack (PyTorch 2.10 / ROCm 7) the c10d watchdog thread may query a "
+                         "collective's event while it is still 'recorded in a capturing stream' (hipErrorCapturedEvent), "
+                         "which terminates the process - seen in 1 of 5 runs with a one-rank RCCL group")
     ap.add_argument("--train-graph-timeout", type=float, default=240.0,
                     help="seconds the graphed data-parallel leg may take before it is reported as timed out")
     return ap.parse_args(argv)
@@ -205,10 +210,23 @@ class Ctx:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             backend = os.environ.get("DVG_DP_BACKEND", "nccl")
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
-            else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            # RCCL prints a version banner on STDOUT when its first communicator comes up: stdout belongs to the one JSON
+            # line, so file descriptor 1 points at stderr until the communicator exists
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                t = torch.zeros(1, device=self.dev)
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.backend = backend
             self.dist = dist
 
@@ -336,7 +354,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     return res
 
 
-def measure_train(ctx: Ctx, args, graphed: bool, allreduce: bool = True) -> dict:
+def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
     """Data-parallel training at BASELINE.json configs[3]'s shape (BAIR-like: dcgan_64, nc=3, 16 clips per GPU,
     2-in/10-out): train_model + both fine-tuning closures per iteration (train.py:354-361), gradients averaged over
     RCCL (dvg_amd/parallel.py).  Weak scaling: the global batch is 16 x ranks."""
@@ -356,7 +374,10 @@ def measure_train(ctx: Ctx, args, graphed: bool, allreduce: bool = True) -> dict
     tr.set_allreduce(allreduce)
     x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor,
                                 synthetic_video(per_gpu, T, 3, 64, seed=args.seed + 31 * ctx.rank))
-    step = train.GraphedIteration(tr, warmup=2) if graphed else tr.iteration
+    # graphed: False = eager, True = ONE hipGraph (collectives captured inside), "segmented" = a chain of hipGraphs cut at
+    # the all-reduces, which stay eager (train.SegmentedIteration: what train.py runs with several ranks)
+    step = (train.SegmentedIteration(tr, warmup=2) if graphed == "segmented" else
+            train.GraphedIteration(tr, warmup=2) if graphed else tr.iteration)
     for _ in range(4 if graphed else 2):   # graphed: 2 eager warm-up iterations, the capture, one replay
         step(x)
     tr.reset_allreduce_stats()
@@ -372,6 +393,8 @@ def measure_train(ctx: Ctx, args, graphed: bool, allreduce: bool = True) -> dict
     st = tr.allreduce_stats()
     if st is not None and not graphed:
         res.update(st)
+    if graphed == "segmented":
+        res["graph_segments"] = step.n_segments
     return res
 
 
@@ -395,13 +418,28 @@ def train_leg(ctx: Ctx, args) -> dict:
                                                      out["eager_no_allreduce"]["ms_per_iter"], 2)
     out["train_frames_per_s"] = out["eager"]["train_frames_per_s"]
     out["allreduce_ms_per_iter"] = out["eager"].get("allreduce_ms_per_iter")
+    if ctx.world > 1:
+        try:
+            g = measure_train(ctx, args, graphed="segmented")
+            out["hipgraph_segmented"] = g
+            if g["train_frames_per_s"] > out["train_frames_per_s"]:
+                out["train_frames_per_s"] = g["train_frames_per_s"]
+                out["launch"] = "hipGraph segments, eager all-reduces between them"
+        except Exception as e:   # noqa: BLE001 - reported, not fatal
+            out["hipgraph_segmented"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
 def graphed_train_leg(ctx: Ctx, args, result: dict, emit) -> None:
     """The same iteration replayed as ONE hipGraph (train.GraphedIteration); with ranks > 1 the graph contains the RCCL
-    all-reduces.  Guarded: a watchdog emits the JSON line without this leg and ends the process if a captured
-    collective hangs, and an exception is reported instead of raised."""
+    all-reduces (the chain-of-graphs form with eager all-reduces has been measured in train_leg by then).  Guarded: a
+    watchdog emits the JSON line without this leg and ends the process if a captured collective hangs, and an exception
+    is reported instead of raised."""
+    if ctx.world > 1 and not args.train_full_graph:
+        result["train"]["hipgraph"] = {"skipped": "collectives are never captured by default (c10d watchdog vs capturing "
+                                                  "stream: intermittent process abort); see hipgraph_segmented, "
+                                                  "--train-full-graph to try"}
+        return
     done = threading.Event()
 
     def watchdog():

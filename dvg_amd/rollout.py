@@ -44,6 +44,10 @@ def _adjacent_view(frames):
 
 _ZERO_STATE = {}
 
+# Graph captures use the thread-local error mode: what OTHER threads do while this thread captures (torch.distributed's
+# watchdog polling the events of earlier collectives when a process group exists) is none of the capture's business.
+CAPTURE_KW = {"capture_error_mode": "thread_local"}
+
 
 def _zero_hidden(frame_predictor):
     """init_hidden() (lstm.py:58-63) without its 2 x n_layers fill launches per rollout: one cached all-zero tensor per
@@ -216,7 +220,7 @@ class GraphedRollout:
         self.graph = torch.cuda.CUDAGraph()
         ops.clear_skip_proj_cache()   # nothing cached eagerly may be referenced by the graph ...
         fused.clear_skip_hoist_cache()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **CAPTURE_KW):
             self.frames = sample_rollout(*self._args, self.static_x, **self._kw)
         ops.clear_skip_proj_cache()   # ... and nothing from the graph's pool by later eager calls
         fused.clear_skip_hoist_cache()
@@ -299,7 +303,7 @@ class GraphedSampler:
             ch["graph"] = torch.cuda.CUDAGraph()
             ops.clear_skip_proj_cache()
             fused.clear_skip_hoist_cache()
-            with torch.cuda.graph(ch["graph"]):
+            with torch.cuda.graph(ch["graph"], **CAPTURE_KW):
                 ch["frames"], ch["ssim"], ch["psnr"] = self._body(ch)
             ops.clear_skip_proj_cache()
             fused.clear_skip_hoist_cache()

@@ -33,17 +33,19 @@ def test_bench_two_ranks_rehearsal():
     assert t["eager"]["allreduces_per_iter"] == 4.0   # decoder / LSTM / GP range, encoder range, LSTM range, GP range
     assert t["eager"]["allreduce_MB_per_iter"] > 40
     assert "eager_no_allreduce" in t and "hipgraph" in t
+    assert t["hipgraph_segmented"]["graph_segments"] == 5, t["hipgraph_segmented"]   # cut at the four all-reduce groups
 
 
 def test_train_py_two_ranks_end_with_identical_parameters():
     """train.py under `torch.distributed.run` with two ranks (rehearsal switches: both on GPU 0, gloo): identical initial
-    parameters on both ranks, different data per rank, gradients averaged over the flat arena in place - after two
+    parameters on both ranks, different data per rank, gradients averaged over the flat arena in place, the iteration
+    replayed as a chain of hipGraphs with the all-reduces eager between them (train.SegmentedIteration) - after four
     iterations (train_model + both fine-tuning closures each) every rank must hold bit-identical parameters, and they must
     differ from a single-rank run on rank 0's data alone (i.e. the other rank's gradients did arrive)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", DVG_PRINT_PARAM_CHECKSUM="1", OMP_NUM_THREADS="2")
     args = ["--model", "dcgan", "--dataset", "smmnist", "--n_past", "2", "--n_future", "3", "--n_eval", "5", "--niter", "1",
-            "--epoch_size", "2", "--no_save", "--save_every", "1000"]
+            "--epoch_size", "4", "--no_save", "--save_every", "1000"]
 
     def run(cmd):
         r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)

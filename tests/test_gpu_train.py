@@ -284,6 +284,54 @@ def test_graphed_iteration_matches_eager(model):
     assert torch.allclose(ha, hb, rtol=2e-3, atol=2e-5)
 
 
+def test_segmented_iteration_cuts_at_the_allreduces_and_matches_eager():
+    """train.SegmentedIteration (the data-parallel form: a chain of hipGraphs cut at the gradient all-reduces, which run
+    eagerly between the segments) on a 1-rank process group with the all-reduces forced: five graph segments, four
+    eager collective groups per iteration, and the same losses / parameters / optimiser state as the eager loop."""
+    import torch.distributed as dist
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1)
+        created = True
+    os.environ["DVG_FORCE_ALLREDUCE"] = "1"
+    try:
+        res = []
+        for seg in (False, True):
+            torch.manual_seed(11)
+            opt = _opt("dcgan")
+            tr = train.Trainer(opt, torch.device("cuda:0"))
+            tr.train_mode()
+            assert tr.reducer.active()
+            gen = SyntheticMovingMNIST(seq_len=4, seed=9)
+            step = train.SegmentedIteration(tr, warmup=2) if seg else tr.iteration
+            losses = []
+            for it in range(5):
+                x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(4))
+                losses.append(step(x) + (tr.last_loss,))
+            if seg:
+                assert step.n_segments == 5, step.n_segments
+                assert [k for k, _ in step.items] == ["graph", "eager"] * 4 + ["graph"]
+                assert tr.reducer.calls == 4 * 5      # 2 eager warm-up iterations + 3 replays; the capture issues none
+            res.append((losses, copy.deepcopy(tr.encoder.state_dict()), copy.deepcopy(tr.decoder.state_dict()),
+                        copy.deepcopy(tr.frame_predictor.state_dict()), copy.deepcopy(tr.gp_layer.state_dict()),
+                        float(tr.encoder_optimizer.state_dict()["state"][0]["step"])))
+    finally:
+        del os.environ["DVG_FORCE_ALLREDUCE"]
+        if created:
+            dist.destroy_process_group()
+    (la, *sa, stepa), (lb, *sb, stepb) = res
+    assert stepa == stepb == 5.0
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            assert abs(u - v) <= 2e-4 * max(1.0, abs(u)), (la, lb)
+    for a, b in zip(sa, sb):
+        for k in a:
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=2e-3, atol=2e-5), k
+
+
 @pytest.mark.parametrize("model", ["dcgan", "vgg"])
 def test_shared_encoder_passes_match_reference_structure(model):
     """Trainer.share_encoder_passes (every frame encoded once per closure, BatchNorm side effects of the second pass

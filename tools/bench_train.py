@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--no_ft", action="store_true")
     ap.add_argument("--graph", action="store_true", help="train.GraphedIteration: the iteration as one hipGraph")
+    ap.add_argument("--segmented", action="store_true",
+                    help="train.SegmentedIteration: a chain of hipGraphs cut at the gradient all-reduces; with "
+                         "DVG_FORCE_ALLREDUCE=1 a 1-rank RCCL group is created so that the collectives really run")
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--image_width", type=int, default=64)
     a = ap.parse_args()
@@ -32,6 +35,16 @@ def main():
                                          "--n_future", str(a.n_future), "--no_save", "--channels", str(a.channels),
                                          "--image_width", str(a.image_width)])
     o.ft, o.rank, o.world, o.local_batch = not a.no_ft, 0, 1, a.batch
+    if os.environ.get("DVG_FORCE_ALLREDUCE") == "1":
+        import torch.distributed as dist
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda:0"))
     torch.manual_seed(1)
     tr = train.Trainer(o, torch.device("cuda:0"))
     tr.train_mode()
@@ -46,8 +59,8 @@ def main():
         tr.train_model(x)
         if o.ft:
             tr.finetune_temporal_encoders(x)
-    if a.graph:
-        g = train.GraphedIteration(tr, warmup=2)
+    if a.graph or a.segmented:
+        g = (train.SegmentedIteration if a.segmented else train.GraphedIteration)(tr, warmup=2)
         run = lambda: g(x)   # noqa: E731
         for _ in range(3):   # 2 eager warm-up iterations + the capture
             run()
@@ -66,7 +79,8 @@ def main():
     ops.set_timer(None)
     agg = timer.summary()
     tot = sum(v["ms"] for v in agg.values())
-    out = {"launch": "hipGraph replay" if a.graph else "eager", "model": f"{a.model}_{a.image_width}", "channels": a.channels, "batch": a.batch, "T": a.n_past + a.n_future, "ms_per_iter": round(dt * 1e3, 1),
+    out = {"launch": ("hipGraph segments (%d) + eager all-reduces" % g.n_segments) if a.segmented else
+           "hipGraph replay" if a.graph else "eager", "model": f"{a.model}_{a.image_width}", "channels": a.channels, "batch": a.batch, "T": a.n_past + a.n_future, "ms_per_iter": round(dt * 1e3, 1),
            "train_frames_per_s": round(a.batch * (a.n_past + a.n_future - 1) / dt, 1),
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "timed_kernel_ms": round(tot, 1),
            "kernels": {k: {"n": v["launches"], "ms": round(v["ms"], 1),

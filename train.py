@@ -79,9 +79,9 @@ def build_parser():
     p.add_argument('--save_every', type=int, default=4)
     p.add_argument('--no_save', action='store_true')
     p.add_argument('--hip_graph', action='store_true',
-                   help='replay each training iteration as one hipGraph (see GraphedIteration).  The default with ONE rank '
-                        '(same losses and parameters as the eager loop, tested; 1.5-2.7x the train frames/s); with more '
-                        'than one rank the graph would contain the RCCL all-reduces: eager unless DVG_HIP_GRAPH_DP=1')
+                   help='(the default) replay each training iteration as one hipGraph (GraphedIteration; same losses and '
+                        'parameters as the eager loop, tested; 1.5-2.7x the train frames/s); with more than one rank: as a '
+                        'chain of hipGraphs cut at the gradient all-reduces, which stay eager (SegmentedIteration)')
     p.add_argument('--no_hip_graph', action='store_true', help='eager launches for every iteration')
     p.add_argument('--synthetic_data', action='store_true',
                    help='datasets other than smmnist: train on synthetic clips of the right shape (--data_root is not read)')
@@ -151,6 +151,27 @@ class Trainer:
         assert self.rng_gp[1] == self.rng_fp[0] and self.rng_fp[1] == self.rng_dec[0] and self.rng_dec[1] == self.rng_enc[0]
 
     # ---- data-parallel switches / statistics (bench.py's training leg) --------------------------
+    def _ar(self, *actions):
+        """Gradient all-reduce actions at this point of the iteration: ("reduce", (lo, hi)) | ("start", key, (lo, hi)) |
+        ("finish", key) on ranges of the flat gradient arena.  Normally run at once; while a SegmentedIteration captures,
+        the graph is cut here instead and the actions are replayed eagerly between the graph segments."""
+        seg = getattr(self, "_segmenter", None)
+        if seg is not None:
+            if self.reducer.active():
+                seg.cut(actions)
+            return
+        self._run_ar(actions)
+
+    def _run_ar(self, actions):
+        pend = self.__dict__.setdefault("_ar_pending", {})
+        for a in actions:
+            if a[0] == "reduce":
+                self.reducer.reduce(*a[1])
+            elif a[0] == "start":
+                pend[a[1]] = self.reducer.start(*a[2])
+            else:
+                self.reducer.finish(pend.pop(a[1], None))
+
     def set_allreduce(self, on: bool):
         self.reducer.enabled = bool(on)
 
@@ -269,7 +290,7 @@ class Trainer:
             max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
         loss.backward()
-        self.reducer.reduce(*self.rng_gp)
+        self._ar(("reduce", self.rng_gp))
         self.optimizer.step()
         return loss.detach()
 
@@ -295,7 +316,7 @@ class Trainer:
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
-        self.reducer.reduce(*self.rng_fp)
+        self._ar(("reduce", self.rng_fp))
         self.frame_predictor_optimizer.step()
         return mse_latent.detach()
 
@@ -354,7 +375,7 @@ class Trainer:
             cur.wait_stream(side)              # the latent path's backward kernels
         if staged:
             # gradients of GP, likelihood, LSTM and decoder are final: their all-reduce runs under the encoder phase
-            pending = self.reducer.start(self.rng_gp[0], self.rng_dec[1])
+            self._ar(("start", "a", (self.rng_gp[0], self.rng_dec[1])))
             outs, seeds = [], []
             for (h, sk), (hd, skd) in zip(enc_out, enc_all):
                 for t, d in [(h, hd)] + list(zip(sk, skd)):
@@ -362,11 +383,9 @@ class Trainer:
                         outs.append(t)
                         seeds.append(d.grad)
             torch.autograd.backward(outs, seeds)
-            pending2 = self.reducer.start(*self.rng_enc)
-            self.reducer.finish(pending)
-            self.reducer.finish(pending2)
+            self._ar(("start", "b", self.rng_enc), ("finish", "a"), ("finish", "b"))
         else:
-            self.reducer.reduce(self.rng_gp[0], self.rng_enc[1])
+            self._ar(("reduce", (self.rng_gp[0], self.rng_enc[1])))
         self.frame_predictor_optimizer.step()
         self.encoder_optimizer.step()
         self.decoder_optimizer.step()
@@ -459,7 +478,7 @@ class GraphedIteration:
             o.begin_capture()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # see rollout.CAPTURE_KW
             mse_latent, loss = tr._train_model_dev(self.static_x)
             fp = gp = None
             if tr.opt.ft:
@@ -491,6 +510,73 @@ class GraphedIteration:
         tr.last_loss = float(loss)
         temp = (float(fp) + float(gp)) / T if tr.opt.ft else 0
         return v, v, temp
+
+
+class SegmentedIteration(GraphedIteration):
+    """The data-parallel form of GraphedIteration: the iteration is captured as a CHAIN of hipGraphs cut at the gradient
+    all-reduces, which run eagerly between the segments (train_model: [forward + decoder / LSTM / GP backward] -> start
+    all-reduce of their ranges -> [encoder backward] -> start the encoder range, wait for both -> [four Adam steps +
+    LSTM closure] -> all-reduce -> [LSTM Adam + GP closure] -> all-reduce -> [GP Adam]).  No collective is ever inside a
+    captured graph - RCCL runs them on its own stream exactly as in the eager loop, overlap with the encoder phase
+    included - and the ≈2 500 launches of an iteration still replay without Python.  All segments share one memory pool
+    and are always replayed in capture order."""
+
+    def _capture(self, x):
+        tr = self.tr
+        self.static_x = [t.clone() for t in x]
+        for o in tr.optimizers():
+            o.begin_capture()
+        torch.cuda.synchronize()
+        seg = self
+        self.items, self._pool, self._cur, self._ctx = [], None, None, None
+        tr._segmenter = seg
+        try:
+            seg._begin()
+            mse_latent, loss = tr._train_model_dev(self.static_x)
+            fp = gp = None
+            if tr.opt.ft:
+                fp = tr._train_fp_dev(self.static_x)
+                gp = tr._train_gp_dev(self.static_x)
+            self.outs = (mse_latent, loss, fp, gp)
+            seg._end()
+        finally:
+            tr._segmenter = None
+        self.graph = self           # GraphedIteration.__call__ replays through .replay()
+        self.sig = self._signature(x)
+
+    def _begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        # thread_local: calls made by OTHER threads while a segment is being captured (the c10d watchdog polling the events
+        # of earlier eager collectives) are none of the capture's business; the autograd engine's worker threads still
+        # launch into the capturing stream
+        kw = {"capture_error_mode": "thread_local"}
+        if self._pool is not None:
+            kw["pool"] = self._pool
+        self._ctx = torch.cuda.graph(self._cur, **kw)
+        self._ctx.__enter__()
+
+    def _end(self):
+        self._ctx.__exit__(None, None, None)
+        if self._pool is None:
+            self._pool = self._cur.pool()
+        self.items.append(("graph", self._cur))
+        self._cur = self._ctx = None
+
+    def cut(self, actions):
+        self._end()
+        self.items.append(("eager", actions))
+        self._begin()
+
+    def replay(self):
+        for kind, item in self.items:
+            if kind == "graph":
+                item.replay()
+            else:
+                self.tr._run_ar(item)
+
+    @property
+    def n_segments(self):
+        return sum(1 for k, _ in self.items if k == "graph")
 
 
 class BatchPrefetcher:
@@ -579,14 +665,16 @@ def main(argv=None):
     torch.manual_seed(opt.seed + 1000 * rank)   # from here on: per-rank randomness (GP samples)
     train_gen = BatchPrefetcher(make_batch_generator(opt, opt.n_past + opt.n_future, opt.seed + 17 * rank, device))
     test_gen = make_batch_generator(opt, opt.n_eval, opt.seed + 7919 + 17 * rank, device)
-    use_graph = (opt.hip_graph or world == 1) and not opt.no_hip_graph
-    if use_graph and world > 1 and os.environ.get("DVG_HIP_GRAPH_DP") != "1":
-        if rank == 0:
-            print("WARNING: --hip_graph with %d ranks would capture the RCCL all-reduces inside the graph; running eager "
-                  "(set DVG_HIP_GRAPH_DP=1 to enable - bench.py's training leg measures that combination)" % world,
-                  file=sys.stderr)
-        use_graph = False
-    step = GraphedIteration(tr) if use_graph else tr.iteration
+    # One rank: the iteration as one hipGraph.  Several ranks: a chain of hipGraphs cut at the gradient all-reduces, which
+    # stay eager (SegmentedIteration).  DVG_HIP_GRAPH_DP=1 captures the RCCL collectives inside ONE graph instead - NOT safe
+    # on this stack: the c10d watchdog thread may query a collective's event while it is "recorded in a capturing stream"
+    # (hipErrorCapturedEvent) and terminate the process (1 of 5 runs with a one-rank RCCL group).
+    if opt.no_hip_graph:
+        step = tr.iteration
+    elif world == 1 or os.environ.get("DVG_HIP_GRAPH_DP") == "1":
+        step = GraphedIteration(tr)
+    else:
+        step = SegmentedIteration(tr)
     for epoch in range(opt.niter):
         tr.train_mode()
         tr.scheduler.step()   # before the epoch, as train.py:347
