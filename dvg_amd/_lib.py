@@ -62,6 +62,8 @@ SIGNATURES = {
     "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _p]),
     "dvg_gp_bwd_lds_bytes": (C.c_size_t, [_i, _i]),
     "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _p]),
+    "dvg_gp_elbo": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _p]),
+    "dvg_gp_elbo_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
     "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _p]),

@@ -601,6 +601,55 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     GP_STAMP(9)
 }
 
+// ---------------------------------------------------------------------------------------
+// VariationalELBO(likelihood, gp, num_data, combine_terms=True)(pred, target) (train.py:112,164-169,225-226) as one launch
+// forward and one backward, instead of ~25 torch launches on (D,B) tensors per GP call:
+//   sig2_d = softplus(raw_noise_d) + 1e-4                       (GaussianLikelihood, noise floor GreaterThan(1e-4))
+//   elbo_d = (1/B) sum_b [ -((y_db - mean_db)^2 + var_db) / (2 sig2_d) - log(sig2_d)/2 - log(2 pi)/2 ] - KL_d / num_data
+// One workgroup per latent dim; target (D,B) with arbitrary strides (the reference hands over h_target.transpose(0,1)).
+// ---------------------------------------------------------------------------------------
+struct GpElboParams {
+    const float* mean; const float* var; const float* kl; const float* target; long t_sd, t_sb;
+    const float* raw_noise; const float* gelbo;
+    float* elbo; float* gmean; float* gvar; float* gkl; float* gtarget; float* graw_noise;
+    int B, D; float inv_num_data;
+};
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void gp_elbo_kernel(const GpElboParams p) {
+    __shared__ float red[4];
+    const int d = blockIdx.x, tid = threadIdx.x, B = p.B;
+    const float raw = p.raw_noise[d];
+    const float nz = softplus_f(raw) + 1e-4f;
+    float acc = 0.f;
+    for (int b = tid; b < B; b += 256) {
+        const float r = p.target[d * p.t_sd + b * p.t_sb] - p.mean[(size_t)d * B + b];
+        acc += fmaf(r, r, p.var[(size_t)d * B + b]);
+    }
+    const float tot = block_sum<256>(acc, red, tid);     // fixed order: deterministic
+    if (!BWD) {
+        if (tid == 0)
+            p.elbo[d] = -0.5f * tot / (nz * (float)B) - 0.5f * logf(nz) - 0.9189385332046727f - p.kl[d] * p.inv_num_data;
+        return;
+    }
+    const float g = p.gelbo[d];
+    const float k = g / (nz * (float)B);
+    for (int b = tid; b < B; b += 256) {
+        const float r = p.target[d * p.t_sd + b * p.t_sb] - p.mean[(size_t)d * B + b];
+        p.gmean[(size_t)d * B + b] = k * r;
+        p.gvar[(size_t)d * B + b] = -0.5f * k;
+        if (p.gtarget) p.gtarget[(size_t)d * B + b] = -k * r;
+    }
+    if (tid == 0) {
+        p.gkl[d] = -g * p.inv_num_data;
+        const float dnz = 0.5f * tot / (nz * nz * (float)B) - 0.5f / nz;
+        const float sig = raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));     // d softplus / d raw
+        p.graw_noise[d] = g * dnz * sig;
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -685,6 +734,34 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
         case 512: return gp_launch<512>(gp_train_bwd_kernel<512>, p, D, lds, stream, "dvg_gp_train_bwd");
         default: return gp_launch<1024>(gp_train_bwd_kernel<1024>, p, D, lds, stream, "dvg_gp_train_bwd");
     }
+}
+
+static int gp_elbo_checks(const float* mean, const float* var, const float* kl, const float* target, const float* raw_noise,
+                          int B, int D, int num_data, const char* who) {
+    DVG_REQUIRE(mean && var && kl && target && raw_noise, DVG_ERR_NULL, "%s: NULL input", who);
+    DVG_REQUIRE(B > 0 && D > 0 && num_data > 0, DVG_ERR_SHAPE, "%s: need B, D, num_data > 0 (got %d, %d, %d)", who, B, D, num_data);
+    return DVG_OK;
+}
+
+extern "C" int dvg_gp_elbo(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
+                           long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data, void* stream) {
+    if (int e = gp_elbo_checks(mean, var, kl, target, raw_noise, B, D, num_data, "dvg_gp_elbo")) return e;
+    DVG_REQUIRE(elbo, DVG_ERR_NULL, "dvg_gp_elbo: NULL output");
+    GpElboParams p{mean, var, kl, target, t_stride_d, t_stride_b, raw_noise, nullptr, elbo, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, B, D, 1.f / (float)num_data};
+    hipLaunchKernelGGL(gp_elbo_kernel<false>, dim3(D), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dvg_gp_elbo");
+}
+
+extern "C" int dvg_gp_elbo_bwd(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
+                               long t_stride_b, const float* raw_noise, const float* gelbo, float* gmean, float* gvar,
+                               float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, void* stream) {
+    if (int e = gp_elbo_checks(mean, var, kl, target, raw_noise, B, D, num_data, "dvg_gp_elbo_bwd")) return e;
+    DVG_REQUIRE(gelbo && gmean && gvar && gkl && graw_noise, DVG_ERR_NULL, "dvg_gp_elbo_bwd: NULL gradient buffer");
+    GpElboParams p{mean, var, kl, target, t_stride_d, t_stride_b, raw_noise, gelbo, nullptr, gmean, gvar, gkl, gtarget,
+                   graw_noise, B, D, 1.f / (float)num_data};
+    hipLaunchKernelGGL(gp_elbo_kernel<true>, dim3(D), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dvg_gp_elbo_bwd");
 }
 
 extern "C" void dvg_debug_set_gp_clockbuf(void* buf, unsigned records) {

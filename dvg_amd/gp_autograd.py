@@ -39,3 +39,25 @@ def gp_train(layer, h, noise):
     if noise is not None:
         var = var + noise.view(-1, 1)
     return {"mean": mean, "var": var, "kl": kl, "sample": None, "cov": None}
+
+
+class _GPElbo(torch.autograd.Function):
+    """VariationalELBO(combine_terms=True)(pred, target) as one launch forward and one backward (dvg_gp_elbo /
+    dvg_gp_elbo_bwd) instead of ~25 torch launches on (D,B) tensors per GP call: 950 of a dcgan_64 iteration's launches."""
+
+    @staticmethod
+    def forward(ctx, mean, var, kl, target, raw_noise, num_data):
+        ctx.save_for_backward(mean, var, kl, target, raw_noise)
+        ctx.num_data = num_data
+        return ops.gp_elbo(mean, var, kl, target, raw_noise, num_data)
+
+    @staticmethod
+    def backward(ctx, gelbo):
+        mean, var, kl, target, raw_noise = ctx.saved_tensors
+        gm, gv, gk, gt, gr = ops.gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, ctx.num_data,
+                                             need_gtarget=ctx.needs_input_grad[3])
+        return gm, gv, gk.view_as(kl), gt, gr.view_as(raw_noise), None
+
+
+def gp_elbo(mean, var, kl, target, raw_noise, num_data):
+    return _GPElbo.apply(mean, var, kl, target, raw_noise, num_data)

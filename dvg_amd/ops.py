@@ -832,6 +832,36 @@ def lstm_gates_bwd(dh, dc, gates, c_prev, c_new):
     return dG, dcp
 
 
+def gp_elbo(mean, var, kl, target, raw_noise, num_data):
+    """VariationalELBO(combine_terms=True) with the Gaussian likelihood's expected log-probability -> (D,) (dvg_gp_elbo).
+    mean, var (D,B) contiguous, kl (D,), target (D,B) with any strides, raw_noise (D,) or (D,1)."""
+    for t, n in ((mean, "mean"), (var, "var"), (kl, "kl"), (target, "target"), (raw_noise, "raw_noise")):
+        _dev_f32(t, "gp_elbo." + n)
+    d, b = mean.shape
+    if tuple(var.shape) != (d, b) or tuple(target.shape) != (d, b) or kl.numel() != d or raw_noise.numel() != d:
+        raise RuntimeError(f"gp_elbo: shapes mean {tuple(mean.shape)} var {tuple(var.shape)} target {tuple(target.shape)}")
+    mean, var, kl, raw = mean.contiguous(), var.contiguous(), kl.contiguous(), raw_noise.reshape(-1).contiguous()
+    out = torch.empty(d, device=mean.device, dtype=torch.float32)
+    check(lib().dvg_gp_elbo(_p(mean), _p(var), _p(kl), _p(target), target.stride(0), target.stride(1), _p(raw), _p(out),
+                            b, d, int(num_data), _stream()), "gp_elbo")
+    return out
+
+
+def gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, num_data, need_gtarget=True):
+    """Gradients of gp_elbo w.r.t. mean, var (D,B), kl (D,), target (D,B; None unless asked for), raw_noise (D,)."""
+    d, b = mean.shape
+    mean, var, kl, raw = mean.contiguous(), var.contiguous(), kl.contiguous(), raw_noise.reshape(-1).contiguous()
+    gelbo = gelbo.contiguous()
+    dev = mean.device
+    gmean, gvar = torch.empty((d, b), device=dev), torch.empty((d, b), device=dev)
+    gkl, graw = torch.empty(d, device=dev), torch.empty(d, device=dev)
+    gtarget = torch.empty((d, b), device=dev) if need_gtarget else None
+    check(lib().dvg_gp_elbo_bwd(_p(mean), _p(var), _p(kl), _p(target), target.stride(0), target.stride(1), _p(raw),
+                                _p(gelbo), _p(gmean), _p(gvar), _p(gkl), _p(gtarget), _p(graw), b, d, int(num_data),
+                                _stream()), "gp_elbo_bwd")
+    return gmean, gvar, gkl, gtarget, graw
+
+
 def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3):
     """Gradients of the train-mode GP prediction (see dvg_gp_train_bwd)."""
     h = h if h.is_contiguous() else h.contiguous()

@@ -203,7 +203,10 @@ class GraphedRollout:
     a rollout (19 encoder + 10 decoder passes, 38 LSTM cells, GEMMs, the GP sample) are launch-latency-bound at
     small batch / for dcgan_64, and the per-step Python + ctypes cost disappears from the critical path.
     Inputs are copied into static buffers; the returned frames are static tensors overwritten by every replay
-    (clone them to keep a sample).  GP noise eps comes from the captured Philox stream (fresh per replay)."""
+    (clone them to keep a sample).  The GP base samples eps (D,B) live in static buffers that every call refills from
+    torch's generator on the replay stream, OUTSIDE the graph: a generator captured inside hands all graphs of a process
+    the same device-side offset tensor, and two graphs replayed on different streams (ConcurrentRollouts) then read the
+    same offset and draw the same sample."""
 
     def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
                  last_frame_skip=False, period=15, warmup=2):
@@ -211,6 +214,9 @@ class GraphedRollout:
         self._kw = dict(n_past=n_past, n_eval=n_eval, last_frame_skip=last_frame_skip, period=period)
         buf = torch.stack([t.contiguous() for t in x])      # one buffer: the conditioning batch is a view of it
         self.static_x = [buf[i] for i in range(len(x))]
+        self.eps = {i: torch.randn(gp_layer.num_dims, x[0].shape[0], device=x[0].device)
+                    for i in (trigger_steps(n_past, n_eval, period) if period else [])}
+        self._kw["eps_by_step"] = self.eps
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -225,11 +231,18 @@ class GraphedRollout:
         ops.clear_skip_proj_cache()   # ... and nothing from the graph's pool by later eager calls
         fused.clear_skip_hoist_cache()
 
-    def __call__(self, x: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+    def __call__(self, x: Optional[Sequence[torch.Tensor]] = None,
+                 eps_by_step: Optional[Dict[int, torch.Tensor]] = None) -> List[torch.Tensor]:
+        """`eps_by_step`: base samples (D,B) per trigger step (parity runs); None = fresh draws from torch's generator."""
         if x is not None:
             for dst, src in zip(self.static_x, x):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
+        for i, e in self.eps.items():
+            if eps_by_step is None:
+                e.normal_()
+            else:
+                e.copy_(eps_by_step[i])
         self.graph.replay()
         return self.frames
 

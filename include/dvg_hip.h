@@ -447,6 +447,20 @@ int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, cons
                      float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
                      float jitter, void* stream);
 
+/* VariationalELBO(likelihood, gp_layer, num_data, combine_terms=True)(pred, target) with the GaussianLikelihood's
+ * expected log-probability (train.py:102,112; called at train.py:164-169,225-226): per latent dim d
+ *   elbo_d = (1/B) sum_b [ -((y_db - mean_db)^2 + var_db) / (2 sig2_d) - log(sig2_d)/2 - log(2 pi)/2 ] - kl_d / num_data,
+ *   sig2_d = softplus(raw_noise_d) + 1e-4.
+ * mean, var [D][B] and kl [D] are dvg_gp_predict's train-mode outputs; target is addressed as
+ * target[d * t_stride_d + b * t_stride_b] (the reference passes h_target.transpose(0,1), a strided view).
+ * dvg_gp_elbo_bwd: given gelbo [D] -> gmean, gvar [D][B], gkl [D], gtarget [D][B] (may be NULL), graw_noise [D]
+ * (soft-plus chain included).  ABI 5. */
+int dvg_gp_elbo(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
+                long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data, void* stream);
+int dvg_gp_elbo_bwd(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
+                    long t_stride_b, const float* raw_noise, const float* gelbo, float* gmean, float* gvar,
+                    float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Small elementwise helpers on the path
  * ------------------------------------------------------------------ */

@@ -574,6 +574,23 @@ def test_concurrent_rollouts_equal_the_serial_chain():
         one = cr.run(2, xs, chains=1)
         torch.cuda.synchronize()
         assert len(one) == 1 and all(torch.equal(one[0][t], ref[t]) for t in range(n_eval))
+    # with the GP trigger on (period 3: steps 6 of 4..8): every chain draws its OWN base sample per replay from the
+    # captured Philox stream - frames before the trigger step equal the deterministic rollout, frames from it on differ
+    # between chains and between replays of one chain
+    mods, _ = _build("dcgan", 64, 1, B, 2900)
+    for m in mods:
+        m.to(dev()).eval()
+    xs = [params.frames(2910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
+    ref = sample_rollout(*mods, xs, n_past, n_eval, period=0)
+    cr = ConcurrentRollouts(*mods, xs, n_past, n_eval, inflight=3, period=3)
+    a = [[f.clone() for f in fr] for fr in cr.run(3)]
+    b = [[f.clone() for f in fr] for fr in cr.run(3)]
+    torch.cuda.synchronize()
+    for fr in a + b:
+        for t in range(7):              # frame 6 is the first one decoded from a GP sample (step i = 6)
+            assert torch.equal(fr[t], ref[t]) == (t < 6), t
+        assert all(bool(torch.isfinite(f).all()) for f in fr)
+    assert not torch.equal(a[0][6], a[1][6]) and not torch.equal(a[1][6], a[2][6]) and not torch.equal(a[0][6], b[0][6])
 
 
 @pytest.mark.parametrize("N,H,C,Cout,pool", [(8, 8, 64, 64, False), (8, 8, 512, 256, True), (8, 16, 256, 256, False),
