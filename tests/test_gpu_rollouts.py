@@ -192,6 +192,12 @@ def test_make_gifs_best_ssim_matches_oracle(inflight):
             g.opt.inflight = inflight
             for k in ("samples", "ssim", "psnr", "best", "posterior"):
                 assert torch.equal(a[k], b[k]), k
+        # without base samples handed in every sample draws its own (torch's generator, per chain, outside the graphs):
+        # all four samples of a batch differ from the trigger step on and agree before it
+        r = g.make_gifs(xs2, 4)["samples"]
+        for i in range(4):
+            for j in range(i + 1, 4):
+                assert torch.equal(r[i, :15], r[j, :15]) and not torch.equal(r[i, 15], r[j, 15]), (i, j)
 
 
 def test_gaussian_encoder_matches_reference_golden(golden):
