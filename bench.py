@@ -418,7 +418,7 @@ def train_leg(ctx: Ctx, args) -> dict:
                                                      out["eager_no_allreduce"]["ms_per_iter"], 2)
     out["train_frames_per_s"] = out["eager"]["train_frames_per_s"]
     out["allreduce_ms_per_iter"] = out["eager"].get("allreduce_ms_per_iter")
-    if ctx.world > 1:
+    if ctx.world > 1 or (ctx.dist is not None and os.environ.get("DVG_FORCE_ALLREDUCE") == "1"):   # 2nd: one-rank RCCL check
         try:
             g = measure_train(ctx, args, graphed="segmented")
             out["hipgraph_segmented"] = g
@@ -435,7 +435,8 @@ def graphed_train_leg(ctx: Ctx, args, result: dict, emit) -> None:
     all-reduces (the chain-of-graphs form with eager all-reduces has been measured in train_leg by then).  Guarded: a
     watchdog emits the JSON line without this leg and ends the process if a captured collective hangs, and an exception
     is reported instead of raised."""
-    if ctx.world > 1 and not args.train_full_graph:
+    collectives = ctx.world > 1 or (ctx.dist is not None and os.environ.get("DVG_FORCE_ALLREDUCE") == "1")
+    if collectives and not args.train_full_graph:
         result["train"]["hipgraph"] = {"skipped": "collectives are never captured by default (c10d watchdog vs capturing "
                                                   "stream: intermittent process abort); see hipgraph_segmented, "
                                                   "--train-full-graph to try"}
