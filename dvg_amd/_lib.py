@@ -115,6 +115,17 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP kernel library has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dvg_amd/csrc`). "
                 "There is no CPU/eager fallback for the DVG hot path.")
+        # Two HIP runtimes live in a PyTorch-ROCm process: the one torch bundles and the system one this library links
+        # (/opt/rocm).  They coexist when torch's comes up FIRST; with the library loaded before torch has initialised its
+        # runtime, every launch from here fails with "no ROCm-capable device is detected" (seen with build() and smoke() in
+        # one process).  So: bring torch's runtime up before the dlopen.  (No GPU - the cross-compile container, the ABI
+        # tests - nothing to initialise.)
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:  # pragma: no cover - a host without torch binds the C ABI directly
+            pass
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover

@@ -58,3 +58,21 @@ def test_train_py_two_ranks_end_with_identical_parameters():
     assert two["0"] == two["1"], two
     one = run([sys.executable, os.path.join(ROOT, "train.py"), "--batch_size", "4"] + args)
     assert one["0"] != two["0"]
+
+
+def test_library_loaded_before_torch_touches_the_gpu_still_launches():
+    """build() followed by smoke() in ONE process loads libdvg_hip.so before torch has initialised its (bundled) HIP
+    runtime; the library links the system runtime, and in that order every launch used to fail with "no ROCm-capable
+    device is detected".  `_lib.lib()` now brings torch's runtime up first."""
+    code = ("from dvg_amd import _lib\n"
+            "assert _lib.lib().dvg_abi_version() == 5\n"
+            "import torch\n"
+            "from dvg_amd import ops\n"
+            "x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32, device='cuda').reshape(2, 3, 4, 5)\n"
+            "y = ops.to_nhwc(x)\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.equal(y, x) and ops.is_nhwc(y)\n"
+            "print('launch ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "launch ok" in r.stdout, r.stderr[-1500:]
