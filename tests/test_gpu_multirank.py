@@ -15,6 +15,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def test_bench_two_ranks_rehearsal():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo")
@@ -53,7 +62,7 @@ def test_train_py_two_ranks_end_with_identical_parameters():
         return {ln.split()[1]: ln.split()[-2:] for ln in r.stdout.splitlines() if "param checksum" in ln}
 
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-               "--master-port", "29577", os.path.join(ROOT, "train.py"), "--batch_size", "8"] + args)
+               "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--batch_size", "8"] + args)
     assert set(two) == {"0", "1"}, two
     assert two["0"] == two["1"], two
     one = run([sys.executable, os.path.join(ROOT, "train.py"), "--batch_size", "4"] + args)

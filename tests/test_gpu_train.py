@@ -294,7 +294,12 @@ def test_segmented_iteration_cuts_at_the_allreduces_and_matches_eager():
     from dvg_amd.data import SyntheticMovingMNIST
     created = False
     if not dist.is_initialized():
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1)
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         created = True
     os.environ["DVG_FORCE_ALLREDUCE"] = "1"
     try:
