@@ -493,6 +493,8 @@ def main():
                    # independent rollouts (samples of the make_gifs loop) in flight at once, one hipGraph + stream each; every
                    # step is a complete rollout, ms_per_step = wall time / steps; `single_chain` = the same steps back to back
                    "rollouts_in_flight": main_res["rollouts_in_flight"],
+                   "step": "one COMPLETE rollout (conditioning + prediction) of one batch; K steps = K rollouts, independent of "
+                           "each other (samples of make_gifs' nsample loop), issued round-robin over the chains",
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's
                    # first conv is computed once per rollout and added in the epilogue (DVG_SKIP_HOIST=0: recompute)
                    "loop_invariant_skip_halves": "hoisted" if fused_mod.SKIP_HOIST else "recomputed every step",
