@@ -468,6 +468,9 @@ class GraphedIteration:
         self.graph = None
         self.sig = None
 
+    def _replay(self):
+        self.graph.replay()
+
     def _signature(self, x):
         lrs = tuple(g['lr'] for o in self.tr.optimizers() for g in o.param_groups)
         return lrs, tuple(tuple(t.shape) for t in x), self.tr.opt.ft, tuple(m.training for m in self.tr.modules)
@@ -497,7 +500,7 @@ class GraphedIteration:
             self._capture(x)
         for dst, src in zip(self.static_x, x):
             dst.copy_(src)
-        self.graph.replay()
+        self._replay()
         tr._iters = getattr(tr, '_iters', 0) + 1
         for o in tr.optimizers():
             o.after_graph_replay()
@@ -542,7 +545,7 @@ class SegmentedIteration(GraphedIteration):
             seg._end()
         finally:
             tr._segmenter = None
-        self.graph = self           # GraphedIteration.__call__ replays through .replay()
+        self.graph = [g for kind, g in self.items if kind == "graph"]   # (truthy: "captured"; replay goes through items)
         self.sig = self._signature(x)
 
     def _begin(self):
@@ -568,7 +571,7 @@ class SegmentedIteration(GraphedIteration):
         self.items.append(("eager", actions))
         self._begin()
 
-    def replay(self):
+    def _replay(self):
         for kind, item in self.items:
             if kind == "graph":
                 item.replay()
