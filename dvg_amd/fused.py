@@ -62,9 +62,16 @@ if WINOGRAD not in (0, 2, 4):
     raise RuntimeError("DVG_WINOGRAD must be 0, 2 or 4")
 
 
+# F(4x4) eligibility: input channels >= 64 (the 64 -> 128 layer at 32x32 included: -1.2 % per vgg_64 rollout, alone and with
+# rollouts in flight; it lost against the direct form before the chained transforms existed), maps up to 32x32 (at 64x64 the
+# HBM-bound transform passes cost what the GEMM saves: 17.89 vs 17.79 ms).  Environment overrides for A/B runs only.
+_WINO_MIN_C = int(os.environ.get("DVG_WINO_MIN_C", "64"))
+_WINO_MAX_HW = int(os.environ.get("DVG_WINO_MAX_HW", "32"))
+
+
 def winograd_tile(n, c, h, w, cout) -> int:
     """Winograd output-tile size (4, 2) for this eval-mode 3x3 layer, or 0 for the direct implicit GEMM."""
-    if WINOGRAD >= 4 and c >= 128 and h <= 32 and w <= 32 and ops.winograd_ok(n, c, h, w, cout, 4):
+    if WINOGRAD >= 4 and c >= _WINO_MIN_C and h <= _WINO_MAX_HW and w <= _WINO_MAX_HW and ops.winograd_ok(n, c, h, w, cout, 4):
         return 4
     if WINOGRAD >= 2 and c >= 256 and ops.winograd_ok(n, c, h, w, cout, 2) and \
             ((h <= 8 and w <= 8) or (h <= 16 and w <= 16 and cout >= 256)):
