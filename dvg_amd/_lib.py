@@ -58,6 +58,8 @@ SIGNATURES = {
     "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_lstm_cell_x": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_stem_gemm": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_gp_precision": (_i, [_i, _i, _i]),
+    "dvg_gp_bwd_precision": (_i, [_i, _i]),
     "dvg_gp_lds_bytes": (C.c_size_t, [_i, _i, _i]),
     "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _p]),
     "dvg_gp_bwd_lds_bytes": (C.c_size_t, [_i, _i]),

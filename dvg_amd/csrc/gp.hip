@@ -41,6 +41,43 @@ struct GpParams {
     unsigned clk_cap;
 };
 
+
+// ---------------------------------------------------------------------------------------
+// Arithmetic type.  Both kernels are templates on T: T = double is the product path (r03) - K_ZZ carries a 1e-3 jitter on
+// an RBF Gram matrix of 40 points, cond(K_ZZ) ~ 1e4..1e5, so fp32 K entries (1 ulp of expf = 6e-8) alone cost
+// cond * 6e-8 ~ 2e-3 of the predictive covariance; assembled, factored, solved and cancelled (k(x,x) - A^T A) in fp64 the
+// kernel meets the 1e-4 bar of BASELINE.json with two decades to spare.  Inputs and outputs stay fp32.  T = float is kept
+// for shapes whose fp64 working set exceeds the 160 KB of LDS (dvg_gp_precision() tells which one a shape gets) and for
+// A/B runs (DVG_GP_FP32=1).  v_fma_f64 issues at the fp32 vector rate on gfx950; the kernels are LDS-latency chains.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float exp_t(float x) { return expf(x); }
+__device__ __forceinline__ double exp_t(double x) { return exp(x); }
+__device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }
+__device__ __forceinline__ float log_t(float x) { return logf(x); }
+__device__ __forceinline__ double log_t(double x) { return log(x); }
+__device__ __forceinline__ float log1p_t(float x) { return log1pf(x); }
+__device__ __forceinline__ double log1p_t(double x) { return log1p(x); }
+__device__ __forceinline__ float abs_t(float x) { return fabsf(x); }
+__device__ __forceinline__ double abs_t(double x) { return fabs(x); }
+__device__ __forceinline__ float max_t(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_t(double a, double b) { return fmax(a, b); }
+
+// value of `v` in lane `src` (compile-time constant after unrolling): v_readlane_b32, not a ds_bpermute round trip
+__device__ __forceinline__ float read_lane(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ double read_lane(double v, int src) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char gp_lds_raw[];
+
 // In-place lower Cholesky of the n x n matrix A (row stride ld, n <= 128) by the WHOLE 256-thread workgroup:
 // right-looking in panels of 8 columns.  The panel (8 columns, all rows below) is factored by wave 0 with dot
 // products of at most 7 terms; the trailing matrix gets its rank-8 update from all 256 threads (thread = one row x
@@ -49,13 +86,13 @@ struct GpParams {
 // wave-serial left-looking version both GP kernels started with spent 242 K cycles on the 64x64 predictive covariance
 // and 96 K on K_ZZ - 72 % of gp_predict.
 // Every thread of the workgroup must call it (it contains __syncthreads).  Only the lower triangle is written.
-// value of `v` in lane `src` (compile-time constant after unrolling): v_readlane_b32, not a ds_bpermute round trip
-__device__ __forceinline__ float read_lane(float v, int src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
 
-template <int NT>
-__device__ void block_cholesky(float* A, int n, int ld, int tid) {
+// PACKED: A holds only the lower triangle, row i at offset i (i + 1) / 2 (the 128 x 128 fp64 predictive covariance does not
+// fit beside the other operands as a full square).  Entries above the diagonal that the panel code touches inside a
+// diagonal block then alias in-bounds entries of the next row; they are read into registers the code never uses.
+template <int NT, typename T, bool PACKED = false>
+__device__ void block_cholesky(T* A, int n, int ld, int tid) {
+    auto at = [ld](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * ld + j; };
     constexpr int NB = 8;
     const int lane = tid & 63, wave = tid >> 6;
     for (int k0 = 0; k0 < n; k0 += NB) {
@@ -66,33 +103,33 @@ __device__ void block_cholesky(float* A, int n, int ld, int tid) {
             // lane q's freshly scaled value - uniform-lane shuffles (v_readlane), no LDS round trip per column.
             const int i0 = k0 + lane, i1 = k0 + lane + 64;
             const bool v0 = i0 < n, v1 = i1 < n;
-            float a0[NB], a1[NB];
+            T a0[NB], a1[NB];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                a0[q] = (v0 && q < kb) ? A[i0 * ld + k0 + q] : 0.f;
-                a1[q] = (v1 && q < kb) ? A[i1 * ld + k0 + q] : 0.f;
+                a0[q] = (v0 && q < kb) ? A[at(i0, k0 + q)] : T(0.);
+                a1[q] = (v1 && q < kb) ? A[at(i1, k0 + q)] : T(0.);
             }
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) {
                 if (jj < kb) {
-                    const float dg = sqrtf(fmaxf(read_lane(a0[jj], jj), 1e-12f));
-                    const float inv = 1.f / dg;
-                    const float l0 = (lane == jj) ? dg : a0[jj] * inv;   // lanes < jj: upper triangle, never read
-                    const float l1 = a1[jj] * inv;
+                    const T dg = sqrt_t(max_t(read_lane(a0[jj], jj), T(1e-12)));
+                    const T inv = T(1.) / dg;
+                    const T l0 = (lane == jj) ? dg : a0[jj] * inv;   // lanes < jj: upper triangle, never read
+                    const T l1 = a1[jj] * inv;
                     a0[jj] = l0;
                     a1[jj] = l1;
 #pragma unroll
                     for (int q = jj + 1; q < NB; ++q) {
-                        const float lq = read_lane(l0, q);               // L[k0+q][k0+jj]
-                        a0[q] = fmaf(-l0, lq, a0[q]);
-                        a1[q] = fmaf(-l1, lq, a1[q]);
+                        const T lq = read_lane(l0, q);               // L[k0+q][k0+jj]
+                        a0[q] = fma_t(-l0, lq, a0[q]);
+                        a1[q] = fma_t(-l1, lq, a1[q]);
                     }
                 }
             }
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                if (v0 && q < kb && lane >= q) A[i0 * ld + k0 + q] = a0[q];
-                if (v1 && q < kb) A[i1 * ld + k0 + q] = a1[q];
+                if (v0 && q < kb && lane >= q) A[at(i0, k0 + q)] = a0[q];
+                if (v1 && q < kb) A[at(i1, k0 + q)] = a1[q];
             }
         }
         __syncthreads();
@@ -101,26 +138,26 @@ __device__ void block_cholesky(float* A, int n, int ld, int tid) {
             const int RL = (n - t0 <= 64) ? 64 : 128, G = NT / RL;
             const int i = t0 + tid % RL, g = tid / RL;
             if (i < n) {
-                float ai[NB];
+                T ai[NB];
 #pragma unroll
-                for (int q = 0; q < NB; ++q) ai[q] = q < kb ? A[i * ld + k0 + q] : 0.f;
+                for (int q = 0; q < NB; ++q) ai[q] = q < kb ? A[at(i, k0 + q)] : T(0.);
                 int j = t0 + g;
                 for (; j + 3 * G <= i; j += 4 * G) {     // four columns per trip: their LDS reads issue together
-                    float dot[4] = {0.f, 0.f, 0.f, 0.f}, cur[4];
+                    T dot[4] = {T(0.), T(0.), T(0.), T(0.)}, cur[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        cur[u] = A[i * ld + j + u * G];
+                        cur[u] = A[at(i, j + u * G)];
 #pragma unroll
-                        for (int q = 0; q < NB; ++q) dot[u] = fmaf(ai[q], q < kb ? A[(j + u * G) * ld + k0 + q] : 0.f, dot[u]);
+                        for (int q = 0; q < NB; ++q) dot[u] = fma_t(ai[q], q < kb ? A[at(j + u * G, k0 + q)] : T(0.), dot[u]);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) A[i * ld + j + u * G] = cur[u] - dot[u];
+                    for (int u = 0; u < 4; ++u) A[at(i, j + u * G)] = cur[u] - dot[u];
                 }
                 for (; j <= i; j += G) {
-                    float dot = 0.f;
+                    T dot = T(0.);
 #pragma unroll
-                    for (int q = 0; q < NB; ++q) dot = fmaf(ai[q], q < kb ? A[j * ld + k0 + q] : 0.f, dot);
-                    A[i * ld + j] -= dot;
+                    for (int q = 0; q < NB; ++q) dot = fma_t(ai[q], q < kb ? A[at(j, k0 + q)] : T(0.), dot);
+                    A[at(i, j)] -= dot;
                 }
             }
         }
@@ -128,15 +165,15 @@ __device__ void block_cholesky(float* A, int n, int ld, int tid) {
     }
 }
 
-template <int NT>
-__device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
+template <int NT, typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch, int tid) {
     // NT threads; scratch >= NT / 64 floats; fixed summation order
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
-    float t = 0.f;
+    T t = T(0.);
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) t += scratch[w];
     return t;
@@ -146,21 +183,21 @@ __device__ __forceinline__ float block_sum(float v, float* scratch, int tid) {
 // rows one thread per column solves the 8x8 triangle, then all 256 threads subtract the block's contribution from the
 // rows below.  One thread per column walking all M rows serially took 49 K cycles (M = 40, 65 columns).
 // Every thread of the workgroup must call it (it contains __syncthreads); ends with a barrier.
-template <int NT>
-__device__ void block_forward_subst(const float* L, int LM, float* X, int LB, int M, int ncol, int tid) {
+template <int NT, typename T>
+__device__ void block_forward_subst(const T* L, int LM, T* X, int LB, int M, int ncol, int tid) {
     constexpr int RB = 8;
     for (int r0 = 0; r0 < M; r0 += RB) {
         const int rb = min(RB, M - r0);
         for (int col = tid; col < ncol; col += NT) {
-            float xv[RB];
+            T xv[RB];
 #pragma unroll
             for (int a = 0; a < RB; ++a) {
-                xv[a] = 0.f;
+                xv[a] = T(0.);
                 if (a < rb) {
-                    float acc = X[(r0 + a) * LB + col];
+                    T acc = X[(r0 + a) * LB + col];
 #pragma unroll
                     for (int q = 0; q < RB; ++q)
-                        if (q < a) acc = fmaf(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
+                        if (q < a) acc = fma_t(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
                     xv[a] = acc / L[(r0 + a) * LM + r0 + a];
                     X[(r0 + a) * LB + col] = xv[a];
                 }
@@ -170,10 +207,10 @@ __device__ void block_forward_subst(const float* L, int LM, float* X, int LB, in
         const int below = M - (r0 + rb);
         for (int e = tid; e < below * ncol; e += NT) {
             const int i = r0 + rb + e / ncol, col = e % ncol;
-            float acc = X[i * LB + col];
+            T acc = X[i * LB + col];
 #pragma unroll
             for (int q = 0; q < RB; ++q)
-                if (q < rb) acc = fmaf(-L[i * LM + r0 + q], X[(r0 + q) * LB + col], acc);
+                if (q < rb) acc = fma_t(-L[i * LM + r0 + q], X[(r0 + q) * LB + col], acc);
             X[i * LB + col] = acc;
         }
         __syncthreads();
@@ -182,21 +219,21 @@ __device__ void block_forward_subst(const float* L, int LM, float* X, int LB, in
 
 // Blocked backward substitution L^T X = R in place, the mirror image: row blocks from the bottom, the 8x8 triangle of a
 // block is the transpose of L's diagonal block, rows ABOVE the block get its contribution.
-template <int NT>
-__device__ void block_backward_subst(const float* L, int LM, float* X, int LB, int M, int ncol, int tid) {
+template <int NT, typename T>
+__device__ void block_backward_subst(const T* L, int LM, T* X, int LB, int M, int ncol, int tid) {
     constexpr int RB = 8;
     for (int r1 = M; r1 > 0; r1 -= RB) {
         const int r0 = max(0, r1 - RB), rb = r1 - r0;
         for (int col = tid; col < ncol; col += NT) {
-            float xv[RB];
+            T xv[RB];
 #pragma unroll
             for (int a = RB - 1; a >= 0; --a) {
-                xv[a] = 0.f;
+                xv[a] = T(0.);
                 if (a < rb) {
-                    float acc = X[(r0 + a) * LB + col];
+                    T acc = X[(r0 + a) * LB + col];
 #pragma unroll
                     for (int q = 0; q < RB; ++q)
-                        if (q > a && q < rb) acc = fmaf(-L[(r0 + q) * LM + r0 + a], xv[q], acc);
+                        if (q > a && q < rb) acc = fma_t(-L[(r0 + q) * LM + r0 + a], xv[q], acc);
                     xv[a] = acc / L[(r0 + a) * LM + r0 + a];
                     X[(r0 + a) * LB + col] = xv[a];
                 }
@@ -205,43 +242,48 @@ __device__ void block_backward_subst(const float* L, int LM, float* X, int LB, i
         __syncthreads();
         for (int e = tid; e < r0 * ncol; e += NT) {
             const int i = e / ncol, col = e % ncol;
-            float acc = X[i * LB + col];
+            T acc = X[i * LB + col];
 #pragma unroll
             for (int q = 0; q < RB; ++q)
-                if (q < rb) acc = fmaf(-L[(r0 + q) * LM + i], X[(r0 + q) * LB + col], acc);
+                if (q < rb) acc = fma_t(-L[(r0 + q) * LM + i], X[(r0 + q) * LB + col], acc);
             X[i * LB + col] = acc;
         }
         __syncthreads();
     }
 }
 
-template <int NT>
+template <int NT, typename T, bool PACKED = false>
 __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    T* sm = reinterpret_cast<T*>(gp_lds_raw);
     const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B;
     const int LM = M + 1;   // row stride of the MxM matrices
     const int LB = B + 2;   // row stride of the M x (B+1) matrices
     const int LS = B + 1;   // row stride of Sigma
-    float* L = sm;                 // [M][LM]   K_ZZ + jitter -> its Cholesky factor
-    float* Ls = L + M * LM;        // [M][LM]   variational Cholesky factor (lower)
-    float* AK = Ls + M * LM;       // [M][LB]   [K_Zx | m-c] -> L^-1 [K_Zx | m-c]
-    float* Wm = AK + M * LB;       // [M][LB]   L_S^T K_Zx
-    float* zs = Wm + M * LB;       // [M]
-    float* xs = zs + M;            // [B]
-    float* mu = xs + B;            // [B]
-    float* red = mu + B;           // [16]
-    float* Sg = red + 16;          // [B][LS]   predictive covariance (only when needed)
+    T* L = sm;                 // [M][LM]   K_ZZ + jitter -> its Cholesky factor
+    T* Ls = L + M * LM;        // [M][LM]   variational Cholesky factor (lower)
+    // PACKED: the covariance triangle (B (B + 1) / 2 entries) will overlay L and L_S, so the operands it is built from start
+    // behind whichever of the two regions is larger (host side: gp_predict_elems_packed)
+    T* AK = PACKED ? sm + max(2 * M * LM, B * (B + 1) / 2) : Ls + M * LM;   // [M][LB]   [K_Zx | m-c] -> L^-1 [K_Zx | m-c]
+    T* Wm = AK + M * LB;       // [M][LB]   L_S^T K_Zx
+    T* zs = Wm + M * LB;       // [M]
+    T* xs = zs + M;            // [B]
+    T* mu = xs + B;            // [B]
+    T* red = mu + B;           // [16]
+    // predictive covariance (only when needed): [B][LS] behind the other operands, or - PACKED - its lower triangle on top
+    // of L and L_S, which are dead once the mean / variance / KL phase has passed the barrier in front of the build
+    T* Sg = PACKED ? sm : red + 16;
+    auto sg = [LS](int r, int q) { return PACKED ? r * (r + 1) / 2 + q : r * LS + q; };
 
     // torch.nn.functional.softplus (beta 1, threshold 20) of the raw parameters when the caller passes them as they are
     // (gp_models.py hyper-parameters / GaussianLikelihood noise with its GreaterThan(1e-4) floor): saves three
     // 90-element launches per GP call
-    auto softplus = [](float x) { return x > 20.f ? x : log1pf(expf(x)); };
-    const float s = p.raw_hypers ? softplus(p.outputscale[d]) : p.outputscale[d];
-    const float ell = p.raw_hypers ? softplus(p.lengthscale[d]) : p.lengthscale[d];
-    const float ninv = -0.5f / (ell * ell);
-    const float c0 = p.mean_const[d];
-    const float noise = p.noise ? (p.raw_hypers ? softplus(p.noise[d]) + 1e-4f : p.noise[d]) : 0.f;
+    auto softplus = [](T x) { return x > T(20.) ? x : log1p_t(exp_t(x)); };
+    const T s = p.raw_hypers ? softplus(p.outputscale[d]) : p.outputscale[d];
+    const T ell = p.raw_hypers ? softplus(p.lengthscale[d]) : p.lengthscale[d];
+    const T ninv = -T(0.5) / (ell * ell);
+    const T c0 = p.mean_const[d];
+    const T noise = p.noise ? (p.raw_hypers ? softplus(p.noise[d]) + T(1e-4) : p.noise[d]) : T(0.);
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
@@ -250,16 +292,16 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     __syncthreads();
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
-        const float dz = zs[r] - zs[q];
-        L[r * LM + q] = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
-        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
+        const T dz = zs[r] - zs[q];
+        L[r * LM + q] = s * exp_t(dz * dz * ninv) + (r == q ? p.jitter : T(0.));
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : T(0.);
     }
     for (int i = tid; i < M * (B + 1); i += NT) {
         const int r = i / (B + 1), b = i % (B + 1);
-        float v;
+        T v;
         if (b < B) {
-            const float dx = zs[r] - xs[b];
-            v = s * expf(dx * dx * ninv);
+            const T dx = zs[r] - xs[b];
+            v = s * exp_t(dx * dx * ninv);
         } else {
             v = p.var_mean[(size_t)d * M + r] - c0;
         }
@@ -271,32 +313,32 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     // W = L_S^T K_Zx (needs the un-solved K_Zx), then chol(K_ZZ) by the whole workgroup
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        float acc = 0.f;
-        for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], AK[j * LB + b], acc);
+        T acc = T(0.);
+        for (int j = r; j < M; ++j) acc = fma_t(Ls[j * LM + r], AK[j * LB + b], acc);
         Wm[r * LB + b] = acc;
     }
-    block_cholesky<NT>(L, M, LM, tid);   // ends with __syncthreads
+    block_cholesky<NT, T>(L, M, LM, tid);   // ends with __syncthreads
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 2] = clock64();
 
     // L X = [K_Zx | m-c]
-    block_forward_subst<NT>(L, LM, AK, LB, M, B + 1, tid);
+    block_forward_subst<NT, T>(L, LM, AK, LB, M, B + 1, tid);
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 3] = clock64();
 
     // predictive mean and marginal variance
     for (int b = tid; b < B; b += NT) {
-        float m = 0.f, qa = 0.f, qw = 0.f;
+        T m = T(0.), qa = T(0.), qw = T(0.);
         for (int i = 0; i < M; ++i) {
-            const float a = AK[i * LB + b], w = Wm[i * LB + b];
-            m = fmaf(a, AK[i * LB + B], m);
-            qa = fmaf(a, a, qa);
-            qw = fmaf(w, w, qw);
+            const T a = AK[i * LB + b], w = Wm[i * LB + b];
+            m = fma_t(a, AK[i * LB + B], m);
+            qa = fma_t(a, a, qa);
+            qw = fma_t(w, w, qw);
         }
         m += c0;
         mu[b] = m;
         if (p.mean) p.mean[(size_t)d * B + b] = m;
         if (p.var) {
-            float dd = s - qa;
-            if (p.train_mode) dd = fmaxf(dd, 0.f);
+            T dd = s - qa;
+            if (p.train_mode) dd = max_t(dd, T(0.));
             p.var[(size_t)d * B + b] = qw + dd + noise;
         }
     }
@@ -304,21 +346,21 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     if (p.kl != nullptr) {
         // KL(q(u)||p(u)) = 0.5 [ -log|K| - log|S'| + tr(S'K) + (m-c)^T K^-1 (m-c) - M ],
         // tr(S'K) = || L^T L_S ||_F^2,  (m-c)^T K^-1 (m-c) = || L^-1 (m-c) ||^2
-        float part = 0.f;
+        T part = T(0.);
         for (int i = tid; i < M * M; i += NT) {
             const int r = i / M, q = i % M;
-            float acc = 0.f;
-            for (int k = (r > q ? r : q); k < M; ++k) acc = fmaf(L[k * LM + r], Ls[k * LM + q], acc);
-            part = fmaf(acc, acc, part);
+            T acc = T(0.);
+            for (int k = (r > q ? r : q); k < M; ++k) acc = fma_t(L[k * LM + r], Ls[k * LM + q], acc);
+            part = fma_t(acc, acc, part);
         }
         for (int i = tid; i < M; i += NT) {
-            const float v = AK[i * LB + B];
-            part = fmaf(v, v, part);
-            part -= 2.f * logf(L[i * LM + i]);
-            part -= 2.f * logf(fabsf(Ls[i * LM + i]));
+            const T v = AK[i * LB + B];
+            part = fma_t(v, v, part);
+            part -= T(2.) * log_t(L[i * LM + i]);
+            part -= T(2.) * log_t(abs_t(Ls[i * LM + i]));
         }
-        const float tot = block_sum<NT>(part, red, tid);
-        if (tid == 0) p.kl[d] = 0.5f * (tot - (float)M);
+        const T tot = block_sum<NT, T>(part, red, tid);
+        if (tid == 0) p.kl[d] = T(0.5) * (tot - (T)M);
     }
 
     if (need_cov) {
@@ -331,11 +373,11 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
             for (int t = tid; t < nt * nt; t += NT) {
                 const int tr = t / nt, tq = t % nt;
                 if (tq > tr) continue;
-                float acc[4][4];
+                T acc[4][4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = 0.f;
+                    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = T(0.);
                 int rr[4], qq[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -343,7 +385,7 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
                     qq[a] = min(tq * 4 + a, B - 1);
                 }
                 for (int k = 0; k < M; ++k) {
-                    float wr[4], wq[4], ar[4], aq[4];
+                    T wr[4], wq[4], ar[4], aq[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         wr[a] = Wm[k * LB + rr[a]];
@@ -354,7 +396,7 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = fmaf(wr[a], wq[b2], fmaf(-ar[a], aq[b2], acc[a][b2]));
+                        for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = fma_t(wr[a], wq[b2], fma_t(-ar[a], aq[b2], acc[a][b2]));
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
@@ -362,11 +404,15 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
                     for (int b2 = 0; b2 < 4; ++b2) {
                         const int r = tr * 4 + a, q = tq * 4 + b2;
                         if (r < B && q < B) {
-                            const float dx = xs[r] - xs[q];
-                            float v = acc[a][b2] + s * expf(dx * dx * ninv);
+                            const T dx = xs[r] - xs[q];
+                            T v = acc[a][b2] + s * exp_t(dx * dx * ninv);
                             if (r == q) v += noise;
-                            Sg[r * LS + q] = v;
-                            Sg[q * LS + r] = v;
+                            if (PACKED) {
+                                Sg[sg(max(r, q), min(r, q))] = v;
+                            } else {
+                                Sg[sg(r, q)] = v;
+                                Sg[sg(q, r)] = v;
+                            }
                             if (p.cov) {
                                 p.cov[((size_t)d * B + r) * B + q] = v;
                                 p.cov[((size_t)d * B + q) * B + r] = v;
@@ -378,12 +424,12 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
         __syncthreads();
         if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 5] = clock64();
         if (p.sample != nullptr) {
-            block_cholesky<NT>(Sg, B, LS, tid);   // ends with __syncthreads
+            block_cholesky<NT, T, PACKED>(Sg, B, LS, tid);   // ends with __syncthreads
         if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 6] = clock64();
             for (int b = tid; b < B; b += NT) {
-                float acc = mu[b];
+                T acc = mu[b];
 #pragma unroll 4
-                for (int j = 0; j <= b; ++j) acc = fmaf(Sg[b * LS + j], p.eps[(size_t)d * B + j], acc);
+                for (int j = 0; j <= b; ++j) acc = fma_t(Sg[sg(b, j)], (T)p.eps[(size_t)d * B + j], acc);
                 p.sample[(size_t)d * B + b] = acc;
             }
         }
@@ -418,35 +464,35 @@ struct GpBwdParams {
 
 #define GP_STAMP(k) if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + (k)] = clock64();
 
-template <int NT>
+template <int NT, typename T>
 __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    T* sm = reinterpret_cast<T*>(gp_lds_raw);
     const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B, LM = M + 1, LB = B + 2;
     const int NP = B + 2 + M, LP = NP + 1;   // P = K^-1 [Kzx | m-c | Kzx gm | I]
-    float* Kj = sm;               // [M][LM] K with jitter
-    float* L = Kj + M * LM;       // chol(K)
-    float* Ls = L + M * LM;       // variational factor
-    float* GK = Ls + M * LM;      // dL/dK
-    float* Kzx = GK + M * LM;     // [M][LB]
-    float* Wm = Kzx + M * LB;     // W, then GW
-    float* G2 = Wm + M * LB;      // dL/dKzx
-    float* P = G2 + M * LB;       // [M][LP]
-    float* zs = P + M * LP;       // [M]
-    float* rr = zs + M;           // m - c
-    float* al = rr + M;           // alpha
-    float* tt = al + M;           // Kzx gm
-    float* tau = tt + M;          // K^-1 tt
-    float* xs = tau + M;          // [B]
-    float* gm = xs + B;
-    float* gv = gm + B;
-    float* gq = gv + B;
-    float* red = gq + B;          // [16]
-    const float* Ki = P + B + 2;  // K^-1 = the last M columns of P (row stride LP)
+    T* Kj = sm;               // [M][LM] K with jitter
+    T* L = Kj + M * LM;       // chol(K)
+    T* Ls = L + M * LM;       // variational factor
+    T* GK = Ls + M * LM;      // dL/dK
+    T* Kzx = GK + M * LM;     // [M][LB]
+    T* Wm = Kzx + M * LB;     // W, then GW
+    T* G2 = Wm + M * LB;      // dL/dKzx
+    T* P = G2 + M * LB;       // [M][LP]
+    T* zs = P + M * LP;       // [M]
+    T* rr = zs + M;           // m - c
+    T* al = rr + M;           // alpha
+    T* tt = al + M;           // Kzx gm
+    T* tau = tt + M;          // K^-1 tt
+    T* xs = tau + M;          // [B]
+    T* gm = xs + B;
+    T* gv = gm + B;
+    T* gq = gv + B;
+    T* red = gq + B;          // [16]
+    const T* Ki = P + B + 2;  // K^-1 = the last M columns of P (row stride LP)
 
-    const float s = p.outputscale[d], ell = p.lengthscale[d];
-    const float ninv = -0.5f / (ell * ell), c0 = p.mean_const[d];
-    const float gk = p.gkl ? p.gkl[d] : 0.f;
+    const T s = p.outputscale[d], ell = p.lengthscale[d];
+    const T ninv = -T(0.5) / (ell * ell), c0 = p.mean_const[d];
+    const T gk = p.gkl ? p.gkl[d] : T(0.);
 
     GP_STAMP(0)
     for (int i = tid; i < M; i += NT) {
@@ -455,22 +501,22 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     }
     for (int b = tid; b < B; b += NT) {
         xs[b] = p.h[(size_t)b * p.D + d];
-        gm[b] = p.gmean ? p.gmean[(size_t)d * B + b] : 0.f;
-        gv[b] = p.gvar ? p.gvar[(size_t)d * B + b] : 0.f;
+        gm[b] = p.gmean ? p.gmean[(size_t)d * B + b] : T(0.);
+        gv[b] = p.gvar ? p.gvar[(size_t)d * B + b] : T(0.);
     }
     __syncthreads();
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
-        const float dz = zs[r] - zs[q];
-        const float v = s * expf(dz * dz * ninv) + (r == q ? p.jitter : 0.f);
+        const T dz = zs[r] - zs[q];
+        const T v = s * exp_t(dz * dz * ninv) + (r == q ? p.jitter : T(0.));
         Kj[r * LM + q] = v;
         L[r * LM + q] = v;
-        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : 0.f;
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : T(0.);
     }
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        const float dx = zs[r] - xs[b];
-        Kzx[r * LB + b] = s * expf(dx * dx * ninv);
+        const T dx = zs[r] - xs[b];
+        Kzx[r * LB + b] = s * exp_t(dx * dx * ninv);
     }
     __syncthreads();
     GP_STAMP(1)
@@ -478,40 +524,40 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     // rank-8 trailing updates; the wave-serial left-looking factorisation this kernel used first took ~40 us of its 159)
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        float acc = 0.f;
-        for (int j = r; j < M; ++j) acc = fmaf(Ls[j * LM + r], Kzx[j * LB + b], acc);
+        T acc = T(0.);
+        for (int j = r; j < M; ++j) acc = fma_t(Ls[j * LM + r], Kzx[j * LB + b], acc);
         Wm[r * LB + b] = acc;
     }
     for (int i = tid; i < M; i += NT) {
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc = fmaf(Kzx[i * LB + b], gm[b], acc);
+        T acc = T(0.);
+        for (int b = 0; b < B; ++b) acc = fma_t(Kzx[i * LB + b], gm[b], acc);
         tt[i] = acc;
     }
     GP_STAMP(2)
-    block_cholesky<NT>(L, M, LM, tid);   // ends with __syncthreads
+    block_cholesky<NT, T>(L, M, LM, tid);   // ends with __syncthreads
     GP_STAMP(3)
     // P <- [Kzx | m-c | Kzx gm | I]; then K^-1 applied column-wise by two blocked TRIANGULAR solves with L
     // (an explicit fp32 K^-1 from L^-1 loses ~cond(K)*eps = 1e-3 and the c / s gradients cancel to 1e-2 of it).  The
     // identity columns give K^-1 itself, which only the KL trace term -gk/2 K^-1 needs.
     for (int i = tid; i < M * NP; i += NT) {
         const int r = i / NP, b = i % NP;
-        P[r * LP + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : (b == B + 1 ? tt[r] : (b - B - 2 == r ? 1.f : 0.f)));
+        P[r * LP + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : (b == B + 1 ? tt[r] : (b - B - 2 == r ? T(1.) : T(0.))));
     }
     __syncthreads();
-    block_forward_subst<NT>(L, LM, P, LP, M, NP, tid);
+    block_forward_subst<NT, T>(L, LM, P, LP, M, NP, tid);
     GP_STAMP(4)
-    block_backward_subst<NT>(L, LM, P, LP, M, NP, tid);
+    block_backward_subst<NT, T>(L, LM, P, LP, M, NP, tid);
     GP_STAMP(5)
     for (int i = tid; i < M; i += NT) {
         al[i] = P[i * LP + B];
         tau[i] = P[i * LP + B + 1];
     }
     __syncthreads();
-    float ds_part = 0.f;
+    T ds_part = T(0.);
     for (int b = tid; b < B; b += NT) {
-        float q = 0.f;
-        for (int i = 0; i < M; ++i) q = fmaf(Kzx[i * LB + b], P[i * LP + b], q);
-        const float mask = (s - q > 0.f) ? 1.f : 0.f;
+        T q = T(0.);
+        for (int i = 0; i < M; ++i) q = fma_t(Kzx[i * LB + b], P[i * LP + b], q);
+        const T mask = (s - q > T(0.)) ? T(1.) : T(0.);
         gq[b] = -gv[b] * mask;
         ds_part += gv[b] * mask;
     }
@@ -519,37 +565,37 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     GP_STAMP(6)
     for (int i = tid; i < M * B; i += NT) {   // GW = 2 gv W (in place)
         const int r = i / B, b = i % B;
-        Wm[r * LB + b] *= 2.f * gv[b];
+        Wm[r * LB + b] *= T(2.) * gv[b];
     }
     __syncthreads();
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        float acc = gm[b] * al[r] + 2.f * gq[b] * P[r * LP + b];
-        for (int k = 0; k <= r; ++k) acc = fmaf(Ls[r * LM + k], Wm[k * LB + b], acc);
+        T acc = gm[b] * al[r] + T(2.) * gq[b] * P[r * LP + b];
+        for (int k = 0; k <= r; ++k) acc = fma_t(Ls[r * LM + k], Wm[k * LB + b], acc);
         G2[r * LB + b] = acc;
     }
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
-        float acc = -tau[r] * al[q];
-        for (int b = 0; b < B; ++b) acc = fmaf(-gq[b] * P[r * LP + b], P[q * LP + b], acc);
-        float sp = 0.f;
+        T acc = -tau[r] * al[q];
+        for (int b = 0; b < B; ++b) acc = fma_t(-gq[b] * P[r * LP + b], P[q * LP + b], acc);
+        T sp = T(0.);
         const int kmax = r < q ? r : q;
-        for (int k = 0; k <= kmax; ++k) sp = fmaf(Ls[r * LM + k], Ls[q * LM + k], sp);
-        acc += 0.5f * gk * (-Ki[r * LP + q] + sp - al[r] * al[q]);
+        for (int k = 0; k <= kmax; ++k) sp = fma_t(Ls[r * LM + k], Ls[q * LM + k], sp);
+        acc += T(0.5) * gk * (-Ki[r * LP + q] + sp - al[r] * al[q]);
         GK[r * LM + q] = acc;
         // dL_S (lower part)
-        float g = 0.f;
+        T g = T(0.);
         if (q <= r) {
-            for (int b = 0; b < B; ++b) g = fmaf(Kzx[r * LB + b], Wm[q * LB + b], g);
-            float kl = (r == q) ? -1.f / Ls[r * LM + r] : 0.f;
-            for (int k = q; k < M; ++k) kl = fmaf(Kj[r * LM + k], Ls[k * LM + q], kl);
-            g = fmaf(gk, kl, g);
+            for (int b = 0; b < B; ++b) g = fma_t(Kzx[r * LB + b], Wm[q * LB + b], g);
+            T kl = (r == q) ? -T(1.) / Ls[r * LM + r] : T(0.);
+            for (int k = q; k < M; ++k) kl = fma_t(Kj[r * LM + k], Ls[k * LM + q], kl);
+            g = fma_t(gk, kl, g);
         }
         p.dls[((size_t)d * M + r) * M + q] = g;
     }
-    float dc_part = 0.f;
+    T dc_part = T(0.);
     for (int i = tid; i < M; i += NT) {
-        const float dr = tau[i] + gk * al[i];
+        const T dr = tau[i] + gk * al[i];
         p.dm[(size_t)d * M + i] = dr;
         dc_part -= dr;
     }
@@ -557,42 +603,42 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     __syncthreads();
     GP_STAMP(7)
     // RBF chain rule
-    float ds_acc = 0.f, dl_acc = 0.f;
-    const float il2 = 1.f / (ell * ell), il3 = il2 / ell;
+    T ds_acc = T(0.), dl_acc = T(0.);
+    const T il2 = T(1.) / (ell * ell), il3 = il2 / ell;
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
-        const float kp = Kj[r * LM + q] - (r == q ? p.jitter : 0.f);
-        const float dz = zs[r] - zs[q];
-        const float g = GK[r * LM + q] * kp;
+        const T kp = Kj[r * LM + q] - (r == q ? p.jitter : T(0.));
+        const T dz = zs[r] - zs[q];
+        const T g = GK[r * LM + q] * kp;
         ds_acc += g;
-        dl_acc = fmaf(g, dz * dz, dl_acc);
+        dl_acc = fma_t(g, dz * dz, dl_acc);
     }
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
-        const float dx = zs[r] - xs[b];
-        const float g = G2[r * LB + b] * Kzx[r * LB + b];
+        const T dx = zs[r] - xs[b];
+        const T g = G2[r * LB + b] * Kzx[r * LB + b];
         ds_acc += g;
-        dl_acc = fmaf(g, dx * dx, dl_acc);
+        dl_acc = fma_t(g, dx * dx, dl_acc);
     }
     for (int i = tid; i < M; i += NT) {
-        float acc = 0.f;
+        T acc = T(0.);
         for (int j = 0; j < M; ++j) {
-            const float kp = Kj[i * LM + j] - (i == j ? p.jitter : 0.f);
-            acc = fmaf((GK[i * LM + j] + GK[j * LM + i]) * kp, -(zs[i] - zs[j]), acc);
+            const T kp = Kj[i * LM + j] - (i == j ? p.jitter : T(0.));
+            acc = fma_t((GK[i * LM + j] + GK[j * LM + i]) * kp, -(zs[i] - zs[j]), acc);
         }
-        for (int b = 0; b < B; ++b) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b]), acc);
+        for (int b = 0; b < B; ++b) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b]), acc);
         p.dz[(size_t)d * M + i] = acc * il2;
     }
     for (int b = tid; b < B; b += NT) {
-        float acc = 0.f;
-        for (int i = 0; i < M; ++i) acc = fmaf(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b], acc);
+        T acc = T(0.);
+        for (int i = 0; i < M; ++i) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b], acc);
         p.dh[(size_t)b * p.D + d] = acc * il2;
     }
     GP_STAMP(8)
-    const float ds_tot = block_sum<NT>(ds_acc, red, tid);
-    const float dl_tot = block_sum<NT>(dl_acc, red, tid);
-    const float dc_tot = block_sum<NT>(dc_part, red, tid);
-    const float dsdir_tot = block_sum<NT>(ds_part, red, tid);
+    const T ds_tot = block_sum<NT, T>(ds_acc, red, tid);
+    const T dl_tot = block_sum<NT, T>(dl_acc, red, tid);
+    const T dc_tot = block_sum<NT, T>(dc_part, red, tid);
+    const T dsdir_tot = block_sum<NT, T>(ds_part, red, tid);
     if (tid == 0) {
         p.ds[d] = ds_tot / s + dsdir_tot;
         p.dell[d] = dl_tot * il3;
@@ -628,7 +674,7 @@ __global__ __launch_bounds__(256) void gp_elbo_kernel(const GpElboParams p) {
         const float r = p.target[d * p.t_sd + b * p.t_sb] - p.mean[(size_t)d * B + b];
         acc += fmaf(r, r, p.var[(size_t)d * B + b]);
     }
-    const float tot = block_sum<256>(acc, red, tid);     // fixed order: deterministic
+    const float tot = block_sum<256, float>(acc, red, tid);     // fixed order: deterministic
     if (!BWD) {
         if (tid == 0)
             p.elbo[d] = -0.5f * tot / (nz * (float)B) - 0.5f * logf(nz) - 0.9189385332046727f - p.kl[d] * p.inv_num_data;
@@ -668,25 +714,55 @@ static int gp_threads(int dflt) {
     const int n = e ? atoi(e) : dflt;
     return (n == 256 || n == 512 || n == 1024) ? n : dflt;
 }
+static bool gp_force_fp32() {
+    static const char* e = getenv("DVG_GP_FP32");   // A/B switch: the r02 all-fp32 arithmetic
+    return e && atoi(e) != 0;
+}
+static constexpr size_t GP_LDS_MAX = 160 * 1024;
 
-template <int NT, typename K, typename P>
-static int gp_launch(K kernel, const P& p, int D, size_t lds, void* stream, const char* who) {
-    static size_t attr_lds = 0;   // per instantiation; one-thread contract of the header
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_lds = lds;
-    }
+template <typename K, typename P>
+static int gp_launch(K kernel, int NT, const P& p, int D, size_t lds, void* stream, const char* who) {
+    // hipFuncSetAttribute is idempotent and cheap; it is legal during stream capture (not a stream operation)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kernel, dim3(D), dim3(NT), lds, (hipStream_t)stream, p);
     return check_launch(who);
 }
 
-extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
+static size_t gp_predict_elems(int B, int M, int need_cov) {
     size_t f = (size_t)2 * M * (M + 1) + (size_t)2 * M * (B + 2) + M + 2 * (size_t)B + 16;
     if (need_cov) f += (size_t)B * (B + 1);
-    return f * 4;
+    return f;
 }
+static size_t gp_bwd_elems(int B, int M) {
+    return (size_t)4 * M * (M + 1) + (size_t)3 * M * (B + 2) + (size_t)M * (B + M + 3) + 5 * (size_t)M + 4 * (size_t)B + 16;
+}
+
+// fp64 with the covariance's lower triangle overlaid on L / L_S (gp_predict_kernel<.., PACKED = true>)
+static size_t gp_predict_elems_packed(int B, int M) {
+    const size_t tri = (size_t)B * (B + 1) / 2, ll = (size_t)2 * M * (M + 1);
+    return (tri > ll ? tri : ll) + (size_t)2 * M * (B + 2) + M + 2 * (size_t)B + 16;
+}
+// 0: fp32, 1: fp64, 2: fp64 packed
+static int gp_predict_variant(int B, int M, int need_cov) {
+    if (gp_force_fp32()) return 0;
+    if (gp_predict_elems(B, M, need_cov) * 8 <= GP_LDS_MAX) return 1;
+    if (need_cov && gp_predict_elems_packed(B, M) * 8 <= GP_LDS_MAX) return 2;
+    return 0;
+}
+extern "C" int dvg_gp_precision(int B, int M, int need_cov) { return gp_predict_variant(B, M, need_cov) ? 64 : 32; }
+extern "C" int dvg_gp_bwd_precision(int B, int M) {
+    return (!gp_force_fp32() && gp_bwd_elems(B, M) * 8 <= GP_LDS_MAX) ? 64 : 32;
+}
+extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
+    switch (gp_predict_variant(B, M, need_cov)) {
+        case 1: return gp_predict_elems(B, M, need_cov) * 8;
+        case 2: return gp_predict_elems_packed(B, M) * 8;
+        default: return gp_predict_elems(B, M, need_cov) * 4;
+    }
+}
+extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) { return gp_bwd_elems(B, M) * (dvg_gp_bwd_precision(B, M) / 8); }
 
 extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_mean, const float* chol_var,
                               const float* mean_const, const float* outputscale, const float* lengthscale,
@@ -700,19 +776,32 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
     DVG_REQUIRE(sample == nullptr || eps != nullptr, DVG_ERR_NULL, "dvg_gp_predict: sample needs eps");
     const int need_cov = (cov != nullptr) || (sample != nullptr);
     const size_t lds = dvg_gp_lds_bytes(B, M, need_cov);
-    DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
+    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
     DVG_REQUIRE(train_mode >= 0 && train_mode <= 3, DVG_ERR_SHAPE, "dvg_gp_predict: train_mode flags must be 0..3");
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
                B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, g_gp_clk, g_gp_clk_cap};
-    switch (gp_threads(GP_PREDICT_THREADS)) {
-        case 256: return gp_launch<256>(gp_predict_kernel<256>, p, D, lds, stream, "dvg_gp_predict");
-        case 512: return gp_launch<512>(gp_predict_kernel<512>, p, D, lds, stream, "dvg_gp_predict");
-        default: return gp_launch<1024>(gp_predict_kernel<1024>, p, D, lds, stream, "dvg_gp_predict");
+    const int nt = gp_threads(GP_PREDICT_THREADS);
+    const char* who = "dvg_gp_predict";
+    const int variant = gp_predict_variant(B, M, need_cov);
+    if (variant == 2) {
+        switch (nt) {
+            case 256: return gp_launch(gp_predict_kernel<256, double, true>, 256, p, D, lds, stream, who);
+            case 512: return gp_launch(gp_predict_kernel<512, double, true>, 512, p, D, lds, stream, who);
+            default: return gp_launch(gp_predict_kernel<1024, double, true>, 1024, p, D, lds, stream, who);
+        }
     }
-}
-
-extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) {
-    return ((size_t)4 * M * (M + 1) + (size_t)3 * M * (B + 2) + (size_t)M * (B + M + 3) + 5 * (size_t)M + 4 * (size_t)B + 16) * 4;
+    if (variant == 1) {
+        switch (nt) {
+            case 256: return gp_launch(gp_predict_kernel<256, double>, 256, p, D, lds, stream, who);
+            case 512: return gp_launch(gp_predict_kernel<512, double>, 512, p, D, lds, stream, who);
+            default: return gp_launch(gp_predict_kernel<1024, double>, 1024, p, D, lds, stream, who);
+        }
+    }
+    switch (nt) {
+        case 256: return gp_launch(gp_predict_kernel<256, float>, 256, p, D, lds, stream, who);
+        case 512: return gp_launch(gp_predict_kernel<512, float>, 512, p, D, lds, stream, who);
+        default: return gp_launch(gp_predict_kernel<1024, float>, 1024, p, D, lds, stream, who);
+    }
 }
 
 extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
@@ -726,13 +815,22 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
     DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
                 "dvg_gp_train_bwd: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
     const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
-    DVG_REQUIRE(lds <= 160 * 1024, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
+    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
                   dh, dz, dm, dls, dc, ds, dell, B, D, M, jitter, g_gp_clk, g_gp_clk_cap};
-    switch (gp_threads(GP_BWD_THREADS)) {
-        case 256: return gp_launch<256>(gp_train_bwd_kernel<256>, p, D, lds, stream, "dvg_gp_train_bwd");
-        case 512: return gp_launch<512>(gp_train_bwd_kernel<512>, p, D, lds, stream, "dvg_gp_train_bwd");
-        default: return gp_launch<1024>(gp_train_bwd_kernel<1024>, p, D, lds, stream, "dvg_gp_train_bwd");
+    const int nt = gp_threads(GP_BWD_THREADS);
+    const char* who = "dvg_gp_train_bwd";
+    if (dvg_gp_bwd_precision(B, M) == 64) {
+        switch (nt) {
+            case 256: return gp_launch(gp_train_bwd_kernel<256, double>, 256, p, D, lds, stream, who);
+            case 512: return gp_launch(gp_train_bwd_kernel<512, double>, 512, p, D, lds, stream, who);
+            default: return gp_launch(gp_train_bwd_kernel<1024, double>, 1024, p, D, lds, stream, who);
+        }
+    }
+    switch (nt) {
+        case 256: return gp_launch(gp_train_bwd_kernel<256, float>, 256, p, D, lds, stream, who);
+        case 512: return gp_launch(gp_train_bwd_kernel<512, float>, 512, p, D, lds, stream, who);
+        default: return gp_launch(gp_train_bwd_kernel<1024, float>, 1024, p, D, lds, stream, who);
     }
 }
 

@@ -296,7 +296,14 @@ int dvg_stem_gemm(const float* vec, int ldv, const float* w_kn, int KP, const fl
  * train_mode is a flag word: bit 0 = train-mode prediction (diagonal variance with the clamp, KL); bit 1 = outputscale /
  * lengthscale / noise point at the RAW parameters (covar_module.raw_outputscale, base_kernel.raw_lengthscale,
  * noise_covar.raw_noise) and the kernel applies soft-plus itself (noise: + the 1e-4 floor of GaussianLikelihood).
+ * Arithmetic (ABI 6): inputs and outputs are fp32; INSIDE the kernel the covariance assembly, chol(K_ZZ), the triangular
+ * solves, the k(x,x) - A^T A cancellation, the KL terms, chol(Sigma) and the sample are computed in fp64 whenever the fp64
+ * working set fits the 160 KiB of LDS (M = 40: every B <= 128; above B = 95 the covariance is kept as a packed lower
+ * triangle on top of the dead K_ZZ factors), otherwise in fp32.
+ * dvg_gp_precision(B, M, cov||sample) returns 64 or 32 accordingly (DVG_GP_FP32=1 in the environment forces 32 for A/B
+ * runs); dvg_gp_lds_bytes the LDS bytes of the variant that will run.
  * Limits: M <= 64, B <= 128 and dvg_gp_lds_bytes(B, M, cov||sample) <= 160 KiB. */
+int dvg_gp_precision(int B, int M, int need_cov);
 size_t dvg_gp_lds_bytes(int B, int M, int need_cov);
 int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
                    const float* chol_var, const float* mean_const,
@@ -439,7 +446,9 @@ int dvg_lstm_gates_bwd(const float* dh, const float* dc, const float* gates, con
 /* Train-mode GP backward (gradients of dvg_gp_predict(train_mode=1) outputs mean / var
  * (without likelihood noise) / kl): upstream gmean [D][B], gvar [D][B], gkl [D] (any may
  * be NULL = zero) -> dh [B][D], dz [D][M], dm [D][M], dls [D][M][M] (lower), dc, ds, dell
- * [D] w.r.t. the soft-plus'ed hyper-parameters.  One workgroup per latent dim, all in LDS. */
+ * [D] w.r.t. the soft-plus'ed hyper-parameters.  One workgroup per latent dim, all in LDS.  fp64 inside when the fp64
+ * working set fits (M = 40: B <= 71; dvg_gp_bwd_precision returns 64 / 32), fp32 I/O either way (ABI 6). */
+int dvg_gp_bwd_precision(int B, int M);
 size_t dvg_gp_bwd_lds_bytes(int B, int M);
 int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
                      const float* mean_const, const float* outputscale, const float* lengthscale,

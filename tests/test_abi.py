@@ -33,7 +33,7 @@ def test_binding_table_covers_header():
     from dvg_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dvg_abi_version() == 5
+    assert lib.dvg_abi_version() == 6
 
 
 def test_host_side_checks_reject_bad_shapes_without_gpu():
@@ -54,7 +54,7 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     assert lib.dvg_conv_splitk_v2(0, 64, 64, 64, 64, 64) == 1          # 2048 workgroups: no split
     assert lib.dvg_conv_splitk_v2(0, 64, 8, 8, 512, 256) == 2          # 256 workgroups, K = 32 chunks
     assert lib.dvg_conv_splitk_v2(0, 16, 8, 8, 512, 512) == 4          # per-GPU batch 16
-    assert lib.dvg_gp_lds_bytes(64, 40, 1) < 64 * 1024
+    assert lib.dvg_gp_lds_bytes(64, 40, 1) <= 160 * 1024 and lib.dvg_gp_precision(64, 40, 1) == 64
 
 
 def test_product_has_no_cpu_fallback():
