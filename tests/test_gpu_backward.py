@@ -293,7 +293,7 @@ def test_gp_train_backward(B, D, M):
     pred = gp(ho.transpose(0, 1).view(D, B, 1))
     loss_o = -(mll(pred, tgt.to(dev())).sum()) + (pred.mean * gmean.to(dev())).sum()
     loss_o.backward()
-    assert abs(float(loss_o) - float(loss_r)) < 2e-3 * abs(float(loss_r)) + 1e-3
+    assert abs(float(loss_o) - float(loss_r)) < 1e-5 * abs(float(loss_r)) + 1e-5
     ours = {k: p.grad for k, p in gp.named_parameters()}
     ours["h"] = ho.grad
     ours["noise"] = like.noise_covar.raw_noise.grad
@@ -302,7 +302,7 @@ def test_gp_train_backward(B, D, M):
     ref["noise"] = rl["noise_covar.raw_noise"].grad
     ref["variational_strategy.variational_distribution.chol_variational_covar"] = torch.tril(
         ref["variational_strategy.variational_distribution.chol_variational_covar"])
-    grads_close(ours, ref, tol=5e-3)
+    grads_close(ours, ref, tol=1e-4)     # fp64 inside dvg_gp_train_bwd (r02, fp32 throughout: 5e-3)
 
 
 def test_fused_elbo_equals_the_torch_composition():

@@ -1,0 +1,130 @@
+"""The reference's REAL generate configuration on the HIP path.
+
+/root/reference generate_frames.py:47-49 forces `n_eval = 105, n_future = 100, batch_size = 50` and :131,170 hard-code
+`.view(90, 50, 1)`: a batch that is not a multiple of 8 (tile / Winograd / split-K selection), a 100-step autoregressive
+rollout and six GP-sampled steps (`i % 15 == 0`: 15, 30, 45, 60, 75, 90).  Covered here:
+  * the backbone modules of both 64x64 families at B = 50 against the oracle (eval mode);
+  * `sample_rollout` at B = 50 with n_past = 5 through TWO trigger steps (15 and 30), eps passed in, against the oracle, for both
+    families (generate_frames.py:143-177);
+  * vgg_64 + GP trigger at the shapes of BASELINE.json configs C1 / C2 (B = 8; n_past 5 and 10, n_eval = 17);
+  * the full-length rollout (n_eval = 105): trigger list exact, hipGraph replay == eager launch sequence, finite frames.
+All GP arithmetic is fp64 inside the kernels (ABI 6), so GP-sampled frames are held to the same 1e-4 as every other frame."""
+import pytest
+import torch
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.common import rel_err
+from tests.test_gpu_configs import _build, _oracle_fns
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FRAME_BAR = 1e-4      # BASELINE.json north_star: "within 1e-4 relative on fp32 frames" (rel_err: max |a - b| / max |b|)
+
+
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_backbone_modules_at_the_reference_generate_batch(family):
+    """encoder / decoder forward at B = 50 (generate_frames.py:49), eval mode, against the oracle: latent, every skip tensor,
+    the decoded frame - and the conditioning batch 4 x 50 = 200 that `condition()` pushes through the encoder at once."""
+    B = 50
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 2100)
+    enc, dec = mods[0].to(DEV).eval(), mods[1].to(DEV).eval()
+    enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
+    x = params.frames(2110, B, 1, 64)
+    vec = params.normal(2111, B, 90, scale=0.5).tanh()
+    with torch.no_grad():
+        h_ref, sk_ref = enc_o(x)
+        y_ref = dec_o(vec, sk_ref)
+        h, sk = enc(x.to(DEV))
+        y = dec([vec.to(DEV), sk])
+    assert h.shape == (B, 90) and y.shape == (B, 1, 64, 64)
+    assert rel_err(h, h_ref) < FRAME_BAR and rel_err(y, y_ref) < FRAME_BAR, (rel_err(h, h_ref), rel_err(y, y_ref))
+    for a, b in zip(sk, sk_ref):
+        assert a.shape == b.shape and rel_err(a, b) < FRAME_BAR
+    # the n_past - 1 = 4 conditioning frames as one batch of 200 (rollout._encode_conditioning): per-sample identical
+    xs = torch.cat([params.frames(2120 + t, B, 1, 64) for t in range(4)], 0)
+    with torch.no_grad():
+        h4, _ = enc(xs.to(DEV))
+        h4_ref = torch.cat([enc_o(xs[i * B:(i + 1) * B])[0] for i in range(4)], 0)
+    assert rel_err(h4, h4_ref) < FRAME_BAR
+
+
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_sample_rollout_at_b50_through_two_triggers(family):
+    """generate_frames.py:143-177 at the reference's batch: n_past = 5, steps 15 and 30 decode a GP sample (eps passed in),
+    every other step the LSTM prediction; 31 frames against the oracle."""
+    from dvg_amd.rollout import sample_rollout, trigger_steps
+    B, n_past, n_eval = 50, 5, 31
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 2200)
+    xs = [params.frames(2210 + t, B, 1, 64) for t in range(n_past)]
+    assert trigger_steps(n_past, n_eval) == [15, 30] == orc.gp_trigger_steps(n_past, n_eval)
+    eps = {i: params.normal(2230 + i, 90, B) for i in (15, 30)}
+    enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.rollout(xs + [None] * (n_eval - n_past), enc_o, dec_o, lsd, gsd, lik, n_past, n_eval, eps)
+    for m in mods:
+        m.to(DEV).eval()
+    ours = sample_rollout(*mods, [t.to(DEV) for t in xs], n_past, n_eval, eps_by_step={k: v.to(DEV) for k, v in eps.items()})
+    assert len(ours) == len(ref) == n_eval
+    errs = [rel_err(ours[t], ref[t]) for t in range(n_eval)]
+    assert max(errs) < FRAME_BAR, [f"{e:.1e}" for e in errs]
+    # the GP-sampled steps really took the other branch: decoding the LSTM prediction instead changes the frame
+    no_gp = sample_rollout(*mods, [t.to(DEV) for t in xs], n_past, 16, period=0)
+    assert rel_err(no_gp[15], ref[15]) > 100 * FRAME_BAR
+
+
+@pytest.mark.parametrize("n_past", [5, 10])
+def test_vgg_gp_trigger_rollout_at_config_batch(n_past):
+    """vgg_64 + GP trigger end to end (generate_frames.py:143-177) at B = 8: n_past = 5 is BASELINE.json configs[0]'s
+    conditioning length (C1, extended past its 5 predicted frames to the first trigger), n_past = 10 the headline's."""
+    from dvg_amd.rollout import GraphedRollout, sample_rollout
+    B, n_eval = 8, 17
+    mods, (esd, dsd, lsd, gsd, lik) = _build("vgg", 64, 1, B, 2300 + n_past)
+    xs = [params.frames(2310 + t, B, 1, 64) for t in range(n_past)]
+    eps = {15: params.normal(2330, 90, B)}
+    enc_o, dec_o = _oracle_fns("vgg", 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.rollout(xs + [None] * (n_eval - n_past), enc_o, dec_o, lsd, gsd, lik, n_past, n_eval, eps)
+    for m in mods:
+        m.to(DEV).eval()
+    xd = [t.to(DEV) for t in xs]
+    ed = {15: eps[15].to(DEV)}
+    ours = sample_rollout(*mods, xd, n_past, n_eval, eps_by_step=ed)
+    errs = [rel_err(ours[t], ref[t]) for t in range(n_eval)]
+    assert max(errs) < FRAME_BAR, [f"{e:.1e}" for e in errs]
+    g = GraphedRollout(*mods, xd, n_past, n_eval)
+    replay = [f.clone() for f in g(xd, ed)]
+    for t in range(n_eval):
+        assert torch.equal(replay[t], ours[t]), t
+
+
+@pytest.mark.parametrize("family", ["dcgan", "vgg"])
+def test_full_length_generate_configuration(family):
+    """n_eval = 105, n_future = 100, batch_size = 50, n_past = 5 (generate_frames.py:47-49 + the default n_past): the GP
+    samples at exactly [15, 30, 45, 60, 75, 90]; the captured hipGraph replays the eager launch sequence bit for bit; every
+    frame is finite and inside the decoder's output range; a different eps at step 90 changes frames 90.. and nothing before."""
+    from dvg_amd.rollout import GraphedRollout, sample_rollout, trigger_steps
+    B, n_past, n_eval = 50, 5, 105
+    steps = trigger_steps(n_past, n_eval)
+    assert steps == [15, 30, 45, 60, 75, 90] == orc.gp_trigger_steps(n_past, n_eval)
+    mods, _ = _build(family, 64, 1, B, 2400)
+    for m in mods:
+        m.to(DEV).eval()
+    xd = [params.frames(2410 + t, B, 1, 64).to(DEV) for t in range(n_past)]
+    eps = {i: params.normal(2420 + i, 90, B).to(DEV) for i in steps}
+    eager = sample_rollout(*mods, xd, n_past, n_eval, eps_by_step=eps)
+    assert len(eager) == n_eval
+    lo, hi = (-1.0, 1.0) if family == "dcgan" else (0.0, 1.0)      # Tanh (dcgan_64.py:75-79) / Sigmoid (vgg_64.py:88-92)
+    for t in range(n_past, n_eval):
+        f = eager[t]
+        assert f.shape == (B, 1, 64, 64) and bool(torch.isfinite(f).all())
+        assert float(f.min()) >= lo and float(f.max()) <= hi
+    g = GraphedRollout(*mods, xd, n_past, n_eval)
+    assert sorted(g.eps) == steps
+    replay = [f.clone() for f in g(xd, eps)]
+    for t in range(n_eval):
+        assert torch.equal(replay[t], eager[t]), t
+    eps2 = dict(eps)
+    eps2[90] = params.normal(2499, 90, B).to(DEV)
+    other = g(xd, eps2)
+    assert all(torch.equal(other[t], eager[t]) for t in range(90)) and not torch.equal(other[90], eager[90])

@@ -1,8 +1,9 @@
 """GPU parity of the orchestration rows S and K of SURVEY.md §8: the step closures' values, the qualitative rollout of
 train.py (`plot`), the posterior rollout and the variance-trigger generation of generate_frames.py, best-of-N selection -
 HIP path vs the oracle's restatements (oracle/dvg_oracle.py), base samples eps passed in.  Integer results (trigger-step
-lists, argmin / argsort indices) must be EXACT; frames hold the 1e-4 bar until a GP sample's fp32 Cholesky noise is
-chained through an autoregressive rollout (5e-3 from there, as in tests/test_gpu_train.py)."""
+lists, argmin / argsort indices) must be EXACT; frames hold the 1e-4 bar, GP-sampled steps included (the GP kernels
+compute in fp64 since ABI 6); the one looser bar left is train-mode BatchNorm at B = 4 in `plot`, which amplifies fp32
+rounding of the conv kernels step by step (2e-3) and has nothing to do with the GP."""
 import numpy as np
 import pytest
 import torch
@@ -77,7 +78,7 @@ def test_plot_rollout_and_best_of_n_match_oracle():
     assert gen.shape == (S, n_eval, B, 1, 64, 64)
     for s in range(S):
         for t in range(n_eval):
-            tol = 1e-4 if t < n_past else (2e-3 if t < 10 else 5e-3)   # train-mode BN at B=4 amplifies fp32 noise per step
+            tol = 1e-4 if t < n_past else 2e-3   # train-mode BN at B=4 amplifies fp32 noise per step; no extra for the GP step
             assert rel_err(gen[s, t], ref[s][t]) < tol, (s, t, rel_err(gen[s, t], ref[s][t]))
     assert best.tolist() == ref_best, (best.tolist(), ref_best)
     # the frames after i == 10 differ between samples (distinct eps), the frames before do not
@@ -135,9 +136,8 @@ def test_gp_trigger_generation_matches_oracle(depth, index):
         assert 0 < len(ref["triggers"]) < total - 12, "both branches must have been taken"
     np.testing.assert_allclose(res["values"], ref["values"], rtol=margin / 4)      # far inside every decision margin
     np.testing.assert_allclose(res["thresholds"], ref["thresholds"], rtol=margin / 4)
-    first = ref["triggers"][0] if ref["triggers"] else total
     for t in range(total):
-        tol = 2e-4 if t < first else 5e-3
+        tol = 2e-4       # before AND after the first GP-sampled step
         assert rel_err(res["batch_frames"][t], ref["frames"][t]) < tol, (t, rel_err(res["batch_frames"][t], ref["frames"][t]))
     with pytest.raises(IndexError):
         g.frame_predictor.batch_size = 2
