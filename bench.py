@@ -220,15 +220,20 @@ class Ctx:
                     dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
                 else:
                     dist.init_process_group(backend, rank=self.rank, world_size=self.world)
-                t = torch.zeros(1, device=self.dev)
+                t = torch.ones(1, device=self.dev)
                 dist.all_reduce(t)
                 torch.cuda.synchronize()
+                self.connected_ranks = int(t.item())
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
             self.backend = backend
             self.dist = dist
+            # BEFORE anything is timed: the collective really spans --gpus ranks (an all-reduce of ones), else no number
+            if self.connected_ranks != args.gpus or dist.get_world_size() != args.gpus:
+                raise RuntimeError(f"bench.py: --gpus {args.gpus} but the {backend} group connects {self.connected_ranks} "
+                                   f"rank(s) (world size {dist.get_world_size()})")
 
     def barrier(self):
         import torch
@@ -237,12 +242,17 @@ class Ctx:
         torch.cuda.synchronize()
 
     def max_over_ranks(self, dt: float) -> float:
+        return max(self.all_ranks(dt))
+
+    def all_ranks(self, dt: float) -> list:
+        """Every rank's value of `dt`, in rank order, on every rank (a straggler is then visible in the JSON line)."""
         import torch
         if self.dist is None:
-            return dt
-        t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+            return [dt]
+        mine = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
 
 
 def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict:
@@ -279,10 +289,13 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     t0 = time.perf_counter()
     out = run(steps)
     ctx.barrier()
-    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    per_rank = ctx.all_ranks(time.perf_counter() - t0)
+    dt = max(per_rank)
     assert bool(torch.isfinite(out[-1]).all())
     frames = args.batch * args.n_future * steps * ctx.world
-    res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3), "rollouts_in_flight": inflight}
+    res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3), "rollouts_in_flight": inflight,
+           # wall time of the K timed steps on every rank, rank order (the reported time is the max)
+           "per_rank_ms_per_step": [round(1000 * t / steps, 3) for t in per_rank]}
     if inflight > 1:   # the same K rollouts as ONE serial chain of launches (one graph, one stream), for comparison
         ctx.barrier()
         t0 = time.perf_counter()
@@ -317,7 +330,16 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
                        "algorithmic_flops_per_launch": round(a["alg_flops"] / a["launches"]),
                        "launches_per_step": a["launches"] // 3,
                        "avg_launch_us": round(1000 * a["ms"] / a["launches"], 2),
-                       "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
+                       "share_of_kernel_time": round(a["ms"] / total_ms, 4),
+                       # SURVEY.md 8(d)'s DIRECT-FORM count of the same launches / the same time: may exceed 1 (Winograd
+                       # executes 1/4 of the direct form's multiplies) - labelled, never the headline `frac`
+                       "frac_direct_form": round(a["alg_flops"] / (a["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       # sum of the HIP-event durations of ALL launches of one step (one chain, eager): against
+                       # `single_chain.ms_per_step` it shows the launch gaps, against `ms_per_step` what the chains overlap
+                       "kernel_time_sum_ms": round(total_ms / 3, 3),
+                       # share of that sum spent in the HBM-bound Winograd transform passes (input / output / fused)
+                       "transform_share": round(sum(v["ms"] for k, v in agg.items()
+                                                    if k.startswith("winograd_") and k != "winograd_gemm") / total_ms, 4)}
     # The 3x3 layers as a whole (SURVEY 8(d) counts a layer's direct-form FLOPs): direct implicit-GEMM launches plus, for the
     # layers that run as Winograd F(4x4) / F(2x2), their transform + batched-GEMM launches.  Can exceed the fp32 MFMA peak:
     # Winograd executes 1/4 (1/2.25) of the direct form's multiplies.
@@ -386,9 +408,10 @@ def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
     for _ in range(args.train_iters):
         step(x)
     ctx.barrier()
-    dt = ctx.max_over_ranks(time.perf_counter() - t0) / args.train_iters
+    per_rank = [t / args.train_iters for t in ctx.all_ranks(time.perf_counter() - t0)]
+    dt = max(per_rank)
     assert all(bool(torch.isfinite(p).all()) for p in tr.encoder.parameters())
-    res = {"ms_per_iter": round(1e3 * dt, 2),
+    res = {"ms_per_iter": round(1e3 * dt, 2), "per_rank_ms_per_iter": [round(1e3 * t, 2) for t in per_rank],
            "train_frames_per_s": round(per_gpu * ctx.world * (T - 1) / dt, 1)}
     st = tr.allreduce_stats()
     if st is not None and not graphed:
@@ -404,13 +427,8 @@ def train_leg(ctx: Ctx, args) -> dict:
                      f"{16 * ctx.world}), 2-in/10-out, train_model + both fine-tuning closures per iteration",
            "parallelism": f"dp{ctx.world}: gradient all-reduce over RCCL, per-replica BatchNorm statistics",
            "scaling": "weak"}
-    if ctx.dist is not None:   # proof that RCCL connected the ranks: an actual all-reduce of ones
-        t = torch.ones(1, device=ctx.dev)
-        ctx.dist.all_reduce(t)
-        out["rccl_ranks"] = int(t.item())
-        assert out["rccl_ranks"] == ctx.dist.get_world_size()
-    else:
-        out["rccl_ranks"] = 1
+    # proof that RCCL connected the ranks: the all-reduce of ones Ctx ran (and checked against --gpus) before any timing
+    out["rccl_ranks"] = ctx.connected_ranks if ctx.dist is not None else 1
     out["eager"] = measure_train(ctx, args, graphed=False)
     if ctx.world > 1:
         out["eager_no_allreduce"] = measure_train(ctx, args, graphed=False, allreduce=False)
@@ -447,8 +465,11 @@ def graphed_train_leg(ctx: Ctx, args, result: dict, emit) -> None:
         if not done.wait(args.train_graph_timeout):
             result["train"]["hipgraph"] = {"error": f"no completion within {args.train_graph_timeout:.0f} s"}
             emit()
-            os._exit(0)
-    if ctx.world > 1:
+            # a hung captured collective cannot be recovered from inside the process: the headline line is out, now FAIL -
+            # the launcher (torch.distributed.run / self_launch) sees a non-zero exit and tears the other ranks down.
+            # os._exit: no atexit / destructor may touch the wedged GPU queue; never re-exec.
+            os._exit(3)
+    if collectives:
         threading.Thread(target=watchdog, daemon=True).start()
     try:
         g = measure_train(ctx, args, graphed=True)

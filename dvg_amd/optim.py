@@ -111,6 +111,16 @@ class FusedAdam(torch.optim.Optimizer):
     def flat_grad(self, gi: int = 0) -> torch.Tensor:
         return self._flat[gi]["g"]
 
+    def state_dict(self):
+        """torch.optim layout, but every per-parameter tensor is a COPY that owns its storage: `exp_avg` / `exp_avg_sq` are
+        views of the flat moment buffers (of the shared arena under train.Trainer), and torch.save writes the whole storage
+        behind a view - the GP optimiser's entry of a checkpoint (train.py:385) would carry the Adam moments of every
+        module (+2 x all parameter bytes)."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (t.detach().clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # torch aliases (does not copy) the tensors of `state_dict`: copy them into our flat buffers right away

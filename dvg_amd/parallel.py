@@ -127,11 +127,45 @@ class FlatGradReducer:
             torch._foreach_copy_(grads, views)
 
 
-def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:
-    """Make every replica start from rank `src`'s parameters and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
+def broadcast_coalesced(tensors: Iterable[torch.Tensor], src: int = 0, group=None) -> int:
+    """Broadcast rank `src`'s values of `tensors` with ONE collective per dtype: the tensors are packed into a flat buffer,
+    broadcast, and copied back in place.  Returns the number of collectives issued."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    n = 0
     with torch.no_grad():
-        for m in modules:
-            for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t, src=src, group=group)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            n += 1
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+    return n
+
+
+def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None, arena_p: Optional[torch.Tensor] = None) -> int:
+    """Make every replica start from rank `src`'s parameters and buffers.  With `arena_p` (the flat parameter buffer of
+    optim.FlatArena, of which every parameter of `modules` is a view) the parameters go as ONE broadcast of that buffer,
+    in place; the buffers (BatchNorm running statistics, step counters) and any parameter outside the arena are packed per
+    dtype.  xGMI is point-to-point: ~200 small broadcasts cost ~200 latencies, two or three large ones use all links.
+    Returns the number of collectives issued (0 with one rank)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    modules = list(modules)
+    n, rest = 0, []
+    with torch.no_grad():
+        if arena_p is not None:
+            dist.broadcast(arena_p, src=src, group=group)
+            n += 1
+            lo = arena_p.data_ptr()
+            hi = lo + arena_p.numel() * arena_p.element_size()
+            rest = [p for m in modules for p in m.parameters() if not (lo <= p.data_ptr() < hi)]
+        else:
+            rest = [p for m in modules for p in m.parameters()]
+        rest += [b for m in modules for b in m.buffers()]
+        if rest:
+            n += broadcast_coalesced(rest, src=src, group=group)
+    return n

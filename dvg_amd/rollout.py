@@ -49,6 +49,38 @@ _ZERO_STATE = {}
 CAPTURE_KW = {"capture_error_mode": "thread_local"}
 
 
+def snapshot_eager_caches() -> list:
+    """Strong references to every tensor the module-level caches hold right now: the LSTM's shared zero state, packed /
+    transposed / Winograd-domain weights, BatchNorm folds, the embed-folded first-cell weights, GEMM-operand forms of the
+    dense ends.  A captured hipGraph reads such tensors by RAW POINTER when they were created eagerly during its warm-up;
+    the caches evict (`.clear()` past 16 / 64 / 4096 entries) and replace entries when a parameter version changes
+    (load_state_dict, an optimiser step), after which the allocator may hand the block to someone else while live graphs
+    still read it.  Every graph holder keeps the snapshot taken right after its capture for as long as it lives."""
+    from . import autograd as ag
+    from .models import lstm as lstm_mod
+    keep = []
+
+    def walk(o):
+        if torch.is_tensor(o):
+            keep.append(o)
+        elif isinstance(o, (tuple, list)):
+            for v in o:
+                walk(v)
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif hasattr(o, "__dict__") and type(o).__module__.startswith("dvg_amd"):
+            walk(vars(o))          # ops.WinoV and similar small holders
+
+    walk(list(_ZERO_STATE.values()))
+    walk(list(ops._WMAT_CACHE.values()))
+    walk(list(ops._SKIP_PROJ_CACHE.values()))
+    walk(list(lstm_mod._FOLD_CACHE.values()))
+    walk(list(ag._pack_cache.values()))
+    walk([dict(d) for d in list(fused._cache.values())])
+    return keep
+
+
 def _zero_hidden(frame_predictor):
     """init_hidden() (lstm.py:58-63) without its 2 x n_layers fill launches per rollout: one cached all-zero tensor per
     (device, batch, hidden size).  Safe to share: no kernel of the recurrent path writes its state in place (dvg_lstm_cell
@@ -228,6 +260,7 @@ class GraphedRollout:
         fused.clear_skip_hoist_cache()
         with torch.cuda.graph(self.graph, **CAPTURE_KW):
             self.frames = sample_rollout(*self._args, self.static_x, **self._kw)
+        self._keepalive = snapshot_eager_caches()   # eager tensors the graph reads by raw pointer live as long as it does
         ops.clear_skip_proj_cache()   # ... and nothing from the graph's pool by later eager calls
         fused.clear_skip_hoist_cache()
 
@@ -318,6 +351,7 @@ class GraphedSampler:
             fused.clear_skip_hoist_cache()
             with torch.cuda.graph(ch["graph"], **CAPTURE_KW):
                 ch["frames"], ch["ssim"], ch["psnr"] = self._body(ch)
+            ch["keepalive"] = snapshot_eager_caches()
             ops.clear_skip_proj_cache()
             fused.clear_skip_hoist_cache()
 

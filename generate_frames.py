@@ -99,7 +99,11 @@ class Generator:
         inflight = getattr(opt, 'inflight', 3)
         if inflight > 0:
             # the nsample rollouts are independent: each is a replay of the captured sample body, `inflight` at a time
-            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight)
+            # parameter / buffer versions are part of the key: the captured graphs read packed weights and BatchNorm folds of
+            # the versions they were captured with, so a weight change (load_state_dict, an optimiser step) re-captures
+            vers = tuple(t._version for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood)
+                         for t in list(m.parameters()) + list(m.buffers()))
+            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight, vers)
             if self._sampler_key != key:
                 self._sampler = GraphedSampler(self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
                                                self.likelihood, state, x, opt.n_past, opt.n_eval, opt.last_frame_skip,

@@ -24,28 +24,40 @@ def _free_port() -> int:
     return port
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_ranks_rehearsal(ranks):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
                         "--model", "dcgan", "--no-families", "--no-cpu-baseline", "--train-iters", "1",
                         "--train-graph-timeout", "120"],
-                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540)
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["n_gpus"] == ranks and d["scaling"] == "weak" and "rehearsal" in d
     assert d["value"] > 0 and d["config"]["rollouts_in_flight"] == 3
+    assert len(d["per_rank_ms_per_step"]) == ranks and max(d["per_rank_ms_per_step"]) == d["ms_per_step"]
     t = d["train"]
-    assert t["rccl_ranks"] == 2                       # from an actual all-reduce of ones over the process group
+    assert t["rccl_ranks"] == ranks                   # from an actual all-reduce of ones, checked against --gpus before timing
+    assert len(t["eager"]["per_rank_ms_per_iter"]) == ranks
     assert t["eager"]["allreduces_per_iter"] == 4.0   # decoder / LSTM / GP range, encoder range, LSTM range, GP range
     assert t["eager"]["allreduce_MB_per_iter"] > 40
     assert "eager_no_allreduce" in t and "hipgraph" in t
     assert t["hipgraph_segmented"]["graph_segments"] == 5, t["hipgraph_segmented"]   # cut at the four all-reduce groups
 
 
-def test_train_py_two_ranks_end_with_identical_parameters():
+def test_bench_refuses_a_group_that_does_not_span_gpus_ranks():
+    """`--gpus 2` under a launcher that only started ONE rank: WORLD_SIZE disagrees -> exit code 2 before any GPU work."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_train_py_ranks_end_with_identical_parameters(ranks):
     """train.py under `torch.distributed.run` with two ranks (rehearsal switches: both on GPU 0, gloo): identical initial
     parameters on both ranks, different data per rank, gradients averaged over the flat arena in place, the iteration
     replayed as a chain of hipGraphs with the all-reduces eager between them (train.SegmentedIteration) - after four
@@ -57,14 +69,15 @@ def test_train_py_two_ranks_end_with_identical_parameters():
             "--epoch_size", "4", "--no_save", "--save_every", "1000"]
 
     def run(cmd):
-        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         return {ln.split()[1]: ln.split()[-2:] for ln in r.stdout.splitlines() if "param checksum" in ln}
 
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--batch_size", "8"] + args)
-    assert set(two) == {"0", "1"}, two
-    assert two["0"] == two["1"], two
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), "--batch_size",
+               str(4 * ranks)] + args)
+    assert set(two) == {str(r) for r in range(ranks)}, two
+    assert all(two[str(r)] == two["0"] for r in range(ranks)), two
     one = run([sys.executable, os.path.join(ROOT, "train.py"), "--batch_size", "4"] + args)
     assert one["0"] != two["0"]
 

@@ -159,6 +159,18 @@ def test_train_script_runs_and_checkpoint_drives_generate(tmp_path):
     tr = train.main(["--model", "dcgan", "--batch_size", "4", "--n_past", "2", "--n_future", "2", "--n_eval", "5",
                      "--niter", "1", "--epoch_size", "2", "--dataset", "smmnist", "--output_path", out])
     assert os.path.exists(os.path.join(out, "model.pth")) and os.path.exists(os.path.join(out, "sample_0.pt"))
+    # checkpoint size = the reference's (train.py:380-388): parameters + buffers of the three pickled modules, the GP /
+    # likelihood state and the GP optimiser's two moments - NOT the shared arena behind the live views
+    mods = (tr.encoder, tr.decoder, tr.frame_predictor)
+    payload = 4 * sum(t.numel() for m in mods for t in list(m.parameters()) + list(m.buffers()))
+    gp_bytes = 4 * sum(p.numel() for p in list(tr.gp_layer.parameters()) + list(tr.likelihood.parameters()))
+    size = os.path.getsize(os.path.join(out, "model.pth"))
+    assert payload + 3 * gp_bytes <= size <= payload + 3 * gp_bytes + (1 << 20), (size, payload, gp_bytes)
+    ck = torch.load(os.path.join(out, "model.pth"), weights_only=False)
+    w = next(ck["encoder"].parameters())
+    assert w.untyped_storage().nbytes() == w.numel() * 4 and w.grad is None       # owns its storage, no gradient pickled
+    m0 = ck["gp_layer_optimizer"]["state"][0]["exp_avg"]
+    assert m0.untyped_storage().nbytes() == m0.numel() * 4
     generate_frames.main(["--model_dir", out, "--dataset", "smmnist", "--batch_size", "4", "--n_eval", "18",
                           "--n_future", "16", "--nsample", "2", "--nbatches", "1", "--log_dir", out + "/logs"])
     res = torch.load(os.path.join(out, "logs", "gen", "sample_lstm_0.pt"))

@@ -67,6 +67,57 @@ def test_flat_grad_allreduce_gloo_world2():
     assert not torch.equal(a["local"][0], b["local"][0])
 
 
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from dvg_amd import parallel
+    from dvg_amd.optim import FlatArena
+    parallel.init_distributed("gloo")
+    torch.manual_seed(rank)                       # replicas start DIFFERENT
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(4, 3))
+    outside = torch.nn.Linear(3, 2)               # a module whose parameters do not live in the arena
+    params = list(net.parameters())
+    arena = FlatArena(FlatArena.size_for(params), "cpu")
+    off = 0
+    with torch.no_grad():
+        for p_ in params:                          # what FusedAdam._build does: parameters become views of arena.p
+            v = arena.p[off:off + p_.numel()].view(p_.shape)
+            v.copy_(p_)
+            p_.data = v
+            off += FlatArena.padded(p_.numel())
+        net[1].running_mean.fill_(float(rank + 1))
+        net[1].num_batches_tracked.fill_(7 * (rank + 1))
+    n = parallel.broadcast_parameters([net, outside], arena_p=arena.p)
+    assert all(p_.data_ptr() >= arena.p.data_ptr() for p_ in params), "parameters must still be views of the arena"
+    q.put({"rank": rank, "collectives": n, "arena": arena.p.numpy().copy(),
+           "params": [p_.detach().numpy().copy() for p_ in list(net.parameters()) + list(outside.parameters())],
+           "bufs": [b.numpy().copy() for b in net.buffers()]})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_parameters_is_one_collective_for_the_arena_gloo_world2():
+    """parallel.broadcast_parameters(arena_p=...): the parameter arena goes as ONE broadcast, buffers and parameters outside
+    the arena packed per dtype (float32 + BatchNorm's int64 counter): 3 collectives here instead of one per tensor (11)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a["collectives"] == b["collectives"] == 3
+    assert np.array_equal(a["arena"], b["arena"])
+    for x, y in zip(a["params"] + a["bufs"], b["params"] + b["bufs"]):
+        assert np.array_equal(x, y)
+    assert float(b["bufs"][0][0]) == 1.0 and int(b["bufs"][2]) == 7          # rank 0's values won
+
+
 def _arena_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))

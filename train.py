@@ -108,7 +108,6 @@ class Trainer:
         self.modules = [self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood]
         for m in self.modules:
             m.to(device)
-        parallel.broadcast_parameters(self.modules)
         # True = the reference's behaviour: train_model does not zero the GP optimiser's gradients (see module docstring)
         self.reference_gp_grad_leak = True
         # True = backward in two phases (decoder / LSTM / GP side, then the encoder) so that the all-reduce of the first
@@ -143,6 +142,9 @@ class Trainer:
         self.mll = VariationalELBO(self.likelihood, self.gp_layer, num_data=opt.batch_size, combine_terms=True)
         self.mse_criterion = nn.MSELoss()
         self.mse_latent_criterion = nn.MSELoss()
+        # every replica starts from rank 0's values: ONE broadcast of the parameter arena (all parameters are views of it by
+        # now) + one packed broadcast per buffer dtype, instead of ~200 per-tensor broadcasts
+        self.broadcast_collectives = parallel.broadcast_parameters(self.modules, arena_p=self.arena.p)
         self.reducer = parallel.ArenaReducer(self.arena.g)
         self.rng_gp = (self.optimizer.flat_range(0)[0], self.optimizer.flat_range(1)[1])
         self.rng_fp = self.frame_predictor_optimizer.flat_range(0)
@@ -361,6 +363,12 @@ class Trainer:
                 gp_mean = gp_pred.mean.transpose(0, 1)
             if side is not None:
                 cur.wait_event(side.record_event())
+                # ORDERING INVARIANT: everything the main stream consumes from the side stream was allocated BY the side
+                # stream; the caching allocator only knows the allocating stream, so tell it about the consumer - a block
+                # freed (in backward: by the main stream's nodes) must not be handed out again on the side stream while
+                # main-stream kernels still read it.  (Until r03 safety rested on the wait_stream at the top of each step.)
+                for t_ in (h_pred, gp_mean):
+                    t_.record_stream(cur)
             with self._share_scope():   # the three decoder calls of a step share the skip halves of their concat convs
                 x_pred = self.decoder([h_pred, skip])
                 x_target_pred = self.decoder([h_target, skip])
@@ -447,9 +455,30 @@ class Trainer:
         return gen, sse.argmin(0)
 
     def save(self, path):
-        torch.save({'encoder': self.encoder, 'decoder': self.decoder, 'frame_predictor': self.frame_predictor,
-                    'likelihood': self.likelihood.state_dict(), 'gp_layer': self.gp_layer.state_dict(),
+        """train.py:380-388: whole-module pickles + GP / likelihood / GP-optimiser state dicts.  Every tensor written owns
+        its storage: the live parameters, gradients and Adam moments are views of the shared FlatArena, and torch.save
+        writes the whole storage behind a view (a checkpoint would carry the arena instead of the GP's moments, and loading
+        only ck['encoder'] would pin all of it)."""
+        own = lambda sd: type(sd)((k, v.detach().clone() if torch.is_tensor(v) else v) for k, v in sd.items())  # noqa: E731
+        torch.save({'encoder': _detached_copy(self.encoder), 'decoder': _detached_copy(self.decoder),
+                    'frame_predictor': _detached_copy(self.frame_predictor),
+                    'likelihood': own(self.likelihood.state_dict()), 'gp_layer': own(self.gp_layer.state_dict()),
                     'gp_layer_optimizer': self.optimizer.state_dict(), 'opt': self.opt}, path)
+
+
+def _detached_copy(module):
+    """A deep copy of `module` whose parameters and buffers are fresh tensors with their OWN storage and no gradient
+    (copy.deepcopy alone clones the whole storage behind every arena view, and would copy `.grad` as well)."""
+    import copy
+    memo = {}
+    for p in module.parameters():
+        memo[id(p)] = torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad)
+    for b in module.buffers():
+        memo[id(b)] = b.detach().clone()
+    hidden = getattr(module, "hidden", None)
+    if hidden is not None:         # lstm.hidden: the recurrent state of the last sequence, may carry an autograd graph
+        memo[id(hidden)] = [(h.detach().clone(), c.detach().clone()) for h, c in hidden]
+    return copy.deepcopy(module, memo)
 
 
 class GraphedIteration:
@@ -467,6 +496,8 @@ class GraphedIteration:
         self.calls = 0
         self.graph = None
         self.sig = None
+        self.failed = False          # a capture raised: eager iterations from then on
+        self.outs = self._keepalive = None
 
     def _replay(self):
         self.graph.replay()
@@ -475,13 +506,29 @@ class GraphedIteration:
         lrs = tuple(g['lr'] for o in self.tr.optimizers() for g in o.param_groups)
         return lrs, tuple(tuple(t.shape) for t in x), self.tr.opt.ft, tuple(m.training for m in self.tr.modules)
 
+    def _release(self):
+        """Drop the captured graph(s) and everything they keep alive BEFORE a re-capture allocates a new private pool
+        (a MultiStepLR milestone re-captures: two pools of 12-17 GB of saved Winograd transforms need not coexist)."""
+        self.graph = None
+        self.outs = None
+        self._keepalive = None
+        torch.cuda.synchronize()
+
     def _capture(self, x):
+        from dvg_amd.rollout import snapshot_eager_caches
         tr = self.tr
+        self._release()
         self.static_x = [t.clone() for t in x]
         for o in tr.optimizers():
             o.begin_capture()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self._capture_body(self.static_x)
+        self._keepalive = snapshot_eager_caches()    # eager tensors the graph reads by raw pointer stay alive with it
+        self.sig = self._signature(x)
+
+    def _capture_body(self, static_x):
+        tr = self.tr
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # see rollout.CAPTURE_KW
             mse_latent, loss = tr._train_model_dev(self.static_x)
             fp = gp = None
@@ -489,15 +536,26 @@ class GraphedIteration:
                 fp = tr._train_fp_dev(self.static_x)
                 gp = tr._train_gp_dev(self.static_x)
             self.outs = (mse_latent, loss, fp, gp)
-        self.sig = self._signature(x)
 
     def __call__(self, x):
         tr = self.tr
         self.calls += 1
-        if self.calls <= self.warmup:
+        if self.calls <= self.warmup or self.failed:
             return tr.iteration(x)
         if self.graph is None or self.sig != self._signature(x):
-            self._capture(x)
+            try:
+                self._capture(x)
+            except Exception as e:   # noqa: BLE001 - out of memory for the pool, a partially used Adam group, ...
+                # A capture executes nothing: parameters, moments and BatchNorm statistics are untouched.  Fall back to the
+                # eager iteration for the rest of the run (no re-exec, no retry: the same capture would fail again).
+                self.failed = True
+                self._release()
+                for o in tr.optimizers():
+                    o._captured_groups = []
+                tr._segmenter = None
+                print(f"train: hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); continuing with eager "
+                      "iterations", file=sys.stderr, flush=True)
+                return tr.iteration(x)
         for dst, src in zip(self.static_x, x):
             dst.copy_(src)
         self._replay()
@@ -525,14 +583,19 @@ class SegmentedIteration(GraphedIteration):
     included - and the ≈2 500 launches of an iteration still replay without Python.  All segments share one memory pool
     and are always replayed in capture order."""
 
+    def _release(self):
+        self.items, self._pool, self._cur, self._ctx = [], None, None, None
+        super()._release()
+
     def _capture(self, x):
+        from dvg_amd.rollout import snapshot_eager_caches
         tr = self.tr
+        self._release()
         self.static_x = [t.clone() for t in x]
         for o in tr.optimizers():
             o.begin_capture()
         torch.cuda.synchronize()
         seg = self
-        self.items, self._pool, self._cur, self._ctx = [], None, None, None
         tr._segmenter = seg
         try:
             seg._begin()
@@ -543,9 +606,18 @@ class SegmentedIteration(GraphedIteration):
                 gp = tr._train_gp_dev(self.static_x)
             self.outs = (mse_latent, loss, fp, gp)
             seg._end()
+        except BaseException:
+            if self._ctx is not None:          # a segment is still being captured: end the capture before unwinding
+                ctx, self._ctx, self._cur = self._ctx, None, None
+                try:
+                    ctx.__exit__(*sys.exc_info())
+                except Exception:   # noqa: BLE001 - the original exception is the one to report
+                    pass
+            raise
         finally:
             tr._segmenter = None
         self.graph = [g for kind, g in self.items if kind == "graph"]   # (truthy: "captured"; replay goes through items)
+        self._keepalive = snapshot_eager_caches()
         self.sig = self._signature(x)
 
     def _begin(self):
