@@ -503,7 +503,7 @@ def main():
         "metric": "predicted frames/sec at 64x64, batch 64, 10-in/10-out",
         "value": main_res["value"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
-        "single_chain": main_res.get("single_chain"),
+        "single_chain": main_res.get("single_chain"), "per_rank_ms_per_step": main_res.get("per_rank_ms_per_step"),
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Moving-MNIST 64x64 rollout (generate_frames.py make_gifs sample loop), "
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "

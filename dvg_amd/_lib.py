@@ -41,6 +41,7 @@ SIGNATURES = {
     "dvg_gemm_batched_k16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dvg_winograd_output": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_winograd_output_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_winograd_output_pool_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_conv3x3_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_convT3x3_last": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_conv4x4s2_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),

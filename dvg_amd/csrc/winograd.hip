@@ -10,6 +10,8 @@
 //
 // xi = 4*a + b over the 4x4 transform positions; t = (n * H/2 + ty) * W/2 + tx over the output tiles.
 // The transforms are HBM-bound elementwise passes (thread = one tile x 4 channels, float4 everywhere).
+#include <cstdlib>
+
 #include "dvg_common.h"
 
 namespace dvg {
@@ -398,6 +400,134 @@ __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __re
     }
 }
 
+// Generalised hand-over (r03): output transform of layer L, optionally its 2x2 max-pool, and the input transform of the
+// layer that consumes the result, in ONE pass per (image, CS-channel block):
+//   POOL = false: two consecutive layers of a vgg block at the same resolution HW (8, 16 or 32) - as winograd4_out_in_kernel,
+//                 but V channels per thread and CS channels per workgroup, so that a workgroup's global accesses are runs of
+//                 CS * 4 bytes (the <16> instantiation above moves 64-byte runs: 3.2-3.7 TB/s; 256-byte runs: > 5);
+//   POOL = true : the LAST layer of an encoder stage (vgg_64.py:51-56): the full-resolution activation is the skip tensor and
+//                 goes to HBM (y), its 2x2 max-pool is staged in LDS and leaves as the next stage's input transform - the
+//                 pooled tensor is never written or re-read and one launch disappears.
+// Arithmetic per element is exactly that of the separate kernels (at4 / scale, shift, activation / max / bt4 in the same
+// order): results are bit-identical to winograd4_output_kernel followed by winograd4_input_kernel.
+template <int HW, int CS, typename V, bool POOL, int NT>
+__global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __restrict__ m, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ y,
+                                                             float* __restrict__ v, int N, int C, int act, float slope) {
+    constexpr int VN = VecN<V>::N;
+    constexpr int WT = HW / 4, TI = WT * WT;         // tiles per image side / per image of layer L
+    constexpr int S2 = POOL ? HW / 2 : HW;           // side of the map layer L + 1 reads
+    constexpr int WT2 = S2 / 4, TI2 = WT2 * WT2;
+    constexpr int CV = CS / VN;                      // channel vectors per workgroup
+    extern __shared__ __attribute__((aligned(16))) float chain_ys[];   // [S2 * S2][CS]
+    float* const ys = chain_ys;
+    const int cblocks = C / CS;
+    const int n = blockIdx.x / cblocks, c0 = (blockIdx.x % cblocks) * CS;
+    const int CVg = C / VN;
+    const long T = (long)N * TI;
+    for (int u = threadIdx.x; u < TI * CV; u += NT) {
+        const int cv = u % CV, t_img = u / CV, ty = t_img / WT, tx = t_img % WT;
+        const long t = (long)n * TI + t_img;
+        const int cg = c0 / VN + cv;
+        V s[4][6];   // A^T q (rows), column b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            V q[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const V*>(m)[((size_t)(a * 6 + b) * T + t) * CVg + cg];
+            V col[4];
+            at4(q, col);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) s[pp][b] = col[pp];
+        }
+        V sc, sf;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            vset(sc, k, scale ? scale[c0 + cv * VN + k] : 1.f);
+            vset(sf, k, shift ? shift[c0 + cv * VN + k] : 0.f);
+        }
+        V val[4][4];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            V o[4];
+            at4(s[pp], o);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+                for (int k = 0; k < VN; ++k) vset(val[pp][qq], k, apply_act(vget(o[qq], k) * vget(sc, k) + vget(sf, k), act, slope));
+                if (POOL)
+                    reinterpret_cast<V*>(y)[(((size_t)n * HW + 4 * ty + pp) * HW + 4 * tx + qq) * CVg + cg] = val[pp][qq];
+                else
+                    *reinterpret_cast<V*>(&ys[((4 * ty + pp) * HW + 4 * tx + qq) * CS + cv * VN]) = val[pp][qq];
+            }
+        }
+        if (POOL) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    V mx;
+#pragma unroll
+                    for (int k = 0; k < VN; ++k)
+                        vset(mx, k, fmaxf(fmaxf(vget(val[2 * pp][2 * qq], k), vget(val[2 * pp][2 * qq + 1], k)),
+                                          fmaxf(vget(val[2 * pp + 1][2 * qq], k), vget(val[2 * pp + 1][2 * qq + 1], k))));
+                    *reinterpret_cast<V*>(&ys[((2 * ty + pp) * S2 + 2 * tx + qq) * CS + cv * VN]) = mx;
+                }
+        }
+    }
+    __syncthreads();
+    const long T2 = (long)N * TI2;
+    for (int u = threadIdx.x; u < TI2 * CV; u += NT) {
+        const int cv = u % CV, t_img = u / CV, ty = t_img / WT2, tx = t_img % WT2;
+        const long t2 = (long)n * TI2 + t_img;
+        const int cg = c0 / VN + cv;
+        V e[6][6];   // B^T d (rows transformed), column b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int xx = 4 * tx - 1 + b;
+            V d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int yy = 4 * ty - 1 + a;
+                d[a] = ((unsigned)yy < (unsigned)S2 && (unsigned)xx < (unsigned)S2)
+                           ? *reinterpret_cast<const V*>(&ys[(yy * S2 + xx) * CS + cv * VN]) : vzero<V>();
+            }
+            V col[6];
+            bt4(d, col);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) e[a][b] = col[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            V o[6];
+            bt4(e[a], o);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(v)[((size_t)(a * 6 + b) * T2 + t2) * CVg + cg] = o[b];
+        }
+    }
+}
+
+template <int HW, int CS, typename V, bool POOL, int NT>
+static int launch_chain(const float* mm, const float* scale, const float* shift, float* y, float* v, int N, int C, int act,
+                        float slope, hipStream_t st) {
+    constexpr int S2 = POOL ? HW / 2 : HW;
+    constexpr size_t lds = (size_t)S2 * S2 * CS * 4;
+    auto kern = winograd4_chain_kernel<HW, CS, V, POOL, NT>;
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)N * (C / CS))), dim3(NT), lds, st, mm, scale, shift, y, v, N, C, act, slope);
+    return check_launch("winograd4_chain");
+}
+
+static int chain_variant() {
+    static const char* e = getenv("DVG_WINO_CHAIN_VARIANT");   // A/B runs only
+    return e ? atoi(e) : 0;
+}
+
 static inline unsigned wgrid(long n) {
     long g = (n + 255) / 256;
     return (unsigned)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -477,22 +607,57 @@ extern "C" int dvg_winograd_wgrad_operands(const float* x, const float* dy, floa
     return DVG_OK;
 }
 
-// M (36, T, C) of layer L -> V (36, T, C) of layer L + 1 (see winograd4_out_in_kernel): H == W in {8, 16}, F(4x4,3x3),
-// C % 64 == 0.  The activation y = act(scale * A^T M A + shift) itself is not written.
+// M (36, T, C) of layer L -> V (36, T, C) of layer L + 1 (winograd4_out_in_kernel / winograd4_chain_kernel): H == W in
+// {8, 16, 32}, F(4x4,3x3), C % 64 == 0.  The activation y = act(scale * A^T M A + shift) itself is not written.
 extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H,
                                          int W, int C, int act, float slope, void* stream) {
     DVG_REQUIRE(mm && v_next, DVG_ERR_NULL, "dvg_winograd_output_input: NULL pointer");
-    DVG_REQUIRE(N > 0 && H == W && (H == 8 || H == 16) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
-                "dvg_winograd_output_input: 8x8 or 16x16 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
+    DVG_REQUIRE(N > 0 && H == W && (H == 8 || H == 16 || H == 32) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_output_input: 8x8, 16x16 or 32x32 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_input: bad act");
+    DVG_REQUIRE(aligned16(mm) && aligned16(v_next), DVG_ERR_ALIGN, "dvg_winograd_output_input: alignment");
     const hipStream_t st = (hipStream_t)stream;
-    if (H == 8)
+    const int var = chain_variant();
+    // Measured per shape (tools/bench_wino_parts.py, us at B = 64 / B = 576; DVG_WINO_CHAIN_VARIANT forces one for A/B runs):
+    //   16x16 256ch: r02 kernel (64-byte runs) 20.3 / 212; <16,64,f32x2> 15.1 / 140; <16,32,float> 13.8 / 160
+    //   32x32 128ch: separate output + input passes 42.2 / 389; <32,16,f32x2> 36.5 / 388; <32,32,f32x4> (128 KB of LDS) 27.3 / 284
+    //    8x8  512ch: r02 kernel 7.6 / 73 = <8,64,float> - kept
+    if (H == 8) {
         hipLaunchKernelGGL(winograd4_out_in_kernel<8>, dim3((unsigned)((long)N * (C / 64))), dim3(256), 0, st, mm, scale, shift,
                            v_next, N, C, act, slope);
-    else
-        hipLaunchKernelGGL(winograd4_out_in_kernel<16>, dim3((unsigned)((long)N * (C / 16))), dim3(256), 0, st, mm, scale, shift,
-                           v_next, N, C, act, slope);
+    } else if (H == 16) {
+        if (var == 9) {
+            hipLaunchKernelGGL(winograd4_out_in_kernel<16>, dim3((unsigned)((long)N * (C / 16))), dim3(256), 0, st, mm, scale,
+                               shift, v_next, N, C, act, slope);
+        } else if (var == 2 || (var == 0 && (long)N * (C / 64) < 1024)) {
+            return launch_chain<16, 32, float, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+        } else {
+            return launch_chain<16, 64, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+        }
+    } else {
+        if (var == 1) return launch_chain<32, 16, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+        return launch_chain<32, 32, f32x4, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+    }
     return check_launch("dvg_winograd_output_input");
+}
+
+// Last layer of an encoder stage (vgg_64.py:51-56): M (36, T, C) -> y = act(scale * A^T M A + shift) (N,H,W,C) NHWC, the
+// skip tensor, AND V' (36, T / 4, C), the F(4x4,3x3) input transform of maxpool2x2(y) for the first layer of the next stage
+// (winograd4_chain_kernel<POOL>).  H == W in {16, 32}, C % 64 == 0.  The pooled tensor itself is not written.
+extern "C" int dvg_winograd_output_pool_input(const float* mm, const float* scale, const float* shift, float* y, float* v_next,
+                                              int N, int H, int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(mm && y && v_next, DVG_ERR_NULL, "dvg_winograd_output_pool_input: NULL pointer");
+    DVG_REQUIRE(N > 0 && H == W && (H == 16 || H == 32) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_output_pool_input: 16x16 or 32x32 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_pool_input: bad act");
+    DVG_REQUIRE(aligned16(mm) && aligned16(y) && aligned16(v_next), DVG_ERR_ALIGN, "dvg_winograd_output_pool_input: alignment");
+    const hipStream_t st = (hipStream_t)stream;
+    const int var = chain_variant();
+    // us at B = 64 / 576 against output(+pool) followed by input: 16 -> 8 (256 ch) 12.2 / 120 vs 18.3 / 124; 32 -> 16 (128 ch)
+    // 21.7 / 244 vs 30.0 / 247 (the 16-channel variant: 33.5 / 324)
+    (void)var;
+    if (H == 16) return launch_chain<16, 64, f32x2, true, 512>(mm, scale, shift, y, v_next, N, C, act, slope, st);
+    return launch_chain<32, 32, f32x2, true, 1024>(mm, scale, shift, y, v_next, N, C, act, slope, st);
 }
 
 extern "C" int dvg_winograd_output(

@@ -362,11 +362,24 @@ def _hoisted_skip(conv, x, skip, partial_fn):
 WINOGRAD_CHAIN = os.environ.get("DVG_WINOGRAD_CHAIN", "1") != "0"
 
 
-def _chain_to(conv_next, n, c, h, w):
-    """True when the layer after this one (conv_next, fed by this layer's (n,c,h,w) output and nothing else) can take a WinoV."""
-    return (WINOGRAD_CHAIN and WINOGRAD >= 4 and conv_next is not None and not conv_next.training
-            and conv_next.weight.shape[1] == c and tuple(conv_next.kernel_size) == (3, 3)
-            and winograd_tile(n, c, h, w, conv_next.weight.shape[0]) == 4 and ops.winograd_chain_ok(n, c, h, w))
+# DVG_WINOGRAD_CHAIN: 0 = every layer writes its activation; 1 = hand-overs inside a block at 8x8 / 16x16 (the r02 set);
+# 2 (default) = also at 32x32 and from the last layer of an encoder stage, through its 2x2 max-pool, to the first layer of the
+# next stage (dvg_winograd_output_pool_input).
+_CHAIN_LEVEL = int(os.environ.get("DVG_WINOGRAD_CHAIN", "2"))
+
+
+def _chain_to(conv_next, n, c, h, w, pool=False):
+    """True when the layer after this one (conv_next, fed by this layer's (n,c,h,w) output - or, `pool`, by its 2x2 max-pool -
+    and by nothing else) can take a WinoV."""
+    if not (WINOGRAD_CHAIN and WINOGRAD >= 4 and conv_next is not None and not conv_next.training
+            and isinstance(conv_next, nn.Conv2d) and conv_next.weight.shape[1] == c and tuple(conv_next.kernel_size) == (3, 3)):
+        return False
+    if pool:
+        return (_CHAIN_LEVEL >= 2 and winograd_tile(n, c, h // 2, w // 2, conv_next.weight.shape[0]) == 4
+                and ops.winograd_pool_chain_ok(n, c, h, w))
+    if h > 16 and _CHAIN_LEVEL < 2:
+        return False
+    return winograd_tile(n, c, h, w, conv_next.weight.shape[0]) == 4 and ops.winograd_chain_ok(n, c, h, w)
 
 
 def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2, next_conv=None):
@@ -382,7 +395,7 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         cout = conv.weight.shape[0]
         if winograd_tile(n, c, h, w, cout) != 4:
             raise RuntimeError("conv3_bn_act: WinoV handed to a layer that is not F(4x4,3x3)")
-        to_v = (not pool) and _chain_to(next_conv, n, cout, h, w)
+        to_v = _chain_to(next_conv, n, cout, h, w, pool)
         return ops.conv3x3_winograd(x, winograd_weight(conv, 4), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
@@ -399,8 +412,8 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         if skip is None and not upsample:
             m = winograd_tile(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.weight.shape[0])
             if m:
-                to_v = m == 4 and (not pool) and not torch.is_grad_enabled() and \
-                    _chain_to(next_conv, x.shape[0], conv.weight.shape[0], x.shape[2], x.shape[3])
+                to_v = m == 4 and not torch.is_grad_enabled() and \
+                    _chain_to(next_conv, x.shape[0], conv.weight.shape[0], x.shape[2], x.shape[3], pool)
                 return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
         return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
     wp = packed_weight(conv)

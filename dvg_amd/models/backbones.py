@@ -123,15 +123,17 @@ class VggEncoder(nn.Module):
         stages, head = self._stages()
         skips = []
         h = _frame(input)
-        for stage in stages:
+        for si, stage in enumerate(stages):
             layers = list(stage)
             for li, layer in enumerate(layers):
                 conv, bn = layer.main[0], layer.main[1]
                 last = li == len(layers) - 1
                 if conv.in_channels % 32:
                     h = fused.conv3_first_bn_act(conv, bn, h)
-                elif last:  # stage output = skip tensor; its 2x2 max-pool feeds the next stage
-                    full, h = fused.conv3_bn_act(conv, bn, h, pool=True)
+                elif last:  # stage output = skip tensor; its 2x2 max-pool feeds the next stage and nothing else (eval: the
+                    # pooled map may be handed over as the next stage's Winograd input transform, an ops.WinoV)
+                    nxt = stages[si + 1][0].main[0] if si + 1 < len(stages) else None
+                    full, h = fused.conv3_bn_act(conv, bn, h, pool=True, next_conv=nxt)
                     skips.append(full)
                 else:       # inner layer: its output has one consumer, the next layer (eval: may hand over an ops.WinoV)
                     h = fused.conv3_bn_act(conv, bn, h, next_conv=layers[li + 1].main[0])

@@ -266,14 +266,20 @@ class WinoV:
 
 def winograd_chain_ok(n, c, h, w):
     """Shapes dvg_winograd_output_input takes (the fused output -> input transform between two F(4x4,3x3) layers)."""
-    return h == w and h in (8, 16) and c % 64 == 0 and n > 0
+    return h == w and h in (8, 16, 32) and c % 64 == 0 and n > 0
+
+
+def winograd_pool_chain_ok(n, c, h, w):
+    """Shapes dvg_winograd_output_pool_input takes (last layer of an encoder stage -> first layer of the next stage)."""
+    return h == w and h in (16, 32) and c % 64 == 0 and n > 0
 
 
 def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False, to_v=False):
     """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
     transform; m (2 or 4) follows from u's leading dimension (16 or 36).  x may be a WinoV (the previous layer's to_v=True
-    result: no input transform); to_v=True returns the NEXT layer's input transform as a WinoV instead of y (m = 4, no pool,
-    winograd_chain_ok shapes: dvg_winograd_output_input)."""
+    result: no input transform); to_v=True returns the NEXT layer's input transform as a WinoV instead of y (m = 4,
+    winograd_chain_ok shapes: dvg_winograd_output_input); pool=True with to_v=True returns (y, WinoV of maxpool2x2(y)): the
+    last layer of an encoder stage handing over to the first layer of the next (dvg_winograd_output_pool_input)."""
     from_v = isinstance(x, WinoV)
     if from_v:
         n, c, h, w = x.shape
@@ -287,7 +293,7 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
     if (from_v or to_v) and (mt != 4 or return_v):
         raise RuntimeError("conv3x3_winograd: WinoV hand-over needs F(4x4,3x3) and no return_v")
-    if to_v and (pool or not winograd_chain_ok(n, cout, h, w)):
+    if to_v and not (winograd_pool_chain_ok(n, cout, h, w) if pool else winograd_chain_ok(n, cout, h, w)):
         raise RuntimeError(f"conv3x3_winograd: to_v unsupported for output {(n, cout, h, w)} pool={pool}")
     t = n * (h // mt) * (w // mt)
     dev = x.device
@@ -302,6 +308,12 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
              _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
+    if to_v and pool:
+        y = nhwc_empty(n, cout, h, w, dev)
+        vn = torch.empty((npos, t // 4, cout), device=dev, dtype=torch.float32)
+        _run("winograd_output_pool_input", 0.0, 4.0 * (m.numel() + y.numel() + vn.numel()), lib().dvg_winograd_output_pool_input,
+             _p(m), _p(scale), _p(shift), _p(y), _p(vn), n, h, w, cout, act, slope, _stream())
+        return y, WinoV(vn, (n, cout, h // 2, w // 2))
     if to_v:
         vn = torch.empty((npos, t, cout), device=dev, dtype=torch.float32)
         _run("winograd_output_input", 0.0, 4.0 * (m.numel() + vn.numel()), lib().dvg_winograd_output_input, _p(m), _p(scale),

@@ -157,11 +157,17 @@ int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y, int NB, i
                          void* stream);
 int dvg_winograd_output(const float* mm, const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
                         int W, int C, int act, float slope, int m, void* stream);
-/* dvg_winograd_output of layer L and dvg_winograd_input of layer L+1 in one pass (m = 4, H == W in {8, 16}, C % 64 == 0) for
+/* dvg_winograd_output of layer L and dvg_winograd_input of layer L+1 in one pass (m = 4, H == W in {8, 16, 32}, C % 64 == 0) for
  * two consecutive eval-mode vgg_layers at one resolution whose intermediate activation has no other consumer (the inner
  * layers of a vgg block, vgg_64.py:24-43,70-87): mm (36, T, C) -> v_next (36, T, C); the activation is not written.     */
 int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H, int W,
                               int C, int act, float slope, void* stream);
+/* Last layer of an encoder stage (vgg_64.py:51-56, `mp` :49): M (36, T, C) -> the stage's skip tensor y = act(scale * A^T M A
+ * + shift) (N,H,W,C) NHWC AND V' (36, T / 4, C), the F(4x4,3x3) input transform of maxpool2x2(y) for the first layer of the
+ * next stage.  The pooled tensor itself is never written.  H == W in {16, 32}, C % 64 == 0.  Bit-identical to
+ * dvg_winograd_output(+pool) followed by dvg_winograd_input.  ABI 6. */
+int dvg_winograd_output_pool_input(const float* m, const float* scale, const float* shift, float* y, float* v_next, int N,
+                                   int H, int W, int C, int act, float slope, void* stream);
 
 /* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
  * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.

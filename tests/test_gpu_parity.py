@@ -711,7 +711,8 @@ def test_eval_backbone_at_winograd_batch_matches_oracle(family, B):
         assert rel_err(a, b) < 1e-4
 
 
-@pytest.mark.parametrize("N,H,C,Cmid,Cout", [(32, 8, 256, 512, 512), (8, 16, 128, 256, 256), (32, 8, 512, 512, 256)])
+@pytest.mark.parametrize("N,H,C,Cmid,Cout", [(32, 8, 256, 512, 512), (8, 16, 128, 256, 256), (32, 8, 512, 512, 256),
+                                             (8, 32, 64, 128, 128), (32, 16, 128, 256, 256)])
 def test_winograd_chain_hands_over_the_input_transform(N, H, C, Cmid, Cout):
     """dvg_winograd_output_input: two consecutive F(4x4,3x3) layers with the first layer's activation never written - the
     second layer's result equals (bit for bit: same kernels around it, same arithmetic inside) the unchained pair's, and both
@@ -740,6 +741,15 @@ def test_winograd_chain_hands_over_the_input_transform(N, H, C, Cmid, Cout):
         a = ops.conv3x3_winograd(v2, u2, d(s2), d(b2), pool=True)
         b = ops.conv3x3_winograd(y2, u2, d(s2), d(b2), pool=True)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # ... and the pooled map handed over to the next STAGE as its input transform (dvg_winograd_output_pool_input):
+        # the skip tensor and the next stage's first layer must come out bit-identical to the unchained route
+        if ops.winograd_pool_chain_ok(N, Cout, H, H) and ops.winograd_ok(N, Cout, H // 2, H // 2, Cout, 4):
+            ysk, vp = ops.conv3x3_winograd(v2, u2, d(s2), d(b2), pool=True, to_v=True)
+            assert isinstance(vp, ops.WinoV) and vp.shape == (N, Cout, H // 2, H // 2)
+            assert torch.equal(ysk, b[0])
+            w3 = params.normal(2507, Cout, Cout, 3, 3, scale=1.2 / (3 * Cout ** 0.5))
+            u3 = ops.winograd_weight(w3.to(dev()), 4)
+            assert torch.equal(ops.conv3x3_winograd(vp, u3, d(s2), d(b2)), ops.conv3x3_winograd(b[1], u3, d(s2), d(b2)))
 
 
 def test_eval_rollout_modules_chain_equals_unchained():
@@ -764,9 +774,12 @@ def test_eval_rollout_modules_chain_equals_unchained():
             fused.WINOGRAD_CHAIN = old
         out[chain] = (h, skips, y, timer.summary())
     n_fused = out[True][3].get("winograd_output_input", {}).get("launches", 0)
-    assert "winograd_output_input" not in out[False][3], list(out[False][3])
+    n_pool = out[True][3].get("winograd_output_pool_input", {}).get("launches", 0)
+    assert "winograd_output_input" not in out[False][3] and "winograd_output_pool_input" not in out[False][3], list(out[False][3])
     if fused.WINOGRAD == 4:
         assert n_fused >= 5, n_fused
+        if fused._CHAIN_LEVEL >= 2:   # c2.0 -> c2.1 at 32x32 inside the block; c2 -> c3 and c3 -> c4 through the max-pool
+            assert n_fused >= 7 and n_pool == 2, (n_fused, n_pool)   # 5 in the encoder (one of them at 32x32), 2 in the decoder
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
     for a, b in zip(out[True][1], out[False][1]):
         assert torch.equal(a, b)
