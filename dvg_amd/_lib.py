@@ -52,9 +52,10 @@ SIGNATURES = {
     "dvg_pixel_proj": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "dvg_convT_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_channel_stats_rows": (_i, [_l]),
-    "dvg_channel_stats": (_i, [_p, _p, _l, _i, _p]),
-    "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p, _i, _p]),
-    "dvg_bn_act_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_channel_stats": (_i, [_p, _p, _l, _i, _i, _p]),
+    "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p, _i, _i, _p, _p]),
+    "dvg_bn_running_update": (_i, [_p, _p, _i, _i, _f, _f, _f, _p, _p, _p, _i, _p]),
+    "dvg_bn_act_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_gemm_nt_bias_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_lstm_cell_x": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
@@ -68,9 +69,9 @@ SIGNATURES = {
     "dvg_gp_elbo": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _p]),
     "dvg_gp_elbo_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
-    "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _p]),
-    "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _p]),
+    "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _i, _p]),
+    "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _i, _p]),
     "dvg_act_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "dvg_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_colsum": (_i, [_p, _p, _i, _i, _i, _p]),

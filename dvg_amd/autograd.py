@@ -254,12 +254,10 @@ def _dgrad3(du, weight, lo, hi):
 
 
 def _bn_forward(bn, u, stats, count, act, slope, pool):
-    """Shared forward tail: batch (train) or running (eval) statistics -> y (, y_pool), mean, invstd."""
+    """Shared forward tail: batch (train) or running (eval) statistics -> y (, y_pool), mean, invstd.  count = elements per
+    channel of the whole batch; inside fused.bn_groups(G) the statistics are per group of count / G (mean, invstd: [G][C])."""
     if bn.training:
-        scale, shift, mean, invstd = ops.bn_finalize(
-            stats, bn.weight.detach(), bn.bias.detach(), bn.running_mean if bn.track_running_stats else None,
-            bn.running_var if bn.track_running_stats else None, count, bn.eps,
-            fused.bn_momentum(bn), save=True, num_batches_tracked=fused.bn_counter(bn), passes=fused.bn_passes_now())
+        scale, shift, mean, invstd = fused._train_bn(bn, fused.group_stats(stats, u), count, save=True)
     else:
         with torch.no_grad():
             mean = bn.running_mean.clone()
@@ -336,7 +334,9 @@ class _ConvBlock(torch.autograd.Function):
         y = out[0] if pool else out
         ctx.save_for_backward(x, skip, weight, gamma, u, y, mean, invstd)
         ctx.params = (weight, bias, gamma, beta)     # the Parameter objects: backward accumulates into their .grad
-        ctx.cfg = dict(cfg, train=bn.training, count=n * h * w, has_bias=bias is not None, x_half=addend is not None)
+        groups = mean.shape[0] if mean.dim() == 2 else 1      # time-batched: statistics (and their backward) per group
+        ctx.cfg = dict(cfg, train=bn.training, count=n * h * w // groups, has_bias=bias is not None,
+                       x_half=addend is not None)
         ctx.wino_v = keep.get("v")                   # the forward's Winograd input transform, for the weight gradient
         return out if pool else y
 
@@ -500,6 +500,43 @@ class _SkipHalf(torch.autograd.Function):
         return dskip, dW, None
 
 
+class _SplitBatch(torch.autograd.Function):
+    """x (G*B, ...) -> G views of B consecutive images each (time-batched training: one encoder launch over all frames of a
+    sequence, consumed frame by frame).  Backward assembles the G gradients in ONE buffer of x's layout (a slice nobody
+    back-propagated into is zero-filled) - torch's own slicing would allocate and zero a full-size gradient per slice."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        b = x.shape[0] // groups
+        ctx.meta = (groups, b)
+        ctx.like = x          # only shape / strides / device are used
+        return tuple(x[g * b:(g + 1) * b] for g in range(groups))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        groups, b = ctx.meta
+        like = ctx.like
+        if all(g is not None and g.stride() == like[:b].stride() for g in grads):
+            out = torch.cat(grads, 0)
+            if out.stride() == like.stride():
+                return out, None
+        out = torch.empty_like(like)         # preserves NHWC-in-memory strides
+        for g, gr in enumerate(grads):
+            if gr is None:
+                out[g * b:(g + 1) * b].zero_()
+            else:
+                out[g * b:(g + 1) * b].copy_(gr)
+        return out, None
+
+
+def split_batch(x, groups):
+    """G views of x's consecutive image groups; differentiable without per-slice full-size gradients (see _SplitBatch)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        b = x.shape[0] // groups
+        return tuple(x[g * b:(g + 1) * b] for g in range(groups))
+    return _SplitBatch.apply(x, groups)
+
+
 def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, act, slope=0.2):
     cfg = {"kind": kind, "bn": bn, "upsample": upsample, "pool": pool, "act": act, "slope": slope}
     if kind in ("conv3", "conv4s2", "convT4s2"):
@@ -539,12 +576,13 @@ class _DenseBlock(torch.autograd.Function):
             u2 = ops.gemm_nt(a, gw, None, b, act=ACT_NONE, period=cout).view(n * kh * kw, cout)
             rows, ch = n * kh * kw, cout
         u4 = u2.view(rows, 1, 1, ch).permute(0, 3, 1, 2)
-        st = ops.channel_stats(u2) if bn.training else None
+        st = ops.channel_stats(u2, fused.bn_groups_now()) if bn.training else None
         y4, mean, invstd = _bn_forward(bn, u4, st, rows, act, slope, False)
         ctx.save_for_backward(a, gw, gamma, u4, y4, mean, invstd)
         ctx.params = (bias, gamma, beta)
+        groups = mean.shape[0] if mean.dim() == 2 else 1
         ctx.cfg = dict(cfg, train=bn.training, rows=rows, ch=ch, xshape=tuple(x.shape), wshape=tuple(w.shape),
-                       has_bias=bias is not None)
+                       has_bias=bias is not None, count=rows // groups)
         if kind == "head":
             return y4.reshape(rows, ch)
         return y4.reshape(n, kh, kw, cout).permute(0, 3, 1, 2)  # NHWC-in-memory (N,512,4,4)
@@ -563,7 +601,7 @@ class _DenseBlock(torch.autograd.Function):
         s_g, s_be = _sink(p_g, ng[3]), _sink(p_be, ng[4])
         s_b = _sink(p_b, ng[2]) if cfg["has_bias"] else None
         bn_direct = s_g is not None and s_be is not None and (s_b is not None or not cfg["has_bias"])
-        du4, dgamma, dbeta, dbias = ops.bn_act_bwd(dy4, None, y4, u4, gamma.detach(), mean, invstd, rows,
+        du4, dgamma, dbeta, dbias = ops.bn_act_bwd(dy4, None, y4, u4, gamma.detach(), mean, invstd, cfg["count"],
                                                    act=cfg["act"], slope=cfg["slope"], train=cfg["train"],
                                                    sinks=(s_g, s_be, s_b) if bn_direct else None)
         if kind == "head":

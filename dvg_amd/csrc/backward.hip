@@ -29,16 +29,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                 const float* __restrict__ y,
                                                                 const float* __restrict__ u, float* __restrict__ dp,
                                                                 float* __restrict__ partial, int N, int H, int W,
-                                                                int C, int act, float slope, int units_per_block) {
+                                                                int C, int act, float slope, int units_per_block,
+                                                                int bpg) {
     __shared__ float red[2 * 256 * 4];
     const int C4 = C >> 2;
     const int TC = C4 < 256 ? C4 : 256;
     const int TP = 256 / TC;
     const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
     const int Hu = POOL ? H >> 1 : H, Wu = POOL ? W >> 1 : W;
-    const long units = (long)N * Hu * Wu;  // windows or pixels
-    const long u0 = (long)blockIdx.x * units_per_block;
-    const long u1 = min(units, u0 + units_per_block);
+    // N = images PER GROUP; group g (time-batched training: an independent BatchNorm batch) owns the `bpg` consecutive
+    // workgroups / partial rows [g * bpg, (g + 1) * bpg): no partial row mixes two groups
+    const long units = (long)N * Hu * Wu;  // windows or pixels of one group
+    const long g_ = blockIdx.x / bpg, lb = blockIdx.x % bpg;
+    const long u0 = g_ * units + lb * units_per_block;
+    const long u1 = min((g_ + 1) * units, u0 + units_per_block);
     for (int c4 = tc; c4 < C4; c4 += TC) {  // C4 > 256 only when C > 1024: not on this path, kept for safety
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         for (long w_ = u0 + tp; w_ < u1; w_ += TP) {
@@ -126,6 +130,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ dbeta, float* __restrict__ dbias,
                                                                int C, double count, int train, int accumulate) {
     __shared__ double red[64 * 16 * 2];
+    // blockIdx.y = group (time-batched training): rows [g * nrows, (g + 1) * nrows) and row g of every [G][C] array -
+    // dgamma / dbeta / dbias included (the host sums them over the groups: dvg_colsum)
+    {
+        const size_t go = (size_t)blockIdx.y * C;
+        partial += (size_t)blockIdx.y * nrows * 2 * C;
+        mean += go; invstd += go; coefA += go; coefB += go; coefC += go;
+        if (dgamma) dgamma += go;
+        if (dbeta) dbeta += go;
+        if (dbias) dbias += go;
+    }
     // 16 channels x 64 row lanes per workgroup, C/16 workgroups (misc_kernels.hip partial_colsums has the history)
     const int lc = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + lc;
@@ -188,9 +202,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 __global__ void affine3_kernel(const float* __restrict__ dp, const float* __restrict__ u,
                                const float* __restrict__ A, const float* __restrict__ B,
                                const float* __restrict__ Cc, float* __restrict__ du, long n4, int C4,
-                               float* __restrict__ sum, int sum_mode) {
+                               float* __restrict__ sum, int sum_mode, long per_group4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
+        const int c = (int)(i % C4) * 4 + (per_group4 ? (int)(i / per_group4) * C4 * 4 : 0);   // coefficients are [G][C]
         const f32x4 d = reinterpret_cast<const f32x4*>(dp)[i];
         const f32x4 uv = reinterpret_cast<const f32x4*>(u)[i];
         const f32x4 a = *reinterpret_cast<const f32x4*>(A + c), b = *reinterpret_cast<const f32x4*>(B + c),
@@ -212,9 +226,10 @@ __global__ void affine3_kernel(const float* __restrict__ dp, const float* __rest
 
 __global__ void affine3_scalar_kernel(const float* __restrict__ dp, const float* __restrict__ u,
                                       const float* __restrict__ A, const float* __restrict__ B,
-                                      const float* __restrict__ Cc, float* __restrict__ du, long n, int C) {
+                                      const float* __restrict__ Cc, float* __restrict__ du, long n, int C,
+                                      long per_group) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
+        const int c = (int)(i % C) + (per_group ? (int)(i / per_group) * C : 0);
         du[i] = fmaf(A[c], dp[i], fmaf(B[c], u[i], Cc[c]));
     }
 }
@@ -225,8 +240,10 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_scalar_kernel(const float*
                                                                     const float* __restrict__ u,
                                                                     float* __restrict__ dp,
                                                                     float* __restrict__ partial, long rows, int C,
-                                                                    int act, float slope, int rows_per_block) {
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+                                                                    int act, float slope, int rows_per_block, int bpg) {
+    // rows = rows PER GROUP, bpg workgroups per group (see bn_act_bwd_reduce_kernel)
+    const long g_ = blockIdx.x / bpg, lb = blockIdx.x % bpg;
+    const long r0 = g_ * rows + lb * rows_per_block, r1 = min((g_ + 1) * rows, r0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (long r = r0; r < r1; ++r) {
@@ -596,18 +613,22 @@ extern "C" int dvg_bn_act_bwd_rows(int N, int H, int W, int pool) {
 }
 
 extern "C" int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const float* y, const float* u, float* dp,
-                                     float* partial, int N, int H, int W, int C, int act, float slope, void* stream) {
+                                     float* partial, int N, int H, int W, int C, int act, float slope, int groups,
+                                     void* stream) {
     DVG_REQUIRE(y && u && dp && partial, DVG_ERR_NULL, "dvg_bn_act_bwd_reduce: NULL pointer");
     DVG_REQUIRE(dy || dyp, DVG_ERR_NULL, "dvg_bn_act_bwd_reduce: no incoming gradient");
-    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: bad shape");
+    DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && N % groups == 0, DVG_ERR_SHAPE,
+                "dvg_bn_act_bwd_reduce: bad shape (groups must divide N)");
+    N /= groups;   // images per group from here on
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: bad act");
     const int pool = dyp != nullptr;
     if (C % 4 != 0) {
         DVG_REQUIRE(!pool, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: pool needs C %% 4 == 0");
         const long rows = (long)N * H * W;
         const int rpb = bwd_units_per_block(rows);
-        hipLaunchKernelGGL(act_bwd_reduce_scalar_kernel, dim3((rows + rpb - 1) / rpb), dim3(C >= 256 ? 256 : 64), 0,
-                           (hipStream_t)stream, dy, y, u, dp, partial, rows, C, act, slope, rpb);
+        const int bpg = (int)((rows + rpb - 1) / rpb);
+        hipLaunchKernelGGL(act_bwd_reduce_scalar_kernel, dim3((unsigned)bpg * groups), dim3(C >= 256 ? 256 : 64), 0,
+                           (hipStream_t)stream, dy, y, u, dp, partial, rows, C, act, slope, rpb, bpg);
         return check_launch("dvg_bn_act_bwd_reduce");
     }
     DVG_REQUIRE(C <= 1024 && (256 % (C / 4 < 256 ? C / 4 : 256)) == 0, DVG_ERR_SHAPE,
@@ -617,31 +638,35 @@ extern "C" int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const fl
     if (pool) DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_bn_act_bwd_reduce: odd H/W with pool");
     const long units = pool ? (long)N * (H / 2) * (W / 2) : (long)N * H * W;
     const int upb = bwd_units_per_block(units);
-    const unsigned grid = (unsigned)((units + upb - 1) / upb);
+    const int bpg = (int)((units + upb - 1) / upb);
+    const unsigned grid = (unsigned)bpg * groups;
     if (pool)
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dyp, y,
-                           u, dp, partial, N, H, W, C, act, slope, upb);
+                           u, dp, partial, N, H, W, C, act, slope, upb, bpg);
     else
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dyp,
-                           y, u, dp, partial, N, H, W, C, act, slope, upb);
+                           y, u, dp, partial, N, H, W, C, act, slope, upb, bpg);
     return check_launch("dvg_bn_act_bwd_reduce");
 }
 
 extern "C" int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
                                    const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
                                    float* dbeta, float* dbias, int C, double count, int train, int accumulate,
-                                   void* stream) {
+                                   int groups, void* stream) {
     DVG_REQUIRE(partial && mean && invstd && coefA && coefB && coefC, DVG_ERR_NULL, "dvg_bn_bwd_finalize: NULL");
-    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
+    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0 && groups > 0 && groups < 65536, DVG_ERR_SHAPE, "dvg_bn_bwd_finalize: bad shape");
+    DVG_REQUIRE(groups == 1 || !accumulate, DVG_ERR_SHAPE,
+                "dvg_bn_bwd_finalize: with several groups dgamma / dbeta / dbias are [G][C] scratch rows (no accumulation)");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16, groups), dim3(1024), 0, (hipStream_t)stream, partial, nrows,
                        gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbeta, dbias, C, count, train, accumulate);
     return check_launch("dvg_bn_bwd_finalize");
 }
 
 extern "C" int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B, const float* Cc,
-                                 float* du, long n, int C, float* sum, int sum_mode, void* stream) {
+                                 float* du, long n, int C, float* sum, int sum_mode, int groups, void* stream) {
     DVG_REQUIRE(dp && u && A && B && Cc && du, DVG_ERR_NULL, "dvg_affine3_apply: NULL pointer");
-    DVG_REQUIRE(n > 0 && C > 0 && n % C == 0, DVG_ERR_SHAPE, "dvg_affine3_apply: bad shape");
+    DVG_REQUIRE(n > 0 && C > 0 && n % C == 0 && groups > 0 && (n / C) % groups == 0, DVG_ERR_SHAPE, "dvg_affine3_apply: bad shape");
+    const long per_group = groups > 1 ? n / groups : 0;   // coefficients [G][C], group = consecutive run of n / G elements
     DVG_REQUIRE(sum_mode >= 0 && sum_mode <= 2 && (sum_mode == 0 || (sum != nullptr && sum != du)), DVG_ERR_SHAPE,
                 "dvg_affine3_apply: bad sum_mode / sum");
     const bool vec = C % 4 == 0 && aligned16(dp) && aligned16(u) && aligned16(du) && aligned16(A) && aligned16(B) &&
@@ -649,10 +674,10 @@ extern "C" int dvg_affine3_apply(const float* dp, const float* u, const float* A
     DVG_REQUIRE(sum_mode == 0 || vec, DVG_ERR_ALIGN, "dvg_affine3_apply: the sum output needs C %% 4 == 0 and 16-byte alignment");
     if (vec)
         hipLaunchKernelGGL(affine3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B, Cc,
-                           du, n / 4, C / 4, sum, sum_mode);
+                           du, n / 4, C / 4, sum, sum_mode, per_group / 4);
     else
         hipLaunchKernelGGL(affine3_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B,
-                           Cc, du, n, C);
+                           Cc, du, n, C, per_group);
     return check_launch("dvg_affine3_apply");
 }
 

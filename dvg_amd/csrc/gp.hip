@@ -65,6 +65,26 @@ __device__ __forceinline__ double abs_t(double x) { return fabs(x); }
 __device__ __forceinline__ float max_t(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double max_t(double a, double b) { return fmax(a, b); }
 
+// 1 / sqrt(x) and 1 / x.  The fp64 forms are an fp32 seed (v_rsq_f32 / v_rcp_f32, ~1 ulp) refined by two Newton steps
+// (relative error 1e-7 -> 1e-14 -> below the fp64 rounding): ten FMAs instead of the ~40-instruction v_sqrt_f64 / v_div
+// fix-up sequences, and these sit on the SERIAL chains of the kernels (the pivot of every Cholesky column, the diagonal
+// solve of every substitution row).
+__device__ __forceinline__ float rsqrt_t(float x) { return 1.f / sqrtf(x); }
+__device__ __forceinline__ double rsqrt_t(double x) {
+    double r = (double)__frsqrt_rn((float)x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ float rcp_t(float x) { return 1.f / x; }
+__device__ __forceinline__ double rcp_t(double x) {
+    double r = (double)__frcp_rn((float)x);
+    r = r * fma(-x, r, 2.0);
+    r = r * fma(-x, r, 2.0);
+    return r;
+}
+
 // value of `v` in lane `src` (compile-time constant after unrolling): v_readlane_b32, not a ds_bpermute round trip
 __device__ __forceinline__ float read_lane(float v, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
@@ -112,8 +132,9 @@ __device__ void block_cholesky(T* A, int n, int ld, int tid) {
 #pragma unroll
             for (int jj = 0; jj < NB; ++jj) {
                 if (jj < kb) {
-                    const T dg = sqrt_t(max_t(read_lane(a0[jj], jj), T(1e-12)));
-                    const T inv = T(1.) / dg;
+                    const T piv = max_t(read_lane(a0[jj], jj), T(1e-12));
+                    const T inv = rsqrt_t(piv);
+                    const T dg = piv * inv;
                     const T l0 = (lane == jj) ? dg : a0[jj] * inv;   // lanes < jj: upper triangle, never read
                     const T l1 = a1[jj] * inv;
                     a0[jj] = l0;
@@ -198,7 +219,7 @@ __device__ void block_forward_subst(const T* L, int LM, T* X, int LB, int M, int
 #pragma unroll
                     for (int q = 0; q < RB; ++q)
                         if (q < a) acc = fma_t(-L[(r0 + a) * LM + r0 + q], xv[q], acc);
-                    xv[a] = acc / L[(r0 + a) * LM + r0 + a];
+                    xv[a] = acc * rcp_t(L[(r0 + a) * LM + r0 + a]);
                     X[(r0 + a) * LB + col] = xv[a];
                 }
             }
@@ -234,7 +255,7 @@ __device__ void block_backward_subst(const T* L, int LM, T* X, int LB, int M, in
 #pragma unroll
                     for (int q = 0; q < RB; ++q)
                         if (q > a && q < rb) acc = fma_t(-L[(r0 + q) * LM + r0 + a], xv[q], acc);
-                    xv[a] = acc / L[(r0 + a) * LM + r0 + a];
+                    xv[a] = acc * rcp_t(L[(r0 + a) * LM + r0 + a]);
                     X[(r0 + a) * LB + col] = xv[a];
                 }
             }

@@ -68,10 +68,13 @@ __global__ void layout_kernel(const float* __restrict__ x, float* __restrict__ y
 
 // per-channel sum / sum of squares of an NHWC tensor viewed as [rows][C]:
 // grid.x slabs of rows, each writes one partial row [2][C] (deterministic).
+// Groups (time-batched training): the rows are `groups` consecutive runs of `rows` rows, every run gets its own `bpg`
+// slabs (no slab straddles two groups) and the partial rows come out group-major.
 __global__ void channel_stats_kernel(const float* __restrict__ u, float* __restrict__ partial, long rows, int C,
-                                     int rows_per_block) {
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    const long r1 = min(rows, r0 + rows_per_block);
+                                     int rows_per_block, int bpg) {
+    const long g = blockIdx.x / bpg, lb = blockIdx.x % bpg;
+    const long r0 = g * rows + lb * rows_per_block;
+    const long r1 = min((g + 1) * rows, r0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (long r = r0; r < r1; ++r) {
@@ -136,10 +139,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, int C, double count,
                                                            float eps, float momentum, long long* __restrict__ nbt,
-                                                           int nbt_inc) {
+                                                           int nbt_inc, float* __restrict__ group_var) {
     __shared__ double red[64 * DVG_COLSUM_CT * 2];
+    // Groups (blockIdx.y; time-batched training: one launch finalises the statistics of G independent BatchNorm batches):
+    // group g owns partial rows [g * nrows, (g + 1) * nrows) and row g of every [G][C] output.  The running statistics
+    // are a recurrence over the groups in call order: the host passes them only with one group, dvg_bn_running_update
+    // applies it otherwise (from save_mean and group_var = the unbiased variance).
+    const int g_ = blockIdx.y;
+    partial += (size_t)g_ * nrows * 2 * C;
+    scale += (size_t)g_ * C;
+    shift += (size_t)g_ * C;
+    if (save_mean) save_mean += (size_t)g_ * C;
+    if (save_invstd) save_invstd += (size_t)g_ * C;
+    if (group_var) group_var += (size_t)g_ * C;
     // num_batches_tracked += passes (nn.BatchNorm2d's int64 counter): one lane of the launch, instead of a torch add
-    if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += nbt_inc;
+    if (nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nbt += nbt_inc;
     const int c = blockIdx.x * DVG_COLSUM_CT + (threadIdx.x & (DVG_COLSUM_CT - 1)), rl = threadIdx.x >> 4;
     double s1, s2;
     partial_colsums(partial, nrows, C, c, rl, red, s1, s2);
@@ -154,19 +168,40 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     shift[c] = b - (float)mean * sc;
     if (save_mean) save_mean[c] = (float)mean;
     if (save_invstd) save_invstd[c] = invstd;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    if (group_var) group_var[c] = (float)unbiased;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+// Running statistics of G consecutive train-mode BatchNorm calls (groups of one time-batched launch) in call order:
+//   running <- (1 - m_g) running + m_g stat_g,   g = 0 .. G-1,   m_0 = mom_first, m_{G-1} = mom_last, else mom_mid
+// - the arithmetic bn_finalize_kernel applies per call, on the float values it stored (mean, unbiased variance).
+// The first / last frame of a sequence is encoded once per closure and every middle frame twice (fused.bn_passes): hence
+// three momenta.  One thread per channel.
+__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ uvar, int G, int C,
+                                         float mom_first, float mom_mid, float mom_last, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, long long* __restrict__ nbt, int nbt_inc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt != nullptr) *nbt += nbt_inc;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < G; ++g) {
+        const float momentum = g == 0 ? mom_first : (g == G - 1 ? mom_last : mom_mid);
+        rm = (1.f - momentum) * rm + momentum * mean[(size_t)g * C + c];
+        rv = (1.f - momentum) * rv + momentum * uvar[(size_t)g * C + c];
     }
+    running_mean[c] = rm;
+    running_var[c] = rv;
 }
 
 // y = act(u*scale+shift), float4 over channels
+// per_group4: float4 elements per coefficient group (scale / shift are [G][C]); 0 = one group
 __global__ void bn_act_kernel(const float* __restrict__ u, const float* __restrict__ scale,
                               const float* __restrict__ shift, float* __restrict__ y, long n4, int C4, int act,
-                              float slope) {
+                              float slope, long per_group4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
+        const int c = (int)(i % C4) * 4 + (per_group4 ? (int)(i / per_group4) * C4 * 4 : 0);
         f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
         const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c);
@@ -179,9 +214,9 @@ __global__ void bn_act_kernel(const float* __restrict__ u, const float* __restri
 // scalar variant for channel counts that are not a multiple of 4 (the (N,90) encoder head)
 __global__ void bn_act_scalar_kernel(const float* __restrict__ u, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ y, long n, int C, int act,
-                                     float slope) {
+                                     float slope, long per_group) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
+        const int c = (int)(i % C) + (per_group ? (int)(i / per_group) * C : 0);
         y[i] = apply_act(u[i] * scale[c] + shift[c], act, slope);
     }
 }
@@ -189,7 +224,8 @@ __global__ void bn_act_scalar_kernel(const float* __restrict__ u, const float* _
 // same + fused 2x2 max-pool: one thread per (pooled pixel, 4 channels)
 __global__ void bn_act_pool_kernel(const float* __restrict__ u, const float* __restrict__ scale,
                                    const float* __restrict__ shift, float* __restrict__ y,
-                                   float* __restrict__ y_pool, int N, int H, int W, int C4, int act, float slope) {
+                                   float* __restrict__ y_pool, int N, int H, int W, int C4, int act, float slope,
+                                   int group_images) {
     const int Hp = H >> 1, Wp = W >> 1;
     const long total = (long)N * Hp * Wp * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -198,8 +234,9 @@ __global__ void bn_act_pool_kernel(const float* __restrict__ u, const float* __r
         const int xp = r % Wp; r /= Wp;
         const int yp = r % Hp;
         const int n = r / Hp;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
-        const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        const int cg = (group_images ? (n / group_images) * C4 * 4 : 0) + c4 * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cg);
+        const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + cg);
         f32x4 mx;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -374,38 +411,54 @@ extern "C" int dvg_channel_stats_rows(long rows) {
     return (int)((rows + rpb - 1) / rpb);
 }
 
-extern "C" int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, void* stream) {
+extern "C" int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, int groups, void* stream) {
     DVG_REQUIRE(u && stats_partial, DVG_ERR_NULL, "dvg_channel_stats: NULL pointer");
-    DVG_REQUIRE(rows > 0 && C > 0, DVG_ERR_SHAPE, "dvg_channel_stats: bad shape");
+    DVG_REQUIRE(rows > 0 && C > 0 && groups > 0, DVG_ERR_SHAPE, "dvg_channel_stats: bad shape");
     long rpb = (rows + 1023) / 1024;
     if (rpb < 16) rpb = 16;
     const int nblk = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
-                       (hipStream_t)stream, u, stats_partial, rows, C, (int)rpb);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)nblk * groups), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
+                       (hipStream_t)stream, u, stats_partial, rows, C, (int)rpb, nblk);
     return check_launch("dvg_channel_stats");
 }
 
 extern "C" int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma, const float* beta,
                                float* scale, float* shift, float* running_mean, float* running_var,
                                float* save_mean, float* save_invstd, int C, double count, float eps, float momentum,
-                               int64_t* num_batches_tracked, int nbt_inc, void* stream) {
+                               int64_t* num_batches_tracked, int nbt_inc, int groups, float* group_var, void* stream) {
     DVG_REQUIRE(stats_partial && scale && shift, DVG_ERR_NULL, "dvg_bn_finalize: NULL pointer");
-    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + DVG_COLSUM_CT - 1) / DVG_COLSUM_CT), dim3(1024), 0, (hipStream_t)stream, stats_partial, nrows,
-                       gamma, beta, scale, shift, running_mean, running_var, save_mean, save_invstd, C, count, eps,
-                       momentum, (long long*)num_batches_tracked, nbt_inc);
+    DVG_REQUIRE(C > 0 && nrows > 0 && count >= 1.0 && groups > 0 && groups < 65536, DVG_ERR_SHAPE, "dvg_bn_finalize: bad shape");
+    DVG_REQUIRE(groups == 1 || (running_mean == nullptr && running_var == nullptr && num_batches_tracked == nullptr),
+                DVG_ERR_SHAPE, "dvg_bn_finalize: with several groups the running statistics are dvg_bn_running_update's job");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + DVG_COLSUM_CT - 1) / DVG_COLSUM_CT, groups), dim3(1024), 0,
+                       (hipStream_t)stream, stats_partial, nrows, gamma, beta, scale, shift, running_mean, running_var,
+                       save_mean, save_invstd, C, count, eps, momentum, (long long*)num_batches_tracked, nbt_inc, group_var);
     return check_launch("dvg_bn_finalize");
 }
 
+extern "C" int dvg_bn_running_update(const float* mean, const float* unbiased_var, int groups, int C, float mom_first,
+                                     float mom_mid, float mom_last, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, int nbt_inc, void* stream) {
+    DVG_REQUIRE(mean && unbiased_var && running_mean && running_var, DVG_ERR_NULL, "dvg_bn_running_update: NULL pointer");
+    DVG_REQUIRE(groups > 0 && C > 0, DVG_ERR_SHAPE, "dvg_bn_running_update: bad shape");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean, unbiased_var,
+                       groups, C, mom_first, mom_mid, mom_last, running_mean, running_var, (long long*)num_batches_tracked,
+                       nbt_inc);
+    return check_launch("dvg_bn_running_update");
+}
+
 extern "C" int dvg_bn_act_apply(const float* u, const float* scale, const float* shift, float* y, float* y_pool, int N,
-                                int H, int W, int C, int act, float slope, void* stream) {
+                                int H, int W, int C, int act, float slope, int group_images, void* stream) {
     DVG_REQUIRE(u && scale && shift && y, DVG_ERR_NULL, "dvg_bn_act_apply: NULL pointer");
     DVG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, DVG_ERR_SHAPE, "dvg_bn_act_apply: bad shape");
+    DVG_REQUIRE(group_images >= 0 && (group_images == 0 || N % group_images == 0), DVG_ERR_SHAPE,
+                "dvg_bn_act_apply: group_images must divide N");
+    if (group_images == N) group_images = 0;   // one group
     if (C % 4 != 0) {
         DVG_REQUIRE(y_pool == nullptr, DVG_ERR_SHAPE, "dvg_bn_act_apply: pool needs C %% 4 == 0");
         const long n = (long)N * H * W * C;
         hipLaunchKernelGGL(bn_act_scalar_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u,
-                           scale, shift, y, n, C, act, slope);
+                           scale, shift, y, n, C, act, slope, (long)group_images * H * W * C);
         return check_launch("dvg_bn_act_apply");
     }
     DVG_REQUIRE(aligned16(u) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(y_pool),
@@ -414,11 +467,11 @@ extern "C" int dvg_bn_act_apply(const float* u, const float* scale, const float*
         DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_bn_act_apply: pool needs even H,W");
         const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
         hipLaunchKernelGGL(bn_act_pool_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u,
-                           scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+                           scale, shift, y, y_pool, N, H, W, C / 4, act, slope, group_images);
     } else {
         const long n4 = (long)N * H * W * (C / 4);
         hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, u, scale,
-                           shift, y, n4, C / 4, act, slope);
+                           shift, y, n4, C / 4, act, slope, (long)group_images * H * W * (C / 4));
     }
     return check_launch("dvg_bn_act_apply");
 }

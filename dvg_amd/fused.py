@@ -175,6 +175,43 @@ def bn_passes_now() -> int:
     return _BN_PASSES
 
 
+# Time-batched training (train.py:213-232 is teacher-forced: the encoder calls of a closure - and, once the latent chain has
+# run, its decoder calls - are independent): G reference calls run as ONE launch over G x B images whose BatchNorm statistics
+# are taken per GROUP of B consecutive images (each reference call is its own BatchNorm batch), and the running statistics
+# advance group after group in the reference's call order.  `bn_groups(G, (p_first, p_mid, p_last))`: the number of groups
+# and how many reference passes the first / a middle / the last group stands for (see bn_passes: a middle frame of a
+# sequence is encoded twice per closure).  Inside it `bn_passes` must be 1.
+_BN_GROUPS = None
+
+
+class bn_groups:
+    def __init__(self, groups: int, passes=(1, 1, 1)):
+        self.val = (int(groups),) + tuple(int(k) for k in passes) if groups > 1 else None
+
+    def __enter__(self):
+        global _BN_GROUPS
+        self.prev, _BN_GROUPS = _BN_GROUPS, self.val
+
+    def __exit__(self, *exc):
+        global _BN_GROUPS
+        _BN_GROUPS = self.prev
+
+
+def bn_groups_now() -> int:
+    return _BN_GROUPS[0] if _BN_GROUPS else 1
+
+
+def group_stats(st, u, aligned=False):
+    """Partial statistics rows that respect the group boundaries: `st` itself with one group or when the producer's rows are
+    known to be group-aligned (tile rows of an un-split igemm launch, image-major), else a dvg_channel_stats pass over u
+    (NHWC-in-memory (N,C,H,W) or [rows][C]) with per-group slabs."""
+    g = bn_groups_now()
+    if g == 1 or (aligned and st is not None and st.shape[0] % g == 0):
+        return st
+    u2 = u if u.dim() == 2 else u.permute(0, 2, 3, 1).reshape(-1, u.shape[1])
+    return ops.channel_stats(u2, g)
+
+
 def bn_counter(bn):
     """The device int64 `num_batches_tracked` of a BatchNorm2d (advanced inside dvg_bn_finalize), or None."""
     return bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None) else None
@@ -201,19 +238,34 @@ class bn_trace:
 
 
 def replay_bn_trace(entries) -> None:
-    global _BN_TRACE
+    global _BN_TRACE, _BN_GROUPS
     prev, _BN_TRACE = _BN_TRACE, None
+    prev_g = _BN_GROUPS
     try:
-        for bn, stats, count, passes in entries:
+        for bn, stats, count, passes, groups in entries:
+            _BN_GROUPS = groups
             with bn_passes(passes):
                 _train_bn(bn, stats, count)
     finally:
-        _BN_TRACE = prev
+        _BN_TRACE, _BN_GROUPS = prev, prev_g
 
 
 def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
+    """count = elements per channel of the WHOLE batch; with groups every group has count / G of them."""
     if _BN_TRACE is not None:
-        _BN_TRACE.append((bn, stats, count, _BN_PASSES))
+        _BN_TRACE.append((bn, stats, count, _BN_PASSES, _BN_GROUPS))
+    if _BN_GROUPS is not None:
+        g, p0, p1, p2 = _BN_GROUPS
+        if _BN_PASSES != 1 or count % g:
+            raise RuntimeError("grouped BatchNorm: bn_passes must be 1 and the groups must divide the batch")
+        m = bn.momentum if bn.momentum is not None else 0.1
+        mom = tuple(1.0 - (1.0 - m) ** k for k in (p0, p1, p2))
+        return ops.bn_finalize(stats, bn.weight.detach() if bn.weight is not None else None,
+                               bn.bias.detach() if bn.bias is not None else None,
+                               bn.running_mean if bn.track_running_stats else None,
+                               bn.running_var if bn.track_running_stats else None, count // g, bn.eps, 0.0, save=save,
+                               num_batches_tracked=bn_counter(bn), passes=p0 + p2 + (g - 2) * p1, groups=g,
+                               group_momenta=mom)
     res = ops.bn_finalize(stats, bn.weight.detach() if bn.weight is not None else None,
                           bn.bias.detach() if bn.bias is not None else None,
                           bn.running_mean if bn.track_running_stats else None,
@@ -420,7 +472,7 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
     u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,
                         act=ACT_NONE, stats=True)
     n, _, h, w = u.shape
-    sc, sh = _train_bn(bn, st, n * h * w)
+    sc, sh = _train_bn(bn, group_stats(st, u), n * h * w)
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, pool=pool, inplace=True)
 
 
@@ -435,7 +487,7 @@ def conv3_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
     u, st = ops.conv3x3_first(x_nchw, conv.weight, None, conv.bias.detach() if conv.bias is not None else None,
                               act=ACT_NONE, stats=True)
     n, _, h, w = u.shape
-    sc, sh = _train_bn(bn, st, n * h * w)
+    sc, sh = _train_bn(bn, group_stats(st, u), n * h * w)
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
@@ -451,7 +503,7 @@ def conv4s2_bn_act(conv, bn, x, *, act=ACT_LRELU, slope=0.2):
     u, st = ops.conv4x4s2(x, wp, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE,
                           stats=True)
     n, _, h, w = u.shape
-    sc, sh = _train_bn(bn, st, n * h * w)
+    sc, sh = _train_bn(bn, group_stats(st, u), n * h * w)
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
@@ -466,7 +518,7 @@ def conv4s2_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
     u, st = ops.conv4x4s2_first(x_nchw, conv.weight, None, conv.bias.detach() if conv.bias is not None else None,
                                 act=ACT_NONE, stats=True)
     n, _, h, w = u.shape
-    sc, sh = _train_bn(bn, st, n * h * w)
+    sc, sh = _train_bn(bn, group_stats(st, u), n * h * w)
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
@@ -485,7 +537,7 @@ def convT4s2_bn_act(conv, bn, x, skip=None, *, act=ACT_LRELU, slope=0.2):
     u, st = ops.convT4x4s2(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE,
                            stats=True)
     n, _, h, w = u.shape
-    sc, sh = _train_bn(bn, st, n * h * w)
+    sc, sh = _train_bn(bn, group_stats(st, u), n * h * w)
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
@@ -505,7 +557,7 @@ def head_bn_tanh(conv, bn, x):
         sc, sh = folded_affine(conv, bn)
         return ops.gemm_nt(a, gw, sc, sh, act=ACT_TANH, splitk=splitk)
     u = ops.gemm_nt(a, gw, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE, splitk=splitk)
-    st = ops.channel_stats(u)
+    st = ops.channel_stats(u, bn_groups_now())
     sc, sh = _train_bn(bn, st, n)
     return ops.bn_act_apply(_as_nhwc_vec(u), sc, sh, act=ACT_TANH, inplace=True).reshape(n, u.shape[1])
 
@@ -531,7 +583,7 @@ def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2):
         return out
     ops.gemm_nt(vec, gw, None, conv.bias.detach() if conv.bias is not None else None, act=ACT_NONE, period=cout,
                 out=out2d)
-    st = ops.channel_stats(out2d.view(n * kh * kw, cout))
+    st = ops.channel_stats(out2d.view(n * kh * kw, cout), bn_groups_now())
     sc, sh = _train_bn(bn, st, n * kh * kw)
     return ops.bn_act_apply(out, sc, sh, act=act, slope=slope, inplace=True)
 

@@ -211,11 +211,19 @@ int dvg_pixel_proj(const float* in, const float* w, float* out, long P, int C, i
 int dvg_convT_gather(const float* d1, const float* d2, const float* bias, float* y_nchw, int ks,
                      int N, int H, int W, int nc, int act, void* stream);
 
-/* Per-channel sum / sum-of-squares of a [rows][C] (NHWC) tensor, written as
- * dvg_channel_stats_rows(rows) partial rows [2][C] (deterministic slab sums).
- * Used for the small BN inputs (encoder head, decoder stem).                  */
+/* ---- GROUPS (ABI 6, time-batched training) ----------------------------------------------------------------------
+ * train.py:213-232 is teacher-forced: the encoder calls of a closure (and, once the latent chain has run, its decoder
+ * calls) do not depend on each other, so they run as ONE launch over G x B images.  Each reference call is its own
+ * BatchNorm batch: the images of such a launch form G consecutive GROUPS of B images, statistics, normalisation and
+ * the BatchNorm backward are per group, and every per-channel array of the entry points below becomes [G][C] (group-
+ * major).  groups = 1 is the plain call.  Partial-row producers never let a row straddle two groups.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Per-channel sum / sum-of-squares of a [groups * rows][C] (NHWC) tensor, written as
+ * groups x dvg_channel_stats_rows(rows) partial rows [2][C] (deterministic slab sums; `rows` = rows PER GROUP).
+ * Used for the small BN inputs (encoder head, decoder stem) and the Winograd-form training layers.        */
 int dvg_channel_stats_rows(long rows);
-int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, void* stream);
+int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, int groups, void* stream);
 
 /* Train-mode BatchNorm2d finalisation (vgg_64.py:9; torch semantics: biased
  * variance for normalisation, unbiased for the running estimate, eps 1e-5):
@@ -223,19 +231,31 @@ int dvg_channel_stats(const float* u, float* stats_partial, long rows, int C, vo
  * elements per channel and produces
  *   scale[c] = gamma[c] / sqrt(var_b[c] + eps),  shift[c] = beta[c] - mean[c]*scale[c]
  * and, when running_mean/var != NULL, updates them with `momentum`.
- * save_mean / save_invstd (optional) are kept for the backward pass.          */
+ * save_mean / save_invstd (optional) are kept for the backward pass.
+ * groups > 1: `nrows` partial rows and `count` elements PER GROUP; scale / shift / save_* are [G][C]; group_var [G][C]
+ * (optional) receives the unbiased variance; running_mean / running_var / num_batches_tracked must be NULL - the running
+ * statistics are a recurrence over the groups in call order: dvg_bn_running_update.                                  */
 int dvg_bn_finalize(const float* stats_partial, int nrows, const float* gamma,
                     const float* beta, float* scale, float* shift, float* running_mean,
                     float* running_var, float* save_mean, float* save_invstd,
                     int C, double count, float eps, float momentum,
-                    int64_t* num_batches_tracked /* may be NULL; += nbt_inc */, int nbt_inc, void* stream);
+                    int64_t* num_batches_tracked /* may be NULL; += nbt_inc */, int nbt_inc, int groups,
+                    float* group_var, void* stream);
+/* running <- (1 - m_g) running + m_g stat_g for g = 0 .. groups-1 in order, the update nn.BatchNorm2d applies per call
+ * (vgg_64.py:9), from dvg_bn_finalize's save_mean and group_var; m_0 = mom_first, m_{G-1} = mom_last, mom_mid otherwise
+ * (the first / last frame of a sequence is encoded once per closure, the others twice: train.py:158-162,184-188,217-221);
+ * num_batches_tracked += nbt_inc.                                                                                   */
+int dvg_bn_running_update(const float* mean, const float* unbiased_var, int groups, int C, float mom_first, float mom_mid,
+                          float mom_last, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          int nbt_inc, void* stream);
 
 /* y = act(u*scale[c]+shift[c]) elementwise over an NHWC tensor of `npix`
  * pixels (train-mode BN apply + activation), optional fused 2x2 max-pool
- * output (H,W needed only then).  In-place (y == u) is allowed.               */
+ * output (H,W needed only then).  In-place (y == u) is allowed.
+ * group_images: images per coefficient group (scale / shift [N / group_images][C]); 0 or N = one group.   */
 int dvg_bn_act_apply(const float* u, const float* scale, const float* shift, float* y,
                      float* y_pool, int N, int H, int W, int C, int act, float slope,
-                     void* stream);
+                     int group_images, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Dense ends and the recurrent predictor
@@ -331,22 +351,26 @@ int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
  *   dp = (dy + scatter_maxpool(dyp)) * act'(y)          (written to `dp`, NHWC)
  *   partial[r] = { sum dp, sum dp*u } per channel, r < dvg_bn_act_bwd_rows(...)
  * y = forward output (post activation), u = conv output before BN.  dy or dyp
- * may be NULL (not both); dyp != NULL selects the pooled variant.               */
+ * may be NULL (not both); dyp != NULL selects the pooled variant.
+ * groups: N must be a multiple; partial holds groups x dvg_bn_act_bwd_rows(N / groups, ...) rows, group-major.   */
 int dvg_bn_act_bwd_rows(int N, int H, int W, int pool);
 int dvg_bn_act_bwd_reduce(const float* dy, const float* dyp, const float* y, const float* u,
                           float* dp, float* partial, int N, int H, int W, int C, int act,
-                          float slope, void* stream);
+                          float slope, int groups, void* stream);
 /* pass 2: per-channel coefficients of du = A*dp + B*u + Cc (train: batch-statistics
- * BN backward; eval: plain affine), plus dgamma, dbeta, dbias (any may be NULL).  */
+ * BN backward; eval: plain affine), plus dgamma, dbeta, dbias (any may be NULL).
+ * groups > 1: nrows / count per group; mean, invstd, coef*, dgamma, dbeta, dbias are [G][C] (the parameter gradients per
+ * group: sum them with dvg_colsum; accumulate must be 0).                                                          */
 int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, const float* mean,
                         const float* invstd, float* coefA, float* coefB, float* coefC,
                         float* dgamma, float* dbeta, float* dbias, int C, double count,
-                        int train, int accumulate /* dgamma / dbeta / dbias += */, void* stream);
+                        int train, int accumulate /* dgamma / dbeta / dbias += */, int groups, void* stream);
 /* pass 3: du = A[c]*dp + B[c]*u + Cc[c] over n elements (n %% C == 0); du may alias dp.  `sum` (optional second output,
  * same shape, not aliasing du): sum_mode 1: sum = du, 2: sum += du, 0: unused - d(addend) of the decoder calls of one
  * time step that share a skip half (train.py:227-231) is collected there instead of by separate additions.           */
 int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B,
-                      const float* Cc, float* du, long n, int C, float* sum, int sum_mode, void* stream);
+                      const float* Cc, float* du, long n, int C, float* sum, int sum_mode,
+                      int groups /* A, B, Cc are [groups][C]; group = run of n / groups elements */, void* stream);
 /* dpre = dy * act'(y), flat tensors (last layers, nn.Linear+Tanh).               */
 int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope,
                 void* stream);

@@ -391,6 +391,84 @@ def test_shared_encoder_passes_match_reference_structure(model):
                 assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))
 
 
+@pytest.mark.parametrize("model,width,batch", [("dcgan", 64, 4), ("vgg", 64, 4), ("dcgan", 128, 2), ("dcgan", 64, 6)])
+def test_time_batched_encoder_matches_the_per_frame_path(model, width, batch):
+    """Trainer.time_batched: the T encoder calls of a closure as ONE pass over T x B frames with per-frame ("grouped")
+    BatchNorm - statistics, normalisation, BatchNorm backward per group of B images, running statistics advanced frame by
+    frame with the per-frame path's pass counts (train.py:213-221 encodes the first / last frame once, the others twice).
+    Against the per-frame path from the same seed: (a) with every learning rate at 0 the three closures leave the same
+    GRADIENTS in the flat arena and the same loss values; (b) with the real learning rates one full iteration gives the
+    same BatchNorm buffers, batch counts and parameter updates.  Differences are fp32 summation order only (one weight-
+    gradient GEMM over T x B images instead of T partial ones)."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST, synthetic_video
+    res = {}
+    for tb in (False, True):
+        torch.manual_seed(21)
+        opt = _opt(model, ["--n_past", "2", "--n_future", "3", "--batch_size", str(batch), "--image_width", str(width),
+                           "--channels", "3" if width == 128 else "1"] + (["--dataset", "ucf", "--synthetic_data"] if width == 128 else []))
+        opt.local_batch = batch
+        tr = train.Trainer(opt, torch.device("cuda:0"))
+        tr.train_mode()
+        tr.time_batched = tb
+        if width == 128:
+            x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, synthetic_video(batch, 5, 3, 128, seed=3))
+        else:
+            x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, SyntheticMovingMNIST(seq_len=5, seed=4).batch(batch))
+        lrs = [[g['lr'] for g in o.param_groups] for o in tr.optimizers()]
+        for o in tr.optimizers():
+            for g in o.param_groups:
+                g['lr'] = 0.0
+        timer_launches = {}
+        grads, vals = [], []
+        for name, fn in (("model", tr.train_model), ("fp", tr.train_frame_predictor), ("gp", tr.train_GP_Frame_predictor)):
+            from dvg_amd import ops
+            t = ops.KernelTimer()
+            ops.set_timer(t)
+            try:
+                out = fn(x)
+            finally:
+                ops.set_timer(None)
+            timer_launches[name] = sum(v["launches"] for v in t.summary().values())
+            vals.append(out if isinstance(out, tuple) else (out,))
+            grads.append(tr.arena.g.clone())
+        bufs0 = {k: v.clone() for m in tr.modules for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        for o, ls in zip(tr.optimizers(), lrs):
+            for g, lr in zip(o.param_groups, ls):
+                g['lr'] = lr
+        before = [copy.deepcopy(m.state_dict()) for m in tr.modules]
+        tr.iteration(x)
+        after = [copy.deepcopy(m.state_dict()) for m in tr.modules]
+        res[tb] = (vals, grads, before, after, [{n for n, _ in m.named_parameters()} for m in tr.modules], timer_launches, bufs0)
+    (va, ga, ba, aa, pn, la, f0a), (vb, gb, bb, ab, _, lb, f0b) = res[False], res[True]
+    for k in f0a:     # buffers after the three lr = 0 closures (identical weights on both sides): tight
+        if k.endswith("num_batches_tracked"):
+            assert int(f0a[k]) == int(f0b[k]), k
+        else:
+            assert torch.allclose(f0a[k], f0b[k], rtol=1e-4, atol=1e-5), (k, float((f0a[k] - f0b[k]).abs().max()))
+    for a, b in zip(va, vb):
+        for u, v in zip(a, b):
+            assert abs(u - v) <= 1e-4 * max(1.0, abs(u)), (va, vb)
+    for k, (a, b) in enumerate(zip(ga, gb)):
+        na, d = float(a.double().norm()), float((a.double() - b.double()).norm())
+        assert na > 0 and d <= 2e-3 * na, (k, d / na)
+    assert lb["model"] < la["model"] and lb["fp"] < la["fp"], (la, lb)      # fewer, larger launches
+    for b0, a, b, pnames in zip(ba, aa, ab, pn):
+        for k in a:
+            if k.endswith("num_batches_tracked"):
+                assert int(a[k]) == int(b[k]), k
+            elif k in pnames:
+                da, db = (a[k] - b0[k]).flatten().double(), (b[k] - b0[k]).flatten().double()
+                if float(da.norm()) == 0.0 and float(db.norm()) == 0.0:
+                    continue
+                cos = float((da @ db) / (da.norm() * db.norm()))
+                assert cos > 0.9, (k, cos)     # one Adam step = lr * sign(g): elements with g ~ 0 flip (vgg at B = 4: a few %)
+            else:   # BatchNorm running statistics after an iteration whose fine-tuning closures ran on weights that one Adam
+                # step (lr * sign(g): elements with g ~ 0 may flip under a change of summation order) had moved: loose
+                assert torch.allclose(a[k].float(), b[k].float(), rtol=5e-2, atol=3e-2), (k, float((a[k] - b[k]).abs().max()))
+
+
 @pytest.mark.parametrize("model", ["dcgan", "vgg"])
 def test_shared_skip_halves_match_reference_structure(model):
     """Trainer.share_skip_halves (the three decoder calls of a time step share the skip half of every concat conv,

@@ -122,6 +122,9 @@ class Trainer:
         self.share_skip_halves = True
         # True = the GP fine-tuning closure reuses the encodings of the LSTM fine-tuning closure that precedes it
         self.share_closure_encodings = True
+        # True = the encoder calls of a closure run as ONE pass over all frames with per-frame ("grouped") BatchNorm
+        # statistics (needs share_encoder_passes); DVG_TIME_BATCH=0: one pass per frame
+        self.time_batched = os.environ.get("DVG_TIME_BATCH", "1") != "0"
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
         self.latent_stream = os.environ.get("DVG_LATENT_STREAM", "1") != "0"
         self._side_stream = None
@@ -236,12 +239,32 @@ class Trainer:
         side effect of the second pass (two momentum updates, num_batches_tracked += 2) in the reference's order.
         (6S encoder passes per iteration become 3(S+1).)"""
         T = self.opt.n_past + self.opt.n_future
+        if self.time_batched and self.encoder.training and T >= 3:
+            return self._encode_sequence_batched(x, grad, T)
         outs = []
         with torch.set_grad_enabled(grad):
             for t in range(T):
                 with fused.bn_passes(1 if (t == 0 or t == T - 1) else 2):
                     outs.append(self.encoder(x[t]))
         return outs
+
+    def _encode_sequence_batched(self, x, grad: bool, T: int):
+        """The T encoder calls of a closure as ONE pass over T x B frames.  train.py:213-221 is teacher-forced - every call
+        encodes a ground-truth frame - so the calls are independent of each other; what ties a reference call together is
+        its BatchNorm batch, and that is kept: statistics, normalisation and their backward are per GROUP of B consecutive
+        images (one group per frame), and the running statistics advance frame by frame in the reference's order with the
+        pass counts of the per-frame path (first / last frame once, middle frames twice).  Same losses, gradients and
+        buffers up to fp32 summation order (tests/test_gpu_train.py); every conv launch is T x larger."""
+        from dvg_amd.autograd import split_batch
+        from dvg_amd.rollout import _adjacent_view
+        frames = _adjacent_view(list(x[:T]))
+        if frames is None:
+            frames = torch.cat(list(x[:T]), 0)
+        with torch.set_grad_enabled(grad), fused.bn_groups(T, (1, 2, 1)):
+            h_all, skips_all = self.encoder(frames)
+        hs = split_batch(h_all, T)
+        sks = [split_batch(s, T) for s in skips_all]
+        return [(hs[t], [sk[t] for sk in sks]) for t in range(T)]
 
     def _share_scope(self):
         import contextlib
