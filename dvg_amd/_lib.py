@@ -33,9 +33,9 @@ SIGNATURES = {
     "dvg_pack_conv_weight_k16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dvg_conv_splitk_v2": (_i, [_i, _i, _i, _i, _i, _i]),
     "dvg_conv_stats_rows_v2": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "dvg_conv3x3_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p]),
+    "dvg_conv3x3_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_conv4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p]),
-    "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p]),
+    "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "dvg_winograd_input": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dvg_gemm_batched_k16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -50,7 +50,7 @@ SIGNATURES = {
     "dvg_eval_frames": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "dvg_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p]),
     "dvg_pixel_proj": (_i, [_p, _p, _p, _l, _i, _i, _p]),
-    "dvg_convT_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dvg_convT_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "dvg_channel_stats_rows": (_i, [_l]),
     "dvg_channel_stats": (_i, [_p, _p, _l, _i, _i, _p]),
     "dvg_bn_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _f, _f, _p, _i, _i, _p, _p]),
@@ -74,6 +74,7 @@ SIGNATURES = {
     "dvg_affine3_apply": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _i, _p]),
     "dvg_act_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "dvg_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_group_sum": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "dvg_colsum": (_i, [_p, _p, _i, _i, _i, _p]),
     "dvg_wgrad_finish": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_k4_to_w3": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),

@@ -299,6 +299,9 @@ class _ConvBlock(torch.autograd.Function):
         need_stats = bn.training
         c1 = x.shape[1]
         keep = {}
+        shared = cfg.get("shared")      # ops.SharedBlocks pattern: `addend` holds blocks shared by the groups of x's batch
+        if shared is not None:
+            addend = shared.like(addend)
         if addend is not None:
             # x half of a concat conv; `addend` = conv(skip, W_skip) shared by the decoder calls of a step (_SkipHalf)
             if kind == "conv3" and up and fused.UPCONV_AS_CONVT:
@@ -410,7 +413,11 @@ class _ConvBlock(torch.autograd.Function):
                                part, s_w, 1, 4, 4, ctot=ct, c_lo=0, beta=beta_w), "xh")
                 if need_x:
                     dx = ops.conv4x4s2(du, _packed(weight, False, 0, c1, 0), None, None, act=ACT_NONE)
-            return (dx, None, dW, dbias, dgamma, dbeta, (du if ng[6] and holder is None else None), None)
+            d_add = None
+            if ng[6] and holder is None:
+                # shared blocks (time-batched decoder calls): d(block) = sum of du over the groups that added it
+                d_add = ops.group_sum(du, cfg["shared"]) if cfg.get("shared") is not None else du
+            return (dx, None, dW, dbias, dgamma, dbeta, d_add, None)
         if kind == "conv3":
             if s_w is not None:
                 _wgrad(MODE_CONV3, x, skip, du, up, q_w,
@@ -541,6 +548,14 @@ def conv_block_autograd(kind, conv, bn, x, skip, *, upsample=False, pool=False, 
     cfg = {"kind": kind, "bn": bn, "upsample": upsample, "pool": pool, "act": act, "slope": slope}
     if kind in ("conv3", "conv4s2", "convT4s2"):
         x = ops.to_nhwc(x)
+    if isinstance(skip, ops.SharedBlocks):
+        # time-batched decoder calls: x holds G groups of B images, group g concatenates block skip.map[g] of the skip
+        # blocks.  The skip half S = conv(skip blocks, W_skip) runs once over the DISTINCT blocks (the three calls of a
+        # step, and all steps once the skip is frozen, share it - fewer than one per step); the x half adds block map[g].
+        if kind not in ("conv3", "convT4s2") or pool:
+            raise RuntimeError("shared skip blocks: concat blocks only")
+        s = _SkipHalf.apply(skip.t, conv.weight, {"kind": kind, "c1": x.shape[1], "ds_holder": {"ds": None}})
+        return _ConvBlock.apply(x, None, conv.weight, conv.bias, bn.weight, bn.bias, s, dict(cfg, shared=skip))
     share = fused.skip_share_scope()
     if share is not None and skip is not None and kind in ("conv3", "convT4s2") and not pool:
         key = (id(conv), id(skip), skip._version)
@@ -642,7 +657,9 @@ class _LastLayer(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         # the product path of the last layer (HBM-bound projection + gather), not the direct kernel (288 us at 16x3x64x64)
         ks = 3 if cfg["kind"] == "convT3" else 4
-        y = ops.convT_last_two_step(x, skip if ks == 4 else None, weight, b, nc, ks, act=cfg["act"])
+        shared = cfg.get("shared")       # time-batched decoder calls: `skip` = the distinct skip blocks
+        sk = None if ks != 4 else (skip if shared is None else shared.like(skip))
+        y = ops.convT_last_two_step(x, sk, weight, b, nc, ks, act=cfg["act"])
         ctx.save_for_backward(x, skip, weight, y)
         ctx.param = weight
         ctx.cfg = dict(cfg, has_bias=bias is not None)
@@ -660,23 +677,28 @@ class _LastLayer(torch.autograd.Function):
         dx = dskip = None
         if ctx.needs_input_grad[0]:   # adjoint of a transposed conv = plain conv with the same weight
             dx = first(dpre, _c(w[:c1]), None, None, act=ACT_NONE)
+        shared = cfg.get("shared")
+        # shared skip blocks: everything on the skip side is linear in dpre, so it runs on the per-block SUM of dpre
+        dpre_sk = dpre if shared is None or skip is None else ops.group_sum(dpre, shared)
         if skip is not None and ctx.needs_input_grad[1]:
-            dskip = first(dpre, _c(w[c1:]), None, None, act=ACT_NONE)
+            dskip = first(dpre_sk, _c(w[c1:]), None, None, act=ACT_NONE)
         s_w, dW = _sink(ctx.param, ctx.needs_input_grad[2]), None
         if s_w is not None:     # rows [0, c1) and [c1, Cin) of the ConvTranspose2d weight's gradient, in place
             ops.wgrad_thin(dpre, x, ks, out=s_w[:c1], beta=1.0)
             if skip is not None:
-                ops.wgrad_thin(dpre, skip, ks, out=s_w[c1:], beta=1.0)
+                ops.wgrad_thin(dpre_sk, skip, ks, out=s_w[c1:], beta=1.0)
         elif ctx.needs_input_grad[2]:
             dW = ops.wgrad_thin(dpre, x, ks)
             if skip is not None:
-                dW = torch.cat([dW, ops.wgrad_thin(dpre, skip, ks)], 0)
+                dW = torch.cat([dW, ops.wgrad_thin(dpre_sk, skip, ks)], 0)
         db = dpre.sum((0, 2, 3)) if cfg["has_bias"] else None  # nc floats
         return dx, dskip, dW, db, None
 
 
 def last_layer_autograd(kind, conv, x, skip, *, act):
     x = ops.to_nhwc(x)
+    if isinstance(skip, ops.SharedBlocks):
+        return _LastLayer.apply(x, ops.to_nhwc(skip.t), conv.weight, conv.bias, {"kind": kind, "act": act, "shared": skip})
     skip = None if skip is None else ops.to_nhwc(skip)
     return _LastLayer.apply(x, skip, conv.weight, conv.bias, {"kind": kind, "act": act})
 

@@ -257,6 +257,24 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_scalar_kernel(const float*
     }
 }
 
+// dst[b] = sum over the groups g (in ascending order: deterministic) with map[g] == b of src[g]; src [groups][m], dst
+// [blocks][m], float4 elements.  The adjoint of the shared addend of the time-batched decoder calls (Igemm2Params::add_map):
+// d(addend block) = the sum of d(pre-activation) of every group that read it.
+__global__ void group_sum_kernel(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst,
+                                 int groups, long m4) {
+    const int b = blockIdx.y;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < m4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < groups; ++g) {
+            if (map[g] != b) continue;
+            const f32x4 v = reinterpret_cast<const f32x4*>(src)[(size_t)g * m4 + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        }
+        reinterpret_cast<f32x4*>(dst)[(size_t)b * m4 + i] = acc;
+    }
+}
+
 // dpre = dy * act'(y) on a flat tensor (last layers: NCHW frames; nn.Linear+Tanh outputs)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dpre,
                                long n, int act, float slope) {
@@ -679,6 +697,20 @@ extern "C" int dvg_affine3_apply(const float* dp, const float* u, const float* A
         hipLaunchKernelGGL(affine3_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dp, u, A, B,
                            Cc, du, n, C, per_group);
     return check_launch("dvg_affine3_apply");
+}
+
+extern "C" int dvg_group_sum(const float* src, const int* map, float* dst, int groups, int blocks, long block_elems,
+                             void* stream) {
+    DVG_REQUIRE(src && map && dst, DVG_ERR_NULL, "dvg_group_sum: NULL pointer");
+    DVG_REQUIRE(groups > 0 && blocks > 0 && block_elems > 0 && block_elems % 4 == 0, DVG_ERR_SHAPE,
+                "dvg_group_sum: bad shape (block_elems %% 4 == 0 needed)");
+    DVG_REQUIRE(aligned16(src) && aligned16(dst), DVG_ERR_ALIGN, "dvg_group_sum: alignment");
+    const long m4 = block_elems / 4;
+    long gx = (m4 + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)gx, (unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, map, dst,
+                       groups, m4);
+    return check_launch("dvg_group_sum");
 }
 
 extern "C" int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope, void* stream) {

@@ -71,7 +71,17 @@ struct Igemm2Params {
     int stage_prio;  // progress-based s_setprio in the stage loop (launch2 decides; see the stage loop)
     long w_image_stride;  // M2_GEMM: floats between the packed weights of consecutive images n
     int gemm_ni;          // M2_GEMM: consecutive images one workgroup runs back to back (one pipeline, one epilogue per image)
+    // Time-batched decoder calls (ABI 6): the images form groups of add_B; group g = n / add_B reads its addend from block
+    // add_map[g] of `addend` (an addend of add_B-image blocks) - the skip half of a concat conv is shared by the three
+    // decoder calls of a time step and, once the skip is frozen, by all later steps (train.py:217-231).  NULL: image n.
+    const int* add_map;
+    int add_B;
 };
+
+// image of `addend` that output image n adds (see Igemm2Params::add_map)
+__device__ __forceinline__ int addend_image(const int* __restrict__ add_map, int add_B, int n) {
+    return add_map ? add_map[n / add_B] * add_B + n % add_B : n;
+}
 
 static unsigned long long* g_clk = nullptr;
 static unsigned g_clk_cap = 0;
@@ -468,6 +478,22 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     float* const yb = p.y + (size_t)n0 * Ho * Wo * p.Cout + c;
     float* const pb = p.y_pool ? p.y_pool + (size_t)n0 * (Ho >> 1) * (Wo >> 1) * p.Cout + c : nullptr;
     const float* const ab = p.addend ? p.addend + (size_t)n0 * Ho * Wo * p.Cout + c : nullptr;
+    // shared addend blocks (add_map): per image of the tile, the distance (floats) from "addend image n" to the image its
+    // group really adds.  A 4-image tile (4x4 maps) may straddle two groups, hence per image.
+    long add_shift[TI];
+#pragma unroll
+    for (int t_ = 0; t_ < TI; ++t_) {
+        const int n_ = min(n0 + t_, p.N - 1);
+        add_shift[t_] = (ab != nullptr && p.add_map != nullptr)
+                            ? (long)(addend_image(p.add_map, p.add_B, n_) - n_) * Ho * Wo * p.Cout : 0;
+    }
+    auto shift_of = [&](int tii) -> long {
+        if (TI == 1) return add_shift[0];
+        long v = add_shift[0];
+#pragma unroll
+        for (int t_ = 1; t_ < TI; ++t_) v = tii == t_ ? add_shift[t_] : v;
+        return v;
+    };
     auto epilogue = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;  // -1: generic (runtime p.act)
 #pragma unroll
@@ -487,7 +513,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     int oy, ox;
                     if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
                     else { oy = y0 + ty; ox = x0 + tx; }
-                    av[reg] = (TI == 1 || n0 + tii < p.N) ? ab[((tii * Ho + oy) * Wo + ox) * p.Cout] : 0.f;
+                    av[reg] = (TI == 1 || n0 + tii < p.N) ? ab[(long)((tii * Ho + oy) * Wo + ox) * p.Cout + shift_of(tii)] : 0.f;
                 }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) v[reg] = (acc[mt][reg] + av[reg]) * sc + sf;
@@ -567,7 +593,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             const float* __restrict__ shift, float* __restrict__ y,
                                                             float* __restrict__ y_pool, float* __restrict__ stats, int N,
                                                             int H, int W, int C, int act, float slope,
-                                                            int units_per_block, const float* __restrict__ addend) {
+                                                            int units_per_block, const float* __restrict__ addend,
+                                                            const int* __restrict__ add_map, int add_B) {
     __shared__ float red[2 * 256 * 4];
     const int C4 = C >> 2;
     const int TC = C4 < 256 ? C4 : 256, TP = 256 / TC;
@@ -612,7 +639,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                 }
             }
             if (addend != nullptr) {   // hoisted skip half: one more (loop-invariant) partial slab
-                const f32x4 t = reinterpret_cast<const f32x4*>(addend)[off];
+                size_t aoff = off;
+                if (add_map != nullptr) {      // time-batched decoder calls: the addend block this image's group shares
+                    const long img4 = (long)H * W * C4;
+                    const int n_ = (int)(off / img4);
+                    aoff = off - (size_t)(n_ - addend_image(add_map, add_B, n_)) * img4;
+                }
+                const f32x4 t = reinterpret_cast<const f32x4*>(addend)[aoff];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] += t[k];
             }
@@ -747,10 +780,10 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
         const unsigned fgrid = (unsigned)((units + upb - 1) / upb);
         if (pool)
             hipLaunchKernelGGL((splitk_finish_kernel<true>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
-                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend);
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend, p.add_map, p.add_B);
         else
             hipLaunchKernelGGL((splitk_finish_kernel<false>), dim3(fgrid), dim3(256), 0, stream, ws, S, p.scale, p.shift, p.y,
-                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend);
+                               y_pool, stats, p.N, Ho, Wo, p.Cout, p.act, p.slope, upb, p.addend, p.add_map, p.add_B);
         return check_launch("splitk_finish");
     }
     return DVG_OK;
@@ -869,10 +902,15 @@ static int checks2(const Igemm2Params& p, const char* who) {
 extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                      const float* shift, float* y, float* y_pool, float* stats, int N, int H, int W,
                                      int C1, int C2, int Cout, int upsample_x, int act, float slope,
-                                     float* workspace, long workspace_floats, const float* addend, void* stream) {
+                                     float* workspace, long workspace_floats, const float* addend,
+                                     const int* addend_map, int addend_block, void* stream) {
     Igemm2Params p{x, skip, w_k16, scale, shift, y, y_pool, stats, N, H, W, C1, C2, Cout, upsample_x ? 1 : 0, act, slope,
                    0, 0, 0, 0, 0, 1, 0, nullptr};
     p.addend = addend;
+    p.add_map = addend ? addend_map : nullptr;
+    p.add_B = addend_block;
+    DVG_REQUIRE(p.add_map == nullptr || (addend_block > 0 && N % addend_block == 0), DVG_ERR_SHAPE,
+                "dvg_conv3x3_bn_act_v2: addend_block must divide N");
     if (int e = checks2(p, "dvg_conv3x3_bn_act_v2")) return e;
     DVG_REQUIRE(aligned16(addend) && (addend == nullptr || y_pool == nullptr), DVG_ERR_SHAPE,
                 "dvg_conv3x3_bn_act_v2: addend must be 16-byte aligned and excludes the pooled output");
@@ -903,10 +941,14 @@ extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const
 extern "C" int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16, const float* scale,
                                         const float* shift, float* y, float* stats, int N, int H, int W, int C1,
                                         int C2, int Cout, int act, float slope, float* workspace, long workspace_floats,
-                                        const float* addend, void* stream) {
+                                        const float* addend, const int* addend_map, int addend_block, void* stream) {
     Igemm2Params p{x, skip, w_k16, scale, shift, y, nullptr, stats, N, H, W, C1, C2, Cout, 0, act, slope, 0, 0, 0, 0, 0,
                    1, 0, nullptr};
     p.addend = addend;
+    p.add_map = addend ? addend_map : nullptr;
+    p.add_B = addend_block;
+    DVG_REQUIRE(p.add_map == nullptr || (addend_block > 0 && N % addend_block == 0), DVG_ERR_SHAPE,
+                "dvg_convT4x4s2_bn_act_v2: addend_block must divide N");
     if (int e = checks2(p, "dvg_convT4x4s2_bn_act_v2")) return e;
     DVG_REQUIRE(aligned16(addend), DVG_ERR_ALIGN, "dvg_convT4x4s2_bn_act_v2: addend must be 16-byte aligned");
     int Hg = H, Wg = W, ti, th, tw;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void convT_last_kernel(const float* __restrict
 template <int KS, int S>
 __global__ void convT_gather_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
                                     const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W, int nc,
-                                    int act) {
+                                    int act, const int* __restrict__ d2_map, int d2_B) {
     const int T = KS * KS * nc;
     const long total = (long)N * H * W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -297,6 +297,8 @@ __global__ void convT_gather_kernel(const float* __restrict__ d1, const float* _
         long t = i / W;
         const int q = t % H;
         const int n = t / H;
+        // d2 (the skip tensor's projection) may hold shared blocks of d2_B images: image n reads block d2_map[n / d2_B]
+        const long d2_shift = d2_map ? ((long)d2_map[n / d2_B] * d2_B + n % d2_B - n) * H * W * T : 0;
         const int Ho = H * S, Wo = W * S;
 #pragma unroll
         for (int co = 0; co < 4; ++co) {
@@ -311,7 +313,7 @@ __global__ void convT_gather_kernel(const float* __restrict__ d1, const float* _
                         const int yy = q + 1 - kh, xx = r + 1 - kw;
                         if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                             const size_t o = (((size_t)n * H + yy) * W + xx) * T + (kh * 3 + kw) * nc + co;
-                            acc += d1[o] + (d2 ? d2[o] : 0.f);
+                            acc += d1[o] + (d2 ? d2[(long)o + d2_shift] : 0.f);
                         }
                     }
                 y[(((size_t)n * nc + co) * Ho + q) * Wo + r] = apply_act(acc, act, 0.f);
@@ -329,7 +331,7 @@ __global__ void convT_gather_kernel(const float* __restrict__ d1, const float* _
                                 const int kh = 1 - py + 2 * a, kw = 1 - px + 2 * bb;
                                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                                     const size_t o = (((size_t)n * H + yy) * W + xx) * T + (kh * 4 + kw) * nc + co;
-                                    acc += d1[o] + (d2 ? d2[o] : 0.f);
+                                    acc += d1[o] + (d2 ? d2[(long)o + d2_shift] : 0.f);
                                 }
                             }
                         y[(((size_t)n * nc + co) * Ho + 2 * q + py) * Wo + 2 * r + px] = apply_act(acc, act, 0.f);
@@ -483,9 +485,11 @@ extern "C" int dvg_convT4x4s2_last(const float* x, const float* skip, const floa
 }
 
 extern "C" int dvg_convT_gather(const float* d1, const float* d2, const float* bias, float* y_nchw, int ks, int N, int H,
-                                int W, int nc, int act, void* stream) {
+                                int W, int nc, int act, const int* d2_map, int d2_block, void* stream) {
     DVG_REQUIRE(d1 && y_nchw, DVG_ERR_NULL, "dvg_convT_gather: NULL pointer");
     DVG_REQUIRE(N > 0 && H > 0 && W > 0 && nc >= 1 && nc <= 4, DVG_ERR_SHAPE, "dvg_convT_gather: bad shape");
+    if (d2 == nullptr) d2_map = nullptr;
+    DVG_REQUIRE(d2_map == nullptr || (d2_block > 0 && N % d2_block == 0), DVG_ERR_SHAPE, "dvg_convT_gather: d2_block must divide N");
     DVG_REQUIRE(ks == 3 || ks == 4, DVG_ERR_SHAPE, "dvg_convT_gather: ks must be 3 or 4");
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_convT_gather: bad act");
     const long total = (long)N * H * W;
@@ -493,10 +497,10 @@ extern "C" int dvg_convT_gather(const float* d1, const float* d2, const float* b
     if (g > 4096) g = 4096;
     if (ks == 3)
         hipLaunchKernelGGL((convT_gather_kernel<3, 1>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d1, d2, bias,
-                           y_nchw, N, H, W, nc, act);
+                           y_nchw, N, H, W, nc, act, d2_map, d2_block);
     else
         hipLaunchKernelGGL((convT_gather_kernel<4, 2>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d1, d2, bias,
-                           y_nchw, N, H, W, nc, act);
+                           y_nchw, N, H, W, nc, act, d2_map, d2_block);
     return check_launch("dvg_convT_gather");
 }
 

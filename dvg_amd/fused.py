@@ -143,7 +143,13 @@ def folded_affine(conv: nn.Module, bn: nn.BatchNorm2d):
 
 
 def _needs_grad(*ts) -> bool:
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+    return torch.is_grad_enabled() and any(
+        t is not None and (t.t if isinstance(t, ops.SharedBlocks) else t).requires_grad for t in ts)
+
+
+def _no_shared(skip, who):
+    if isinstance(skip, ops.SharedBlocks):
+        raise RuntimeError(f"{who}: shared skip blocks (time-batched decoder calls) are a training-path operand (autograd)")
 
 
 # A train-mode forward pass that stands for k identical reference passes (train.py encodes every middle frame of a
@@ -452,6 +458,7 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("conv3", conv, bn, x, skip, upsample=upsample, pool=pool, act=act, slope=slope)
+    _no_shared(skip, "conv3_bn_act")
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
         if not pool:
@@ -527,6 +534,7 @@ def convT4s2_bn_act(conv, bn, x, skip=None, *, act=ACT_LRELU, slope=0.2):
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("convT4s2", conv, bn, x, skip, act=act, slope=slope)
+    _no_shared(skip, "convT4s2_bn_act")
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
         hs = _hoisted_skip(conv, x, skip, lambda ps: ops.convT4x4s2(skip, None, ps, None, None, act=ACT_NONE))
@@ -607,5 +615,6 @@ def convT4s2_last(conv, x, skip, *, act=ACT_TANH):
     if _needs_grad(x, skip, conv.weight):
         from .autograd import last_layer_autograd
         return last_layer_autograd("convT4s2", conv, x, skip, act=act)
+    _no_shared(skip, "convT4s2_last")
     return ops.convT_last_two_step(x, skip, conv.weight, conv.bias.detach() if conv.bias is not None else None,
                                    conv.weight.shape[1], 4, act=act)

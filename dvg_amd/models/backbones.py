@@ -37,6 +37,14 @@ _DCGAN_ENC = {64: [("nc", 64), (64, 128), (128, 256), (256, 512)],
 _DCGAN_DEC = {64: [(1024, 256), (512, 128), (256, 64)], 128: [(1024, 512), (1024, 256), (512, 128), (256, 64)]}
 
 
+def _skip_nhwc(s):
+    """A skip operand as the kernels take it: NHWC in memory; an ops.SharedBlocks (the time-batched decoder calls of
+    train.py:227-231 share skip tensors across calls) keeps its sharing pattern."""
+    if isinstance(s, ops.SharedBlocks):
+        return s.like(ops.to_nhwc(s.t))
+    return ops.to_nhwc(s)
+
+
 def _frame(x: torch.Tensor) -> torch.Tensor:
     if x.dim() != 4:
         raise RuntimeError(f"expected a (B,C,H,W) frame batch, got {tuple(x.shape)}")
@@ -168,7 +176,7 @@ class VggDecoder(nn.Module):
             n += 1
         d = fused.stem_bn_act(self.upc1[0], self.upc1[1], vec)
         for s in range(2, n + 1):
-            sk = ops.to_nhwc(skip[n - s])
+            sk = _skip_nhwc(skip[n - s])
             first = True
             mods = list(getattr(self, f"upc{s}"))
             for li, layer in enumerate(mods):
@@ -273,10 +281,10 @@ class DcganDecoder(nn.Module):
         d = fused.stem_bn_act(self.upc1[0], self.upc1[1], vec)
         for s in range(2, n):
             layer = getattr(self, f"upc{s}")
-            d = fused.convT4s2_bn_act(layer.main[0], layer.main[1], d, ops.to_nhwc(skip[n - s]))
+            d = fused.convT4s2_bn_act(layer.main[0], layer.main[1], d, _skip_nhwc(skip[n - s]))
         last = getattr(self, f"upc{n}")
         act = ACT_SIGMOID if isinstance(last[1], nn.Sigmoid) else ACT_TANH
-        return fused.convT4s2_last(last[0], d, ops.to_nhwc(skip[0]), act=act)
+        return fused.convT4s2_last(last[0], d, _skip_nhwc(skip[0]), act=act)
 
     @torch.no_grad()
     def precompute_frozen_skips(self, skip) -> None:

@@ -183,14 +183,78 @@ def _stats_buf(rows: int, cout: int, device):
     return torch.empty((rows, 2, cout), device=device, dtype=torch.float32)
 
 
+class SharedBlocks:
+    """A tensor of `blocks` consecutive blocks of `block` images each, shared by the groups of a larger batch: group g (the
+    g-th run of `block` images of that batch) uses block map[g].  The time-batched decoder calls of train.py:227-231: the
+    three calls of a time step share the step's skip tensors, and once the skip is frozen (i >= n_past) every later step
+    shares them too.  `map_dev`: int32 device tensor [groups]; `map_host`: the same as a tuple."""
+    __slots__ = ("t", "block", "map_dev", "map_host")
+
+    def __init__(self, t, block, map_dev, map_host):
+        self.t, self.block, self.map_dev, self.map_host = t, int(block), map_dev, tuple(map_host)
+
+    @property
+    def blocks(self):
+        return self.t.shape[0] // self.block
+
+    @property
+    def groups(self):
+        return len(self.map_host)
+
+    def like(self, t):
+        """The same sharing pattern over another tensor of blocks (e.g. a conv of this one)."""
+        return SharedBlocks(t, self.block, self.map_dev, self.map_host)
+
+
+_MAP_CACHE = {}
+
+
+def shared_map(map_host, device):
+    """int32 device tensor of a group -> block map, cached per (map, device): created eagerly (an H2D copy is not capturable),
+    so the first - eager, warm-up - iteration of a training run creates the ones the captured iterations use."""
+    key = (tuple(map_host), str(device))
+    m = _MAP_CACHE.get(key)
+    if m is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("shared_map: a new group map cannot be created while a hipGraph is being captured")
+        m = _MAP_CACHE[key] = torch.tensor(list(map_host), dtype=torch.int32, device=device)
+    return m
+
+
+def group_sum(src, shared: "SharedBlocks"):
+    """dst[b] = sum_{g: map[g] == b} src[g] (deterministic order): src (groups * block, ...) -> (blocks * block, ...), the
+    adjoint of reading a SharedBlocks operand (dvg_group_sum)."""
+    _dev_f32(src, "group_sum")
+    g, blk = shared.groups, shared.block
+    if src.shape[0] != g * blk:
+        raise RuntimeError(f"group_sum: {src.shape[0]} images are not {g} groups of {blk}")
+    per_image = src.numel() // src.shape[0]
+    if src.stride(0) != per_image:     # images must be dense and consecutive (NCHW-contiguous or NHWC-in-memory alike)
+        src = src.contiguous()
+    dst = torch.empty_strided((shared.blocks * blk,) + tuple(src.shape[1:]), src.stride(), device=src.device,
+                              dtype=torch.float32)
+    elems = src.numel() // g
+    check(lib().dvg_group_sum(_p(src), _p(shared.map_dev), _p(dst), g, shared.blocks, elems, _stream()), "group_sum")
+    return dst
+
+
 def _check_addend(addend, y, excluded):
+    """Returns (addend tensor, map pointer, block) for the kernels; addend may be a SharedBlocks."""
     if addend is None:
-        return
+        return None, None, 0
     if excluded:
         raise RuntimeError("addend excludes the pooled output")
+    if isinstance(addend, SharedBlocks):
+        t = addend.t
+        _dev_f32(t, "addend")
+        if (tuple(t.shape[1:]) != tuple(y.shape[1:]) or t.stride() != y.stride() or
+                y.shape[0] != addend.groups * addend.block):
+            raise RuntimeError(f"shared addend {tuple(t.shape)} x {addend.groups} groups does not match {tuple(y.shape)}")
+        return t, addend.map_dev, addend.block
     _dev_f32(addend, "addend")
     if tuple(addend.shape) != tuple(y.shape) or addend.stride() != y.stride():
         raise RuntimeError(f"addend {tuple(addend.shape)} must match the output {tuple(y.shape)} (NHWC in memory)")
+    return addend, None, 0
 
 
 def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0.2, pool=False, stats=False,
@@ -212,7 +276,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
         raise RuntimeError(f"conv3x3: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, h, w, x.device)
     yp = nhwc_empty(n, cout, h // 2, w // 2, x.device) if pool else None
-    _check_addend(addend, y, pool)
+    addend, amap, ablk = _check_addend(addend, y, pool)
     ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None))
@@ -221,7 +285,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
                                                       wp.numel())
     _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
          _p(yp), _p(st), n, h, w, c1, c2, cout, int(upsample), act, slope, _p(ws), 0 if ws is None else ws.numel(),
-         _p(addend), _stream())
+         _p(addend), _p(amap), ablk, _stream())
     out = (y, yp) if pool else y
     return (out, st) if stats else out
 
@@ -405,7 +469,7 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     if taps != 16 or cin != c1 + c2:
         raise RuntimeError(f"convT4x4s2: packed weight {tuple(wp.shape)} does not match Cin={c1 + c2}")
     y = nhwc_empty(n, cout, 2 * h, 2 * w, x.device)
-    _check_addend(addend, y, False)
+    addend, amap, ablk = _check_addend(addend, y, False)
     ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None))
@@ -414,7 +478,7 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     by = 4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel())
     _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
          _p(y), _p(st), n, h, w, c1, c2, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _p(addend),
-         _stream())
+         _p(amap), ablk, _stream())
     return (y, st) if stats else y
 
 
@@ -1007,12 +1071,18 @@ def convT_last_two_step(x, skip, w, bias, nc, ks, *, act):
     t = ks * ks * nc
     d1 = pixel_proj(x, _last_wmat_cached(w, 0, c1, t))
     d2 = None
-    if skip is not None:
+    d2_map, d2_blk = None, 0
+    if isinstance(skip, SharedBlocks):      # time-batched decoder calls: the projection of the DISTINCT skip blocks only
+        d2 = pixel_proj(skip.t, _last_wmat_cached(w, c1, wdet.shape[0], t))
+        d2_map, d2_blk = skip.map_dev, skip.block
+        if n != skip.groups * skip.block:
+            raise RuntimeError("convT_last_two_step: shared skip does not match the batch")
+    elif skip is not None:
         d2 = _cached_skip_proj(skip, lambda: _last_wmat_cached(w, c1, wdet.shape[0], t), w)
     s = 2 if ks == 4 else 1
     y = torch.empty((n, nc, s * h, s * wd), device=x.device, dtype=torch.float32)
     _run("convT_gather", 0.0, 4.0 * (d1.numel() * (2 if skip is not None else 1) + y.numel()), lib().dvg_convT_gather,
-         _p(d1), _p(d2), _p(bias), _p(y), ks, n, h, wd, nc, act, _stream())
+         _p(d1), _p(d2), _p(bias), _p(y), ks, n, h, wd, nc, act, _p(d2_map), d2_blk, _stream())
     return y
 
 

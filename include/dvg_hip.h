@@ -128,7 +128,12 @@ int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                           const float* scale, const float* shift, float* y, float* y_pool,
                           float* stats, int N, int H, int W, int C1, int C2, int Cout,
                           int upsample_x, int act, float slope, float* workspace,
-                          long workspace_floats, const float* addend, void* stream);
+                          long workspace_floats, const float* addend,
+                          /* ABI 6, time-batched decoder calls (train.py:227-231): the images form groups of addend_block;
+                           * group g = n / addend_block adds block addend_map[g] (device ints) of an addend made of
+                           * addend_block-image blocks - the skip half shared by the three decoder calls of a time step
+                           * and, once the skip is frozen, by every later step.  NULL: image n adds addend image n.     */
+                          const int* addend_map, int addend_block, void* stream);
 /* dcgan_conv = Conv2d(nin,nout,4,2,1)+BN+LReLU (dcgan_64.py:4-14): K = 16*Cin,
  * x NHWC (N,H,W,Cin) -> y NHWC (N,H/2,W/2,Cout).                                          */
 int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
@@ -141,7 +146,8 @@ int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* sca
 int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                              const float* scale, const float* shift, float* y, float* stats,
                              int N, int H, int W, int C1, int C2, int Cout, int act, float slope,
-                             float* workspace, long workspace_floats, const float* addend, void* stream);
+                             float* workspace, long workspace_floats, const float* addend,
+                             const int* addend_map /* as dvg_conv3x3_bn_act_v2 */, int addend_block, void* stream);
 
 /* Winograd F(m x m, 3x3), m = 2 or 4, form of vgg_layer for the deep eval-mode layers (vgg_64.py:5-15 at 16x16 / 8x8 maps
  * with 256-512 channels): fp32 throughout, 2.25x (m = 2) / 4x (m = 4) fewer multiply-adds, P = (m+2)^2 transform
@@ -209,7 +215,9 @@ int dvg_pixel_proj(const float* in, const float* w, float* out, long P, int C, i
  * concatenated input, d2 may be NULL), column order (kh, kw, co).  ks = 3: ConvTranspose2d(.,nc,3,1,1)
  * (vgg_64.py:88-92); ks = 4: ConvTranspose2d(.,nc,4,2,1) (dcgan_64.py:75-79).                          */
 int dvg_convT_gather(const float* d1, const float* d2, const float* bias, float* y_nchw, int ks,
-                     int N, int H, int W, int nc, int act, void* stream);
+                     int N, int H, int W, int nc, int act,
+                     const int* d2_map /* NULL, or: image n reads block d2_map[n / d2_block] of d2 (shared skip) */,
+                     int d2_block, void* stream);
 
 /* ---- GROUPS (ABI 6, time-batched training) ----------------------------------------------------------------------
  * train.py:213-232 is teacher-forced: the encoder calls of a closure (and, once the latent chain has run, its decoder
@@ -371,6 +379,10 @@ int dvg_bn_bwd_finalize(const float* partial, int nrows, const float* gamma, con
 int dvg_affine3_apply(const float* dp, const float* u, const float* A, const float* B,
                       const float* Cc, float* du, long n, int C, float* sum, int sum_mode,
                       int groups /* A, B, Cc are [groups][C]; group = run of n / groups elements */, void* stream);
+/* dst[b] = sum over the groups g with map[g] == b, in ascending g (deterministic), of src[g]: src [groups][block_elems],
+ * dst [blocks][block_elems], map = device ints.  The adjoint of the shared addend (addend_map above): d(addend block) =
+ * the sum of d(pre-activation) over the decoder calls that read it.  block_elems % 4 == 0.  ABI 6.                    */
+int dvg_group_sum(const float* src, const int* map, float* dst, int groups, int blocks, long block_elems, void* stream);
 /* dpre = dy * act'(y), flat tensors (last layers, nn.Linear+Tanh).               */
 int dvg_act_bwd(const float* dy, const float* y, float* dpre, long n, int act, float slope,
                 void* stream);

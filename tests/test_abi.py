@@ -42,7 +42,7 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     lib = _lib.lib()
     one = ctypes.c_void_p(16)  # fake, never dereferenced: the call must fail in the checks
     rc = lib.dvg_conv3x3_bn_act_v2(one, None, one, None, None, one, None, None, 1, 8, 8, 40, 0, 64, 0, 1, 0.2, None, 0,
-                                   None, None)
+                                   None, None, 0, None)
     assert rc == 1 and b"16" in lib.dvg_last_error(), lib.dvg_last_error()
     rc = lib.dvg_lstm_cell(one, one, one, one, one, one, one, one, one, None, 4, 100, None)
     assert rc == 1

@@ -124,7 +124,10 @@ class Trainer:
         self.share_closure_encodings = True
         # True = the encoder calls of a closure run as ONE pass over all frames with per-frame ("grouped") BatchNorm
         # statistics (needs share_encoder_passes); DVG_TIME_BATCH=0: one pass per frame
-        self.time_batched = os.environ.get("DVG_TIME_BATCH", "1") != "0"
+        self.time_batched = os.environ.get("DVG_TIME_BATCH", "2") != "0"
+        # True (with time_batched) = train_model's 3 S decoder calls as one decoder pass with shared skip blocks
+        # (_train_model_batched); DVG_TIME_BATCH=1: encoder only
+        self.time_batched_decoder = os.environ.get("DVG_TIME_BATCH", "2") not in ("0", "1")
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
         self.latent_stream = os.environ.get("DVG_LATENT_STREAM", "1") != "0"
         self._side_stream = None
@@ -345,8 +348,89 @@ class Trainer:
         self.frame_predictor_optimizer.step()
         return mse_latent.detach()
 
+    def _train_model_batched(self, x):
+        """train_model (train.py:200-248) with the encoder AND decoder calls time-batched.  The closure is teacher-forced:
+        step i reads the encodings of the ground-truth frames x[i-1], x[i]; so (1) all T frames are encoded in one pass
+        (grouped BatchNorm, _encode_sequence_batched); (2) the latent chain - LSTM step, GP posterior + ELBO term, latent
+        MSE, the only part with a recurrence - runs step by step on slices of those encodings; (3) the 3 S decoder calls
+        (x_pred, x_target_pred, x_pred_gp for every step, :227-232) run as ONE decoder pass over 3 S B latents in the
+        reference's call order, BatchNorm per call (group), with the skip tensors as SHARED BLOCKS: the three calls of a
+        step read the same skip, and from step n_past on the skip is frozen (:217-220), so the skip half of every concat
+        conv is computed (and back-propagated) once per DISTINCT skip - n_past - 1 times, not 3 S times.  Losses, gradients
+        and buffers equal the step-by-step path up to fp32 summation order (tests/test_gpu_train.py)."""
+        from dvg_amd import ops
+        from dvg_amd.autograd import split_batch
+        from dvg_amd.rollout import _adjacent_view
+        opt = self.opt
+        T = opt.n_past + opt.n_future
+        S = T - 1
+        B = x[0].shape[0]
+        self.encoder_optimizer.zero_grad()
+        self.decoder_optimizer.zero_grad()
+        self.frame_predictor_optimizer.zero_grad()
+        if not self.reference_gp_grad_leak:
+            self.optimizer.zero_grad()
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        frames = _adjacent_view(list(x[:T]))
+        if frames is None:
+            frames = torch.cat(list(x[:T]), 0)
+        with fused.bn_groups(T, (1, 2, 1)):
+            h_all, skips_all = self.encoder(frames)
+        staged = self.staged_backward
+        if staged:     # cut the graph at the encoder outputs (see _train_model_dev)
+            h_leaf = h_all.detach().requires_grad_(True)
+            sk_leaf = [s.detach().requires_grad_(True) for s in skips_all]
+        else:
+            h_leaf, sk_leaf = h_all, list(skips_all)
+        hs = split_batch(h_leaf, T)
+        # latent chain (the only recurrence): step i reads h(x[i-1]) and the target h(x[i])
+        mse_latent = 0
+        max_ll = 0
+        vecs = []
+        for i in range(1, T):
+            h, h_target = hs[i - 1], hs[i]
+            h_pred = self.frame_predictor(h)
+            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+            gp_pred = self.gp_layer(self._gp_in(h))
+            max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
+            vecs += [h_pred, h_target, gp_pred.mean.transpose(0, 1)]
+        vec_all = torch.cat(vecs, 0)                              # (3 S B, g_dim), reference call order
+        # skip of step i: the encoder's skips of frame i-1 while i < n_past (or always with last_frame_skip), frozen after
+        nblk = S if opt.last_frame_skip else max(1, opt.n_past - 1)
+        gmap = tuple(min(g // 3, nblk - 1) for g in range(3 * S))
+        mdev = ops.shared_map(gmap, vec_all.device)
+        shared = [ops.SharedBlocks(s[:nblk * B], B, mdev, gmap) for s in sk_leaf]
+        with fused.bn_groups(3 * S, (1, 1, 1)):
+            x_all = self.decoder([vec_all, shared])               # (3 S B, nc, H, W)
+        tgt = frames[B:].view(S, 1, B, *frames.shape[1:])
+        per = x_all.view(S, 3, B, *frames.shape[1:]) - tgt
+        # nn.MSELoss per call, summed over the steps = sum of squares / elements per call
+        sq = (per * per).sum((0, 2, 3, 4, 5)) / float(per[0, 0].numel())
+        mse, ae_mse, mse_gp = sq[0], sq[1], sq[2]
+        loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
+        loss.backward()
+        if staged:
+            self._ar(("start", "a", (self.rng_gp[0], self.rng_dec[1])))
+            outs, seeds = [h_all], [h_leaf.grad]
+            for s, l in zip(skips_all, sk_leaf):
+                if l.grad is not None:
+                    outs.append(s)
+                    seeds.append(l.grad)
+            torch.autograd.backward(outs, seeds)
+            self._ar(("start", "b", self.rng_enc), ("finish", "a"), ("finish", "b"))
+        else:
+            self._ar(("reduce", (self.rng_gp[0], self.rng_enc[1])))
+        self.frame_predictor_optimizer.step()
+        self.encoder_optimizer.step()
+        self.decoder_optimizer.step()
+        self.optimizer.step()
+        return mse_latent.detach(), loss.detach()
+
     def _train_model_dev(self, x):
         opt = self.opt
+        if (self.time_batched and self.time_batched_decoder and self.share_encoder_passes and self.encoder.training
+                and self.decoder.training and opt.n_past >= 2 and opt.n_past + opt.n_future >= 3):
+            return self._train_model_batched(x)
         self.encoder_optimizer.zero_grad()            # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203)
         self.decoder_optimizer.zero_grad()
         self.frame_predictor_optimizer.zero_grad()
