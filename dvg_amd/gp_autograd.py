@@ -41,6 +41,31 @@ def gp_train(layer, h, noise):
     return {"mean": mean, "var": var, "kl": kl, "sample": None, "cov": None}
 
 
+def gp_elbo_steps(layer, mll, hin, htgt):
+    """The GP posterior + ELBO term of S teacher-forced time steps in ONE forward and ONE backward launch each
+    (train.py:164-169 and :225-226 call `mll(gp_layer(h_i), h_target_i)` once per step; the steps share the GP's parameters
+    and do not depend on each other).  hin, htgt: (S, B, D).  The S x D (step, latent dim) pairs are laid out as S * D
+    virtual latent dims - the kernels are one workgroup per dim and index every parameter by dim - with the parameters
+    tiled S times (torch `repeat`: its backward sums the S gradient copies) and the steps' codes side by side in a
+    (B, S * D) matrix.  Returns (elbo (S * D,), mean (S, B, D)): `-elbo.sum()` is the closure's sum over the steps of
+    `-mll(...).sum()`, mean[i] what `gp_layer(h_i).mean.transpose(0, 1)` would be.  Values per (step, dim) are exactly
+    the per-step calls' (same kernels, same arithmetic)."""
+    from .models.gp_models import JITTER
+    layer.ensure_initialized()
+    S, B, D = hin.shape
+    vs = layer.variational_strategy
+    vd = vs.variational_distribution
+    s, ell, c = layer.hypers()
+    hp = hin.permute(1, 0, 2).reshape(B, S * D)
+    mean, var, kl = _GPTrain.apply(hp, vs.inducing_points.squeeze(-1).repeat(S, 1), vd.variational_mean.repeat(S, 1),
+                                   vd.chol_variational_covar.repeat(S, 1, 1), c.repeat(S), s.repeat(S), ell.repeat(S),
+                                   JITTER)
+    tgt = htgt.permute(1, 0, 2).reshape(B, S * D).transpose(0, 1)          # (S * D, B), strided like h_target.transpose(0, 1)
+    raw_noise = mll.likelihood.noise_covar.raw_noise.reshape(-1).repeat(S)
+    elbo = gp_elbo(mean, var, kl, tgt, raw_noise, mll.num_data)
+    return elbo, mean.view(S, D, B).transpose(1, 2)
+
+
 class _GPElbo(torch.autograd.Function):
     """VariationalELBO(combine_terms=True)(pred, target) as one launch forward and one backward (dvg_gp_elbo /
     dvg_gp_elbo_bwd) instead of ~25 torch launches on (D,B) tensors per GP call: 950 of a dcgan_64 iteration's launches."""

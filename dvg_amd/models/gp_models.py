@@ -174,13 +174,16 @@ class GPRegressionLayer1(nn.Module):
             vs.variational_distribution.variational_mean).to(torch.float32))
         vs.variational_params_initialized.fill_(1)
 
-    def forward(self, x):
-        """x: (D,B,1) as produced by `h.transpose(0,1).view(D,B,1)` (train.py:225) — a strided view
-        that shares storage with h — or directly h (B,D)."""
+    def ensure_initialized(self):
         if not getattr(self, "_init_checked", False):   # host-side flag: no device sync per call (graph-capturable)
             if not int(self.variational_strategy.variational_params_initialized.item()):
                 self.initialize_variational_dist()
             self._init_checked = True
+
+    def forward(self, x):
+        """x: (D,B,1) as produced by `h.transpose(0,1).view(D,B,1)` (train.py:225) — a strided view
+        that shares storage with h — or directly h (B,D)."""
+        self.ensure_initialized()
         if x.dim() == 3:
             if x.shape[0] != self.num_dims or x.shape[2] != 1:
                 raise RuntimeError(f"GP input must be ({self.num_dims},B,1), got {tuple(x.shape)}")

@@ -307,15 +307,22 @@ class Trainer:
             fused.replay_bn_trace(cache[2])          # ... and the BatchNorm side effects of re-encoding them, replayed
         else:
             enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
-        for i in range(1, opt.n_past + opt.n_future):
-            # Only the GP optimiser steps after this closure (train.py:170-171): the reference back-propagates into
-            # the encoder and then discards those gradients (encoder.zero_grad() opens the next train_model).  The
-            # encoder therefore runs without autograd here - same outputs, same BatchNorm running-stat updates, same
-            # parameter updates, none of the wasted encoder backward.
-            h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
-            h_target = self._enc(enc_all, x, i, g)[0].detach()
-            h_pred = self.gp_layer(self._gp_in(h))
-            max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
+        if self.time_batched and enc_all is not None and not g and self.gp_layer.training:
+            # no recurrence in this closure: all S GP posteriors + ELBO terms as one launch (gp_autograd.gp_elbo_steps)
+            from dvg_amd.gp_autograd import gp_elbo_steps
+            hcat = torch.stack([e[0].detach() for e in enc_all])          # (T, B, D)
+            elbo, _ = gp_elbo_steps(self.gp_layer, self.mll, hcat[:-1], hcat[1:])
+            max_ll = -elbo
+        else:
+            for i in range(1, opt.n_past + opt.n_future):
+                # Only the GP optimiser steps after this closure (train.py:170-171): the reference back-propagates into
+                # the encoder and then discards those gradients (encoder.zero_grad() opens the next train_model).  The
+                # encoder therefore runs without autograd here - same outputs, same BatchNorm running-stat updates, same
+                # parameter updates, none of the wasted encoder backward.
+                h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
+                h_target = self._enc(enc_all, x, i, g)[0].detach()
+                h_pred = self.gp_layer(self._gp_in(h))
+                max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
         loss.backward()
         self._ar(("reduce", self.rng_gp))
@@ -383,17 +390,19 @@ class Trainer:
         else:
             h_leaf, sk_leaf = h_all, list(skips_all)
         hs = split_batch(h_leaf, T)
-        # latent chain (the only recurrence): step i reads h(x[i-1]) and the target h(x[i])
+        # the GP posterior + ELBO term of all S steps (no recurrence there: step i reads h(x[i-1]), h(x[i])): one launch
+        from dvg_amd.gp_autograd import gp_elbo_steps
+        D = h_leaf.shape[1]
+        elbo, gp_means = gp_elbo_steps(self.gp_layer, self.mll, h_leaf[:S * B].view(S, B, D), h_leaf[B:].view(S, B, D))
+        max_ll = -elbo
+        # latent chain (the only recurrence): the LSTM steps
         mse_latent = 0
-        max_ll = 0
         vecs = []
         for i in range(1, T):
             h, h_target = hs[i - 1], hs[i]
             h_pred = self.frame_predictor(h)
             mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
-            gp_pred = self.gp_layer(self._gp_in(h))
-            max_ll = max_ll - self.mll(gp_pred, h_target.transpose(0, 1))
-            vecs += [h_pred, h_target, gp_pred.mean.transpose(0, 1)]
+            vecs += [h_pred, h_target, gp_means[i - 1]]
         vec_all = torch.cat(vecs, 0)                              # (3 S B, g_dim), reference call order
         # skip of step i: the encoder's skips of frame i-1 while i < n_past (or always with last_frame_skip), frozen after
         nblk = S if opt.last_frame_skip else max(1, opt.n_past - 1)
