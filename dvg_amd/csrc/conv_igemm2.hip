@@ -37,6 +37,11 @@
 #define DVG_STAGE_PRIO 1
 #endif
 
+//  DVG_ABLATE (timing experiments only, WRONG results): 1 = the stage loop issues no global loads (the next stage's LDS
+//  stores write stale registers), 2 = and no LDS stores, 3 = and no workgroup barriers - what the staging costs the loop
+#ifndef DVG_ABLATE
+#define DVG_ABLATE 0
+#endif
 //  DVG_GEMM_WGS_PER_CU: workgroups per CU the 64-row GEMM-mode tile is compiled for (register budget 512 / this per lane)
 #ifndef DVG_GEMM_WGS_PER_CU
 #define DVG_GEMM_WGS_PER_CU 4
@@ -85,6 +90,12 @@ __device__ __forceinline__ int addend_image(const int* __restrict__ add_map, int
 
 static unsigned long long* g_clk = nullptr;
 static unsigned g_clk_cap = 0;
+
+// What a halo / out-of-image slot of the A tile loads: 16 bytes of zeros.  The slot's ADDRESS is selected (before the load
+// is issued), not its data afterwards: with `v = ok ? loaded : 0` hipcc placed the v_cndmask right behind the load and with
+// it an `s_waitcnt vmcnt(0)` in the middle of the stage's MFMA stream - every stage of every mode waited out a full
+// global-load latency for its first A loads (r03, found in the ISA of all nine instantiations).
+__device__ __attribute__((aligned(16))) float dvg_zero_slot[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int MODE, int TI, int TH, int TW>
 struct Cfg2 {
@@ -207,9 +218,14 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         const bool from_x = GEMM || c0 < p.C1;
         const float* src = (from_x ? p.x + c0 : p.skip + (c0 - p.C1)) + (GEMM ? ld_a_off : 0);
 #pragma unroll
-        for (int i = 0; i < NLA; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(src + (GEMM ? offx[i % NLA1] + (i / NLA1) * 16
-                                                                : (from_x ? offx[GEMM ? 0 : i] : offs[GEMM ? 0 : i])));
+        for (int i = 0; i < NLA; ++i) {
+            if (GEMM) {    // whole tiles only (host checks): every slot is valid
+                ra[i] = *reinterpret_cast<const f32x4*>(src + offx[i % NLA1] + (i / NLA1) * 16);
+            } else {
+                const float* a = src + (from_x ? offx[GEMM ? 0 : i] : offs[GEMM ? 0 : i]);
+                ra[i] = *reinterpret_cast<const f32x4*>(((okmask >> i) & 1u) ? a : dvg_zero_slot);
+            }
+        }
     };
     auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[GT]) {
 #pragma unroll
@@ -222,8 +238,8 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
-            const f32x4 v = ((okmask >> i) & 1u) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&As[(i / NLA1) * C::SLAB + (idx >> 2) * LD + (idx & 3) * 4]) = v;  // rows >= HP: padding
+            // halo / out-of-image slots already hold zeros (gload_a read dvg_zero_slot for them); rows >= HP: padding
+            *reinterpret_cast<f32x4*>(&As[(i / NLA1) * C::SLAB + (idx >> 2) * LD + (idx & 3) * 4]) = ra[i];
         }
     };
     auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
@@ -260,8 +276,10 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         constexpr int ngrp = (grp + 1) % NG;
         constexpr bool next_a = has_next && ngrp == 0;
         const int nchunk = nchunk_override >= 0 ? nchunk_override : chunk + (ngrp == 0 ? CPS : 0);
-        if constexpr (next_a) gload_a(nchunk * C::KC, ra);
-        if constexpr (has_next) gload_b(nchunk, ngrp, rb);
+        if (DVG_ABLATE < 1) {
+            if constexpr (next_a) gload_a(nchunk * C::KC, ra);
+            if constexpr (has_next) gload_b(nchunk, ngrp, rb);
+        }
 
         // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
         f32x4 fa[2][MT][2], fb[2][2];
@@ -293,9 +311,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 // The last tap's fragments are in registers: every wave is done reading this stage's tiles after
                 // this barrier, and the next stage's ds_writes interleave with the last tap's MFMAs instead of
                 // forming an MFMA-less pass between two barriers.
-                __syncthreads();
-                if constexpr (next_a) lds_store_a(ra);
-                lds_store_b(rb);
+                if (DVG_ABLATE < 3) __syncthreads();
+                if (DVG_ABLATE < 2) {
+                    if constexpr (next_a) lds_store_a(ra);
+                    lds_store_b(rb);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 if constexpr (next_a) lds_store_a(ra);
                 lds_store_b(rb);
             }
-            __syncthreads();
+            if (DVG_ABLATE < 3) __syncthreads();
         }
     };
     using std::integral_constant;
