@@ -14,7 +14,7 @@ import torch
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import rel_err
+from tests.common import rel_err, rel_err_elem
 from tests.test_gpu_configs import _build, _oracle_fns
 
 pytestmark = pytest.mark.gpu
@@ -39,6 +39,8 @@ def test_backbone_modules_at_the_reference_generate_batch(family):
         y = dec([vec.to(DEV), sk])
     assert h.shape == (B, 90) and y.shape == (B, 1, 64, 64)
     assert rel_err(h, h_ref) < FRAME_BAR and rel_err(y, y_ref) < FRAME_BAR, (rel_err(h, h_ref), rel_err(y, y_ref))
+    # element-wise as well (entries below 1 % of the largest magnitude are floored there): latents are not frames
+    assert rel_err_elem(h, h_ref) < 2e-3 and rel_err_elem(y, y_ref) < 2e-3, (rel_err_elem(h, h_ref), rel_err_elem(y, y_ref))
     for a, b in zip(sk, sk_ref):
         assert a.shape == b.shape and rel_err(a, b) < FRAME_BAR
     # the n_past - 1 = 4 conditioning frames as one batch of 200 (rollout._encode_conditioning): per-sample identical
