@@ -36,10 +36,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 # profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
 # direct-form FLOPs of one B = 64, 10-in/10-out rollout (19 encoder + 10 decoder passes + 19 LSTM steps)
 SURVEY_FLOPS_PER_ROLLOUT = {"vgg": 4.99e12, "dcgan": 0.51e12}
-TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r02_conv3x3_traffic.json",
-                 ("vgg", "winograd_gemm"): "r02_winograd_gemm_traffic.json",
-                 ("dcgan", "conv4x4s2_igemm"): "r02_conv4x4s2_traffic.json",
-                 ("dcgan", "convT4x4s2_igemm"): "r02_convT4x4s2_traffic.json"}
+TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r03_conv3x3_traffic.json",
+                 ("vgg", "winograd_gemm"): "r03_winograd_gemm_traffic.json",
+                 ("dcgan", "conv4x4s2_igemm"): "r03_conv4x4s2_traffic.json",
+                 ("dcgan", "convT4x4s2_igemm"): "r03_convT4x4s2_traffic.json"}
 
 
 def parse_args(argv=None):

@@ -312,9 +312,9 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 // this barrier, and the next stage's ds_writes interleave with the last tap's MFMAs instead of
                 // forming an MFMA-less pass between two barriers.
                 if (DVG_ABLATE < 3) __syncthreads();
-                if (DVG_ABLATE < 2) {
-                    if constexpr (next_a) lds_store_a(ra);
-                    lds_store_b(rb);
+                if (DVG_ABLATE < 2 || DVG_ABLATE >= 4) {      // 4: no B stores, 5: no A stores (timing only)
+                    if constexpr (next_a) { if (DVG_ABLATE != 5) lds_store_a(ra); }
+                    if (DVG_ABLATE != 4) lds_store_b(rb);
                 }
             }
 #pragma unroll
