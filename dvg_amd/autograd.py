@@ -238,7 +238,8 @@ def _conv3_raw(x, weight, b, need_stats, lo=None, hi=None, keep_v=None):
         u = ops.conv3x3_winograd(x, _wino(weight, m, lo, hi), None, b, act=ACT_NONE, return_v=want_v)
         if want_v:
             u, keep_v["v"] = u
-        return (u, ops.channel_stats(u.permute(0, 2, 3, 1).reshape(-1, cout))) if need_stats else u
+        # (inside fused.bn_groups the statistics are per group right away: no second pass in fused.group_stats)
+        return (u, ops.channel_stats(u.permute(0, 2, 3, 1).reshape(-1, cout), fused.bn_groups_now())) if need_stats else u
     wp = _packed(weight) if lo is None else _packed(weight, False, lo, hi, 1)
     return ops.conv3x3(x, None, wp, None, b, act=ACT_NONE, stats=need_stats)
 

@@ -188,6 +188,7 @@ def bn_passes_now() -> int:
 # and how many reference passes the first / a middle / the last group stands for (see bn_passes: a middle frame of a
 # sequence is encoded twice per closure).  Inside it `bn_passes` must be 1.
 _BN_GROUPS = None
+_GROUP_STATS_RECOMPUTE = os.environ.get("DVG_GROUP_STATS_RECOMPUTE", "0") == "1"
 
 
 class bn_groups:
@@ -207,12 +208,18 @@ def bn_groups_now() -> int:
     return _BN_GROUPS[0] if _BN_GROUPS else 1
 
 
-def group_stats(st, u, aligned=False):
-    """Partial statistics rows that respect the group boundaries: `st` itself with one group or when the producer's rows are
-    known to be group-aligned (tile rows of an un-split igemm launch, image-major), else a dvg_channel_stats pass over u
-    (NHWC-in-memory (N,C,H,W) or [rows][C]) with per-group slabs."""
+def group_stats(st, u):
+    """Partial statistics rows that respect the group boundaries: `st` itself with one group, or when its rows are per-tile
+    sums in image-major order whose tiles do not straddle groups (ops._stats_buf records that: un-split igemm launches and
+    the first-layer kernels), else a dvg_channel_stats pass over u (NHWC-in-memory (N,C,H,W) or [rows][C]) with per-group
+    slabs.  DVG_GROUP_STATS_RECOMPUTE=1 always takes the extra pass (A/B and tests)."""
     g = bn_groups_now()
-    if g == 1 or (aligned and st is not None and st.shape[0] % g == 0):
+    if g == 1:
+        return st
+    if st is not None and getattr(st, "grouped", 0) == g:
+        return st
+    ti = getattr(st, "tile_images", 0) if st is not None else 0
+    if ti and not _GROUP_STATS_RECOMPUTE and st.shape[0] % g == 0 and (u.shape[0] // g) % ti == 0:
         return st
     u2 = u if u.dim() == 2 else u.permute(0, 2, 3, 1).reshape(-1, u.shape[1])
     return ops.channel_stats(u2, g)

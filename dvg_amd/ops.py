@@ -177,10 +177,23 @@ def _splitk_ws(mode, n, h, w, cin, cout, out_numel, device):
     return torch.empty(s * out_numel, device=device, dtype=torch.float32)
 
 
-def _stats_buf(rows: int, cout: int, device):
+def _stats_buf(rows: int, cout: int, device, tile_images: int = 0):
+    """tile_images > 0: the rows are per-TILE partial sums in image-major order, a tile spanning `tile_images` consecutive
+    images (recorded on the tensor: fused.group_stats may then cut the rows into per-group runs without another pass);
+    0: rows of a split-K finish launch, whose blocks do not respect image boundaries."""
     if rows <= 0:
         raise RuntimeError("unsupported shape for fused BN statistics")
-    return torch.empty((rows, 2, cout), device=device, dtype=torch.float32)
+    st = torch.empty((rows, 2, cout), device=device, dtype=torch.float32)
+    st.tile_images = tile_images
+    return st
+
+
+def _tile_images(mode, n, h, w, cin, cout, gh, gw, ws):
+    """Images per statistics row of an igemm launch (see _stats_buf): 4 on 4x4 tile grids, else 1; 0 when the launch
+    splits K (its finish kernel writes the statistics)."""
+    if ws is not None and lib().dvg_conv_splitk_v2(mode, n, h, w, cin, cout) != 1:
+        return 0
+    return 4 if (gh, gw) == (4, 4) else 1
 
 
 class SharedBlocks:
@@ -280,7 +293,7 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
     ws = _splitk_ws(MODE_CONV3, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV3, n, h, w, cin, cout, int(pool), int(ws is not None))
-    st = _stats_buf(rows, cout, x.device) if stats else None
+    st = _stats_buf(rows, cout, x.device, _tile_images(MODE_CONV3, n, h, w, cin, cout, h, w, ws)) if stats else None
     fl, by = 2.0 * n * h * w * cout * 9 * cin, 4.0 * (x.numel() + (skip.numel() if c2 else 0) + n * h * w * cout +
                                                       wp.numel())
     _run("conv3x3_igemm", fl, by, lib().dvg_conv3x3_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift), _p(y),
@@ -401,7 +414,7 @@ def conv3x3_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fa
     if tuple(w.shape) != (cout, nc, 3, 3) or not w.is_contiguous():
         raise RuntimeError("conv3x3_first: weight must be contiguous (Cout,nc,3,3)")
     y = nhwc_empty(n, cout, h, wd, x.device)
-    st = _stats_buf(lib().dvg_conv_first_stats_rows(3, n, h, wd), cout, x.device) if stats else None
+    st = _stats_buf(lib().dvg_conv_first_stats_rows(3, n, h, wd), cout, x.device, 1) if stats else None
     _run("conv3x3_first", 2.0 * n * h * wd * cout * 9 * nc, 4.0 * (x.numel() + n * h * wd * cout),
          lib().dvg_conv3x3_first, _p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
          _stream())
@@ -432,7 +445,7 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     ws = _splitk_ws(MODE_CONV4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV4S2, n, h, w, cin, cout, 0, int(ws is not None))
-    st = _stats_buf(rows, cout, x.device) if stats else None
+    st = _stats_buf(rows, cout, x.device, _tile_images(MODE_CONV4S2, n, h, w, cin, cout, h // 2, w // 2, ws)) if stats else None
     fl, by = 2.0 * n * (h // 2) * (w // 2) * cout * 16 * cin, 4.0 * (x.numel() + y.numel() + wp.numel())
     _run("conv4x4s2_igemm", fl, by, lib().dvg_conv4x4s2_bn_act_v2, _p(x), _p(wp), _p(scale), _p(shift), _p(y), _p(st),
          n, h, w, cin, cout, act, slope, _p(ws), 0 if ws is None else ws.numel(), _stream())
@@ -448,7 +461,7 @@ def conv4x4s2_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=
     if tuple(w.shape) != (cout, nc, 4, 4) or not w.is_contiguous():
         raise RuntimeError("conv4x4s2_first: weight must be contiguous (Cout,nc,4,4)")
     y = nhwc_empty(n, cout, h // 2, wd // 2, x.device)
-    st = _stats_buf(lib().dvg_conv_first_stats_rows(4, n, h, wd), cout, x.device) if stats else None
+    st = _stats_buf(lib().dvg_conv_first_stats_rows(4, n, h, wd), cout, x.device, 1) if stats else None
     _run("conv4x4s2_first", 2.0 * n * (h // 2) * (wd // 2) * cout * 16 * nc, 4.0 * (x.numel() + y.numel()),
          lib().dvg_conv4x4s2_first, _p(x), _p(w), _p(scale), _p(shift), _p(y), _p(st), n, h, wd, nc, cout, act, slope,
          _stream())
@@ -473,7 +486,7 @@ def convT4x4s2(x, skip, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fal
     ws = _splitk_ws(MODE_CONVT4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONVT4S2, n, h, w, cin, cout, 0, int(ws is not None))
-    st = _stats_buf(rows, cout, x.device) if stats else None
+    st = _stats_buf(rows, cout, x.device, _tile_images(MODE_CONVT4S2, n, h, w, cin, cout, h, w, ws)) if stats else None
     fl = 2.0 * n * h * w * cout * 16 * cin
     by = 4.0 * (x.numel() + (skip.numel() if c2 else 0) + y.numel() + wp.numel())
     _run("convT4x4s2_igemm", fl, by, lib().dvg_convT4x4s2_bn_act_v2, _p(x), _p(skip), _p(wp), _p(scale), _p(shift),
@@ -513,6 +526,7 @@ def channel_stats(u2d: torch.Tensor, groups: int = 1) -> torch.Tensor:
     r = lib().dvg_channel_stats_rows(rows // groups)
     st = torch.empty((groups * r, 2, c), device=u2d.device, dtype=torch.float32)
     check(lib().dvg_channel_stats(_p(u2d), _p(st), rows // groups, c, groups, _stream()), "channel_stats")
+    st.grouped = groups       # rows are per-group runs already (fused.group_stats)
     return st
 
 
