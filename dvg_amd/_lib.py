@@ -37,10 +37,10 @@ SIGNATURES = {
     "dvg_conv4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p]),
     "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),
-    "dvg_winograd_input": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "dvg_winograd_input": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_gemm_batched_k16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "dvg_winograd_output": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "dvg_winograd_output_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_winograd_output": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
+    "dvg_winograd_output_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "dvg_winograd_output_pool_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_conv3x3_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_convT3x3_last": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

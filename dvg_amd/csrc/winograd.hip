@@ -194,10 +194,12 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
 // (accesses stay coalesced: consecutive lanes take consecutive channels) and need a quarter of the registers.
 template <typename V>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
-                                                              int H, int W, int C4, long Tt, long t_off) {
+                                                              int H, int W, int C4, long Tt, long t_off, int up) {
     // Tt / t_off: tiles per position of the destination and this call's first tile (the weight-gradient path concatenates
     // the tiles of several uses of a layer; Tt = N * tiles per image, t_off = 0 otherwise)
-    const int Ht = H >> 2, Wt = W >> 2;
+    // up = 1: x is stored at (N, H/2, W/2, C) and read through nearest-x2 upsampling (the x half of a decoder block's first
+    // conv, vgg_64.py:93,98-105: the upsampled tensor never exists)
+    const int Ht = H >> 2, Wt = W >> 2, Hs = H >> up, Ws = W >> up;
     const long T = (long)N * Ht * Wt, total = T * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float* __res
             for (int a = 0; a < 6; ++a) {
                 const int yy = 4 * ty - 1 + a;
                 const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-                d[a] = ok ? reinterpret_cast<const V*>(x)[(((size_t)n * H + yy) * W + xx) * C4 + c4] : vzero<V>();
+                d[a] = ok ? reinterpret_cast<const V*>(x)[(((size_t)n * Hs + (yy >> up)) * Ws + (xx >> up)) * C4 + c4] : vzero<V>();
             }
             V col[6];
             bt4(d, col);
@@ -283,7 +285,9 @@ template <bool POOL, typename V>
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                float* __restrict__ y_pool, int N, int H, int W, int C4,
-                                                               int act, float slope) {
+                                                               int act, float slope, const float* __restrict__ addend) {
+    // addend (optional): raw partial sums in y's shape, y = act((A^T M A + addend) * scale + shift) - the hoisted skip half
+    // of a decoder block's first conv (the same role as the igemm kernels' addend)
     constexpr int VN = VecN<V>::N;
     const int Ht = H >> 2, Wt = W >> 2;
     const long T = (long)N * Ht * Wt, total = T * C4;
@@ -317,9 +321,13 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
             at4(s[pp], o);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
+                const size_t px = (((size_t)n * H + 4 * ty + pp) * W + 4 * tx + qq) * C4 + c4;
+                V ad = vzero<V>();
+                if (addend) ad = reinterpret_cast<const V*>(addend)[px];
 #pragma unroll
-                for (int k = 0; k < VN; ++k) vset(val[pp][qq], k, apply_act(vget(o[qq], k) * vget(sc, k) + vget(sf, k), act, slope));
-                reinterpret_cast<V*>(y)[(((size_t)n * H + 4 * ty + pp) * W + 4 * tx + qq) * C4 + c4] = val[pp][qq];
+                for (int k = 0; k < VN; ++k)
+                    vset(val[pp][qq], k, apply_act((vget(o[qq], k) + vget(ad, k)) * vget(sc, k) + vget(sf, k), act, slope));
+                reinterpret_cast<V*>(y)[px] = val[pp][qq];
             }
         }
         if (POOL) {
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
 template <int HW>
 __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ v, int N,
-                                                               int C, int act, float slope) {
+                                                               int C, int act, float slope, const float* __restrict__ addend) {
     constexpr int WT = HW / 4, TI = WT * WT, CS = 256 / TI;    // tiles per image side / per image, channels per workgroup
     __shared__ float ys[HW * HW * CS];
     const int tid = threadIdx.x, cl = tid % CS, t_img = tid / CS, ty = t_img / WT, tx = t_img % WT;
@@ -371,8 +379,10 @@ __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __re
             float o[4];
             at4(sq[pp], o);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                ys[((4 * ty + pp) * HW + 4 * tx + qq) * CS + cl] = apply_act(o[qq] * sc + sf, act, slope);
+            for (int qq = 0; qq < 4; ++qq) {
+                const float ad = addend ? addend[(((size_t)n * HW + 4 * ty + pp) * HW + 4 * tx + qq) * C + c] : 0.f;
+                ys[((4 * ty + pp) * HW + 4 * tx + qq) * CS + cl] = apply_act((o[qq] + ad) * sc + sf, act, slope);
+            }
         }
     }
     __syncthreads();
@@ -413,7 +423,8 @@ __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __re
 template <int HW, int CS, typename V, bool POOL, int NT>
 __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ y,
-                                                             float* __restrict__ v, int N, int C, int act, float slope) {
+                                                             float* __restrict__ v, int N, int C, int act, float slope,
+                                                             const float* __restrict__ addend) {
     constexpr int VN = VecN<V>::N;
     constexpr int WT = HW / 4, TI = WT * WT;         // tiles per image side / per image of layer L
     constexpr int S2 = POOL ? HW / 2 : HW;           // side of the map layer L + 1 reads
@@ -453,8 +464,11 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
             at4(s[pp], o);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
+                V ad = vzero<V>();
+                if (addend) ad = reinterpret_cast<const V*>(addend)[(((size_t)n * HW + 4 * ty + pp) * HW + 4 * tx + qq) * CVg + cg];
 #pragma unroll
-                for (int k = 0; k < VN; ++k) vset(val[pp][qq], k, apply_act(vget(o[qq], k) * vget(sc, k) + vget(sf, k), act, slope));
+                for (int k = 0; k < VN; ++k)
+                    vset(val[pp][qq], k, apply_act((vget(o[qq], k) + vget(ad, k)) * vget(sc, k) + vget(sf, k), act, slope));
                 if (POOL)
                     reinterpret_cast<V*>(y)[(((size_t)n * HW + 4 * ty + pp) * HW + 4 * tx + qq) * CVg + cg] = val[pp][qq];
                 else
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
 
 template <int HW, int CS, typename V, bool POOL, int NT>
 static int launch_chain(const float* mm, const float* scale, const float* shift, float* y, float* v, int N, int C, int act,
-                        float slope, hipStream_t st) {
+                        float slope, hipStream_t st, const float* addend = nullptr) {
     constexpr int S2 = POOL ? HW / 2 : HW;
     constexpr size_t lds = (size_t)S2 * S2 * CS * 4;
     auto kern = winograd4_chain_kernel<HW, CS, V, POOL, NT>;
@@ -519,7 +533,8 @@ static int launch_chain(const float* mm, const float* scale, const float* shift,
         if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)N * (C / CS))), dim3(NT), lds, st, mm, scale, shift, y, v, N, C, act, slope);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)N * (C / CS))), dim3(NT), lds, st, mm, scale, shift, y, v, N, C, act, slope,
+                       addend);
     return check_launch("winograd4_chain");
 }
 
@@ -550,10 +565,13 @@ extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, 
     return check_launch("dvg_winograd_weight");
 }
 
-extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, void* stream) {
+extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, int upsample, void* stream) {
     DVG_REQUIRE(x && v, DVG_ERR_NULL, "dvg_winograd_input: NULL pointer");
     DVG_REQUIRE((m == 2 || m == 4) && N > 0 && H > 0 && W > 0 && H % m == 0 && W % m == 0 && C > 0 && C % 4 == 0,
                 DVG_ERR_SHAPE, "dvg_winograd_input: m 2 or 4, H and W multiples of m, C %% 4 == 0 needed");
+    DVG_REQUIRE(upsample == 0 || (upsample == 1 && m == 4 && H % 2 == 0 && W % 2 == 0), DVG_ERR_SHAPE,
+                "dvg_winograd_input: upsample needs m = 4 and even H, W");
+    const int up = upsample;
     DVG_REQUIRE(aligned16(x) && aligned16(v), DVG_ERR_ALIGN, "dvg_winograd_input: alignment");
     const long tiles = (long)N * (H / m) * (W / m);
     const hipStream_t st = (hipStream_t)stream;
@@ -562,11 +580,11 @@ extern "C" int dvg_winograd_input(const float* x, float* v, int N, int H, int W,
     } else {
         // channels per thread: the widest form that still gives >= 1024 workgroups (see the kernel)
         if (tiles * (C / 4) >= 1024L * 256)
-            hipLaunchKernelGGL(winograd4_input_kernel<f32x4>, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4, tiles, 0L);
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x4>, dim3(wgrid(tiles * (C / 4))), dim3(256), 0, st, x, v, N, H, W, C / 4, tiles, 0L, up);
         else if (tiles * (C / 2) >= 1024L * 256)
-            hipLaunchKernelGGL(winograd4_input_kernel<f32x2>, dim3(wgrid(tiles * (C / 2))), dim3(256), 0, st, x, v, N, H, W, C / 2, tiles, 0L);
+            hipLaunchKernelGGL(winograd4_input_kernel<f32x2>, dim3(wgrid(tiles * (C / 2))), dim3(256), 0, st, x, v, N, H, W, C / 2, tiles, 0L, up);
         else
-            hipLaunchKernelGGL(winograd4_input_kernel<float>, dim3(wgrid(tiles * C)), dim3(256), 0, st, x, v, N, H, W, C, tiles, 0L);
+            hipLaunchKernelGGL(winograd4_input_kernel<float>, dim3(wgrid(tiles * C)), dim3(256), 0, st, x, v, N, H, W, C, tiles, 0L, up);
     }
     return check_launch("dvg_winograd_input");
 }
@@ -586,21 +604,21 @@ extern "C" int dvg_winograd_wgrad_operands(const float* x, const float* dy, floa
     DVG_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(v) && aligned16(dm), DVG_ERR_ALIGN,
                 "dvg_winograd_wgrad_operands: alignment");
     const hipStream_t st = (hipStream_t)stream;
-#define WOPS(KERNEL_, SRC_, DST_, C_)                                                                                          \
+#define WOPS(KERNEL_, SRC_, DST_, C_, ...)                                                                                        \
     do {                                                                                                                       \
         if (tiles * ((C_) / 4) >= 1024L * 256)                                                                                 \
-            hipLaunchKernelGGL(KERNEL_<f32x4>, dim3(wgrid(tiles * ((C_) / 4))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 4, t_total, t_off); \
+            hipLaunchKernelGGL(KERNEL_<f32x4>, dim3(wgrid(tiles * ((C_) / 4))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 4, t_total, t_off __VA_ARGS__); \
         else if (tiles * ((C_) / 2) >= 1024L * 256)                                                                            \
-            hipLaunchKernelGGL(KERNEL_<f32x2>, dim3(wgrid(tiles * ((C_) / 2))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 2, t_total, t_off); \
+            hipLaunchKernelGGL(KERNEL_<f32x2>, dim3(wgrid(tiles * ((C_) / 2))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_) / 2, t_total, t_off __VA_ARGS__); \
         else                                                                                                                   \
-            hipLaunchKernelGGL(KERNEL_<float>, dim3(wgrid(tiles * (C_))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_), t_total, t_off);           \
+            hipLaunchKernelGGL(KERNEL_<float>, dim3(wgrid(tiles * (C_))), dim3(256), 0, st, SRC_, DST_, N, H, W, (C_), t_total, t_off __VA_ARGS__);           \
     } while (0)
     if (x && v) {
-        WOPS(winograd4_input_kernel, x, v, Cin);
+        WOPS(winograd4_input_kernel, x, v, Cin, , 0);
         if (int e = check_launch("dvg_winograd_wgrad_operands (input)")) return e;
     }
     if (dy && dm) {
-        WOPS(winograd4_dy_kernel, dy, dm, Cout);
+        WOPS(winograd4_dy_kernel, dy, dm, Cout, );
         if (int e = check_launch("dvg_winograd_wgrad_operands (dy)")) return e;
     }
 #undef WOPS
@@ -610,8 +628,9 @@ extern "C" int dvg_winograd_wgrad_operands(const float* x, const float* dy, floa
 // M (36, T, C) of layer L -> V (36, T, C) of layer L + 1 (winograd4_out_in_kernel / winograd4_chain_kernel): H == W in
 // {8, 16, 32}, F(4x4,3x3), C % 64 == 0.  The activation y = act(scale * A^T M A + shift) itself is not written.
 extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H,
-                                         int W, int C, int act, float slope, void* stream) {
+                                         int W, int C, int act, float slope, const float* addend, void* stream) {
     DVG_REQUIRE(mm && v_next, DVG_ERR_NULL, "dvg_winograd_output_input: NULL pointer");
+    DVG_REQUIRE(aligned16(addend), DVG_ERR_ALIGN, "dvg_winograd_output_input: addend alignment");
     DVG_REQUIRE(N > 0 && H == W && (H == 8 || H == 16 || H == 32) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
                 "dvg_winograd_output_input: 8x8, 16x16 or 32x32 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_input: bad act");
@@ -624,19 +643,19 @@ extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, co
     //    8x8  512ch: r02 kernel 7.6 / 73 = <8,64,float> - kept
     if (H == 8) {
         hipLaunchKernelGGL(winograd4_out_in_kernel<8>, dim3((unsigned)((long)N * (C / 64))), dim3(256), 0, st, mm, scale, shift,
-                           v_next, N, C, act, slope);
+                           v_next, N, C, act, slope, addend);
     } else if (H == 16) {
         if (var == 9) {
             hipLaunchKernelGGL(winograd4_out_in_kernel<16>, dim3((unsigned)((long)N * (C / 16))), dim3(256), 0, st, mm, scale,
-                               shift, v_next, N, C, act, slope);
+                               shift, v_next, N, C, act, slope, addend);
         } else if (var == 2 || (var == 0 && (long)N * (C / 64) < 1024)) {
-            return launch_chain<16, 32, float, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+            return launch_chain<16, 32, float, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st, addend);
         } else {
-            return launch_chain<16, 64, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+            return launch_chain<16, 64, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st, addend);
         }
     } else {
-        if (var == 1) return launch_chain<32, 16, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
-        return launch_chain<32, 32, f32x4, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+        if (var == 1) return launch_chain<32, 16, f32x2, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st, addend);
+        return launch_chain<32, 32, f32x4, false, 512>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st, addend);
     }
     return check_launch("dvg_winograd_output_input");
 }
@@ -662,8 +681,10 @@ extern "C" int dvg_winograd_output_pool_input(const float* mm, const float* scal
 
 extern "C" int dvg_winograd_output(
 const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
-                                   int H, int W, int C, int act, float slope, int mt, void* stream) {
+                                   int H, int W, int C, int act, float slope, int mt, const float* addend, void* stream) {
     DVG_REQUIRE(m && y, DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
+    DVG_REQUIRE(addend == nullptr || (mt == 4 && y_pool == nullptr && aligned16(addend)), DVG_ERR_SHAPE,
+                "dvg_winograd_output: addend needs m = 4, no pooled output, 16-byte alignment");
     DVG_REQUIRE((mt == 2 || mt == 4) && N > 0 && H > 0 && W > 0 && H % mt == 0 && W % mt == 0 && C > 0 && C % 4 == 0,
                 DVG_ERR_SHAPE, "dvg_winograd_output: m 2 or 4, H and W multiples of m, C %% 4 == 0 needed");
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output: bad act");
@@ -679,7 +700,7 @@ const float* m, const float* scale, const float* shift, float* y, float* y_pool,
         const long tiles = (long)N * (H / 4) * (W / 4);
 #define W4OUT(POOL_, V_, CW_)                                                                                             \
     hipLaunchKernelGGL((winograd4_output_kernel<POOL_, V_>), dim3(wgrid(tiles * (C / CW_))), dim3(256), 0, st, m, scale, shift, \
-                       y, y_pool, N, H, W, C / CW_, act, slope)
+                       y, y_pool, N, H, W, C / CW_, act, slope, addend)
         if (tiles * (C / 4) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x4, 4); else W4OUT(false, f32x4, 4); }
         else if (tiles * (C / 2) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x2, 2); else W4OUT(false, f32x2, 2); }
         else { if (y_pool) W4OUT(true, float, 1); else W4OUT(false, float, 1); }

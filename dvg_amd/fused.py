@@ -91,6 +91,24 @@ def winograd_weight(conv: nn.Module, m: int) -> torch.Tensor:
     return u
 
 
+# x half of a decoder block's upsample + concat conv in Winograd F(4x4) form when the skip half is hoisted (eval-mode
+# rollouts); DVG_UPCONV_WINOGRAD=0: the transposed-conv (K4) form
+UPCONV_WINOGRAD = os.environ.get("DVG_UPCONV_WINOGRAD", "1") != "0"
+_UPCONV_WINO_MAX = int(os.environ.get("DVG_UPCONV_WINO_MAX", "16"))     # largest output map side that takes this form
+
+
+def _winograd_weight_x(conv: nn.Module, c1: int) -> torch.Tensor:
+    """U = G g G^T of the x half W[:, :c1] of a concat conv (F(4x4,3x3)), cached per parameter version."""
+    slot = _slot(conv)
+    key = (_ver(conv.weight), c1)
+    hit = slot.get("wino_x")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    u = ops.winograd_weight(conv.weight.detach()[:, :c1].contiguous(), 4)
+    slot["wino_x"] = (key, u)
+    return u
+
+
 def gemm_weight(conv: nn.Module, kind: str) -> torch.Tensor:
     """Weights of the two dense ends as [N][K] GEMM operands in NHWC flatten order.
 
@@ -471,6 +489,19 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         if not pool:
             hs = _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE))
             if hs is not None:
+                if upsample and UPCONV_WINOGRAD:
+                    # x half of upsample + concat conv in Winograd form: the input transform reads x through the nearest-x2
+                    # upsampling, the hoisted skip half enters the output transform as `addend` - a quarter of the direct
+                    # form's multiplies (the K4 transposed-conv form below: 4/9), and the next layer of the block can take
+                    # its input transform straight from this layer's output transform
+                    n_, c1_, hx_, wx_ = x.shape
+                    cout_ = conv.weight.shape[0]
+                    # measured per layer pair at B = 64 (tools/_exp_up.py; this layer + the next one, K4 form -> Winograd form):
+                    # 8x8 139.8 -> 125.8 us, 16x16 145.2 -> 134.4 us, 32x32 (K = 128: bandwidth-bound GEMM) 174.7 -> 189.5 us
+                    if 2 * hx_ <= _UPCONV_WINO_MAX and winograd_tile(n_, c1_, 2 * hx_, 2 * wx_, cout_) == 4:
+                        to_v = not torch.is_grad_enabled() and _chain_to(next_conv, n_, cout_, 2 * hx_, 2 * wx_)
+                        return ops.conv3x3_winograd(x, _winograd_weight_x(conv, c1_), sc, sh, act=act, slope=slope,
+                                                    upsample=True, addend=hs[1], to_v=to_v)
                 if upsample and UPCONV_AS_CONVT:
                     return ops.convT4x4s2(x, None, _upconv_packed(conv, x.shape[1]), sc, sh, act=act, slope=slope,
                                           addend=hs[1])

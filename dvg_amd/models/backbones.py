@@ -181,8 +181,10 @@ class VggDecoder(nn.Module):
             mods = list(getattr(self, f"upc{s}"))
             for li, layer in enumerate(mods):
                 if isinstance(layer, vgg_layer):
-                    if first:  # nearest x2 + cat(skip) fused into the tile loader
-                        d = fused.conv3_bn_act(layer.main[0], layer.main[1], d, sk, upsample=True)
+                    if first:  # nearest x2 + cat(skip) fused into the tile loader (eval rollouts: x half in Winograd form)
+                        nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None
+                        d = fused.conv3_bn_act(layer.main[0], layer.main[1], d, sk, upsample=True,
+                                               next_conv=None if nxt is None else nxt.main[0])
                         first = False
                     else:      # an inner layer followed by another vgg_layer of the block may hand over an ops.WinoV
                         nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None

@@ -351,12 +351,15 @@ def winograd_pool_chain_ok(n, c, h, w):
     return h == w and h in (16, 32) and c % 64 == 0 and n > 0
 
 
-def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False, to_v=False):
+def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False, to_v=False,
+                     upsample=False, addend=None):
     """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
     transform; m (2 or 4) follows from u's leading dimension (16 or 36).  x may be a WinoV (the previous layer's to_v=True
     result: no input transform); to_v=True returns the NEXT layer's input transform as a WinoV instead of y (m = 4,
     winograd_chain_ok shapes: dvg_winograd_output_input); pool=True with to_v=True returns (y, WinoV of maxpool2x2(y)): the
-    last layer of an encoder stage handing over to the first layer of the next (dvg_winograd_output_pool_input)."""
+    last layer of an encoder stage handing over to the first layer of the next (dvg_winograd_output_pool_input).
+    upsample (m = 4): x is read through nearest-x2 upsampling (output 2H x 2W).  addend (m = 4, no pool): raw partial sums
+    in the output's shape, y = act((conv + addend) * scale + shift) - the hoisted skip half of a decoder block's first conv."""
     from_v = isinstance(x, WinoV)
     if from_v:
         n, c, h, w = x.shape
@@ -364,12 +367,20 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
         _dev_f32(x, "conv3x3_winograd.x")
         assert is_nhwc(x), "conv3x3_winograd: x must be NHWC in memory"
         n, c, h, w = x.shape
+        if upsample:
+            h, w = 2 * h, 2 * w
     cout, npos = u.shape[3], u.shape[0]
     mt = {16: 2, 36: 4}.get(npos, 0)
     if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, 16) or not winograd_ok(n, c, h, w, cout, mt):
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
-    if (from_v or to_v) and (mt != 4 or return_v):
-        raise RuntimeError("conv3x3_winograd: WinoV hand-over needs F(4x4,3x3) and no return_v")
+    if (from_v or to_v or upsample or addend is not None) and (mt != 4 or return_v):
+        raise RuntimeError("conv3x3_winograd: WinoV hand-over / upsample / addend need F(4x4,3x3) and no return_v")
+    if (upsample and from_v) or (addend is not None and pool):
+        raise RuntimeError("conv3x3_winograd: upsample excludes a WinoV input, addend excludes the pooled output")
+    if addend is not None:
+        _dev_f32(addend, "conv3x3_winograd.addend")
+        if tuple(addend.shape) != (n, cout, h, w) or not is_nhwc(addend):
+            raise RuntimeError(f"conv3x3_winograd: addend {tuple(addend.shape)} must be NHWC {(n, cout, h, w)}")
     if to_v and not (winograd_pool_chain_ok(n, cout, h, w) if pool else winograd_chain_ok(n, cout, h, w)):
         raise RuntimeError(f"conv3x3_winograd: to_v unsupported for output {(n, cout, h, w)} pool={pool}")
     t = n * (h // mt) * (w // mt)
@@ -382,7 +393,7 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
     else:
         v = torch.empty((npos, t, c), device=dev, dtype=torch.float32)
         _run("winograd_input", 0.0, 4.0 * (x.numel() + v.numel()), lib().dvg_winograd_input, _p(x), _p(v), n, h, w, c, mt,
-             _stream())
+             int(upsample), _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
     if to_v and pool:
@@ -394,12 +405,12 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
     if to_v:
         vn = torch.empty((npos, t, cout), device=dev, dtype=torch.float32)
         _run("winograd_output_input", 0.0, 4.0 * (m.numel() + vn.numel()), lib().dvg_winograd_output_input, _p(m), _p(scale),
-             _p(shift), _p(vn), n, h, w, cout, act, slope, _stream())
+             _p(shift), _p(vn), n, h, w, cout, act, slope, _p(addend), _stream())
         return WinoV(vn, (n, cout, h, w))
     y = nhwc_empty(n, cout, h, w, dev)
     yp = nhwc_empty(n, cout, h // 2, w // 2, dev) if pool else None
     _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
-         _p(y), _p(yp), n, h, w, cout, act, slope, mt, _stream())
+         _p(y), _p(yp), n, h, w, cout, act, slope, mt, _p(addend), _stream())
     if return_v:   # the input transform (P, T, C): the Winograd-form weight gradient's second operand (training)
         return ((y, yp) if pool else y), v
     return (y, yp) if pool else y

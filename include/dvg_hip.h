@@ -158,16 +158,21 @@ int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k
  *   dvg_winograd_output   y NHWC (N,H,W,Cout) (+ y_pool, MaxPool2d(2,2) vgg_64.py:49: pool windows never straddle tiles)
  * H, W multiples of m; C, Cout % 64 == 0; T % 128 == 0.                                                               */
 int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, int m, void* stream);
-int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, void* stream);
+/* upsample = 1 (ABI 6, m = 4): x is stored at (N, H/2, W/2, C) and read through nn.UpsamplingNearest2d(2) (vgg_64.py:93) -
+ * the x half of a decoder block's first conv in Winograd form; the upsampled tensor never exists.                       */
+int dvg_winograd_input(const float* x, float* v, int N, int H, int W, int C, int m, int upsample, void* stream);
 int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y, int NB, int H, int W, int Cin, int Cout,
                          void* stream);
+/* addend (ABI 6; optional, m = 4, no y_pool): raw partial sums (N,H,W,Cout) NHWC added before scale / shift / activation -
+ * the hoisted skip half of a decoder block's first conv, as in dvg_conv3x3_bn_act_v2.                                  */
 int dvg_winograd_output(const float* mm, const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
-                        int W, int C, int act, float slope, int m, void* stream);
+                        int W, int C, int act, float slope, int m, const float* addend, void* stream);
 /* dvg_winograd_output of layer L and dvg_winograd_input of layer L+1 in one pass (m = 4, H == W in {8, 16, 32}, C % 64 == 0) for
  * two consecutive eval-mode vgg_layers at one resolution whose intermediate activation has no other consumer (the inner
  * layers of a vgg block, vgg_64.py:24-43,70-87): mm (36, T, C) -> v_next (36, T, C); the activation is not written.     */
 int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H, int W,
-                              int C, int act, float slope, void* stream);
+                              int C, int act, float slope, const float* addend /* as dvg_winograd_output; may be NULL */,
+                              void* stream);
 /* Last layer of an encoder stage (vgg_64.py:51-56, `mp` :49): M (36, T, C) -> the stage's skip tensor y = act(scale * A^T M A
  * + shift) (N,H,W,C) NHWC AND V' (36, T / 4, C), the F(4x4,3x3) input transform of maxpool2x2(y) for the first layer of the
  * next stage.  The pooled tensor itself is never written.  H == W in {16, 32}, C % 64 == 0.  Bit-identical to

@@ -575,6 +575,41 @@ def test_decoder_stem_kernel_matches_generic_gemm(family):
         assert rel_err(got.permute(0, 2, 3, 1).reshape(B, -1), ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,H,C1,Cout", [(32, 4, 512, 512), (8, 8, 256, 256), (2, 16, 128, 128), (64, 8, 256, 256)])
+def test_upsample_conv3x3_winograd_with_hoisted_skip_half(N, H, C1, Cout):
+    """The x half of a decoder block's first conv (vgg_64.py:93,98-105) in Winograd F(4x4,3x3) form: the input transform
+    reads x through the nearest-x2 upsampling (dvg_winograd_input(upsample=1)), the hoisted skip half S enters the output
+    transform as `addend`: y = act((conv3x3(up2(x), W_x) + S) * scale + shift) against the fp64 reference and against the
+    transposed-conv (K4) form it replaces; handed over to the next layer (to_v) it must give that layer bit-identical results."""
+    from dvg_amd import ops
+    x = params.normal(3000, N, C1, H, H)
+    w = params.normal(3001, Cout, C1, 3, 3, scale=1.2 / (3 * C1 ** 0.5))
+    w2 = params.normal(3002, Cout, Cout, 3, 3, scale=1.2 / (3 * Cout ** 0.5))
+    sc, sh = 1 + 0.1 * params.normal(3003, Cout), 0.1 * params.normal(3004, Cout)
+    S = params.normal(3005, N, Cout, 2 * H, 2 * H, scale=0.3)
+    d = lambda t: t.to(dev())   # noqa: E731
+    up = F.interpolate(x, scale_factor=2, mode="nearest").double()
+    ref = F.leaky_relu((F.conv2d(up, w.double(), padding=1) + S.double()) * sc.double().view(1, -1, 1, 1) +
+                       sh.double().view(1, -1, 1, 1), 0.2)
+    assert ops.winograd_ok(N, C1, 2 * H, 2 * H, Cout, 4)
+    u = ops.winograd_weight(d(w), 4)
+    y = ops.conv3x3_winograd(nhwc(x), u, d(sc), d(sh), upsample=True, addend=nhwc(S))
+    assert y.shape == (N, Cout, 2 * H, 2 * H) and rel_err(y, ref) < 1e-4, rel_err(y, ref)
+    # the form it replaces (fused._upconv_packed): same result up to fp32 summation order
+    k4 = torch.zeros((Cout, C1, 4, 4))
+    for ty in range(3):
+        for tx in range(3):
+            k4[:, :, 2 - ty:4 - ty, 2 - tx:4 - tx] += w[:, :, ty:ty + 1, tx:tx + 1]
+    yk = ops.convT4x4s2(nhwc(x), None, ops.pack_igemm_weight(d(k4.permute(1, 0, 2, 3).contiguous()), transposed=True), d(sc),
+                        d(sh), addend=nhwc(S))
+    assert rel_err(y, yk) < 5e-5
+    if ops.winograd_chain_ok(N, Cout, 2 * H, 2 * H):
+        u2 = ops.winograd_weight(d(w2), 4)
+        v = ops.conv3x3_winograd(nhwc(x), u, d(sc), d(sh), upsample=True, addend=nhwc(S), to_v=True)
+        assert isinstance(v, ops.WinoV)
+        assert torch.equal(ops.conv3x3_winograd(v, u2, d(sc), d(sh)), ops.conv3x3_winograd(y, u2, d(sc), d(sh)))
+
+
 def test_rollout_precomputes_frozen_skip_halves_on_a_second_stream():
     """rollout.condition() computes the decoder's loop-invariant skip halves on a side stream while the LSTM warm-up runs;
     the rollout must equal the one without hoisting, eager and as a hipGraph."""

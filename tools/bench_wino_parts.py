@@ -43,16 +43,16 @@ def main():
             y = ops.nhwc_empty(N, Cout, H, H, dev)
             yp = ops.nhwc_empty(N, Cout, H // 2, H // 2, dev) if pool else None
             s = ops._stream
-            t_in = time_fn(lambda: lib().dvg_winograd_input(p(x), p(v), N, H, H, C, 4, s()))
+            t_in = time_fn(lambda: lib().dvg_winograd_input(p(x), p(v), N, H, H, C, 4, 0, s()))
             t_g = time_fn(lambda: lib().dvg_gemm_batched_k16(p(v), p(u), p(m), 36, T // 16, 16, C, Cout, s()))
-            t_out = time_fn(lambda: lib().dvg_winograd_output(p(m), p(sc), p(sh), p(y), p(yp), N, H, H, Cout, 1, 0.2, 4, s()))
+            t_out = time_fn(lambda: lib().dvg_winograd_output(p(m), p(sc), p(sh), p(y), p(yp), N, H, H, Cout, 1, 0.2, 4, None, s()))
             line = (f"{name:7s} {H:2d}x{H:<2d} {C:3d}->{Cout:3d}  in {t_in:7.1f} us {4e-6 * (x.numel() + v.numel()) / t_in:5.2f} TB/s | "
                     f"gemm {t_g:7.1f} us {2e-6 * 36 * T * C * Cout / t_g:6.1f} TF ({4e-6 * (v.numel() + m.numel() + u.numel()) / t_g:5.2f} TB/s) | "
                     f"out {t_out:7.1f} us {4e-6 * (m.numel() + y.numel() * (1.25 if pool else 1)) / t_out:5.2f} TB/s")
             tot["gemm"] += t_g
             if ops.winograd_chain_ok(N, Cout, H, H):
                 vn = torch.empty((36, T, Cout), device=dev)
-                t_f = time_fn(lambda: lib().dvg_winograd_output_input(p(m), p(sc), p(sh), p(vn), N, H, H, Cout, 1, 0.2, s()))
+                t_f = time_fn(lambda: lib().dvg_winograd_output_input(p(m), p(sc), p(sh), p(vn), N, H, H, Cout, 1, 0.2, None, s()))
                 line += f" | fused {t_f:7.1f} us {4e-6 * (m.numel() + vn.numel()) / t_f:5.2f} TB/s"
             else:
                 t_f = None
