@@ -10,8 +10,10 @@
 //     cycles of matrix work;
 //   * fragments are double-buffered in registers across taps, so the LDS reads of tap t+1 are in
 //     flight while the MFMAs of tap t issue;
-//   * weights are re-packed [Cin/16][tap][Cout][16]: a stage's weight tile is one contiguous 36 KB
-//     run (fully coalesced 16-B loads).
+//   * weights are re-packed [Cin/16][Cout/64][tap][64][row of 16 k-values]: a stage's weight tile is one
+//     contiguous 36 KB (55 KB as bf16 triples) run (fully coalesced 16-B loads);
+//   * DVG_BF16X3 (dvg_common.h, default): the products run on the bf16 matrix pipe - operands split exactly
+//     into three bf16 terms, activations when the stage tile is written to LDS, weights when they are packed.
 // BN is fixed at 64 (2 waves along N) so that two workgroups share a CU (<= 67 KB LDS each) and
 // cover each other's stage hand-offs.
 #include <cstdlib>
@@ -44,7 +46,7 @@
 #endif
 //  DVG_GEMM_WGS_PER_CU: workgroups per CU the 64-row GEMM-mode tile is compiled for (register budget 512 / this per lane)
 #ifndef DVG_GEMM_WGS_PER_CU
-#define DVG_GEMM_WGS_PER_CU 4
+#define DVG_GEMM_WGS_PER_CU (DVG_BF16X3 ? 3 : 4)
 #endif
 
 namespace dvg {
@@ -57,7 +59,7 @@ enum { M2_CONV3 = 0, M2_CONV4S2 = 1, M2_CONVT4S2 = 2, M2_GEMM = 3 };
 struct Igemm2Params {
     const float* x;
     const float* skip;
-    const float* w;      // packed [Cin/16][taps][Cout][16]
+    const float* w;      // packed [Cin/16][Cout/64][taps][64][DVG_WROW] (dvg_pack_conv_weight_k16); GEMM: [image][Cout/64][Cin/16][64][DVG_WROW]
     const float* scale;
     const float* shift;
     float* y;
@@ -114,12 +116,20 @@ struct Cfg2 {
     static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : (GEMM ? DVG_GEMM_GT : 4));  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
-    static constexpr int KC = 16, LD = 20;  // 80-B LDS rows: b128 lane groups land on distinct 16-B slots
+    static constexpr bool X3 = DVG_BF16X3 != 0;
+    // LDS rows (floats).  f32: 16 k-values + 4 of padding (80 B: b128 lane groups land on distinct 16-B slots).  bf16 triples:
+    // 3 planes x 16 bf16 = 96 B; the weight rows (and the GEMM modes' A rows, whose tap offsets are whole slabs) swap the two
+    // 16-B halves of a plane on rows with bit 3 set instead of padding, the conv modes' halo rows are padded to 112 B (their
+    // tap offsets move a lane to another row, so the swap cannot be folded into a per-lane base).
+    static constexpr int KC = 16, LD = X3 ? (GEMM ? 24 : 28) : 20, LDB = X3 ? 24 : 20, WROW = DVG_WROW;
+    static constexpr int NP = X3 ? 3 : 2, PSTEP = X3 ? 8 : 4;   // 16-B pieces of a lane's fragment (planes / k halves), floats between them
+    static constexpr int B_TILE4 = GT * 64 * WROW / 4;          // float4s of a stage's packed weight tile
+    static constexpr int NLB = (B_TILE4 + 255) / 256;            // of them per thread
     static constexpr int NLA1 = (HP * 4 + 255) / 256;                                 // float4 loads per thread per slab
     static constexpr int NLA = NLA1 * (GEMM ? GT : 1);
     static constexpr int SLAB = NLA1 * 64 * LD;                                       // floats of one A slab (GEMM mode)
     // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
-    static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LD;
+    static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LDB;
     static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
 };
@@ -128,8 +138,8 @@ template <int MODE, int TI, int TH, int TW>
 __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : 2) void conv_igemm2_kernel(const Igemm2Params p) {
     using C = Cfg2<MODE, TI, TH, TW>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
-                  BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1;
-    constexpr bool GEMM = C::GEMM;
+                  BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1, LDB = C::LDB, NP = C::NP, PSTEP = C::PSTEP, NLB = C::NLB;
+    constexpr bool GEMM = C::GEMM, X3 = C::X3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + C::A_FLOATS;
@@ -164,9 +174,10 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     for (int mt = 0; mt < MT; ++mt) {
         const int m = wm * (C::BM / 2) + mt * 32 + l31;
         const int ti = m / (TH * TW), r = m % (TH * TW);
-        a_base[mt] = ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * LD + hh * 8;
+        const int pos = (ti * HH + (r / TW) * S) * HW + (r % TW) * S;
+        a_base[mt] = pos * LD + (X3 ? (hh ^ (GEMM ? (pos >> 3) & 1 : 0)) * 4 : hh * 8);
     }
-    const int b_base = (wn * 32 + l31) * LD + hh * 8;
+    const int b_base = (wn * 32 + l31) * LDB + (X3 ? (hh ^ ((l31 >> 3) & 1)) * 4 : hh * 8);
 
     f32x16 acc[MT];
 #pragma unroll
@@ -197,12 +208,6 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             offx[GEMM ? i % NLA1 : i] = (aoff_t)(ok ? ((((long)(GEMM ? 0 : n) * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : 0);
         if (!GEMM) offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
     }
-    const int brow = tid >> 2, bq = tid & 3;  // weight tile: one float4 per thread per tap
-
-    auto tap_w = [&](int grp, int tt) -> int {
-        if (MODE == M2_CONVT4S2) return (2 + py - 2 * (tt >> 1)) * 4 + (2 + px - 2 * (tt & 1));
-        return grp * GT + tt;
-    };
     auto tap_lds = [&](int grp, int tt) -> int {
         if (GEMM) return tt * C::SLAB;
         int th, tw;
@@ -227,31 +232,56 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
         }
     };
-    auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[GT]) {
+    // a stage's weight tile is ONE contiguous run of the packed tensor (GT slots x 64 rows): thread t takes float4 t + 256 j
+    auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[NLB]) {
+        const float* tile;
+        if (GEMM) tile = ld_w + ((size_t)nb * (Cin / C::KC) + chunk) * (64 * C::WROW);
+        else tile = wbase + (((size_t)chunk * p.nblk_n + nb) * C::NTAPS + (MODE == M2_CONVT4S2 ? par * 4 : grp * GT)) * (64 * C::WROW);
 #pragma unroll
-        for (int tt = 0; tt < GT; ++tt)
-            rb[tt] = *reinterpret_cast<const f32x4*>(
-                (GEMM ? ld_w : wbase) + (GEMM ? ((size_t)(chunk + tt) * p.Cout + nb0 + brow) * 16 + bq * 4
-                              : (((size_t)chunk * C::NTAPS + tap_w(grp, tt)) * p.Cout + nb0 + brow) * 16 + bq * 4));
+        for (int j = 0; j < NLB; ++j) {
+            int i = tid + j * 256;
+            if (C::B_TILE4 % 256) i = min(i, C::B_TILE4 - 1);   // the last pass of a tile that is not whole passes re-reads its last float4
+            rb[j] = reinterpret_cast<const f32x4*>(tile)[i];
+        }
     };
     auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
+            const int hp = idx >> 2, q = idx & 3;
             // halo / out-of-image slots already hold zeros (gload_a read dvg_zero_slot for them); rows >= HP: padding
-            *reinterpret_cast<f32x4*>(&As[(i / NLA1) * C::SLAB + (idx >> 2) * LD + (idx & 3) * 4]) = ra[i];
+            if constexpr (X3) {
+                // the thread's four k-values as three bf16 quadruples, 8 bytes into each plane of the row
+                u32x2_t h, m, l;
+                unsigned t0, t1, t2;
+                bf16x3_split_pair(ra[i][0], ra[i][1], t0, t1, t2);
+                h[0] = t0; m[0] = t1; l[0] = t2;
+                bf16x3_split_pair(ra[i][2], ra[i][3], t0, t1, t2);
+                h[1] = t0; m[1] = t1; l[1] = t2;
+                float* d = &As[(i / NLA1) * C::SLAB + hp * LD + ((q >> 1) ^ (GEMM ? (hp >> 3) & 1 : 0)) * 4 + (q & 1) * 2];
+                *reinterpret_cast<u32x2_t*>(d) = h;
+                *reinterpret_cast<u32x2_t*>(d + 8) = m;
+                *reinterpret_cast<u32x2_t*>(d + 16) = l;
+            } else {
+                *reinterpret_cast<f32x4*>(&As[(i / NLA1) * C::SLAB + hp * LD + q * 4]) = ra[i];
+            }
         }
     };
-    auto lds_store_b = [&](const f32x4 (&rb)[GT]) {
+    auto lds_store_b = [&](const f32x4 (&rb)[NLB]) {
 #pragma unroll
-        for (int tt = 0; tt < GT; ++tt) *reinterpret_cast<f32x4*>(&Bs[(tt * BN + brow) * LD + bq * 4]) = rb[tt];
+        for (int j = 0; j < NLB; ++j) {
+            int i = tid + j * 256;
+            if (C::B_TILE4 % 256) i = min(i, C::B_TILE4 - 1);
+            if constexpr (X3) reinterpret_cast<f32x4*>(Bs)[i] = rb[j];           // the packed tile IS the LDS image
+            else *reinterpret_cast<f32x4*>(&Bs[(i >> 2) * LDB + (i & 3) * 4]) = rb[j];
+        }
     };
 
     // chunk = index of a 16-channel chunk; a stage consumes CPS of them (1, or GT slabs in GEMM mode)
     constexpr int CPS = C::CHUNKS_PER_STAGE;
     const int chunk_begin = split * p.cps;
     const int chunk_end = min(Cin / C::KC, chunk_begin + p.cps);
-    f32x4 ra[NLA], rb[GT];
+    f32x4 ra[NLA], rb[NLB];
     unsigned long long clk0 = 0, wclk0 = 0;
     if (p.clk) {   // wave-uniform condition: the stamps live in SGPRs (under `threadIdx.x == 0` they cost 8 VGPRs kernel-wide)
         clk0 = clock64();
@@ -282,15 +312,17 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         }
 
         // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
-        f32x4 fa[2][MT][2], fb[2][2];
+        // a lane's fragment of a tap: NP 16-byte pieces per 32-row tile - f32: its k-values 0..3 and 4..7 of the lane's
+        // half of the chunk; bf16 triples: its eight k-values in each of the planes h, m, l
+        f32x4 fa[2][MT][NP], fb[2][NP];
         {
             const int ao = tap_lds(grp, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NP; ++j) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    fa[0][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
-                fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + j * 4]);
+                    fa[0][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * PSTEP]);
+                fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + j * PSTEP]);
             }
         }
 #pragma unroll
@@ -299,11 +331,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             if (tt + 1 < GT) {
                 const int ao = tap_lds(grp, tt + 1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NP; ++j) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * 4]);
-                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LD + j * 4]);
+                        fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * PSTEP]);
+                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LDB + j * PSTEP]);
                 }
             }
             constexpr bool overlap_writes = DVG_WRITE_OVERLAP && has_next;
@@ -317,20 +349,40 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     if (DVG_ABLATE != 4) lds_store_b(rb);
                 }
             }
+            if constexpr (X3) {
+                // six bf16 MFMAs per 32 x 32 tile and K = 16 slab, small terms first: (l,h) (m,m) (h,l) (m,h) (h,m) (h,h)
+                auto mm = [&](int mt, int pa, int pb) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[cur][mt][pa]),
+                                                                      __builtin_bit_cast(bf16x8_t, fb[cur][pb]), acc[mt], 0, 0, 0);
+                };
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 2, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 1, 1);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][j][e], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 1, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][j][e], acc[mt], 0, 0, 0);
+            }
             // Pin the software pipeline: hipcc otherwise sinks the next tap's ds_reads down to their first use
             // (ds_read x3 -> s_waitcnt -> mfma x8), exposing the LDS latency every 8 MFMAs.  One ds_read_b128 per two
             // MFMAs, issued a full tap (16 / 8 MFMAs) ahead of its consumer.
-            constexpr int NREAD = 2 * MT + 2, NMFMA = 8 * MT;
+            constexpr int NREAD = NP * (MT + 1), NMFMA = (X3 ? 6 : 8) * MT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
             // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
-            constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? GT : 0);
+            constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? NLB : 0);
             constexpr int POLICY = DVG_VMEM_POLICY;
             // policy 4 (default): spread over the taps that are followed by another tap, starting at tap 2 in the 9-tap
             // mode and at tap 0 in the 4- / 8-tap modes, as many per tap as it takes to place ALL of them (with the
@@ -348,11 +400,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
                 for (int r = 0; r < NREAD; ++r) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
                 }
-                if (NMFMA > 2 * NREAD) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NREAD, 0);
+                if (NMFMA > MPR * NREAD) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - MPR * NREAD, 0);
             } else if (overlap_writes) {
-                constexpr int NW = (next_a ? NLA : 0) + GT;
+                constexpr int NW = (next_a ? NLA * (X3 ? 3 : 1) : 0) + NLB;
 #pragma unroll
                 for (int r = 0; r < NW; ++r) {
                     if (r < NMFMA) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -834,24 +886,38 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
 
 __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
                                 int kw, int transposed) {
-    // dst[chunk][t][co][16]  <-  conv: w[co][ci][a][b]   convT: w[ci][co][KH-1-a][KW-1-b]
+    // dst[chunk][co / 64][slot][co % 64][row of 16 k-values]  <-  conv: w[co][ci][a][b]   convT: w[ci][co][KH-1-a][KW-1-b]
+    // slot = the tap t = a * kw + b, except for the 4 x 4 taps of a transposed conv (the stride-2 transposed mode): there the
+    // four taps an output parity (py, px) uses are consecutive, slot = (py * 2 + px) * 4 + tt with tap row 2 + py - 2 (tt >> 1)
+    // and tap column 2 + px - 2 (tt & 1), so that a stage's weight tile is contiguous in every mode
     const long total = (long)cout * cin * kh * kw;
+    const int nblk = cout >> 6, taps = kh * kw;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = i & 15;
         long r = i >> 4;
         const int co = r % cout; r /= cout;
-        const int t = r % (kh * kw);
-        const int chunk = r / (kh * kw);
+        const int t = r % taps;
+        const int chunk = r / taps;
         const int ci = chunk * 16 + k, a = t / kw, b = t % kw;
         const long j = transposed ? ((((long)ci * cout + co) * kh + (kh - 1 - a)) * kw + (kw - 1 - b))
                                   : ((((long)co * cin + ci) * kh + a) * kw + b);
-        dst[i] = src[j];
+        int slot = t;
+        if (transposed && kh == 4 && kw == 4) {
+            const int py = a & 1, px = b & 1;
+            slot = (py * 2 + px) * 4 + ((2 + py - a) >> 1) * 2 + ((2 + px - b) >> 1);
+        }
+        wrow_store(dst, (((size_t)chunk * nblk + (co >> 6)) * taps + slot) * 64 + (co & 63), co & 63, k, src[j]);
     }
 }
 
 }  // namespace dvg
 
 using namespace dvg;
+
+// 0: the native f32 MFMA; 1: fp32 operands as exact bf16 triples on the bf16 MFMA (dvg_common.h)
+extern "C" int dvg_mfma_mode(void) { return DVG_BF16X3 ? 1 : 0; }
+// floats per packed weight row (16 k-values of one output channel): what dvg_pack_conv_weight_k16 / dvg_winograd_weight write
+extern "C" int dvg_packed_row_floats(void) { return DVG_WROW; }
 
 extern "C" void dvg_debug_set_clockbuf(void* buf, unsigned records) {   // records of 8 x u64, one per workgroup
     g_clk = (unsigned long long*)buf;
@@ -861,8 +927,8 @@ extern "C" void dvg_debug_set_clockbuf(void* buf, unsigned records) {   // recor
 extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                                         int transposed, void* stream) {
     DVG_REQUIRE(w && w_packed, DVG_ERR_NULL, "dvg_pack_conv_weight_k16: NULL pointer");
-    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0 && kh > 0 && kw > 0, DVG_ERR_SHAPE,
-                "dvg_pack_conv_weight_k16: Cin must be a multiple of 16");
+    DVG_REQUIRE(cout > 0 && cout % 64 == 0 && cin > 0 && cin % 16 == 0 && kh > 0 && kw > 0, DVG_ERR_SHAPE,
+                "dvg_pack_conv_weight_k16: Cin must be a multiple of 16, Cout of 64");
     const long total = (long)cout * cin * kh * kw;
     long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -992,7 +1058,7 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     DVG_REQUIRE(Cin % (16 * DVG_GEMM_GT) == 0 && H % 8 == 0 && W % 8 == 0, DVG_ERR_SHAPE,
                 "dvg_gemm_batched_k16: Cin=%d must be a multiple of %d, H=%d W=%d multiples of 8", Cin, 16 * DVG_GEMM_GT, H, W);
     DVG_REQUIRE((long)H * W * Cin < (1L << 31), DVG_ERR_SHAPE, "dvg_gemm_batched_k16: image of %d x %d x %d floats too large", H, W, Cin);
-    p.w_image_stride = (long)Cin * Cout;
+    p.w_image_stride = (long)Cin / 16 * Cout * DVG_WROW;
     float* workspace = nullptr;
     const long workspace_floats = 0;
     int Hg = H, Wg = W, ti, th, tw;

@@ -370,7 +370,7 @@ __global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, c
 
 using namespace dvg;
 
-extern "C" int dvg_abi_version(void) { return 6; }  // 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision
+extern "C" int dvg_abi_version(void) { return 7; }  // 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
 extern "C" const char* dvg_last_error(void) { return err_buf(); }
 
 #define PACK_ENTRY(NAME, TR, UN, A0, A1)                                                                        \

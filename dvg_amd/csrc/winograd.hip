@@ -36,7 +36,8 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
             const float r[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                u[(((size_t)(a * 4 + b) * (cin / 16) + ci / 16) * cout + co) * 16 + (ci & 15)] = r[b];
+                wrow_store(u, (((size_t)(a * 4 + b) * (cout >> 6) + (co >> 6)) * (cin / 16) + ci / 16) * 64 + (co & 63), co & 63,
+                           ci & 15, r[b]);
         }
     }
 }
@@ -184,8 +185,8 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                u[(((size_t)(a * 6 + b) * (cin / 16) + ci / 16) * cout + co) * 16 + (ci & 15)] =
-                    t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                wrow_store(u, (((size_t)(a * 6 + b) * (cout >> 6) + (co >> 6)) * (cin / 16) + ci / 16) * 64 + (co & 63), co & 63,
+                           ci & 15, t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
     }
 }
 
@@ -554,8 +555,8 @@ using namespace dvg;
 
 extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, int m, void* stream) {
     DVG_REQUIRE(w_oihw && u_k16, DVG_ERR_NULL, "dvg_winograd_weight: NULL pointer");
-    DVG_REQUIRE(cout > 0 && cin > 0 && cin % 16 == 0 && (m == 2 || m == 4), DVG_ERR_SHAPE,
-                "dvg_winograd_weight: Cin must be a multiple of 16, m 2 or 4");
+    DVG_REQUIRE(cout > 0 && cout % 64 == 0 && cin > 0 && cin % 16 == 0 && (m == 2 || m == 4), DVG_ERR_SHAPE,
+                "dvg_winograd_weight: Cin must be a multiple of 16, Cout of 64, m 2 or 4");
     if (m == 2)
         hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            u_k16, cout, cin);

@@ -130,23 +130,30 @@ def pack_convT_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def packed_row_floats() -> int:
+    """Floats per packed weight row (the 16 k-values of one output channel): 16 for the native f32-MFMA build of the library,
+    24 (three planes of 16 bf16) for the default build, whose fp32 products run as exact bf16 triples on the bf16 MFMA."""
+    return int(lib().dvg_packed_row_floats())
+
+
 def pack_igemm_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-    """Weight in the layout the implicit-GEMM kernels read: [Cin/16][taps][Cout][16]."""
+    """Weight in the layout the implicit-GEMM kernels read; logical shape [Cin/16][taps][Cout][row], in memory
+    [Cin/16][Cout/64][tap slot][64][row] (conv_igemm2.hip: pack_k16_kernel).  Cout % 64 == 0."""
     _dev_f32(w, "pack_igemm_weight")
     w = w.detach().contiguous()
     if transposed:
         ci, co, kh, kw = w.shape
     else:
         co, ci, kh, kw = w.shape
-    out = torch.empty((ci // 16, kh * kw, co, 16), device=w.device, dtype=torch.float32)
+    out = torch.empty((ci // 16, kh * kw, co, packed_row_floats()), device=w.device, dtype=torch.float32)
     check(lib().dvg_pack_conv_weight_k16(_p(w), _p(out), co, ci, kh, kw, int(transposed), _stream()), "pack_k16")
     return out
 
 
 def _wp_dims(wp: torch.Tensor):
-    """(taps, cout, cin) of a packed igemm weight [Cin/16][taps][Cout][16]."""
-    if wp.dim() != 4 or wp.shape[3] != 16:
-        raise RuntimeError(f"packed igemm weight must be [Cin/16][taps][Cout][16], got {tuple(wp.shape)}")
+    """(taps, cout, cin) of a packed igemm weight [Cin/16][taps][Cout][row]."""
+    if wp.dim() != 4 or wp.shape[3] != packed_row_floats():
+        raise RuntimeError(f"packed igemm weight must be [Cin/16][taps][Cout][{packed_row_floats()}], got {tuple(wp.shape)}")
     return wp.shape[1], wp.shape[2], wp.shape[0] * 16
 
 
@@ -308,13 +315,13 @@ def conv3x3(x, skip, wp, scale, shift, *, upsample=False, act=ACT_LRELU, slope=0
 # ----------------------------------------------------------------------------------
 def winograd_weight(w: torch.Tensor, m: int = 2) -> torch.Tensor:
     """U = G g G^T of a Conv2d weight (Cout,Cin,3,3) for F(m x m, 3x3), in the k16 layout of the (m+2)^2 batched GEMMs:
-    ((m+2)^2, Cin/16, 1, Cout, 16)."""
+    logical shape ((m+2)^2, Cin/16, 1, Cout, row), in memory [(m+2)^2][Cout/64][Cin/16][64][row]."""
     _dev_f32(w, "winograd_weight")
     w = w.detach().contiguous()
     co, ci, kh, kw = w.shape
     if (kh, kw) != (3, 3) or ci % 16 or m not in (2, 4):
         raise RuntimeError("winograd_weight: (Cout, Cin % 16 == 0, 3, 3) and m in (2, 4) expected")
-    u = torch.empty(((m + 2) ** 2, ci // 16, 1, co, 16), device=w.device, dtype=torch.float32)
+    u = torch.empty(((m + 2) ** 2, ci // 16, 1, co, packed_row_floats()), device=w.device, dtype=torch.float32)
     check(lib().dvg_winograd_weight(_p(w), _p(u), co, ci, m, _stream()), "winograd_weight")
     return u
 
@@ -371,7 +378,7 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
             h, w = 2 * h, 2 * w
     cout, npos = u.shape[3], u.shape[0]
     mt = {16: 2, 36: 4}.get(npos, 0)
-    if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, 16) or not winograd_ok(n, c, h, w, cout, mt):
+    if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, packed_row_floats()) or not winograd_ok(n, c, h, w, cout, mt):
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
     if (from_v or to_v or upsample or addend is not None) and (mt != 4 or return_v):
         raise RuntimeError("conv3x3_winograd: WinoV hand-over / upsample / addend need F(4x4,3x3) and no return_v")

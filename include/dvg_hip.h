@@ -107,10 +107,23 @@ int dvg_unpack_convT_weight(const float* w_packed, float* w_iohw, int cin, int c
 int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
 
 /* The three implicit-GEMM convs (conv_igemm2.hip; the "_v2" suffix is historical: the first
- * schedule and its un-suffixed entry points were retired in ABI 3).  Weights are packed
- * [Cin/16][tap][Cout][16] by dvg_pack_conv_weight_k16 (transposed != 0: ConvTranspose2d weight
- * (Cin,Cout,KH,KW), flipped) and `stats` has dvg_conv_stats_rows_v2(...) rows.
- * C1, C2 multiples of 16; Cout multiple of 64.                                          */
+ * schedule and its un-suffixed entry points were retired in ABI 3).  Weights are packed by
+ * dvg_pack_conv_weight_k16 (transposed != 0: ConvTranspose2d weight (Cin,Cout,KH,KW), flipped) into
+ * Cin/16 * KH*KW * Cout rows of dvg_packed_row_floats() floats, [Cin/16][Cout/64][tap slot][64][row]
+ * (a 4x4 transposed pack orders the slots by output parity: it feeds dvg_convT4x4s2_bn_act_v2, a 4x4
+ * plain pack dvg_conv4x4s2_bn_act_v2, a 3x3 pack dvg_conv3x3_bn_act_v2), and `stats` has
+ * dvg_conv_stats_rows_v2(...) rows.  C1, C2 multiples of 16; Cout multiple of 64.
+ *
+ * ABI 7 - arithmetic of the implicit-GEMM kernels.  dvg_mfma_mode() == 1 (the default build): every fp32
+ * operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significant bits; activations when a tile is
+ * staged in LDS, weights when they are packed: a packed row is 3 x 16 bf16 = 24 floats) and a K = 16 slab
+ * of the product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped cross terms are
+ * below 2^-23 |a||b|, under the rounding of one fp32 product, and the measured error against fp64 is
+ * that of the f32 MFMA or below.  dvg_mfma_mode() == 0 (library built with -DDVG_BF16X3=0): the native
+ * v_mfma_f32_32x32x2_f32, packed rows of 16 floats.  Callers size packed buffers with
+ * dvg_packed_row_floats() and are otherwise unaffected.                                          */
+int dvg_mfma_mode(void);
+int dvg_packed_row_floats(void);
 int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                              int transposed, void* stream);
 /* Split-K: when a layer would launch < 384 workgroups (deep, narrow layers; small per-GPU batches) and the caller

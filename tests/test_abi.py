@@ -33,7 +33,7 @@ def test_binding_table_covers_header():
     from dvg_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dvg_abi_version() == 6
+    assert lib.dvg_abi_version() == 7
 
 
 def test_host_side_checks_reject_bad_shapes_without_gpu():
