@@ -32,6 +32,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 16 x the f32 MFMA rate (v_mfma_f32_32x32x16_bf16)
+# the default library forms every fp32 product slab as SIX bf16 MFMAs on exact bf16 triples (include/dvg_hip.h, ABI 7): the
+# roof of an fp32 kernel in that formulation is the bf16 peak / 6
+PEAK_F32_AS_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+F32MFMA_LIB = os.path.join(ROOT, "dvg_amd", "csrc", "libdvg_hip_f32mfma.so")
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command, committed under
 # profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
 # direct-form FLOPs of one B = 64, 10-in/10-out rollout (19 encoder + 10 decoder passes + 19 LSTM steps)
@@ -60,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-families", action="store_true", help="skip the other model family")
     ap.add_argument("--no-roofline", action="store_true", help="skip the eager HIP-event leg (timeline profiling runs)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training leg")
+    ap.add_argument("--no-f32mfma-leg", action="store_true",
+                    help="skip the comparison run on the native f32-MFMA build of the library (a child process, N = 1 only)")
     ap.add_argument("--train-iters", type=int, default=6)
     ap.add_argument("--train-full-graph", action="store_true",
                     help="with several ranks, also try the iteration as ONE hipGraph with the RCCL all-reduces captured "
@@ -321,10 +328,19 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     if tfile and args.batch == 64 and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
         traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["traffic_bytes_per_launch"]
         tsrc = f"profiles/{tfile}: committed rocprofv3 PMC passes of this command (constant, NOT measured by this run)"
-    res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                       "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+    from dvg_amd import _lib
+    x3 = _lib.lib().dvg_mfma_mode() == 1 and dom in ("winograd_gemm", "conv3x3_igemm", "conv4x4s2_igemm", "convT4x4s2_igemm")
+    peak = PEAK_F32_AS_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                       "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                        "traffic_source": tsrc,
-                       "achieved_is": "EXECUTED flops of the kernel / its HIP-event time (kernel quality against the fp32 MFMA roof)",
+                       "achieved_is": "EXECUTED fp32 flops of the kernel (2 x its multiply-adds, each counted once) / its HIP-event time",
+                       "peak_is": ("bf16 dense MFMA peak / 6: the kernel forms each fp32 product slab as six v_mfma_f32_32x32x16_bf16 "
+                                   "on exact bf16 triples, so `frac` is also the busy fraction of the bf16 matrix pipe"
+                                   if x3 else "f32-input dense MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                       # the same achieved rate against the NATIVE f32-MFMA roof (the peak r01 / r02 lines were priced on): above
+                       # 1 means the kernel beats anything the f32-input MFMA could do
+                       "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                        "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
                        "executed_flops_per_launch": round(a["flops"] / a["launches"]),
                        "algorithmic_flops_per_launch": round(a["alg_flops"] / a["launches"]),
@@ -374,6 +390,34 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
                           "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
                       for k, v in agg.items()}
     return res
+
+
+def f32mfma_leg(args) -> dict:
+    """The SAME rollout measurement on the native f32-MFMA build of the library (libdvg_hip_f32mfma.so, `make f32mfma`),
+    in a child process (one process holds one build of the library), after this process's own timed region: what the bf16-triple
+    arithmetic buys, measured on the same box minutes apart.  Reported beside `value`, never as `value`."""
+    import subprocess
+    if not os.path.exists(F32MFMA_LIB):
+        return {"skipped": "dvg_amd/csrc/libdvg_hip_f32mfma.so not built (make -C dvg_amd/csrc f32mfma)"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--model", args.model, "--batch", str(args.batch), "--n_past", str(args.n_past), "--n_future", str(args.n_future),
+           "--seed", str(args.seed), "--inflight", str(args.inflight), "--no-families", "--no-cpu-baseline", "--no-train-leg",
+           "--no-f32mfma-leg"] + (["--no-graph"] if args.no_graph else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DVG_HIP_LIB"] = F32MFMA_LIB
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "timed out"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"skipped": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+    d = json.loads(lines[-1])
+    rf = d.get("roofline", {})
+    return {"library": "dvg_amd/csrc/libdvg_hip_f32mfma.so (-DDVG_BF16X3=0)", "value": d["value"], "ms_per_step": d["ms_per_step"],
+            "single_chain": d.get("single_chain"),
+            "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us", "launches_per_step",
+                                                "kernel_time_sum_ms", "transform_share")}}
 
 
 def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
@@ -497,7 +541,7 @@ def main():
         sys.exit(2)
     ctx = Ctx(args)
 
-    from dvg_amd import fused as fused_mod
+    from dvg_amd import _lib, fused as fused_mod
     main_res = measure_rollout(ctx, args, args.model, args.steps, args.warmup)
     result = {
         "metric": "predicted frames/sec at 64x64, batch 64, 10-in/10-out",
@@ -505,6 +549,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
         "single_chain": main_res.get("single_chain"), "per_rank_ms_per_step": main_res.get("per_rank_ms_per_step"),
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # how the implicit-GEMM kernels form their fp32 products (dvg_mfma_mode(), include/dvg_hip.h): inputs, outputs, weights,
+        # accumulators and every other kernel are fp32 in both builds
+        "arithmetic": ("fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per K=16 slab, fp32 accumulate "
+                       "(dropped cross terms < 2^-23 |a||b|; measured error vs fp64 <= the f32 MFMA's)"
+                       if _lib.lib().dvg_mfma_mode() == 1 else "native f32-input MFMA"),
         "config": {"workload": f"Moving-MNIST 64x64 rollout (generate_frames.py make_gifs sample loop), "
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "
                                f"{args.n_past}-in/{args.n_future}-out", "model_family": args.model,
@@ -550,6 +599,9 @@ def main():
         if "families" in result:
             for other, fam in result["families"].items():
                 fam["cpu_baseline"] = cpu_baseline(other, args.batch, args.n_past, n_eval, args.seed, budget_s=4.0)
+    if (ctx.rank == 0 and ctx.world == 1 and not args.no_f32mfma_leg and _lib.lib().dvg_mfma_mode() == 1
+            and "DVG_HIP_LIB" not in os.environ):
+        result["f32_mfma_build"] = f32mfma_leg(args)
     if not args.no_train_leg:
         ctx.barrier()
         result["train"] = train_leg(ctx, args)

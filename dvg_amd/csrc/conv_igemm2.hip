@@ -99,21 +99,26 @@ static unsigned g_clk_cap = 0;
 // global-load latency for its first A loads (r03, found in the ISA of all nine instantiations).
 __device__ __attribute__((aligned(16))) float dvg_zero_slot[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int MODE, int TI, int TH, int TW>
+// NT: 32-column tiles per wave (workgroup tile BM x 64 NT).  NT = 2 exists for the bf16-triple GEMM mode only: with the
+// matrix pipe 2.7x faster the LDS, not the MFMA, bounds a 128 x 64 tile (per MFMA 384 B of tile stores at ~80 B/clk and
+// 768 B of fragment reads at 256 B/clk: 97 % of the LDS cycles); 128 x 128 with 64 x 64 per wave needs 256 + 512 B (65 %).
+template <int MODE, int TI, int TH, int TW, int NT_ = 1>
 struct Cfg2 {
+    static constexpr int NT = NT_;
     static constexpr bool GEMM = MODE == M2_GEMM;
     static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;
     static constexpr int SPAN = GEMM ? 1 : ((MODE == M2_CONV4S2) ? 4 : 3);
     static constexpr int HH = (TH - 1) * S + SPAN, HW = (TW - 1) * S + SPAN;
     static constexpr int HP = TI * HH * HW;
-    static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64;
+    static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64 * NT;
     static constexpr int NTAPS = GEMM ? 1 : ((MODE == M2_CONV3) ? 9 : 16);
     // DVG_GEMM_GT: 16-channel slabs per stage of the GEMM modes.  4 (K = 64, 60 KB of LDS with the 128-row tile); 8 was
     // measured 10-25 % slower on every Winograd shape (80 KB per workgroup: the second workgroup no longer fits the CU).
 #ifndef DVG_GEMM_GT
 #define DVG_GEMM_GT 4
 #endif
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : (GEMM ? DVG_GEMM_GT : 4));  // taps (GEMM: 16-channel slabs) per stage
+    // (NT = 2: two slabs, K = 32, so that two 48 KB workgroups share a CU)
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : (GEMM ? (NT == 2 ? 2 : DVG_GEMM_GT) : 4));  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr bool X3 = DVG_BF16X3 != 0;
@@ -123,8 +128,10 @@ struct Cfg2 {
     // tap offsets move a lane to another row, so the swap cannot be folded into a per-lane base).
     static constexpr int KC = 16, LD = X3 ? (GEMM ? 24 : 28) : 20, LDB = X3 ? 24 : 20, WROW = DVG_WROW;
     static constexpr int NP = X3 ? 3 : 2, PSTEP = X3 ? 8 : 4;   // 16-B pieces of a lane's fragment (planes / k halves), floats between them
-    static constexpr int B_TILE4 = GT * 64 * WROW / 4;          // float4s of a stage's packed weight tile
+    static constexpr int BLK4 = GT * 64 * WROW / 4;             // float4s of a stage's packed weight tile, per 64-column block
+    static constexpr int B_TILE4 = NT * BLK4;
     static constexpr int NLB = (B_TILE4 + 255) / 256;            // of them per thread
+    static_assert(NT == 1 || (DVG_BF16X3 != 0 && MODE == M2_GEMM && BLK4 % 256 == 0), "NT = 2: bf16-triple GEMM mode only");
     static constexpr int NLA1 = (HP * 4 + 255) / 256;                                 // float4 loads per thread per slab
     static constexpr int NLA = NLA1 * (GEMM ? GT : 1);
     static constexpr int SLAB = NLA1 * 64 * LD;                                       // floats of one A slab (GEMM mode)
@@ -134,9 +141,9 @@ struct Cfg2 {
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
 };
 
-template <int MODE, int TI, int TH, int TW>
+template <int MODE, int TI, int TH, int TW, int NT = 1>
 __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : 2) void conv_igemm2_kernel(const Igemm2Params p) {
-    using C = Cfg2<MODE, TI, TH, TW>;
+    using C = Cfg2<MODE, TI, TH, TW, NT>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
                   BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1, LDB = C::LDB, NP = C::NP, PSTEP = C::PSTEP, NLB = C::NLB;
     constexpr bool GEMM = C::GEMM, X3 = C::X3;
@@ -177,11 +184,18 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         const int pos = (ti * HH + (r / TW) * S) * HW + (r % TW) * S;
         a_base[mt] = pos * LD + (X3 ? (hh ^ (GEMM ? (pos >> 3) & 1 : 0)) * 4 : hh * 8);
     }
-    const int b_base = (wn * 32 + l31) * LDB + (X3 ? (hh ^ ((l31 >> 3) & 1)) * 4 : hh * 8);
-
-    f32x16 acc[MT];
+    // LDS image of the weight tile: [64-column block][tap][64 rows][LDB]; the wave's 32-column tile nt is rows
+    // (wn * NT + nt) * 32 ... + 31 of the BN columns
+    int b_base[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = (wn * NT + nt) * 32 + l31;
+        b_base[nt] = ((col >> 6) * GT * 64 + (col & 63)) * LDB + (X3 ? (hh ^ ((l31 >> 3) & 1)) * 4 : hh * 8);
+    }
+
+    f32x16 acc[MT * NT];     // [mt][nt]
+#pragma unroll
+    for (int mt = 0; mt < MT * NT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
@@ -235,13 +249,15 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     // a stage's weight tile is ONE contiguous run of the packed tensor (GT slots x 64 rows): thread t takes float4 t + 256 j
     auto gload_b = [&](int chunk, int grp, f32x4 (&rb)[NLB]) {
         const float* tile;
-        if (GEMM) tile = ld_w + ((size_t)nb * (Cin / C::KC) + chunk) * (64 * C::WROW);
-        else tile = wbase + (((size_t)chunk * p.nblk_n + nb) * C::NTAPS + (MODE == M2_CONVT4S2 ? par * 4 : grp * GT)) * (64 * C::WROW);
+        if (GEMM) tile = ld_w + ((size_t)nb * NT * (Cin / C::KC) + chunk) * (64 * C::WROW);
+        else tile = wbase + (((size_t)chunk * (p.Cout >> 6) + nb) * C::NTAPS + (MODE == M2_CONVT4S2 ? par * 4 : grp * GT)) * (64 * C::WROW);
 #pragma unroll
         for (int j = 0; j < NLB; ++j) {
             int i = tid + j * 256;
             if (C::B_TILE4 % 256) i = min(i, C::B_TILE4 - 1);   // the last pass of a tile that is not whole passes re-reads its last float4
-            rb[j] = reinterpret_cast<const f32x4*>(tile)[i];
+            // NT = 2 (GEMM): the second 64-column block's run lies Cin/16 rows of 64 further on (whole passes per block)
+            const size_t blk = (NT > 1 && j * 256 >= C::BLK4) ? (size_t)(Cin / C::KC) * (64 * C::WROW / 4) - C::BLK4 : 0;
+            rb[j] = reinterpret_cast<const f32x4*>(tile)[i + blk];
         }
     };
     auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
         // a lane's fragment of a tap: NP 16-byte pieces per 32-row tile - f32: its k-values 0..3 and 4..7 of the lane's
         // half of the chunk; bf16 triples: its eight k-values in each of the planes h, m, l
-        f32x4 fa[2][MT][NP], fb[2][NP];
+        f32x4 fa[2][MT][NP], fb[2][NT][NP];
         {
             const int ao = tap_lds(grp, 0);
 #pragma unroll
@@ -322,20 +338,38 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     fa[0][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * PSTEP]);
-                fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + j * PSTEP]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[0][nt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base[nt] + j * PSTEP]);
             }
         }
 #pragma unroll
         for (int tt = 0; tt < GT; ++tt) {
             const int cur = tt & 1, nxt = cur ^ 1;
-            if (tt + 1 < GT) {
+            // LEAN (the 64 x 64 wave tile): the next tap's planes are read when the current tap no longer needs the plane -
+            // h up front into a second buffer, l after the two groups that use l, m after the three that use m - so that 16
+            // instead of 48 VGPRs double-buffer the fragments (the whole set twice does not fit 256 registers)
+            constexpr bool LEAN = X3 && NT == 2;
+            auto read_plane = [&](int j) {
+                const int ao = tap_lds(grp, tt + 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * PSTEP]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[nxt][nt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base[nt] + (tt + 1) * 64 * LDB + j * PSTEP]);
+            };
+            if (LEAN && tt + 1 < GT) read_plane(0);
+            if (!LEAN && tt + 1 < GT) {
                 const int ao = tap_lds(grp, tt + 1);
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         fa[nxt][mt][j] = *reinterpret_cast<const f32x4*>(&As[a_base[mt] + ao + j * PSTEP]);
-                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base + (tt + 1) * BN * LDB + j * PSTEP]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        fb[nxt][nt][j] = *reinterpret_cast<const f32x4*>(&Bs[b_base[nt] + (tt + 1) * 64 * LDB + j * PSTEP]);
                 }
             }
             constexpr bool overlap_writes = DVG_WRITE_OVERLAP && has_next;
@@ -351,22 +385,32 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
             if constexpr (X3) {
                 // six bf16 MFMAs per 32 x 32 tile and K = 16 slab, small terms first: (l,h) (m,m) (h,l) (m,h) (h,m) (h,h)
-                auto mm = [&](int mt, int pa, int pb) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[cur][mt][pa]),
-                                                                      __builtin_bit_cast(bf16x8_t, fb[cur][pb]), acc[mt], 0, 0, 0);
+                auto mm = [&](int pa, int pb) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8_t, fa[cur][mt][pa]), __builtin_bit_cast(bf16x8_t, fb[cur][nt][pb]),
+                                acc[mt * NT + nt], 0, 0, 0);
                 };
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 2, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 1, 1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 2);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 1, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mm(mt, 0, 0);
+                if constexpr (LEAN) {
+                    mm(2, 0);
+                    mm(0, 2);
+                    if (tt + 1 < GT) read_plane(2);
+                    mm(1, 1);
+                    mm(1, 0);
+                    mm(0, 1);
+                    if (tt + 1 < GT) read_plane(1);
+                    mm(0, 0);
+                } else {
+                    mm(2, 0);
+                    mm(1, 1);
+                    mm(0, 2);
+                    mm(1, 0);
+                    mm(0, 1);
+                    mm(0, 0);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -374,12 +418,12 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][j][e], acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][j][e], fb[cur][0][j][e], acc[mt], 0, 0, 0);
             }
             // Pin the software pipeline: hipcc otherwise sinks the next tap's ds_reads down to their first use
             // (ds_read x3 -> s_waitcnt -> mfma x8), exposing the LDS latency every 8 MFMAs.  One ds_read_b128 per two
             // MFMAs, issued a full tap (16 / 8 MFMAs) ahead of its consumer.
-            constexpr int NREAD = NP * (MT + 1), NMFMA = (X3 ? 6 : 8) * MT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
+            constexpr int NREAD = NP * (MT + NT), NMFMA = (X3 ? 6 : 8) * MT * NT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
             // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
             constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? NLB : 0);
@@ -396,7 +440,26 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 if (POLICY == 1 && NVMEM > 0) __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // tap 0's own fragments
             }
-            if (tt + 1 < GT) {
+            if (LEAN && tt + 1 < GT) {
+                constexpr int G = MT * NT, R = MT + NT;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {      // next h planes behind the first MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * G - R, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {      // l planes are free: next l
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * G - R, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {      // m planes are free: next m
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            } else if (tt + 1 < GT) {
 #pragma unroll
                 for (int r = 0; r < NREAD; ++r) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -454,7 +517,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         // GEMMs have K = 128 ... 512, i.e. only 2 ... 8 stages per image.
         const int spi = (chunk_end - chunk_begin) / CPS;
         const long a_img = (long)p.H * p.W * p.C1;
-        float* const yimg = p.y + (size_t)n0 * p.H * p.W * p.Cout + nb0 + wn * 32 + l31;
+        float* const yimg = p.y + (size_t)n0 * p.H * p.W * p.Cout + nb0 + wn * 32 * NT + l31;
         for (int img = 0; img < p.gemm_ni; ++img) {
             for (int sg = 0; sg < spi; ++sg) {
                 const bool wrap = sg == spi - 1, last = wrap && img == p.gemm_ni - 1;
@@ -470,11 +533,13 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             for (int mt = 0; mt < MT; ++mt) {
                 const int mbase = wm * (C::BM / 2) + mt * 32;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout] = acc[mt][reg];
-                    acc[mt][reg] = 0.f;
-                }
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout + nt * 32] = acc[mt * NT + nt][reg];
+                        acc[mt * NT + nt][reg] = 0.f;
+                    }
             }
         }
     } else {
@@ -776,10 +841,10 @@ static int choose_splitk(long wgs, int nchunks) {
     return s < 2 ? 1 : (int)s;
 }
 
-template <int MODE, int TI, int TH, int TW>
+template <int MODE, int TI, int TH, int TW, int NT = 1>
 static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hipStream_t stream) {
-    using C = Cfg2<MODE, TI, TH, TW>;
-    if (Hg % TH || Wg % TW || p.Cout % 64) return fail(DVG_ERR_SHAPE, "conv_igemm2: tile does not divide shape");
+    using C = Cfg2<MODE, TI, TH, TW, NT>;
+    if (Hg % TH || Wg % TW || p.Cout % C::BN) return fail(DVG_ERR_SHAPE, "conv_igemm2: tile does not divide shape");
     p.tiles_y = Hg / TH;
     p.tiles_x = Wg / TW;
     p.tiles_n = (p.N + TI - 1) / TI;
@@ -795,7 +860,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
         p.gemm_ni = ni;
         p.tiles_n = p.N / ni;
     }
-    p.nblk_n = p.Cout / 64;
+    p.nblk_n = p.Cout / C::BN;
     p.clk = g_clk;
     p.clk_cap = g_clk_cap;
     const long wgs = (long)p.tiles_y * p.tiles_x * p.tiles_n * p.nblk_n * (MODE == M2_CONVT4S2 ? 4 : 1);
@@ -804,7 +869,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
         // launch; a must divide nblk_n, and a group must hold at least one XCD's share of pixel tiles
         const long tiles = (long)p.tiles_y * p.tiles_x * p.tiles_n;
         const double per_xcd = (double)tiles * p.nblk_n / 8.0;
-        const double wb = (double)C::NTAPS * (p.C1 + p.C2) * 64 * 4, ib = (double)C::BM * (p.C1 + p.C2) * 4;
+        const double wb = (double)C::NTAPS * (p.C1 + p.C2) * C::BN * 4, ib = (double)C::BM * (p.C1 + p.C2) * 4;
         int best = p.nblk_n;
         double cost = 1e300;
         for (int a = 1; a <= p.nblk_n; ++a) {
@@ -838,12 +903,12 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.stage_prio = (MODE == M2_CONV3 || grid <= 3 * 256) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW, NT>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
     if (int e = check_launch("conv_igemm2")) return e;
     if (S > 1) {
         const bool pool = y_pool != nullptr;
@@ -1064,6 +1129,16 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_GEMM, NB, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
                 "dvg_gemm_batched_k16: no tile for %dx%d", H, W);
+#if DVG_BF16X3
+    {
+        // 128 x 128 workgroup tile (64 x 64 per wave, K = 32 stages): measured, NOT the default.  At B = 576 it ties the
+        // 64-row tile (16x16 256->256: 341 vs 349 us), at B = 64 it loses 15-25 % (576 workgroups on 512 slots; 50 spilled
+        // registers around the per-image epilogue).  DVG_GEMM_NT=2 selects it for A/B runs.
+        static const char* force_nt = getenv("DVG_GEMM_NT");
+        const bool wide = Cout % 128 == 0 && Wg % 16 == 0 && Cin % 32 == 0 && force_nt && atoi(force_nt) == 2;
+        if (wide) return launch2<M2_GEMM, 1, 8, 16, 2>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
+    }
+#endif
     D2(M2_GEMM, 1, 8, 16)
     D2(M2_GEMM, 1, 8, 8)
     return fail(DVG_ERR_SHAPE, "dvg_gemm_batched_k16: no kernel");
