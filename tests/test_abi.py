@@ -36,6 +36,20 @@ def test_binding_table_covers_header():
     assert lib.dvg_abi_version() == 7
 
 
+def test_both_builds_of_the_library_load_and_say_which_arithmetic_they_run():
+    """libdvg_hip.so forms the implicit-GEMM kernels' fp32 products as exact bf16 triples on the bf16 MFMA (packed weight
+    rows of 3 x 16 bf16 = 24 floats), libdvg_hip_f32mfma.so (make f32mfma; built by __graft_entry__.build()) with the native
+    f32 MFMA (rows of 16 floats); both export the same ABI."""
+    from dvg_amd import _lib
+    assert _lib.lib().dvg_mfma_mode() == 1 and _lib.lib().dvg_packed_row_floats() == 24
+    native = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdvg_hip_f32mfma.so")
+    assert os.path.exists(native), "libdvg_hip_f32mfma.so not built (make -C dvg_amd/csrc f32mfma)"
+    h = ctypes.CDLL(native)
+    for s in header_symbols():
+        assert hasattr(h, s), f"{s} missing from the f32-MFMA build"
+    assert h.dvg_abi_version() == 7 and h.dvg_mfma_mode() == 0 and h.dvg_packed_row_floats() == 16
+
+
 def test_host_side_checks_reject_bad_shapes_without_gpu():
     """Shape validation happens on the host before any launch, so it is testable on CPU."""
     from dvg_amd import _lib

@@ -818,3 +818,70 @@ def test_eval_rollout_modules_chain_equals_unchained():
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
     for a, b in zip(out[True][1], out[False][1]):
         assert torch.equal(a, b)
+
+
+_PRECISION_PROBE = r"""
+import json, sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from dvg_amd import ops
+dev = torch.device("cuda:0")
+out = {}
+for (N, H, C, Cout) in [(8, 64, 64, 64), (16, 32, 128, 128), (32, 16, 256, 256), (64, 8, 512, 512)]:
+    g = torch.Generator(device="cpu").manual_seed(1000 + H)
+    xn = torch.randn(N, C, H, H, generator=g).to(dev)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    ref = F.conv2d(xn.double(), w.double(), padding=1)
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    x = ops.to_nhwc(xn)
+    forms = {"direct": ops.conv3x3(x, None, ops.pack_igemm_weight(w), one, zero, act=ops.ACT_NONE)}
+    if ops.winograd_ok(N, C, H, H, Cout, 4):
+        forms["f4"] = ops.conv3x3_winograd(x, ops.winograd_weight(w, 4), one, zero, act=ops.ACT_NONE)
+    k4 = torch.zeros((Cout, C, 4, 4), device=dev)
+    for ty in range(3):
+        for tx in range(3):
+            k4[:, :, 2 - ty:4 - ty, 2 - tx:4 - tx] += w[:, :, ty:ty + 1, tx:tx + 1]
+    xs = ops.to_nhwc(xn[:, :, ::2, ::2].contiguous())
+    refT = F.conv2d(F.interpolate(xs.double(), scale_factor=2, mode="nearest"), w.double(), padding=1)
+    yT = ops.convT4x4s2(xs, None, ops.pack_igemm_weight(k4.permute(1, 0, 2, 3).contiguous(), transposed=True), one, zero,
+                        act=ops.ACT_NONE)
+    for name, y, r in [(k, v, ref) for k, v in forms.items()] + [("convT", yT, refT)]:
+        d = y.double() - r
+        out[f"{name}/{H}"] = [float(d.abs().max() / r.abs().max()), float(d.pow(2).mean().sqrt() / r.pow(2).mean().sqrt()),
+                             float(d.mean() / r.abs().mean())]
+print("PROBE " + json.dumps(out))
+"""
+
+
+def test_bf16_triple_products_are_as_accurate_as_the_f32_mfma():
+    """ABI 7: the implicit-GEMM kernels of the default library form fp32 products as six bf16 MFMAs on exact bf16 triples.
+    Against an fp64 convolution, per layer form (direct 3x3, Winograd F(4x4), the 4-tap transposed form of the upsample convs)
+    and per vgg_64 layer shape, their error must not exceed the native f32-MFMA build's (libdvg_hip_f32mfma.so, run in a child
+    process on the same inputs): max and rms within 1.25x of it (the measured ratio is 0.8-1.0: the split drops less than one
+    fp32 product rounding and the bf16 MFMA rounds its sum once per 16 products, the f32 MFMA once per 2) and a mean error
+    (bias) below 5e-7 of the mean magnitude."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from dvg_amd import _lib
+    assert _lib.lib().dvg_mfma_mode() == 1, "the product library must be the bf16-triple build"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    native = os.path.join(root, "dvg_amd", "csrc", "libdvg_hip_f32mfma.so")
+    assert os.path.exists(native)
+
+    def probe(lib_path):
+        env = dict(os.environ)
+        env.pop("DVG_HIP_LIB", None)
+        if lib_path:
+            env["DVG_HIP_LIB"] = lib_path
+        r = subprocess.run([sys.executable, "-c", _PRECISION_PROBE % root], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1][6:])
+
+    x3, f32 = probe(None), probe(native)
+    assert set(x3) == set(f32) and len(x3) >= 10
+    for k in x3:
+        (mx, rms, bias), (mx0, rms0, _) = x3[k], f32[k]
+        assert mx < 1.25 * mx0 + 1e-7 and rms < 1.25 * rms0 + 1e-8 and abs(bias) < 5e-7, (k, x3[k], f32[k])
+        assert mx < 3e-5 and rms < 1e-5, (k, x3[k])          # the F(4x4) transforms' own rounding dominates: 1-2e-5 max
