@@ -1,3 +1,5 @@
+"""Winograd batched GEMM and direct 3x3 conv per vgg_64 layer shape, back to back at steady clocks (GPU only): the A/B
+workload for builds of the library (DVG_HIP_LIB=..., tools/ab_variants.sh, make f32mfma) and the DVG_GEMM_* switches."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvg_amd import ops

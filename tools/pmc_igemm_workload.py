@@ -1,3 +1,5 @@
+"""The two launches tools/profile_pmc_igemm.sh counts: the Winograd batched GEMM of the 16x16 256->256 layer at the conditioning
+batch (B = 576) and the direct 3x3 conv of the 64x64 64->64 layer at B = 64, five launches each."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvg_amd import ops
