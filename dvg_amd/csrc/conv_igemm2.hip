@@ -118,8 +118,13 @@ struct Cfg2 {
 #define DVG_GEMM_GT 4
 #endif
     // (NT = 2: two slabs, K = 32, so that two 48 KB workgroups share a CU)
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 8 : (GEMM ? (NT == 2 ? 2 : DVG_GEMM_GT) : 4));  // taps (GEMM: 16-channel slabs) per stage
-    static constexpr int NG = (MODE == M2_CONV4S2) ? 2 : 1;                           // stages per K chunk
+    // The stride-2 conv takes its 16 taps in two stages of 8 with f32 tiles (72 KB of LDS) and in four stages of 4 with bf16
+    // triples: with 8 taps the tile would be 92 KB (43 KB of halo rows at 112 B + 49 KB of weights), one workgroup per CU.
+#ifndef DVG_CONV4S2_GT
+#define DVG_CONV4S2_GT (DVG_BF16X3 ? 4 : 8)
+#endif
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? DVG_CONV4S2_GT : (GEMM ? (NT == 2 ? 2 : DVG_GEMM_GT) : 4));  // taps (GEMM: 16-channel slabs) per stage
+    static constexpr int NG = (MODE == M2_CONV4S2) ? 16 / GT : 1;                     // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr bool X3 = DVG_BF16X3 != 0;
     // LDS rows (floats).  f32: 16 k-values + 4 of padding (80 B: b128 lane groups land on distinct 16-B slots).  bf16 triples:
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         if (GEMM) return tt * C::SLAB;
         int th, tw;
         if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
-        else if (MODE == M2_CONV4S2) { th = grp * 2 + (tt >> 2); tw = tt & 3; }
+        else if (MODE == M2_CONV4S2) { const int tap = grp * GT + tt; th = tap >> 2; tw = tap & 3; }
         else { th = 1 + py - (tt >> 1); tw = 1 + px - (tt & 1); }
         return (th * HW + tw) * LD;
     };
@@ -543,22 +548,25 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
         }
     } else {
-    for (; chunk + CPS < chunk_end; chunk += CPS) {
+    // the NG stages of a chunk, the last one of the last chunk without a successor
+    auto chunk_stages = [&](const int ch, auto last_c) {
+        constexpr bool last = decltype(last_c)::value;
         set_prio(st++);
-        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
-        if constexpr (NG == 2) {
+        stage(ch, integral_constant<int, 0>{}, integral_constant<bool, !(last && NG == 1)>{});
+        if constexpr (NG >= 2) {
             set_prio(st++);
-            stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+            stage(ch, integral_constant<int, 1>{}, integral_constant<bool, !(last && NG == 2)>{});
         }
-    }
-    set_prio(st++);
-    if constexpr (NG == 2) {
-        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, true>{});
-        set_prio(st++);
-        stage(chunk, integral_constant<int, 1>{}, integral_constant<bool, false>{});
-    } else {
-        stage(chunk, integral_constant<int, 0>{}, integral_constant<bool, false>{});
-    }
+        if constexpr (NG >= 4) {
+            set_prio(st++);
+            stage(ch, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+            set_prio(st++);
+            stage(ch, integral_constant<int, 3>{}, integral_constant<bool, !last>{});
+        }
+        static_assert(NG == 1 || NG == 2 || NG == 4, "stages per chunk");
+    };
+    for (; chunk + CPS < chunk_end; chunk += CPS) chunk_stages(chunk, integral_constant<bool, false>{});
+    chunk_stages(chunk, integral_constant<bool, true>{});
     }
 #if DVG_STAGE_PRIO
     __builtin_amdgcn_s_setprio(0);
