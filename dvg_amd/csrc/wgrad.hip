@@ -11,6 +11,13 @@
 // fragment is shared by every tap).  K is split across workgroups; partial sums go to
 // partial[split][tap][Cout][Cin] and are reduced by dvg_reduce_partials (deterministic, no atomics).
 // The input loader fuses nearest-upsample + concat exactly like the forward kernel.
+//
+// DVG_BF16X3 (dvg_common.h, default): the products run on the bf16 matrix pipe as in conv_igemm2.hip - both tiles are split
+// into exact bf16 triples when they are written to LDS, [pixel][plane h, m, l][64 channels] (384 B per pixel) - and because K
+// is the PIXEL index while the tiles are channel-contiguous, the MFMA operands (8 consecutive k per lane) are fetched with the
+// transposing read `ds_read_b64_tr_b16`: a group of 16 lanes reads a block of 4 pixels x 16 channels and each lane receives
+// the 4 pixels of one channel.  Two such reads per plane make one v_mfma_f32_32x32x16_bf16 operand; six MFMAs per tap and
+// 16 pixels replace eight f32 MFMAs per tap and 2 pixels x 8.
 #include "dvg_common.h"
 
 namespace dvg {
@@ -49,17 +56,23 @@ struct WCfg {
     static constexpr int NTAPS_ALL = (MODE == W_CONV3) ? 9 : 16;
     static constexpr int GT = (MODE == W_CONV3) ? 9 : (MODE == W_CONV4S2 ? 8 : 4);  // taps per workgroup
     static constexpr int NG = NTAPS_ALL / GT + (MODE == W_CONV3 ? 0 : 0);           // groups: 1, 2, 4
-    static constexpr int LDS_BYTES = (P * 64 + HP * 64) * 4;
-    static_assert(P % 2 == 0, "P");
+    static constexpr bool X3 = DVG_BF16X3 != 0;
+    static constexpr int PIX = X3 ? 96 : 64;                   // floats per pixel of an LDS tile (3 planes x 64 bf16 / 64 floats)
+    static constexpr int LDS_BYTES = (P + HP) * PIX * 4;
+    static_assert(P % 2 == 0 && (!X3 || (P % 16 == 0 && TW % 4 == 0)), "P");
 };
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 template <int MODE, int TI, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p) {
     using C = WCfg<MODE, TI, TH, TW>;
-    constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, P = C::P, GT = C::GT;
+    constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, P = C::P, GT = C::GT, PIX = C::PIX;
+    constexpr bool X3 = C::X3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ad = smem;            // [P][64]   dOut tile, this co tile
-    float* Xh = smem + P * 64;   // [HP][64]  input halo tile, this ci tile
+    float* Ad = smem;             // [P][PIX]   dOut tile, this co tile
+    float* Xh = smem + P * PIX;   // [HP][PIX]  input halo tile, this ci tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kk = lane >> 5;
@@ -103,11 +116,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
         if (MODE == W_CONV3) { th = t2 / 3; tw = t2 % 3; }
         else if (MODE == W_CONV4S2) { const int tap = grp * GT + t2; th = tap >> 2; tw = tap & 3; }
         else { th = 1 + py - (t2 >> 1); tw = 1 + px - (t2 & 1); }
-        return (th * HW + tw) * 64;
+        return (th * HW + tw) * (X3 ? 1 : 64);     // X3: in pixels
     };
     auto frag_base = [&](int pp) -> int {
         const int ti = pp / (TH * TW), r = pp % (TH * TW);
-        return ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * 64;
+        return ((ti * HH + (r / TW) * S) * HW + (r % TW) * S) * (X3 ? 1 : 64);
+    };
+    // ---- bf16-triple image helpers ---------------------------------------------------------------------------------------
+    // byte offset of (pixel r, plane pl, channel c) inside a tile: the two 32-channel halves of a plane row are swapped on
+    // pixels with bit 1 set, so that the 4 pixel rows x 64 B a 32-lane half of a transposed read touches (4 consecutive
+    // pixels, one 32-channel half) fall into the four 64-byte quarters of the 256-byte bank space
+    auto img_off = [&](int r, int pl, int c) -> int {
+        return r * 384 + pl * 128 + (((c >> 5) ^ ((r >> 1) & 1)) << 6) + (c & 31) * 2;
+    };
+    // one MFMA operand (8 consecutive pixels k0 + 8 (lane >> 5) ... of channel cb + (lane & 31)) of plane pl: two transposed
+    // reads of 4 pixels x 16 channels per 16-lane group; lane 4 q + p of a group addresses pixel q, channels 4 p .. 4 p + 3
+    const int trq = (lane & 15) >> 2, trc = ((lane >> 4) & 1) * 16 + (lane & 3) * 4, trk = (lane >> 5) * 8;
+    // r0 / r1: the tile rows (pixels) this lane addresses in the two reads
+    auto tr_operand = [&](const float* tile, int r0, int r1, int cb, int pl) -> s16x8_t {
+        const char* base = reinterpret_cast<const char*>(tile);
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(base + img_off(r0, pl, cb + trc)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(base + img_off(r1, pl, cb + trc)));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     unsigned long long c_stage = 0, c_mfma = 0, c_t0 = p.clk ? clock64() : 0, c_mark = c_t0;
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -145,11 +177,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
         };
         auto store_slot = [&](int i, const f32x4& v, bool ok) {
             const f32x4 z = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < NLD) {
-                *reinterpret_cast<f32x4*>(&Ad[((tid + i * 256) >> 4) * 64 + q4]) = z;
+            const int r = i < NLD ? (tid + i * 256) >> 4 : (tid + (i - NLD) * 256) >> 4;
+            if (i >= NLD && !(NLH * 256 == HP * 16 || r < HP)) return;
+            float* tile = i < NLD ? Ad : Xh;
+            if constexpr (X3) {
+                u32x2_t h, m, l;
+                unsigned t0, t1, t2;
+                bf16x3_split_pair(z[0], z[1], t0, t1, t2);
+                h[0] = t0; m[0] = t1; l[0] = t2;
+                bf16x3_split_pair(z[2], z[3], t0, t1, t2);
+                h[1] = t0; m[1] = t1; l[1] = t2;
+                char* d = reinterpret_cast<char*>(tile);
+                *reinterpret_cast<u32x2_t*>(d + img_off(r, 0, q4)) = h;
+                *reinterpret_cast<u32x2_t*>(d + img_off(r, 1, q4)) = m;
+                *reinterpret_cast<u32x2_t*>(d + img_off(r, 2, q4)) = l;
             } else {
-                const int hp = (tid + (i - NLD) * 256) >> 4;
-                if (NLH * 256 == HP * 16 || hp < HP) *reinterpret_cast<f32x4*>(&Xh[hp * 64 + q4]) = z;
+                *reinterpret_cast<f32x4*>(&tile[r * 64 + q4]) = z;
             }
         };
         {
@@ -174,6 +217,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradParams p
         }
         __syncthreads();
         if (p.clk && tid == 0) { const unsigned long long now = clock64(); c_stage += now - c_mark; c_mark = now; }
+        if constexpr (X3) {
+            // k loop over the tile's pixels, 16 per step: three planes of the dOut operand, then per tap three planes of the
+            // input operand and the six MFMAs (l,h) (m,m) (h,l) (m,h) (h,m) (h,h)
+#pragma unroll 1
+            for (int k0 = 0; k0 < P; k0 += 16) {
+                // the two pixels this lane addresses (one per read: k0 + 8 (lane >> 5) + {0, 4} + q) and their halo positions
+                const int pa0 = k0 + trk + trq, pa1 = pa0 + 4;
+                const int hb0 = frag_base(pa0), hb1 = frag_base(pa1);
+                s16x8_t a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = tr_operand(Ad, pa0, pa1, wr * 32, pl);
+                s16x8_t bcur[3], bnxt[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bcur[pl] = tr_operand(Xh, hb0 + tap_off(0), hb1 + tap_off(0), wc * 32, pl);
+#pragma unroll
+                for (int t2 = 0; t2 < GT; ++t2) {
+                    if (t2 + 1 < GT) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            bnxt[pl] = tr_operand(Xh, hb0 + tap_off(t2 + 1), hb1 + tap_off(t2 + 1), wc * 32, pl);
+                    }
+                    auto mm = [&](int pa, int pb) {
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[pa]),
+                                                                          __builtin_bit_cast(bf16x8_t, bcur[pb]), acc[t2], 0, 0, 0);
+                    };
+                    mm(2, 0); mm(1, 1); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0);
+                    if (t2 + 1 < GT) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) bcur[pl] = bnxt[pl];
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {     // next tap's six transposed reads, one per MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                    }
+                }
+            }
+            if (p.clk && tid == 0) { const unsigned long long now = clock64(); c_mfma += now - c_mark; c_mark = now; }
+            continue;
+        }
         // k loop over the tile's pixels, two per MFMA; fragments of step k+1 are read while step k's MFMAs run
         float a_cur = Ap[kk * 64], b_cur[GT];
         {
@@ -253,7 +336,8 @@ static int wgrad_tile(int mode, int Hg, int Wg, int* ti, int* th, int* tw) {
         if (Hg == 4 && Wg == 4) { *ti = 2; *th = 4; *tw = 4; return 0; }
         return -1;
     }
-    if (Hg % 8 == 0 && Wg % 16 == 0) { *ti = 1; *th = 8; *tw = 16; return 0; }
+    // (bf16 triples: the 8 x 16 tile's LDS image is 118 KB, one workgroup per CU: the 8 x 8 tile, 63 KB, everywhere)
+    if (!DVG_BF16X3 && Hg % 8 == 0 && Wg % 16 == 0) { *ti = 1; *th = 8; *tw = 16; return 0; }
     // 8x8 maps: one image per tile.  The two-image tile (2,8,8) needs 84 KB of LDS, i.e. ONE workgroup per CU and no
     // interleaving of staging and MFMA phases (94 TF against 112 TF for the other layers).
     if (Hg % 8 == 0 && Wg % 8 == 0) { *ti = 1; *th = 8; *tw = 8; return 0; }
