@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // ---- DVG_BF16X3: fp32 products on the bf16 matrix pipe ------------------------------------------------------------------

@@ -213,6 +213,155 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_kernel(const WwParams 
     }   // segments
 }
 
+// ---- the same product on the bf16 matrix pipe (DVG_BF16X3, dvg_common.h) -------------------------------------------------
+// Operands as exact bf16 triples, six v_mfma_f32_32x32x16_bf16 per 32 x 32 tile and 16 tiles of K.  A thread loads 8
+// consecutive K rows of two columns per operand (dwords: 256 contiguous bytes per row per wave), splits them and stores, per
+// column and plane, the 8 k-values as ONE 16-byte run: the LDS image [k octet][plane][column][8 bf16] is the MFMA operand
+// layout (lanes 0-31 take octet 2 s, lanes 32-63 octet 2 s + 1 of k-step s), a fragment is one conflict-free ds_read_b128.
+// Same work split, slabs and epilogue as the f32 kernel above.
+constexpr int ww3_opf() { return 4 * 3 * WW_BM * 4; }           // floats of one operand stage: 4 octets x 3 planes x 128 columns x 16 B
+constexpr int ww3_lds_bytes() { return 2 * ww3_opf() * 4; }
+
+__global__ __launch_bounds__(256, 2) void wino_wgrad_gemm_x3_kernel(const WwParams p) {
+    constexpr int KS = 32, OPF = ww3_opf();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;
+    float* const Bs = smem + OPF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int w = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int oct = tid >> 6, cp = tid & 63;     // loader: K rows 8 oct ... + 7 of columns cp and cp + 64
+    const float* A = nullptr;
+    int xi = 0;
+    long b_thread = 0;
+
+    float ra[16], rb[16];
+    auto gload = [&](int st) {
+        const float* a = A + (size_t)st * KS * p.Cout;
+        const int row = st * KS, item = row / p.t_item;     // wave-uniform: which use's V this stage reads
+        const float* b = p.v[item] + ((size_t)xi * p.t_item + (row - item * p.t_item)) * p.Cin + b_thread;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                ra[c * 8 + r] = a[(size_t)r * p.Cout + 64 * c];
+                rb[c * 8 + r] = b[(size_t)r * p.Cin + 64 * c];
+            }
+    };
+    auto lstore = [&]() {
+        auto put = [&](float* tile, const float (&v)[16], int c) {
+            u32x4_t h, m, l;
+            unsigned t0, t1, t2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x3_split_pair(v[c * 8 + 2 * i], v[c * 8 + 2 * i + 1], t0, t1, t2);
+                h[i] = t0; m[i] = t1; l[i] = t2;
+            }
+            float* d = &tile[((oct * 3) * WW_BM + cp + 64 * c) * 4];
+            *reinterpret_cast<u32x4_t*>(d) = h;
+            *reinterpret_cast<u32x4_t*>(d + WW_BM * 4) = m;
+            *reinterpret_cast<u32x4_t*>(d + 2 * WW_BM * 4) = l;
+        };
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            put(As, ra, c);
+            put(Bs, rb, c);
+        }
+    };
+    // fragment of k-step s (16 k), plane pl, 32-column tile m: floats ((2 s + hh) * 3 + pl) * 128 * 4 + column * 4
+    const int fa_off = (hh * 3 * WW_BM + wr * 64 + l31) * 4, fb_off = (hh * 3 * WW_BM + wc * 64 + l31) * 4;
+    const int u_end = min((w + 1) * p.q, p.total);
+    for (int u = w * p.q; u < u_end;) {
+    const int blk = u / p.nst;
+    const int st0 = u - blk * p.nst, st1 = min(p.nst, st0 + (u_end - u));
+    const int seg = w - blk * p.nst / p.q;
+    const int bj = blk % p.nbj, bi = (blk / p.nbj) % p.nbi;
+    xi = blk / (p.nbj * p.nbi);
+    A = p.dm + ((size_t)xi * p.Tp + oct * 8) * p.Cout + bi * WW_BM + cp;
+    b_thread = (long)oct * 8 * p.Cin + bj * WW_BM + cp;
+    u += st1 - st0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    gload(st0);
+    lstore();
+    __syncthreads();
+    auto stage = [&](const int st, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        if (more) gload(st + 1);
+        f32x4 fa[2][2][3], fb[2][2][3];     // [buffer][tile][plane]
+        auto read_step = [&](int buf, int s2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    fa[buf][m][pl] = *reinterpret_cast<const f32x4*>(&As[fa_off + ((2 * s2) * 3 + pl) * WW_BM * 4 + m * 128]);
+                    fb[buf][m][pl] = *reinterpret_cast<const f32x4*>(&Bs[fb_off + ((2 * s2) * 3 + pl) * WW_BM * 4 + m * 128]);
+                }
+        };
+        read_step(0, 0);
+        if (more) __builtin_amdgcn_sched_group_barrier(0x020, 32, 0);   // the next stage's global loads first
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 0) read_step(1, 1);
+            if (s2 == 1 && more) {
+                __syncthreads();     // every wave holds its last fragments: the next stage's tiles may overwrite the image
+                lstore();
+            }
+            auto mm = [&](int pa, int pb) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[s2][m][pa]),
+                                                                            __builtin_bit_cast(bf16x8_t, fb[s2][n][pb]), acc[m][n], 0, 0, 0);
+            };
+            mm(2, 0); mm(1, 1); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0);
+            if (s2 == 0) {
+#pragma unroll
+                for (int r = 0; r < 12; ++r) {     // the second k-step's twelve reads, one per two MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            } else if (more) {
+#pragma unroll
+                for (int r = 0; r < 12; ++r) {     // the twelve ds_write_b128 of the next stage between the MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int st = st0; st + 1 < st1; ++st) stage(st, std::integral_constant<bool, true>{});
+    stage(st1 - 1, std::integral_constant<bool, false>{});
+
+    const size_t slab = (size_t)36 * p.Cout * p.Cin;
+    const int nzero = st1 == p.nst ? p.S - 1 - seg : 0;   // the block's last segment: zero the slabs it did not use
+    float* out = p.part + (size_t)seg * slab + (((size_t)xi * p.Cout + bi * WW_BM + wr * 64) * p.Cin + bj * WW_BM + wc * 64 + l31);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                out[(size_t)row * p.Cin + n * 32] = acc[m][n][reg];
+            }
+    float* zbase = p.part + (size_t)(seg + 1) * slab + ((size_t)xi * p.Cout + bi * WW_BM) * p.Cin + bj * WW_BM;
+#pragma unroll 1
+    for (int z = 0; z < nzero; ++z, zbase += slab)
+#pragma unroll 1
+        for (int i = tid; i < WW_BM * (WW_BM / 4); i += 256)
+            *reinterpret_cast<f32x4*>(zbase + (size_t)(i >> 5) * p.Cin + (i & 31) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }   // segments
+}
+
 // packed[3a + b][co][ci] = (G^T (sum_s P[s]) G)[a][b]: the layout dvg_conv_wgrad's slabs have (S = 1), so that
 // dvg_wgrad_finish places either form into the parameter's gradient.
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ packed,
@@ -332,6 +481,21 @@ static int ww_gemm(const float* dm, const float* const* v_items, int items, long
     static const char* env = getenv("DVG_WW_DB");   // A/B runs only
     const bool db = env ? atoi(env) != 0 : WW_DEFAULT_DB;
     const hipStream_t st = (hipStream_t)stream;
+#if DVG_BF16X3
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_gemm_x3_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, ww3_lds_bytes());
+            if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        (void)db;
+        const unsigned grid = (unsigned)((p.total + p.q - 1) / p.q);
+        hipLaunchKernelGGL(wino_wgrad_gemm_x3_kernel, dim3(grid), dim3(256), ww3_lds_bytes(), st, p);
+        return check_launch("dvg_winograd_wgrad_gemm");
+    }
+#endif
     return db ? ww_launch<true, 32>(p, st) : ww_launch<false, 32>(p, st);
 }
 
