@@ -864,6 +864,8 @@ def test_bf16_triple_products_are_as_accurate_as_the_f32_mfma():
     import subprocess
     import sys
     from dvg_amd import _lib
+    if os.environ.get("DVG_HIP_LIB"):
+        pytest.skip("an alternative build of the library is loaded (DVG_HIP_LIB): this test compares the product build")
     assert _lib.lib().dvg_mfma_mode() == 1, "the product library must be the bf16-triple build"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     native = os.path.join(root, "dvg_amd", "csrc", "libdvg_hip_f32mfma.so")
