@@ -863,6 +863,16 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
         // prologues and the finer-grained workgroups balance the CUs better: 1 image is fastest or tied on every vgg_64
         // shape (tools/ab_gemm_ni.sh: e.g. 16x16 256->256 48.4 us vs 52.0 (2) / 59.0 (4); 8x8 512->256 31.7 vs 41.7 / 57.6).
         int ni = 1;
+#if DVG_BF16X3
+        // bf16 triples: the 64-row tile runs three workgroups per CU (768 resident), and with the matrix work 2.7 x shorter a
+        // workgroup's prologue weighs more.  When the launch is a whole number r <= 6 of residency rounds, ONE round of
+        // workgroups that run r images back to back in one pipeline is faster (16x16 256->256: 39.6 -> 36.1 us,
+        // 32x32 128->128: 43.2 -> 40.4 us); otherwise the finer grain balances better (8x8 512->512, 1.5 rounds: 38.6 vs 39.5).
+        if (TW == 8 && NT == 1) {
+            const long w1 = (long)p.tiles_y * p.tiles_x * p.N * (p.Cout / C::BN), slots = 256L * DVG_GEMM_WGS_PER_CU;
+            if (w1 % slots == 0 && w1 / slots >= 2 && w1 / slots <= 6 && p.N % (w1 / slots) == 0) ni = (int)(w1 / slots);
+        }
+#endif
         static const char* force_ni = getenv("DVG_GEMM_NI");   // A/B runs only
         if (force_ni && p.N % atoi(force_ni) == 0) ni = atoi(force_ni);
         p.gemm_ni = ni;
