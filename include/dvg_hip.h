@@ -165,7 +165,8 @@ int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k
 /* Winograd F(m x m, 3x3), m = 2 or 4, form of vgg_layer for the deep eval-mode layers (vgg_64.py:5-15 at 16x16 / 8x8 maps
  * with 256-512 channels): fp32 throughout, 2.25x (m = 2) / 4x (m = 4) fewer multiply-adds, P = (m+2)^2 transform
  * positions.  y = act(scale * A^T[(G g G^T) .* (B^T d B)]A + shift):
- *   dvg_winograd_weight   U (P, Cin/16, 1, Cout, 16) from the Conv2d weight (Cout,Cin,3,3)           once per weight version
+ *   dvg_winograd_weight   U: P * Cin/16 * Cout packed rows of dvg_packed_row_floats() floats, [P][Cout/64][Cin/16][64][row],
+ *                         from the Conv2d weight (Cout,Cin,3,3)                                       once per weight version
  *   dvg_winograd_input    V (P, T, C)  from x NHWC (N,H,W,C), T = N*(H/m)*(W/m) tiles, zero padding 1
  *   dvg_gemm_batched_k16  M (P, T, Cout) = V x U: P GEMMs; the tensors are passed as P "images" of (T/16) x 16 pixels
  *   dvg_winograd_output   y NHWC (N,H,W,Cout) (+ y_pool, MaxPool2d(2,2) vgg_64.py:49: pool windows never straddle tiles)
