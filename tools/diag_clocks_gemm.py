@@ -24,7 +24,7 @@ def main():
     buf = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
     for t, c, co in SHAPES:
         v = torch.randn(36, t, c, device=dev)
-        u = torch.randn(36, c // 16, 1, co, 16, device=dev) * 0.05
+        u = torch.randn(36, c // 16, 1, co, ops.packed_row_floats(), device=dev) * 0.05
         m = torch.empty(36, t, co, device=dev)
         fn = lambda: ops.check(lib().dvg_gemm_batched_k16(ops._p(v), ops._p(u), ops._p(m), 36, t // 16, 16, c, co,
                                                           ops._stream()), "gemm")   # noqa: E731
