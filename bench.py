@@ -552,7 +552,7 @@ def main():
         # how the implicit-GEMM kernels form their fp32 products (dvg_mfma_mode(), include/dvg_hip.h): inputs, outputs, weights,
         # accumulators and every other kernel are fp32 in both builds
         "arithmetic": ("fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per K=16 slab, fp32 accumulate "
-                       "(dropped cross terms < 2^-23 |a||b|; measured error vs fp64 <= the f32 MFMA's)"
+                       "(round-to-nearest split, dropped cross terms < 2^-24 |a||b|; measured error vs fp64 <= the f32 MFMA's)"
                        if _lib.lib().dvg_mfma_mode() == 1 else "native f32-input MFMA"),
         "config": {"workload": f"Moving-MNIST 64x64 rollout (generate_frames.py make_gifs sample loop), "
                                f"{args.model}_64 + lstm + GP trigger sample at i%15==0, batch {args.batch} per GPU, "

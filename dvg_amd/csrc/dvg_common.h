@@ -29,11 +29,12 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // ---- DVG_BF16X3: fp32 products on the bf16 matrix pipe ------------------------------------------------------------------
 // gfx950's f32-input MFMA runs at 1/16 of the bf16 rate (157 vs 2516 TFLOP/s).  With DVG_BF16X3 = 1 the implicit-GEMM
-// kernels (conv_igemm2.hip) split every fp32 operand EXACTLY into three bf16 terms, a = h + m + l with 8 + 8 + 8 significant
-// bits (truncation: h = the top 16 bits of a, m the top 16 bits of the exact remainder a - h, l the rest, which has at most
-// 8 significant bits left), and form a K = 16 slab of the product as six v_mfma_f32_32x32x16_bf16 with fp32 accumulation -
-// (l,h) (m,m) (h,l) (m,h) (h,m) (h,h); bf16 x bf16 products are exact in fp32 and the dropped terms (m,l) (l,m) (l,l) are
-// below 2^-23 |a||b|, i.e. below the rounding of ONE fp32 product - instead of eight v_mfma_f32_32x32x2_f32: 192 instead of
+// kernels (conv_igemm2.hip, wgrad.hip, wino_wgrad.hip) split every fp32 operand EXACTLY into three bf16 terms, a = h + m + l
+// with 8 + 8 + 8 significant bits (h = a rounded to nearest bf16, m = the exact remainder a - h rounded to nearest bf16, l the
+// rest: |m| <= 2^-8 |a|, |l| <= 2^-17 |a|, and l is a bf16 exactly), and form a K = 16 slab of the product as six
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation - (l,h) (m,m) (h,l) (m,h) (h,m) (h,h); bf16 x bf16 products are exact in
+// fp32 and the dropped terms (m,l) (l,m) (l,l) are below 2^-24 |a||b| with no preferred sign, i.e. below the rounding of ONE
+// fp32 product (tests/test_bf16x3_split.py restates this in numpy) - instead of eight v_mfma_f32_32x32x2_f32: 192 instead of
 // 512 matrix-pipe cycles per slab.  Measured error against fp64: equal to or below the f32 MFMA's on every layer shape
 // (tools/diag_mfma_precision.py, tests/test_gpu_parity.py).  The split is done ONCE per element: activations when a stage's
 // tile is written to LDS, weights when they are packed (the packed row of 16 k-values is 3 x 16 bf16 = 24 floats).
@@ -43,17 +44,25 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #endif
 #define DVG_WROW (DVG_BF16X3 ? 24 : 16)   // floats per packed weight row (16 k-values of one output channel)
 
-// two fp32 values -> their three bf16 terms, each pair packed into one dword (low half = the first value)
+// two fp32 values -> their three bf16 terms, each pair packed into one dword (low half = the first value).  Nine VALU
+// instructions: v_cvt_pk_bf16_f32 (round to nearest even) x 3, the two halves of a packed pair back to fp32 (shift / mask) x 2,
+// v_pk_add_f32 x 2.  (A truncating split - mask instead of convert - costs the same and leaves dropped terms of up to
+// 2^-20 |a||b|, all with the product's sign.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack_rn(float a0, float a1) {
+    const f32x2_t v = {a0, a1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void bf16x3_split_pair(float a0, float a1, unsigned& ph, unsigned& pm, unsigned& pl) {
     const unsigned M = 0xffff0000u;
     const f32x2_t a = {a0, a1};
-    const f32x2_t h = {__uint_as_float(__float_as_uint(a0) & M), __uint_as_float(__float_as_uint(a1) & M)};
+    ph = bf16_pack_rn(a0, a1);
+    const f32x2_t h = {__uint_as_float(ph << 16), __uint_as_float(ph & M)};
     const f32x2_t r = a - h;
-    const f32x2_t m = {__uint_as_float(__float_as_uint(r[0]) & M), __uint_as_float(__float_as_uint(r[1]) & M)};
+    pm = bf16_pack_rn(r[0], r[1]);
+    const f32x2_t m = {__uint_as_float(pm << 16), __uint_as_float(pm & M)};
     const f32x2_t t = r - m;
-    ph = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
-    pm = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+    pl = bf16_pack_rn(t[0], t[1]);
 }
 
 // Packed weight rows.  A row = the 16 k-values (one 16-channel chunk) of ONE output channel; rows are stored in blocks of
@@ -64,13 +73,12 @@ __device__ __forceinline__ void bf16x3_split_pair(float a0, float a1, unsigned& 
 __device__ __forceinline__ void wrow_store(float* __restrict__ rows, size_t row, int co_local, int k, float v) {
 #if DVG_BF16X3
     unsigned short* d = reinterpret_cast<unsigned short*>(rows + row * 24);
-    const unsigned M = 0xffff0000u;
-    const float h = __uint_as_float(__float_as_uint(v) & M), r = v - h;
-    const float m = __uint_as_float(__float_as_uint(r) & M), l = r - m;
+    unsigned ph, pm, pl;
+    bf16x3_split_pair(v, 0.f, ph, pm, pl);      // the same roundings as the activations' split
     const int pos = (((k >> 3) ^ ((co_local >> 3) & 1)) << 3) + (k & 7);
-    d[pos] = (unsigned short)(__float_as_uint(h) >> 16);
-    d[16 + pos] = (unsigned short)(__float_as_uint(m) >> 16);
-    d[32 + pos] = (unsigned short)(__float_as_uint(l) >> 16);
+    d[pos] = (unsigned short)(ph & 0xffffu);
+    d[16 + pos] = (unsigned short)(pm & 0xffffu);
+    d[32 + pos] = (unsigned short)(pl & 0xffffu);
 #else
     (void)co_local;
     rows[row * 16 + k] = v;

@@ -118,7 +118,7 @@ int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
  * operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significant bits; activations when a tile is
  * staged in LDS, weights when they are packed: a packed row is 3 x 16 bf16 = 24 floats) and a K = 16 slab
  * of the product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped cross terms are
- * below 2^-23 |a||b|, under the rounding of one fp32 product, and the measured error against fp64 is
+ * below 2^-24 |a||b|, under the rounding of one fp32 product, and the measured error against fp64 is
  * that of the f32 MFMA or below.  dvg_mfma_mode() == 0 (library built with -DDVG_BF16X3=0): the native
  * v_mfma_f32_32x32x2_f32, packed rows of 16 floats.  Callers size packed buffers with
  * dvg_packed_row_floats() and are otherwise unaffected.                                          */
