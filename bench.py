@@ -573,7 +573,7 @@ def main():
                    "upsample_conv3x3": "as transposed 4x4/s2 conv" if (fused_mod.SKIP_HOIST and fused_mod.UPCONV_AS_CONVT)
                    else "9-tap conv on the upsampled grid",
                    # eval-mode 3x3 layers on maps up to 32x32 with >= 64 input channels run as Winograd F(4x4,3x3) (F(2x2) where only
-                   # its tile count fits): fp32 throughout, 4x / 2.25x fewer multiplies (DVG_WINOGRAD=0: direct form everywhere)
+                   # its tile count fits): fp32 data and transforms, 4x / 2.25x fewer multiplies (DVG_WINOGRAD=0: direct form everywhere)
                    "conv3x3_deep_layers": {0: "direct implicit GEMM", 2: "Winograd F(2x2,3x3)", 4: "Winograd F(4x4,3x3) / F(2x2,3x3)"}[
                        fused_mod.WINOGRAD]},
     }

@@ -1,5 +1,5 @@
 // Winograd F(2x2, 3x3) for the deep 3x3 layers of the eval-mode rollout (vgg_64.py:5-15 at 16x16 and 8x8, 256-512
-// channels: 60 % of the rollout's conv FLOPs).  Exact fp32 arithmetic, 2.25x fewer multiply-adds than the direct form:
+// channels: 60 % of the rollout's conv FLOPs).  fp32 data and transforms (the batched GEMM's products as in conv_igemm2.hip), 2.25x fewer multiply-adds than the direct form:
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, d = the 4x4 input patch around it (pad 1)
 //

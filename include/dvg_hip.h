@@ -163,7 +163,7 @@ int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k
                              const int* addend_map /* as dvg_conv3x3_bn_act_v2 */, int addend_block, void* stream);
 
 /* Winograd F(m x m, 3x3), m = 2 or 4, form of vgg_layer for the deep eval-mode layers (vgg_64.py:5-15 at 16x16 / 8x8 maps
- * with 256-512 channels): fp32 throughout, 2.25x (m = 2) / 4x (m = 4) fewer multiply-adds, P = (m+2)^2 transform
+ * with 256-512 channels): fp32 data and transforms, 2.25x (m = 2) / 4x (m = 4) fewer multiply-adds, P = (m+2)^2 transform
  * positions.  y = act(scale * A^T[(G g G^T) .* (B^T d B)]A + shift):
  *   dvg_winograd_weight   U: P * Cin/16 * Cout packed rows of dvg_packed_row_floats() floats, [P][Cout/64][Cin/16][64][row],
  *                         from the Conv2d weight (Cout,Cin,3,3)                                       once per weight version
