@@ -6,6 +6,8 @@ arithmetic op of the hot path is a kernel of libdvg_hip.so.  Activations travel 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -179,7 +181,7 @@ def unpack_convT_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
 def _splitk_ws(mode, n, h, w, cin, cout, out_numel, device):
     """Workspace for the split-K path of the implicit GEMM (None when the launch fills the chip on its own)."""
     s = lib().dvg_conv_splitk_v2(mode, n, h, w, cin, cout)
-    if s <= 1:
+    if s <= 1 or os.environ.get("DVG_NO_SPLITK") == "1":     # (the switch: A/B runs)
         return None
     return torch.empty(s * out_numel, device=device, dtype=torch.float32)
 
