@@ -36,6 +36,7 @@ SIGNATURES = {
     "dvg_conv_splitk_v2": (_i, [_i, _i, _i, _i, _i, _i]),
     "dvg_conv_stats_rows_v2": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dvg_conv3x3_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
+    "dvg_conv3x3_first_pair": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_conv4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p]),
     "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),

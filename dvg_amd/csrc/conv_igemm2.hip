@@ -83,6 +83,14 @@ struct Igemm2Params {
     // decoder calls of a time step and, once the skip is frozen, by all later steps (train.py:217-231).  NULL: image n.
     const int* add_map;
     int add_B;
+    // FIRST (dvg_conv3x3_first_pair): the input of this 64-channel 3x3 layer is itself the first layer of the encoder,
+    // vgg_layer(1, 64) on the raw frame (vgg_64.py:23-24): the workgroup computes the halo tile of that layer from the frame
+    // patch under it instead of loading it, so the 64-channel activation between the two layers is never written or read
+    const float* first_frame;   // (N, 1, H, W)
+    const float* first_w;       // the first layer's weights transposed to [9 taps][64 channels]
+    const float* first_scale;   // folded BatchNorm of the first layer, 64 each
+    const float* first_shift;
+    float first_slope;
 };
 
 // image of `addend` that output image n adds (see Igemm2Params::add_map)
@@ -102,9 +110,10 @@ __device__ __attribute__((aligned(16))) float dvg_zero_slot[4] = {0.f, 0.f, 0.f,
 // NT: 32-column tiles per wave (workgroup tile BM x 64 NT).  NT = 2 exists for the bf16-triple GEMM mode only: with the
 // matrix pipe 2.7x faster the LDS, not the MFMA, bounds a 128 x 64 tile (per MFMA 384 B of tile stores at ~80 B/clk and
 // 768 B of fragment reads at 256 B/clk: 97 % of the LDS cycles); 128 x 128 with 64 x 64 per wave needs 256 + 512 B (65 %).
-template <int MODE, int TI, int TH, int TW, int NT_ = 1>
+template <int MODE, int TI, int TH, int TW, int NT_ = 1, bool FIRST_ = false>
 struct Cfg2 {
     static constexpr int NT = NT_;
+    static constexpr bool FIRST = FIRST_;
     static constexpr bool GEMM = MODE == M2_GEMM;
     static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;
     static constexpr int SPAN = GEMM ? 1 : ((MODE == M2_CONV4S2) ? 4 : 3);
@@ -141,14 +150,20 @@ struct Cfg2 {
     static constexpr int NLA = NLA1 * (GEMM ? GT : 1);
     static constexpr int SLAB = NLA1 * 64 * LD;                                       // floats of one A slab (GEMM mode)
     // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
-    static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LDB;
-    static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int A_FLOATS = (FIRST ? HP : NLA * 64) * LD, B_FLOATS = GT * BN * LDB;
+    // FIRST: the frame patch under the halo tile, (HH + 2) x (HW + 2) floats, in LDS (the first layer's weights, scale and
+    // shift of a stage's 16 channels travel in registers).  Two workgroups must share a CU: measured, two 80.6 KB allocations
+    // are both admitted and then CORRUPT each other's last kilobytes (one 80.6 KB workgroup per CU: correct; 76.8 KB x 2:
+    // correct), so this variant drops the A tile's 12 padding rows and stays below the 76.8 KB the plain kernel uses.
+    static constexpr int FP_W = HW + 2, FP_FLOATS = (HH + 2) * FP_W, FIRST_FLOATS = FIRST ? FP_FLOATS : 0;
+    static_assert(!FIRST || (MODE == M2_CONV3 && TI == 1 && NT == 1), "FIRST: 3x3 mode, one image per tile");
+    static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS + FIRST_FLOATS) * 4;
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
 };
 
-template <int MODE, int TI, int TH, int TW, int NT = 1>
+template <int MODE, int TI, int TH, int TW, int NT = 1, bool FIRST = false>
 __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : 2) void conv_igemm2_kernel(const Igemm2Params p) {
-    using C = Cfg2<MODE, TI, TH, TW, NT>;
+    using C = Cfg2<MODE, TI, TH, TW, NT, FIRST>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
                   BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1, LDB = C::LDB, NP = C::NP, PSTEP = C::PSTEP, NLB = C::NLB;
     constexpr bool GEMM = C::GEMM, X3 = C::X3;
@@ -238,7 +253,45 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     // M2_GEMM: image (relative to n0) whose operands the NEXT loads fetch; the stage loop moves it on at image boundaries
     long ld_a_off = GEMM ? (long)n0 * p.H * p.W * p.C1 : 0;
     const float* ld_w = wbase;
+    // FIRST: the frame patch behind the two tiles (origin (yin0 - 1, xin0 - 1)); the first layer's weights / scale / shift of
+    // the NEXT stage's 16 channels in registers: this thread's four channels (all its halo slots share q = tid & 3)
+    float* const Fp = smem + C::A_FLOATS + C::B_FLOATS;
+    f32x4 fw[FIRST ? 11 : 1];      // [tap 0..8] weights of channels c0 + 4 q .. + 3, [9] scale, [10] shift
+    auto first_tile = [&](f32x4 (&ra)[NLA]) {
+        if constexpr (FIRST) {
+            // the halo tile's channels of vgg_layer(1, 64) from the frame patch: 9 taps per value, folded BatchNorm, LeakyReLU;
+            // slots outside the image are the SECOND layer's zero padding
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                const int hp = min((tid + i * 256) >> 2, HP - 1);
+                const float* f = Fp + (hp / HW) * C::FP_W + hp % HW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float px = f[(t / 3) * C::FP_W + t % 3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(fw[t][e], px, v[e]);
+                }
+                // LeakyReLU as max(a, slope a) (0 < slope < 1) and the padding as a multiply by 0 / 1: no lane masks in this block
+                const float okf = (float)((okmask >> i) & 1u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = v[e] * fw[9][e] + fw[10][e];
+                    v[e] = fmaxf(a, a * p.first_slope) * okf;
+                }
+                ra[i] = v;
+            }
+        }
+    };
     auto gload_a = [&](int c0, f32x4 (&ra)[NLA]) {
+        if constexpr (FIRST) {      // no activation to load: the tile is computed where it is stored (first_tile, lds_store_a)
+            const float* w = p.first_w + c0 + (tid & 3) * 4;                      // [9 taps][64 channels]
+#pragma unroll
+            for (int t = 0; t < 9; ++t) fw[t] = *reinterpret_cast<const f32x4*>(w + t * 64);
+            fw[9] = *reinterpret_cast<const f32x4*>(p.first_scale + c0 + (tid & 3) * 4);
+            fw[10] = *reinterpret_cast<const f32x4*>(p.first_shift + c0 + (tid & 3) * 4);
+            return;
+        }
         const bool from_x = GEMM || c0 < p.C1;
         const float* src = (from_x ? p.x + c0 : p.skip + (c0 - p.C1)) + (GEMM ? ld_a_off : 0);
 #pragma unroll
@@ -265,11 +318,13 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             rb[j] = reinterpret_cast<const f32x4*>(tile)[i + blk];
         }
     };
-    auto lds_store_a = [&](const f32x4 (&ra)[NLA]) {
+    auto lds_store_a = [&](f32x4 (&ra)[NLA]) {
+        if constexpr (FIRST) first_tile(ra);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
             const int hp = idx >> 2, q = idx & 3;
+            if (FIRST && hp >= HP) continue;        // (FIRST: the A region has no padding rows)
             // halo / out-of-image slots already hold zeros (gload_a read dvg_zero_slot for them); rows >= HP: padding
             if constexpr (X3) {
                 // the thread's four k-values as three bf16 quadruples, 8 bytes into each plane of the row
@@ -307,6 +362,14 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     if (p.clk) {   // wave-uniform condition: the stamps live in SGPRs (under `threadIdx.x == 0` they cost 8 VGPRs kernel-wide)
         clk0 = clock64();
         wclk0 = wall_clock64();
+    }
+    if constexpr (FIRST) {
+        const float* fr = p.first_frame + (size_t)n0 * p.H * p.W;
+        for (int i = tid; i < C::FP_FLOATS; i += 256) {
+            const int yy = yin0 - 1 + i / C::FP_W, xx = xin0 - 1 + i % C::FP_W;
+            Fp[i] = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) ? fr[(size_t)yy * p.W + xx] : 0.f;   // layer 1's padding
+        }
+        __syncthreads();
     }
     gload_a(chunk_begin * C::KC, ra);
     gload_b(chunk_begin, 0, rb);
@@ -431,7 +494,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             constexpr int NREAD = NP * (MT + NT), NMFMA = (X3 ? 6 : 8) * MT * NT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
             // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
-            constexpr int NVMEM = (next_a ? NLA : 0) + (has_next ? NLB : 0);
+            constexpr int NVMEM = (next_a ? (FIRST ? 11 : NLA) : 0) + (has_next ? NLB : 0);
             constexpr int POLICY = DVG_VMEM_POLICY;
             // policy 4 (default): spread over the taps that are followed by another tap, starting at tap 2 in the 9-tap
             // mode and at tap 0 in the 4- / 8-tap modes, as many per tap as it takes to place ALL of them (with the
@@ -849,9 +912,9 @@ static int choose_splitk(long wgs, int nchunks) {
     return s < 2 ? 1 : (int)s;
 }
 
-template <int MODE, int TI, int TH, int TW, int NT = 1>
+template <int MODE, int TI, int TH, int TW, int NT = 1, bool FIRST = false>
 static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hipStream_t stream) {
-    using C = Cfg2<MODE, TI, TH, TW, NT>;
+    using C = Cfg2<MODE, TI, TH, TW, NT, FIRST>;
     if (Hg % TH || Wg % TW || p.Cout % C::BN) return fail(DVG_ERR_SHAPE, "conv_igemm2: tile does not divide shape");
     p.tiles_y = Hg / TH;
     p.tiles_x = Wg / TW;
@@ -921,12 +984,12 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.stage_prio = (MODE == M2_CONV3 || grid <= 3 * 256) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm2_kernel<MODE, TI, TH, TW, NT, FIRST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail(DVG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW, NT>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW, NT, FIRST>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
     if (int e = check_launch("conv_igemm2")) return e;
     if (S > 1) {
         const bool pool = y_pool != nullptr;
@@ -1090,6 +1153,24 @@ extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const fl
     D2(M2_CONV3, 1, 8, 16)
     D2(M2_CONV3, 1, 8, 8)
     return fail(DVG_ERR_SHAPE, "dvg_conv3x3_bn_act_v2: no kernel");
+}
+
+// vgg_64's first stage c1 = vgg_layer(1, 64) -> vgg_layer(64, Cout) (vgg_64.py:23-26) in eval mode as ONE launch: the second
+// layer's implicit GEMM computes its input tile from the frame (see Igemm2Params::first_*).  frame (N,1,H,W); w0 = the first
+// layer's (64,1,3,3) weight TRANSPOSED to [9 taps][64 channels];
+// scale0 / shift0 the first layer's folded BatchNorm (64 each); the rest as dvg_conv3x3_bn_act_v2 with C1 = 64, no skip,
+// no split-K.  H % 8 == 0, W % 16 == 0, at least 512 workgroups (the 8 x 16 tile).
+extern "C" int dvg_conv3x3_first_pair(const float* frame, const float* w0, const float* scale0, const float* shift0,
+                                      const float* w1_k16, const float* scale1, const float* shift1, float* y, float* y_pool,
+                                      int N, int H, int W, int Cout, int act, float slope, void* stream) {
+    DVG_REQUIRE(frame && w0 && scale0 && shift0, DVG_ERR_NULL, "dvg_conv3x3_first_pair: NULL pointer");
+    Igemm2Params p{frame /* never read as an activation */, nullptr, w1_k16, scale1, shift1, y, y_pool, nullptr, N, H, W, 64, 0, Cout, 0,
+                   act, slope, 0, 0, 0, 0, 0, 1, 0, nullptr};
+    p.first_frame = frame; p.first_w = w0; p.first_scale = scale0; p.first_shift = shift0; p.first_slope = 0.2f;
+    if (int e = checks2(p, "dvg_conv3x3_first_pair")) return e;
+    DVG_REQUIRE(H % 8 == 0 && W % 16 == 0 && (long)N * (H / 8) * (W / 16) * (Cout / 64) >= 512, DVG_ERR_SHAPE,
+                "dvg_conv3x3_first_pair: H %% 8, W %% 16 and >= 512 workgroups needed (N=%d H=%d W=%d Cout=%d)", N, H, W, Cout);
+    return launch2<M2_CONV3, 1, 8, 16, 1, true>(p, H, W, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale, const float* shift,

@@ -536,6 +536,29 @@ def conv3_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
+# eval mode: the encoder's first stage vgg_layer(1, 64) -> vgg_layer(64, C) (+ pool) as one launch (DVG_FIRST_PAIR=0: two)
+FIRST_PAIR = os.environ.get("DVG_FIRST_PAIR", "1") != "0"
+
+
+def first_pair_applies(conv0, bn0, conv1, bn1, x_nchw) -> bool:
+    if not FIRST_PAIR or bn0.training or bn1.training or _needs_grad(x_nchw, conv0.weight, bn0.weight, conv1.weight, bn1.weight):
+        return False
+    n, nc, h, w = x_nchw.shape
+    return conv0.out_channels == 64 and conv1.in_channels == 64 and ops.first_pair_ok(n, nc, h, w, conv1.out_channels)
+
+
+def conv3_first_pair(conv0, bn0, conv1, bn1, x_nchw, *, pool=False, slope=0.2):
+    """vgg_64.py:23-26 (+ :49): c1 on the raw frame, both layers in one kernel (eval mode, one input channel)."""
+    sc0, sh0 = folded_affine(conv0, bn0)
+    sc1, sh1 = folded_affine(conv1, bn1)
+    slot, key = _slot(conv0), _ver(conv0.weight)
+    hit = slot.get("w_t9x64")
+    if hit is None or hit[0] != key:
+        hit = (key, conv0.weight.detach().reshape(64, 9).t().contiguous())      # [tap][channel]
+        slot["w_t9x64"] = hit
+    return ops.conv3x3_first_pair(x_nchw, hit[1], sc0, sh0, packed_weight(conv1), sc1, sh1, slope=slope, pool=pool)
+
+
 def conv4s2_bn_act(conv, bn, x, *, act=ACT_LRELU, slope=0.2):
     """dcgan_conv (dcgan_64.py:4-14)."""
     if _needs_grad(x, conv.weight, bn.weight):

@@ -133,6 +133,13 @@ class VggEncoder(nn.Module):
         h = _frame(input)
         for si, stage in enumerate(stages):
             layers = list(stage)
+            if si == 0 and len(layers) == 2 and fused.first_pair_applies(layers[0].main[0], layers[0].main[1],
+                                                                         layers[1].main[0], layers[1].main[1], h):
+                # eval mode, one input channel: both layers of c1 in one launch (the 64-channel map between them stays on chip)
+                full, h = fused.conv3_first_pair(layers[0].main[0], layers[0].main[1], layers[1].main[0], layers[1].main[1], h,
+                                                 pool=True)
+                skips.append(full)
+                continue
             for li, layer in enumerate(layers):
                 conv, bn = layer.main[0], layer.main[1]
                 last = li == len(layers) - 1

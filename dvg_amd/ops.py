@@ -441,6 +441,32 @@ def conv3x3_first(x_nchw, w, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=Fa
     return (y, st) if stats else y
 
 
+def first_pair_ok(n, nc, h, w, cout) -> bool:
+    """Shapes `conv3x3_first_pair` takes: one input channel, 8 x 16 tiles, a launch that fills the chip."""
+    return nc == 1 and h % 8 == 0 and w % 16 == 0 and cout % 64 == 0 and n * (h // 8) * (w // 16) * (cout // 64) >= 512
+
+
+def conv3x3_first_pair(x_nchw, w0, scale0, shift0, wp1, scale1, shift1, *, act=ACT_LRELU, slope=0.2, pool=False):
+    """vgg_layer(1, 64) -> vgg_layer(64, Cout) (+ 2x2 max-pool) of the encoder's first stage in eval mode as ONE launch
+    (dvg_conv3x3_first_pair): the 64-channel activation between the two layers is never materialised.
+    w0: the first layer's (64,1,3,3) weight as a contiguous (9, 64) tensor [tap][channel]."""
+    _dev_f32(x_nchw, "conv3x3_first_pair.x")
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    n, nc, h, wd = x.shape
+    taps, cout, cin = _wp_dims(wp1)
+    w0 = w0.detach()
+    if nc != 1 or tuple(w0.shape) != (9, 64) or not w0.is_contiguous() or (taps, cin) != (9, 64) or \
+            not first_pair_ok(n, nc, h, wd, cout):
+        raise RuntimeError(f"conv3x3_first_pair: unsupported shapes x {tuple(x.shape)} w0 {tuple(w0.shape)} wp1 {tuple(wp1.shape)}")
+    y = nhwc_empty(n, cout, h, wd, x.device)
+    yp = nhwc_empty(n, cout, h // 2, wd // 2, x.device) if pool else None
+    flops = 2.0 * n * h * wd * (64 * 9 + cout * 9 * 64)
+    _run("conv3x3_igemm", flops, 4.0 * (x.numel() + y.numel() * (1.25 if pool else 1.0) + wp1.numel()),
+         lib().dvg_conv3x3_first_pair, _p(x), _p(w0), _p(scale0), _p(shift0), _p(wp1), _p(scale1), _p(shift1), _p(y), _p(yp),
+         n, h, wd, cout, act, slope, _stream(), alg_flops=flops)
+    return (y, yp) if pool else y
+
+
 def convT3x3_last(x, w, bias, nc, *, act=ACT_SIGMOID):
     _dev_f32(x, "convT3x3_last.x")
     assert is_nhwc(x)

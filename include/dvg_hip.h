@@ -149,6 +149,15 @@ int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
                           const int* addend_map, int addend_block, void* stream);
 /* dcgan_conv = Conv2d(nin,nout,4,2,1)+BN+LReLU (dcgan_64.py:4-14): K = 16*Cin,
  * x NHWC (N,H,W,Cin) -> y NHWC (N,H/2,W/2,Cout).                                          */
+/* vgg_64's first stage in eval mode, c1 = vgg_layer(1, 64) -> vgg_layer(64, Cout) (vgg_64.py:23-26, 49), as ONE launch: the
+ * second layer's implicit GEMM computes its input tile from the frame patch under it, so the 64-channel activation between
+ * the two layers (67 MB at B = 64) is never written or read.  frame (N,1,H,W) NCHW; w0 = the first layer's (64,1,3,3) weight
+ * transposed to [9 taps][64 channels]; scale0 / shift0 = the first
+ * layer's folded BatchNorm (64 each; LeakyReLU `slope`); w1_k16 / scale1 / shift1 / y / y_pool / act as in
+ * dvg_conv3x3_bn_act_v2 with C1 = 64.  H % 8 == 0, W % 16 == 0, N * H/8 * W/16 * Cout/64 >= 512.                          */
+int dvg_conv3x3_first_pair(const float* frame, const float* w0, const float* scale0, const float* shift0,
+                           const float* w1_k16, const float* scale1, const float* shift1, float* y, float* y_pool,
+                           int N, int H, int W, int Cout, int act, float slope, void* stream);
 int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
                             const float* shift, float* y, float* stats, int N, int H, int W,
                             int Cin, int Cout, int act, float slope, float* workspace,

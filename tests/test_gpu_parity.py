@@ -887,3 +887,45 @@ def test_bf16_triple_products_are_as_accurate_as_the_f32_mfma():
         (mx, rms, bias), (mx0, rms0, _) = x3[k], f32[k]
         assert mx < 1.25 * mx0 + 1e-7 and rms < 1.25 * rms0 + 1e-8 and abs(bias) < 5e-7, (k, x3[k], f32[k])
         assert mx < 3e-5 and rms < 1e-5, (k, x3[k])          # the F(4x4) transforms' own rounding dominates: 1-2e-5 max
+
+
+@pytest.mark.parametrize("N", [16, 50])
+def test_first_stage_as_one_launch_matches_two_launches_and_fp64(N):
+    """dvg_conv3x3_first_pair: vgg_64's c1 = vgg_layer(1, 64) -> vgg_layer(64, 64) + MaxPool (vgg_64.py:23-26, 49) in eval mode
+    with the first layer's activation computed inside the second layer's kernel - against the two-launch path (same kernels'
+    arithmetic otherwise) and an fp64 torch composition, skip tensor and pooled map, at a batch that is not a multiple of 8."""
+    import torch.nn as nn
+    from dvg_amd import fused, ops
+    g = torch.Generator().manual_seed(4100 + N)
+    conv0, bn0, conv1, bn1 = nn.Conv2d(1, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.Conv2d(64, 64, 3, 1, 1), nn.BatchNorm2d(64)
+    with torch.no_grad():
+        for conv, bn, fan in ((conv0, bn0, 9), (conv1, bn1, 576)):
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / fan) ** 0.5)
+            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
+            bn.weight.copy_(1 + 0.2 * torch.randn(64, generator=g))
+            bn.bias.copy_(0.1 * torch.randn(64, generator=g))
+            bn.running_mean.copy_(0.1 * torch.randn(64, generator=g))
+            bn.running_var.copy_(0.5 + torch.rand(64, generator=g))
+    x = torch.rand(N, 1, 64, 64, generator=g)
+    mods = nn.Sequential(conv0, bn0, nn.LeakyReLU(0.2), conv1, bn1, nn.LeakyReLU(0.2)).double().eval()
+    with torch.no_grad():
+        ref = mods(x.double())
+        ref_pool = F.max_pool2d(ref, 2, 2)
+    for m in (conv0, bn0, conv1, bn1):
+        m.float().to("cuda:0").eval()
+    xd = x.to("cuda:0")
+    with torch.no_grad():
+        assert fused.first_pair_applies(conv0, bn0, conv1, bn1, xd)
+        y, yp = fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)
+        h0 = fused.conv3_first_bn_act(conv0, bn0, xd)
+        y2, yp2 = fused.conv3_bn_act(conv1, bn1, h0, pool=True)
+    assert ops.is_nhwc(y) and y.shape == (N, 64, 64, 64) and yp.shape == (N, 64, 32, 32)
+    assert rel_err(y, ref) < 1e-5 and rel_err(yp, ref_pool) < 1e-5, (rel_err(y, ref), rel_err(yp, ref_pool))
+    assert rel_err(y, y2) < 5e-6 and rel_err(yp, yp2) < 5e-6, (rel_err(y, y2), rel_err(yp, yp2))
+    # pooled map == max-pool of the full map the same launch wrote, bit for bit
+    assert torch.equal(yp, F.max_pool2d(y, 2, 2))
+    # and the launch is deterministic (a first version selected the LeakyReLU branch and the zero padding with lane masks
+    # inside the MFMA-interleaved store phase and produced run-to-run different tiles with two workgroups per CU)
+    with torch.no_grad():
+        for _ in range(10):
+            assert torch.equal(fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)[0], y)
