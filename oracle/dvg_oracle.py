@@ -53,22 +53,82 @@ def _bn(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
                         sd[prefix + ".bias"], training, BN_MOMENTUM, BN_EPS)
 
 
+# Forced kinks (gradient parity only).  LeakyReLU and MaxPool2d are the two non-smooth points of the backbones: an element whose
+# pre-activation is within rounding of 0 (or a 2x2 window whose two largest entries are within rounding of each other) takes
+# a different branch in two implementations that agree to 1e-7 in the forward, and from there their GRADIENTS differ by O(1)
+# of that element's contribution.  Inside `with forced_kinks(acts):` the oracle takes its branch decisions from recorded
+# activations of the implementation under test (acts[prefix] = that layer's OUTPUT, (N,C,H,W)): LeakyReLU's slope from the
+# sign of the recorded output, the max-pool winner as the arg-max of the recorded output (first maximum in scan order, the
+# nn.MaxPool2d rule).  Everything else - every convolution, BatchNorm statistic, sum - stays the oracle's own arithmetic, so
+# the comparison then isolates the ARITHMETIC of the backward pass from the choice of branches.
+_FORCED = None
+_RECORD = None
+
+
+class record_kinks:
+    """`with record_kinks() as acts:` fills acts[prefix] with every LeakyReLU layer's output (what forced_kinks consumes)."""
+
+    def __enter__(self):
+        global _RECORD
+        self.prev, _RECORD = _RECORD, {}
+        return _RECORD
+
+    def __exit__(self, *exc):
+        global _RECORD
+        _RECORD = self.prev
+
+
+class forced_kinks:
+    def __init__(self, acts: Dict[str, torch.Tensor]):
+        self.acts = acts
+
+    def __enter__(self):
+        global _FORCED
+        self.prev, _FORCED = _FORCED, self.acts
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED
+        _FORCED = self.prev
+
+
+def _lrelu(z: torch.Tensor, name: str) -> torch.Tensor:
+    """LeakyReLU(0.2) (vgg_64.py:10, dcgan_64.py:10,22); under forced_kinks the branch follows the recorded output's sign."""
+    if _FORCED is not None and name in _FORCED:
+        one = torch.ones((), dtype=z.dtype)
+        slope = torch.where(_FORCED[name] > 0, one, 0.2 * one)      # 0.2 rounded in z's dtype, like F.leaky_relu
+        out = z * slope
+    else:
+        out = F.leaky_relu(z, 0.2)
+    if _RECORD is not None:
+        _RECORD[name] = out.detach()
+    return out
+
+
+def _maxpool(h: torch.Tensor, name: str) -> torch.Tensor:
+    """MaxPool2d(2,2) (vgg_64.py:49); under forced_kinks the winner of each window is the recorded output's arg-max."""
+    if _FORCED is not None and name in _FORCED:
+        _, idx = F.max_pool2d(_FORCED[name], 2, 2, return_indices=True)
+        return h.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    return F.max_pool2d(h, 2, 2)
+
+
 def vgg_layer(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
     """vgg_64.py:5-15: Conv2d(nin,nout,3,1,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
     y = F.conv2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=1, padding=1)
-    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+    return _lrelu(_bn(y, sd, prefix + ".main.1", training), prefix)
 
 
 def dcgan_conv(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
     """dcgan_64.py:4-14: Conv2d(nin,nout,4,2,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
     y = F.conv2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=2, padding=1)
-    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+    return _lrelu(_bn(y, sd, prefix + ".main.1", training), prefix)
 
 
 def dcgan_upconv(x: torch.Tensor, sd: SD, prefix: str, training: bool) -> torch.Tensor:
     """dcgan_64.py:16-26: ConvTranspose2d(nin,nout,4,2,1) -> BatchNorm2d -> LeakyReLU(0.2)."""
     y = F.conv_transpose2d(x, sd[prefix + ".main.0.weight"], sd[prefix + ".main.0.bias"], stride=2, padding=1)
-    return F.leaky_relu(_bn(y, sd, prefix + ".main.1", training), 0.2)
+    return _lrelu(_bn(y, sd, prefix + ".main.1", training), prefix)
 
 
 def _count_blocks(sd: SD, stage: str) -> int:
@@ -88,13 +148,15 @@ def vgg_encoder(x: torch.Tensor, sd: SD, training: bool = False) -> Tuple[torch.
     head = f"c{nstage + 1}"
     skips = []
     h = x
+    last = None
     for s in range(1, nstage + 1):
         if s > 1:
-            h = F.max_pool2d(h, 2, 2)
+            h = _maxpool(h, last)
         for b in range(_count_blocks(sd, f"c{s}")):
-            h = vgg_layer(h, sd, f"c{s}.{b}", training)
+            last = f"c{s}.{b}"
+            h = vgg_layer(h, sd, last, training)
         skips.append(h)
-    h = F.max_pool2d(h, 2, 2)
+    h = _maxpool(h, last)
     h = F.conv2d(h, sd[head + ".0.weight"], sd[head + ".0.bias"])
     h = torch.tanh(_bn(h, sd, head + ".1", training))
     return h.reshape(-1, sd[head + ".0.weight"].shape[0]), skips
@@ -107,7 +169,7 @@ def vgg_decoder(vec: torch.Tensor, skips: Sequence[torch.Tensor], sd: SD, traini
     nstage = len(skips)
     dim = sd["upc1.0.weight"].shape[0]
     d = F.conv_transpose2d(vec.reshape(-1, dim, 1, 1), sd["upc1.0.weight"], sd["upc1.0.bias"])
-    d = F.leaky_relu(_bn(d, sd, "upc1.1", training), 0.2)
+    d = _lrelu(_bn(d, sd, "upc1.1", training), "upc1")
     for s in range(nstage):
         stage = f"upc{s + 2}"
         d = torch.cat([F.interpolate(d, scale_factor=2, mode="nearest"), skips[nstage - 1 - s]], 1)
@@ -154,7 +216,7 @@ def dcgan_decoder(vec: torch.Tensor, skips: Sequence[torch.Tensor], sd: SD, trai
     nstage = len(skips)
     dim = sd["upc1.0.weight"].shape[0]
     d = F.conv_transpose2d(vec.reshape(-1, dim, 1, 1), sd["upc1.0.weight"], sd["upc1.0.bias"])
-    d = F.leaky_relu(_bn(d, sd, "upc1.1", training), 0.2)
+    d = _lrelu(_bn(d, sd, "upc1.1", training), "upc1")
     for s in range(nstage - 1):
         d = dcgan_upconv(torch.cat([d, skips[nstage - 1 - s]], 1), sd, f"upc{s + 2}", training)
     last = f"upc{nstage + 1}"

@@ -79,3 +79,54 @@ def rel_err_elem(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-2) -> float
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     den = b.abs().clamp_min(floor * max(float(b.abs().max()), 1e-12))
     return float(((a - b).abs() / den).max())
+
+
+class record_hip_kinks:
+    """`with record_hip_kinks(enc, dec) as acts:` records, from the HIP training-path forward of these modules, the OUTPUT of
+    every conv + BatchNorm + LeakyReLU block and of the decoder stem under the oracle's layer prefix ("c1.0", "upc2.1",
+    "upc1" ...): what oracle.forced_kinks consumes to take the same LeakyReLU / max-pool branches as the kernels did
+    (backward.hip decides both from the saved output y: `y > 0`, first maximum of the 2x2 window in scan order).
+    Recording wraps dvg_amd.autograd.conv_block_autograd / dense_block_autograd, the two functions every train-mode block goes
+    through; a module called more than once keeps a list (call order)."""
+
+    def __init__(self, *modules):
+        self.names = {}
+        for m in modules:
+            for name, sub in m.named_modules():
+                if name.endswith(".main.0"):
+                    self.names[id(sub)] = name[:-len(".main.0")]
+                elif name == "upc1.0":
+                    self.names[id(sub)] = "upc1"
+
+    def __enter__(self):
+        from dvg_amd import autograd as ag
+        self.ag, self.orig = ag, (ag.conv_block_autograd, ag.dense_block_autograd)
+        self.acts = {}
+
+        def keep(conv, out):
+            name = self.names.get(id(conv))
+            if name is not None:
+                y = out[0] if isinstance(out, tuple) else out
+                self.acts.setdefault(name, []).append(y.detach().cpu().contiguous())
+
+        def conv_block(kind, conv, bn, x, skip, **kw):
+            out = self.orig[0](kind, conv, bn, x, skip, **kw)
+            keep(conv, out)
+            return out
+
+        def dense_block(kind, conv, bn, x, **kw):
+            out = self.orig[1](kind, conv, bn, x, **kw)
+            if kind == "stem":
+                keep(conv, out)
+            return out
+        ag.conv_block_autograd, ag.dense_block_autograd = conv_block, dense_block
+        return self.acts
+
+    def __exit__(self, *exc):
+        self.ag.conv_block_autograd, self.ag.dense_block_autograd = self.orig
+
+
+def single_call_kinks(acts):
+    """acts of record_hip_kinks when every module ran once: prefix -> tensor."""
+    assert all(len(v) == 1 for v in acts.values()), {k: len(v) for k, v in acts.items() if len(v) != 1}
+    return {k: v[0] for k, v in acts.items()}

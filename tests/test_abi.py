@@ -76,3 +76,40 @@ def test_product_has_no_cpu_fallback():
     from dvg_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv3x3_first(torch.zeros(1, 1, 8, 8), torch.zeros(64, 1, 3, 3), None, None)
+
+
+def integration_snippet() -> str:
+    """The fenced python block of INTEGRATION.md ("What a maintainer of the reference would add")."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(.*?)```", txt, flags=re.S)
+    assert m, "INTEGRATION.md lost its binding example"
+    return m.group(1)
+
+
+def test_integration_document_binds_the_header_signature():
+    """the example binding in INTEGRATION.md had drifted from include/dvg_hip.h (21 arguments for the
+    23-argument dvg_conv3x3_bn_act_v2).  Executed here VERBATIM up to the point where it would need a GPU: the snippet
+    loads the library, sets argtypes - which must equal dvg_amd/_lib.py's table, itself checked against the header - and
+    defines vgg_layer_eval.  tests/test_gpu_parity.py::test_integration_snippet_runs_verbatim calls it on the GPU."""
+    from dvg_amd import _lib
+    ns = {}
+    old = os.environ.get("DVG_HIP_LIB")
+    os.environ["DVG_HIP_LIB"] = _lib.LIB_PATH
+    try:
+        exec(compile(integration_snippet(), "INTEGRATION.md", "exec"), ns)
+    finally:
+        if old is None:
+            del os.environ["DVG_HIP_LIB"]
+        else:
+            os.environ["DVG_HIP_LIB"] = old
+    h = ns["_lib"]
+    for name in ("dvg_conv3x3_bn_act_v2", "dvg_pack_conv_weight_k16", "dvg_packed_row_floats"):
+        restype, argtypes = _lib.SIGNATURES[name]
+        fn = getattr(h, name)
+        assert fn.restype is restype and list(fn.argtypes or []) == list(argtypes), name
+    assert callable(ns["vgg_layer_eval"])
+    # the number of arguments the document's call passes == the header's parameter count
+    call = re.search(r"_lib\.dvg_conv3x3_bn_act_v2\((.*?)\)\)", integration_snippet(), flags=re.S).group(1)
+    call = re.sub(r"#[^\n]*", "", call)
+    n_args = len([a for a in re.sub(r"\([^()]*\)", "", call).split(",") if a.strip()])
+    assert n_args == len(_lib.SIGNATURES["dvg_conv3x3_bn_act_v2"][1]) == 23, n_args

@@ -167,71 +167,106 @@ def _oracle_grads(family, esd, dsd, x, gy, gh, dtype):
     return h.detach(), y.detach(), e, d
 
 
+def _hip_grads(family, seed, record=False):
+    """encoder -> decoder([h, skips]) in train mode at B=16 on the HIP path, `.backward()` of sum(y*Gy) + sum(h*Gh)."""
+    from tests.common import record_hip_kinks, single_call_kinks
+    enc, dec, esd, dsd, x, gy, gh = _reference_case(family, seed)
+    enc.to(dev()).train(), dec.to(dev()).train()
+    with record_hip_kinks(enc, dec) as acts:
+        ho, so = enc(x.to(dev()))
+        yo = dec([ho, so])
+    ((yo * gy.to(dev())).sum() + (ho * gh.to(dev())).sum()).backward()
+    grads = {"enc": {k: p.grad.double().cpu() for k, p in enc.named_parameters()},
+             "dec": {k: p.grad.double().cpu() for k, p in dec.named_parameters()}}
+    return (esd, dsd, x, gy, gh), ho.detach().cpu(), yo.detach().cpu(), grads, single_call_kinks(acts)
+
+
+def _tensor_errors(ours, ref):
+    """(max |diff| / max |ref|, ||diff|| / ||ref||) over ALL entries of a gradient tensor."""
+    diff = ours.double() - ref.double()
+    return (float(diff.abs().max()) / max(float(ref.abs().max()), 1e-30),
+            float(diff.norm() / ref.double().norm().clamp_min(1e-30)))
+
+
+KINK_MAX, KINK_L2 = 1e-3, 2e-4
+
+
 @pytest.mark.parametrize("family,seed", [("dcgan", 200), ("vgg", 210)])
 def test_module_backward_matches_reference_gradients(family, seed, golden):
-    """encoder -> decoder([h, skips]) in train mode at B=16, `.backward()` of sum(y*Gy) + sum(h*Gh):
-      (1) against the fp64 autograd of the oracle (pinned on CPU to the reference's own gradients) over the FULL tensors:
-          max error <= 1e-2 of the largest entry and L2 error <= 2e-3 ...
-      (2) ... and against the gradients of the REFERENCE's own modules and autograd (tests/golden: per-parameter
-          fingerprints = 64 strided samples + sum of squares), which are fp32 themselves.
-    B=16 keeps single LeakyReLU-kink flips (an element within rounding of 0 switches its derivative between 1 and 0.2) from
-    dominating.  dcgan_64 (10 layers) holds the bars as they stand.  For vgg_64 (22 layers, batch-statistics BatchNorm
-    after each) fp32 itself does not: the reference's arithmetic run in fp32 on the CPU (the oracle, same torch kernels)
-    deviates from its fp64 run by up to 6e-3 (L2) / 1.9e-2 (max) per tensor - measured in this test - so a tensor passes
-    when it is within 4x that fp32-CPU deviation of fp64 (or within the fixed bars, whichever is larger): the deviation is
-    driven by which near-zero pre-activations flip, i.e. by the forward rounding pattern, and a sequential fp32 MFMA K loop
-    (up to 9216 terms) or a Winograd-form layer rounds differently from the CPU's blocked sums (measured: HIP 5.4-7.2e-3
-    where the CPU's own fp32 run - a single sample of the same noise - has 1.7-3.9e-3).  Conv biases that feed a train-mode BatchNorm
-    have an analytically zero gradient and are skipped."""
+    """encoder -> decoder([h, skips]) in train mode at B=16, `.backward()` of sum(y*Gy) + sum(h*Gh): EVERY parameter gradient,
+    EVERY entry (nothing dropped), against the fp64 autograd of the oracle - which tests/test_oracle_golden.py pins on CPU to
+    the gradients of the reference's own modules and `.backward()` - at max error <= 1e-3 of the tensor's largest entry and
+    L2 error <= 2e-4 of its norm.
+
+    The oracle takes its LeakyReLU / max-pool BRANCHES from the HIP forward (oracle.forced_kinks fed by
+    tests.common.record_hip_kinks: slope from the sign of the layer output the kernels saved, pool winner = its arg-max);
+    all arithmetic stays the oracle's.  A pre-activation within rounding of 0 (or a pool window whose two largest entries are
+    within rounding of each other) otherwise sends two implementations that agree to 1e-7 in the FORWARD down different
+    branches, and each such flip moves individual gradient entries by percents (22 layers of batch-statistics BatchNorm:
+    the reference's own arithmetic in fp32 deviates from its fp64 run by 4.6e-2 max / 5.5e-3 L2 for that reason alone, and by
+    3e-5 / 1.3e-5 once the branches are shared - tests/test_oracle_golden.py::test_forced_kinks_isolate_backward_arithmetic).
+    With the branches shared a defect that hits one entry per tile is visible at the 1e-3 bar.  The free-running comparison
+    (different branches, noise-limited) is the statistical test below.  Also: the forward against the reference's golden
+    latent and the fp64 frame at 1e-4, and for dcgan_64 (10 layers: flips do not dominate) the reference's own fp32 gradient
+    fingerprints (tests/golden) at 1e-2 / 2e-3.  Conv biases that feed a train-mode BatchNorm have an analytically zero
+    gradient and are skipped."""
     from tests.test_oracle_golden import fingerprint_errors, is_bn_fed_conv_bias
-    enc, dec, esd, dsd, x, gy, gh = _reference_case(family, seed)
-    h64, y64, e64, d64 = _oracle_grads(family, esd, dsd, x, gy, gh, torch.float64)
-    h32, y32, e32, d32 = _oracle_grads(family, esd, dsd, x, gy, gh, torch.float32)
-    enc.to(dev()).train(), dec.to(dev()).train()
-    ho, so = enc(x.to(dev()))
-    yo = dec([ho, so])
-    ((yo * gy.to(dev())).sum() + (ho * gh.to(dev())).sum()).backward()
+    (esd, dsd, x, gy, gh), ho, yo, grads, acts = _hip_grads(family, seed)
+    with orc.forced_kinks({k: v.double() for k, v in acts.items()}):
+        h64, y64, e64, d64 = _oracle_grads(family, esd, dsd, x, gy, gh, torch.float64)
     tag = f"{family}_64/grad"
     assert rel_err(ho, torch.from_numpy(golden[f"{tag}/h"])) < 1e-4
-    assert rel_err(yo, y64) < 1e-4
+    assert rel_err(yo, y64) < 1e-4 and rel_err(ho, h64) < 1e-4
     bad, n, worst = [], 0, [0.0, 0.0]
-    for name, r64, r32, ours in (("enc", e64, e32, dict(enc.named_parameters())),
-                                 ("dec", d64, d32, dict(dec.named_parameters()))):
-        for k, p in ours.items():
+    for name, r64 in (("enc", e64), ("dec", d64)):
+        for k, g in grads[name].items():
             if is_bn_fed_conv_bias(k):
                 continue
-            g = r64[k].grad
-            scale, norm = max(float(g.abs().max()), 1e-30), g.norm().clamp_min(1e-30)
-            diff = p.grad.double().cpu() - g
-            err, l2 = float(diff.abs().max()) / scale, float(diff.norm() / norm)
-            cdiff = r32[k].grad.double() - g
-            cpu_err, cpu_l2 = float(cdiff.abs().max()) / scale, float(cdiff.norm() / norm)
-            # vgg_64, max-entry bar: ONE flipped pixel of an 8x8 map at B=16 is 1 of 1024 terms of a dW / dgamma / dbeta entry
-            # whose typical size is the random-walk sum of those terms: it moves individual entries by ~1/32 = 3e-2
-            # while barely moving the L2 norm - so the L2 bar is the tight one, the max bar a ceiling.  WHICH pixels flip is a
-            # property of the forward rounding pattern, so the worst entry differs from build to build at equal L2 error
-            # (tools/diag_backward_noise.py on one box: f32-MFMA build 7.5e-2 at c4.0, bf16-triple build 1.08e-1 at c4.2,
-            # both with per-tensor L2 errors of 8-9e-3 against the fp32 CPU run's 4e-3)
-            # (tools/diag_backward_noise.py, seeds 210-214 on one box: worst entry 4.7e-2 ... 1.56e-1 with the bf16-triple
-            # build, 5.4e-2 ... 7.5e-2 with the f32-MFMA build; mean per-tensor L2 error 6.7e-3 / 7.4e-3: the same noise).
-            # The L2 figures of vgg_64 therefore leave out the single worst entry per 1024 (and the worst of a fingerprint's
-            # 64 samples): a flip is ONE entry, an arithmetic defect is not.
-            bar_err, bar_l2 = max(2e-1, 4.0 * cpu_err), max(2e-3, 4.0 * cpu_l2)
-            if family == "dcgan":
-                bar_err, bar_l2 = 1e-2, 2e-3
-            else:
-                kept = diff.flatten().abs()
-                kept = kept.topk(kept.numel() - max(1, kept.numel() // 1024), largest=False).values
-                l2 = float(kept.norm() / norm)
-            err_f, l2_f, sq_f = fingerprint_errors(p.grad, golden[f"{tag}/{name}/{k}"],   # fp32 vs fp32: both sides round
-                                                   drop_worst=0 if family == "dcgan" else 1)
+            err, l2 = _tensor_errors(g, r64[k].grad)
             n += 1
             worst = [max(worst[0], err), max(worst[1], l2)]
-            if not (err < bar_err and l2 < bar_l2 and err_f < 2 * bar_err and l2_f < 2 * bar_l2 and sq_f < 4 * bar_l2):
-                bad.append((name, k, err, l2, cpu_err, cpu_l2, err_f, l2_f, sq_f))
+            ok = err < KINK_MAX and l2 < KINK_L2
+            if family == "dcgan":       # the reference's own fp32 gradients, branches free on both sides
+                err_f, l2_f, sq_f = fingerprint_errors(g, golden[f"{tag}/{name}/{k}"])
+                ok = ok and err_f < 2e-2 and l2_f < 4e-3 and sq_f < 8e-3
+            if not ok:
+                bad.append((name, k, err, l2))
     assert n >= (14 if family == "dcgan" else 40)
+    print(f"{family}: forced kinks: worst max-err {worst[0]:.2e}, worst L2 {worst[1]:.2e} over {n} tensors")
     assert not bad, [tuple(f"{v:.3e}" if isinstance(v, float) else v for v in b) for b in bad[:8]]
-    print(f"{family}: worst max-err {worst[0]:.2e}, worst L2 {worst[1]:.2e} over {n} tensors")
+
+
+def test_vgg_backward_free_running_noise_is_the_fp32_noise(golden):
+    """The second, statistical check of vgg_64's 22-layer backward: branches FREE on every side (HIP, the oracle in fp32, the
+    oracle in fp64), seeds 210-214.  Per tensor the deviation from the fp64 run is then dominated by which near-zero
+    pre-activations flip, a property of each side's forward rounding pattern; the HIP path must be the same KIND of noise as
+    the reference's own arithmetic in fp32 on the CPU: over all tensors of all seeds, HIP's median and 95th-percentile
+    per-tensor L2 error (and max-entry error) stay within NOISE_RATIO x the fp32 oracle's, and the reference's own gradient
+    fingerprints of seed 210 (tests/golden, fp32 with its own flips) are met at 4 x that noise in the sum of squares."""
+    from tests.test_oracle_golden import fingerprint_errors, is_bn_fed_conv_bias
+    NOISE_RATIO = 2.5
+    hip, cpu = [], []
+    for seed in range(210, 215):
+        (esd, dsd, x, gy, gh), ho, yo, grads, _ = _hip_grads("vgg", seed)
+        _, _, e64, d64 = _oracle_grads("vgg", esd, dsd, x, gy, gh, torch.float64)
+        _, _, e32, d32 = _oracle_grads("vgg", esd, dsd, x, gy, gh, torch.float32)
+        for name, r64, r32 in (("enc", e64, e32), ("dec", d64, d32)):
+            for k, g in grads[name].items():
+                if is_bn_fed_conv_bias(k):
+                    continue
+                hip.append(_tensor_errors(g, r64[k].grad))
+                cpu.append(_tensor_errors(r32[k].grad, r64[k].grad))
+                if seed == 210:
+                    sq_f = fingerprint_errors(g, golden[f"vgg_64/grad/{name}/{k}"])[2]
+                    assert sq_f < 4 * max(2e-3, 2 * cpu[-1][1]), (k, sq_f, cpu[-1])
+    hip, cpu = np.array(hip), np.array(cpu)
+    stats = {}
+    for j, what in enumerate(("max", "l2")):
+        for q in (50, 95):
+            stats[(what, q)] = (float(np.percentile(hip[:, j], q)), float(np.percentile(cpu[:, j], q)))
+    print("vgg_64 free-running noise (HIP, fp32 oracle):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in stats.items()})
+    for k, (a, b) in stats.items():
+        assert a <= NOISE_RATIO * b, (k, a, b)
 
 
 def test_lstm_bptt_matches_reference_gradients(golden):
@@ -349,6 +384,52 @@ def test_fused_elbo_equals_the_torch_composition():
     assert ea.shape == (D,) and rel_err(ea, eb) < 1e-5
     for k in ga:
         assert rel_err(ga[k], gb[k]) < 2e-4, (k, rel_err(ga[k], gb[k]))
+
+
+@pytest.mark.parametrize("S,B,D", [(3, 16, 90), (14, 50, 90), (2, 7, 12)])
+def test_gp_elbo_steps_equals_the_per_step_loop(S, B, D):
+    """gp_autograd.gp_elbo_steps (the GP posterior + ELBO term of S teacher-forced steps as ONE forward and ONE backward
+    launch: S x D virtual latent dims with the parameters tiled S times) against the loop it replaces,
+    `mll(gp_layer(h_i), h_target_i)` per step (train.py:164-169,225-226): the ELBO per (step, dim), the posterior means, and
+    every gradient - inducing points, variational mean / Cholesky factor, constant mean, raw output scale / length scale,
+    raw noise, and the input codes - under a weighting that differs per step and per dim (the closure-level
+    test only saw this through a whole-arena norm)."""
+    from dvg_amd.gp_autograd import gp_elbo_steps
+    from dvg_amd.models import gp_models as gm
+    M = 40
+    sd, lik = params.gp_state(540, D=D, M=M)
+    hin = params.normal(541, S, B, D, scale=0.7).tanh()
+    htgt = params.normal(542, S, B, D, scale=0.5)
+    w_elbo = params.normal(543, S, D).to(dev())
+    w_mean = params.normal(544, S, B, D).to(dev())
+    res = {}
+    for batched in (True, False):
+        gp, like = gm.GPRegressionLayer1(D, M), gm.GaussianLikelihood(batch_size=D)
+        gp.load_state_dict(sd)
+        like.load_state_dict(lik)
+        gp.to(dev()).train(), like.to(dev()).train()
+        mll = gm.VariationalELBO(like, gp, num_data=37)
+        hi = hin.to(dev()).requires_grad_(True)
+        ht = htgt.to(dev())
+        if batched:
+            elbo, mean = gp_elbo_steps(gp, mll, hi, ht)
+            elbo = elbo.view(S, D)
+        else:
+            es, ms = [], []
+            for i in range(S):
+                pred = gp(hi[i].transpose(0, 1).view(D, B, 1))
+                es.append(mll(pred, ht[i].transpose(0, 1)))
+                ms.append(pred.mean.transpose(0, 1))
+            elbo, mean = torch.stack(es), torch.stack(ms)
+        ((elbo * w_elbo).sum() + (mean * w_mean).sum()).backward()
+        g = {k: p.grad.clone() for k, p in gp.named_parameters()}
+        g.update(h=hi.grad.clone(), noise=like.noise_covar.raw_noise.grad.clone())
+        res[batched] = (elbo.detach().clone(), mean.detach().clone(), g)
+    (ea, ma, ga), (eb, mb, gb) = res[True], res[False]
+    assert ea.shape == (S, D) and ma.shape == (S, B, D)
+    assert torch.equal(ea, eb) and torch.equal(ma, mb), "same kernels, same arithmetic per (step, dim)"
+    for k in gb:
+        assert rel_err(ga[k], gb[k]) < 1e-5, (k, rel_err(ga[k], gb[k]))   # S gradient copies summed in a different order
 
 
 @pytest.mark.parametrize("family", ["dcgan", "vgg"])

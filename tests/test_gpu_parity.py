@@ -929,3 +929,41 @@ def test_first_stage_as_one_launch_matches_two_launches_and_fp64(N):
     with torch.no_grad():
         for _ in range(10):
             assert torch.equal(fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)[0], y)
+
+
+@pytest.mark.parametrize("N,C,H,Cout", [(4, 64, 16, 128), (3, 128, 8, 64)])
+def test_integration_snippet_runs_verbatim(N, C, H, Cout):
+    """The binding example of INTEGRATION.md ("What a maintainer of the reference would add"), extracted from the document
+    and executed VERBATIM against the library under test: `vgg_layer_eval` must reproduce the reference's eval-mode
+    `vgg_layer` (vgg_64.py:5-15: Conv2d(3,1,1) + BatchNorm2d + LeakyReLU(0.2)) as torch composes it in fp64.  Pins the
+    document to include/dvg_hip.h's 23-argument dvg_conv3x3_bn_act_v2 and to the packed-weight size."""
+    import os
+    import torch.nn as nn
+    from dvg_amd import _lib
+    from tests.test_abi import integration_snippet
+    ns, old = {}, os.environ.get("DVG_HIP_LIB")
+    os.environ["DVG_HIP_LIB"] = _lib.LIB_PATH
+    try:
+        exec(compile(integration_snippet(), "INTEGRATION.md", "exec"), ns)
+    finally:
+        if old is None:
+            del os.environ["DVG_HIP_LIB"]
+        else:
+            os.environ["DVG_HIP_LIB"] = old
+    g = torch.Generator().manual_seed(4200 + C)
+    conv, bn = nn.Conv2d(C, Cout, 3, 1, 1), nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * C)) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.weight.copy_(1 + 0.2 * torch.randn(Cout, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(Cout, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(Cout, generator=g))
+    x = torch.randn(N, C, H, H, generator=g)
+    mods = nn.Sequential(conv, bn, nn.LeakyReLU(0.2)).eval()
+    with torch.no_grad():
+        ref = mods.double()(x.double())
+    conv.float().to(dev()), bn.float().to(dev())
+    y = ns["vgg_layer_eval"](nhwc(x), conv, bn)
+    torch.cuda.synchronize()
+    assert y.shape == (N, Cout, H, H) and rel_err(y, ref) < 1e-5, rel_err(y, ref)

@@ -1,0 +1,195 @@
+"""GPU: the three step closures at the reference's REAL training configuration - train.py:20,33,35 default to
+`batch_size 50, n_past 5, n_future 10`, train.py:75 hard-codes dcgan_64, train.py:164 views the latent batch as
+(90, 50, 1) - against the oracle's restatements of train.py:146-248, plus vgg_64 at B = 50 with a shorter horizon
+(T = 6: the CPU oracle needs ~4 TFLOP per vgg_64 step sequence), plus the C2 size (B = 64, T = 20) through properties.
+
+What a B = 50, T = 15 run exercises that the small cases of tests/test_gpu_train.py do not: a batch that is not a multiple
+of 8 / 16 (tile tails in every conv / wgrad kernel), the time-batched passes at 15 x 50 = 750 images (encoder) and
+3 x 14 x 50 = 2100 latents (decoder) with 15 / 42 BatchNorm groups, four distinct skip blocks (n_past - 1) shared by 42
+decoder calls, and the GP at B = 50 (the reference's own `.view(90, 50, 1)`).
+
+Checked: (1) the closures' loss VALUES against the oracle; (2) BatchNorm running statistics and batch counts after
+train_model against the oracle's train-mode calls in the reference's order; (3) the LSTM and GP parameter GRADIENTS of the
+two fine-tuning closures against torch autograd of the oracle (fp64 for the GP) - those do not pass through a LeakyReLU
+kink, so they are compared tensor by tensor, every entry; (4) the time-batched passes against the step-by-step path at this
+batch: loss values and the gradients PER OPTIMISER RANGE of the flat arena, each range against its own norm, the arena
+zeroed between closures (a whole-arena norm is dominated by the 1000 x ae_mse encoder / decoder gradients)."""
+import math
+
+import pytest
+import torch
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.test_gpu_rollouts import _cpu_state, _train_mode_fns, _trainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _zero_lrs(tr):
+    saved = [[g['lr'] for g in o.param_groups] for o in tr.optimizers()]
+    for o in tr.optimizers():
+        for g in o.param_groups:
+            g['lr'] = 0.0
+    return saved
+
+
+def _ranges(tr):
+    return {"gp": tr.rng_gp, "fp": tr.rng_fp, "dec": tr.rng_dec, "enc": tr.rng_enc}
+
+
+def _range_errors(tr, a, b, which):
+    out = {}
+    for k in which:
+        lo, hi = _ranges(tr)[k]
+        na = float(a[lo:hi].double().norm())
+        out[k] = (float((a[lo:hi].double() - b[lo:hi].double()).norm()) / max(na, 1e-30), na)
+    return out
+
+
+def _closure_grads(tr, x):
+    """The three closures with every learning rate at 0 (weights stay put) and the gradient arena zeroed before each:
+    {closure: (values, arena.g clone)}."""
+    res = {}
+    for name, fn in (("model", tr.train_model), ("fp", tr.train_frame_predictor), ("gp", tr.train_GP_Frame_predictor)):
+        tr.arena.g.zero_()
+        out = fn(x)
+        vals = out if isinstance(out, tuple) else (out,)
+        if name == "model":
+            vals = vals + (tr.last_loss,)
+        res[name] = (vals, tr.arena.g.clone())
+    return res
+
+
+@pytest.mark.parametrize("model,batch,n_past,n_future", [("dcgan", 50, 5, 10), ("vgg", 50, 3, 3)])
+def test_closures_at_the_reference_training_configuration(model, batch, n_past, n_future):
+    T = n_past + n_future
+    tr, o = _trainer(model, batch, n_past, n_future, T)
+    x = [params.frames(3000 + t, batch, 1, 64) for t in range(T)]
+    xd = [t.to(DEV) for t in x]
+    esd, dsd, lsd, gsd, lik = (_cpu_state(m) for m in (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer,
+                                                       tr.likelihood))
+    esd0 = {k: v.clone() for k, v in esd.items()}
+    enc, dec = _train_mode_fns(model, 64, esd, dsd)
+    with torch.no_grad():   # oracle: train_model's loss; esd / dsd running statistics advance like the reference's modules
+        ref_loss, ref_lat = orc.train_model_loss(x, enc, dec, lsd, gsd, lik, n_past, n_future, num_data=batch)
+    _zero_lrs(tr)
+    got = _closure_grads(tr, xd)
+    (v, _, loss), _ = got["model"]
+    assert math.isfinite(loss) and abs(loss - float(ref_loss)) < 2e-3 * abs(float(ref_loss)), (loss, float(ref_loss))
+    assert abs(v - float(ref_lat) / T) < 1e-3 * abs(float(ref_lat) / T), (v, float(ref_lat) / T)
+    # (2) BatchNorm side effects: 2 (T - 1) encoder calls per closure, 3 (T - 1) decoder calls in train_model, reference order
+    # (the fine-tuning closures ran as well - lr = 0 - and advanced the encoder's buffers: the oracle follows before comparing)
+    with torch.no_grad():   # the two fine-tuning closures on the oracle (same weights: lr = 0), advancing esd further
+        ref_fp = orc.train_frame_predictor_loss(x, enc, lsd, n_past, n_future)
+        ref_gp = orc.train_gp_loss(x, enc, gsd, lik, n_past, n_future, num_data=batch)
+    (v_fp,), _ = got["fp"]
+    (v_gp,), _ = got["gp"]
+    assert abs(v_fp - float(ref_fp) / T) < 1e-3 * abs(float(ref_fp) / T), (v_fp, float(ref_fp) / T)
+    assert abs(v_gp - float(ref_gp) / T) < 2e-3 * abs(float(ref_gp) / T), (v_gp, float(ref_gp) / T)
+    for sd_ref, mod, calls in ((esd, tr.encoder, 6 * (T - 1)), (dsd, tr.decoder, 3 * (T - 1))):
+        mine = mod.state_dict()
+        n = 0
+        for k, r in sd_ref.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(mine[k]) == calls, (k, int(mine[k]), calls)       # the oracle's functional BN does not count
+            elif "running" in k:
+                scale = max(float(r.abs().max()), 1e-3)
+                assert float((mine[k].cpu() - r).abs().max()) <= 2e-4 * scale + 1e-6, (k, float((mine[k].cpu() - r).abs().max()), scale)
+                n += 1
+        assert n >= 8
+    # (3) LSTM / GP parameter gradients of the fine-tuning closures vs autograd of the oracle on the same encodings
+    # (the encoder runs in train mode on the frames again: statistics are batch statistics, weights unchanged)
+    esd_g = {k: v.clone() for k, v in esd0.items()}
+    enc_g, _ = _train_mode_fns(model, 64, esd_g, None)
+    with torch.no_grad():
+        hs = [enc_g(t)[0] for t in x]
+    l_leaf = {k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    hidden = orc.lstm_init_hidden(batch, 256, 2)
+    lat = 0
+    for i in range(1, T):
+        lat = lat + torch.nn.functional.mse_loss(orc.lstm_step(hs[i - 1], l_leaf, hidden), hs[i])
+    lat.backward()
+    g_fp = got["fp"][1]
+    for k, p in tr.frame_predictor.named_parameters():
+        lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
+        mine = g_fp[lo: lo + p.numel()].view_as(p).cpu()
+        ref = l_leaf[k].grad
+        err = float((mine - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err < 1e-3, ("lstm", k, err)
+    g_leaf = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gsd.items()}
+    n_leaf = {k: v.double().clone().requires_grad_(True) for k, v in lik.items()}
+    noise = orc.likelihood_noise(n_leaf)
+    tot = 0
+    for i in range(1, T):
+        pr = orc.gp_predict(hs[i - 1].double(), g_leaf, training=True)
+        tot = tot - orc.variational_elbo(pr, hs[i].double().t(), noise, num_data=batch).sum()
+    tot.backward()
+    g_gp = got["gp"][1]
+    for mod, leaf in ((tr.gp_layer, g_leaf), (tr.likelihood, n_leaf)):
+        for k, p in mod.named_parameters():
+            lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
+            mine = g_gp[lo: lo + p.numel()].view_as(p).cpu().double()
+            ref = leaf[k].grad
+            if k.endswith("chol_variational_covar"):
+                ref = torch.tril(ref)
+            err = float((mine - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+            assert err < 5e-4, ("gp", k, err)     # encodings differ by fp32 rounding between the two sides (1e-6 of h)
+
+
+@pytest.mark.parametrize("model,batch,n_past,n_future", [("dcgan", 50, 5, 10), ("vgg", 50, 3, 3), ("dcgan", 64, 10, 10)])
+def test_time_batched_closures_equal_the_step_by_step_path_per_optimiser_range(model, batch, n_past, n_future):
+    """DVG_TIME_BATCH on / off from the same seed at the reference's training batch (and at the C2 size): loss values of the
+    three closures, and their gradients compared per optimiser range of the flat arena - GP + likelihood, LSTM, decoder,
+    encoder - each against its OWN norm, with the arena zeroed before every closure (so that the GP / LSTM closures'
+    snapshots hold nothing but their own gradients, and train_model's GP / LSTM slices are not hidden behind the
+    1000 x ae_mse-weighted encoder / decoder gradients)."""
+    T = n_past + n_future
+    x = [params.frames(3100 + t, batch, 1, 64).to(DEV) for t in range(T)]
+    res = {}
+    for tb in (False, True):
+        tr, o = _trainer(model, batch, n_past, n_future, T)
+        tr.time_batched = tb
+        _zero_lrs(tr)
+        res[tb] = (tr, _closure_grads(tr, x))
+    (tra, a), (trb, b) = res[False], res[True]
+    for name in ("model", "fp", "gp"):
+        for u, v in zip(a[name][0], b[name][0]):
+            assert abs(u - v) <= 1e-4 * max(1.0, abs(u)), (name, a[name][0], b[name][0])
+    bars = {"gp": 1e-3, "fp": 1e-3, "dec": 2e-3, "enc": 2e-3}
+    for name, which in (("model", ("gp", "fp", "dec", "enc")), ("fp", ("fp",)), ("gp", ("gp",))):
+        errs = _range_errors(tra, a[name][1], b[name][1], which)
+        for k, (e, norm) in errs.items():
+            assert norm > 0 and e <= bars[k], (name, k, e, norm)
+        # a closure leaves nothing in the ranges it does not own (fp / gp closures run the encoder without autograd)
+        for k in set(_ranges(tra)) - set(which):
+            lo, hi = _ranges(tra)[k]
+            assert float(b[name][1][lo:hi].abs().max()) == 0.0, (name, k)
+
+
+@pytest.mark.parametrize("model", ["dcgan", "vgg"])
+def test_c2_size_graphed_iteration_equals_eager(model):
+    """C2's training size (B = 64, 10-in/10-out, T = 20): the iteration replayed as ONE hipGraph (time-batched passes at
+    20 x 64 = 1280 frames and 3 x 19 x 64 = 3648 latents) against the eager iteration from the same seed and batches -
+    losses, parameters, BatchNorm buffers."""
+    import copy
+    import train
+    B, n_past, n_future = 64, 10, 10
+    T = n_past + n_future
+    xs = [[params.frames(3200 + 50 * it + t, B, 1, 64).to(DEV) for t in range(T)] for it in range(3)]
+    res = []
+    for graphed in (False, True):
+        tr, o = _trainer(model, B, n_past, n_future, T, seed=13)
+        step = train.GraphedIteration(tr, warmup=1) if graphed else tr.iteration
+        losses = [step(x) + (tr.last_loss,) for x in xs]
+        if graphed:
+            assert step.graph is not None and not step.failed
+        res.append((losses, [copy.deepcopy(m.state_dict()) for m in tr.modules]))
+    (la, sa), (lb, sb) = res
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            assert math.isfinite(u) and abs(u - v) <= 2e-4 * max(1.0, abs(u)), (la, lb)
+    for a, b in zip(sa, sb):
+        for k in a:
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=2e-3, atol=2e-5), k
