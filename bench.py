@@ -599,9 +599,13 @@ def main():
         if "families" in result:
             for other, fam in result["families"].items():
                 fam["cpu_baseline"] = cpu_baseline(other, args.batch, args.n_past, n_eval, args.seed, budget_s=4.0)
+    # under rocprofv3 the child would inherit the preloaded tool: its f32-MFMA kernels would land in the same output
+    # directory and pollute the per-kernel statistics / PMC sums of THIS command - skipped there
+    profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (ctx.rank == 0 and ctx.world == 1 and not args.no_f32mfma_leg and _lib.lib().dvg_mfma_mode() == 1
             and "DVG_HIP_LIB" not in os.environ):
-        result["f32_mfma_build"] = f32mfma_leg(args)
+        result["f32_mfma_build"] = {"skipped": "running under a profiler"} if profiled else f32mfma_leg(args)
     if not args.no_train_leg:
         ctx.barrier()
         result["train"] = train_leg(ctx, args)

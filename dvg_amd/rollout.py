@@ -23,6 +23,27 @@ import torch
 from . import fused, ops
 
 
+def drop_version_keyed_caches() -> None:
+    """Forget every tensor the module-level caches hold (packed / transposed / Winograd-domain weights, BatchNorm folds,
+    embed-folded cell weights, GEMM-operand forms, hoisted skip halves and projections, device index maps, the LSTM's shared
+    zero state).  For the one situation in which an entry can be WRONG although its key matches: a hipGraph capture that
+    raised part-way.  During a capture a cache miss allocates from the graph's private pool and records the kernels that
+    would fill the tensor - nothing executes - and the entry is stored under the current parameter version; when the
+    capture is abandoned the pool is freed, but the entry would still be hit by the next eager call, which would read
+    never-written (and freed) memory.  Everything here is rebuilt on demand from the parameters."""
+    from . import autograd as ag
+    from .models import lstm as lstm_mod
+    ag._pack_cache.clear()
+    for slot in list(fused._cache.values()):
+        slot.clear()
+    ops._WMAT_CACHE.clear()
+    ops._MAP_CACHE.clear()
+    ops.clear_skip_proj_cache()
+    fused.clear_skip_hoist_cache()
+    lstm_mod._FOLD_CACHE.clear()
+    _ZERO_STATE.clear()
+
+
 def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
     return [i for i in range(n_past, n_eval) if i % period == 0]
 

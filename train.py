@@ -307,7 +307,7 @@ class Trainer:
             fused.replay_bn_trace(cache[2])          # ... and the BatchNorm side effects of re-encoding them, replayed
         else:
             enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
-        if self.time_batched and enc_all is not None and not g and self.gp_layer.training:
+        if self.time_batched and enc_all is not None and not g and self.gp_layer.training and _fused_elbo():
             # no recurrence in this closure: all S GP posteriors + ELBO terms as one launch (gp_autograd.gp_elbo_steps)
             from dvg_amd.gp_autograd import gp_elbo_steps
             hcat = torch.stack([e[0].detach() for e in enc_all])          # (T, B, D)
@@ -438,7 +438,7 @@ class Trainer:
     def _train_model_dev(self, x):
         opt = self.opt
         if (self.time_batched and self.time_batched_decoder and self.share_encoder_passes and self.encoder.training
-                and self.decoder.training and opt.n_past >= 2 and opt.n_past + opt.n_future >= 3):
+                and self.decoder.training and opt.n_past >= 2 and opt.n_past + opt.n_future >= 3 and _fused_elbo()):
             return self._train_model_batched(x)
         self.encoder_optimizer.zero_grad()            # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203)
         self.decoder_optimizer.zero_grad()
@@ -575,11 +575,22 @@ class Trainer:
         its storage: the live parameters, gradients and Adam moments are views of the shared FlatArena, and torch.save
         writes the whole storage behind a view (a checkpoint would carry the arena instead of the GP's moments, and loading
         only ck['encoder'] would pin all of it)."""
-        own = lambda sd: type(sd)((k, v.detach().clone() if torch.is_tensor(v) else v) for k, v in sd.items())  # noqa: E731
+        def own(sd):
+            out = type(sd)((k, v.detach().clone() if torch.is_tensor(v) else v) for k, v in sd.items())
+            if hasattr(sd, "_metadata"):          # module version info torch's state_dict carries (and load_state_dict reads)
+                out._metadata = sd._metadata
+            return out
         torch.save({'encoder': _detached_copy(self.encoder), 'decoder': _detached_copy(self.decoder),
                     'frame_predictor': _detached_copy(self.frame_predictor),
                     'likelihood': own(self.likelihood.state_dict()), 'gp_layer': own(self.gp_layer.state_dict()),
                     'gp_layer_optimizer': self.optimizer.state_dict(), 'opt': self.opt}, path)
+
+
+def _fused_elbo() -> bool:
+    """DVG_FUSED_ELBO=0 (gp_models.FUSED_ELBO): the ELBO as the torch composition of the per-step `mll(...)` calls; the
+    closures then take their step-by-step GP path (gp_elbo_steps is built on the fused dvg_gp_elbo launch)."""
+    from dvg_amd.models import gp_models
+    return bool(gp_models.FUSED_ELBO)
 
 
 def _detached_copy(module):
@@ -669,6 +680,13 @@ class GraphedIteration:
                 for o in tr.optimizers():
                     o._captured_groups = []
                 tr._segmenter = None
+                # ... except the module-level caches: a miss DURING the capture stored a tensor from the graph's pool whose
+                # fill was recorded, never run, under the current parameter version.  The eager iteration below must not
+                # hit those entries (never-written, freed memory): drop every version-keyed cache, rebuilt on demand.
+                from dvg_amd.rollout import drop_version_keyed_caches
+                drop_version_keyed_caches()
+                tr._ft_cache = None
+                tr.frame_predictor.hidden = None
                 print(f"train: hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); continuing with eager "
                       "iterations", file=sys.stderr, flush=True)
                 return tr.iteration(x)
