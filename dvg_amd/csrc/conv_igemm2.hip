@@ -40,9 +40,14 @@
 #endif
 
 //  DVG_ABLATE (timing experiments only, WRONG results): 1 = the stage loop issues no global loads (the next stage's LDS
-//  stores write stale registers), 2 = and no LDS stores, 3 = and no workgroup barriers - what the staging costs the loop
+//  stores write stale registers), 2 = and no LDS stores, 3 = and no workgroup barriers - what the staging costs the loop;
+//  4 / 5 = no weight / activation LDS stores; 6 / 7 = neither loads nor stores of the weight / activation tile in the loop
+//  (6: what a weight-stationary workgroup would save at most)
 #ifndef DVG_ABLATE
 #define DVG_ABLATE 0
+#endif
+#ifndef DVG_FIRST_SELECTS
+#define DVG_FIRST_SELECTS 0
 #endif
 //  DVG_GEMM_WGS_PER_CU: workgroups per CU the 64-row GEMM-mode tile is compiled for (register budget 512 / this per lane)
 #ifndef DVG_GEMM_WGS_PER_CU
@@ -150,11 +155,14 @@ struct Cfg2 {
     static constexpr int NLA = NLA1 * (GEMM ? GT : 1);
     static constexpr int SLAB = NLA1 * 64 * LD;                                       // floats of one A slab (GEMM mode)
     // the A region is padded to whole 256-thread store passes (NLA * 64 rows): the halo store is branch-free
-    static constexpr int A_FLOATS = (FIRST ? HP : NLA * 64) * LD, B_FLOATS = GT * BN * LDB;
+    static constexpr int A_FLOATS = NLA * 64 * LD, B_FLOATS = GT * BN * LDB;
     // FIRST: the frame patch under the halo tile, (HH + 2) x (HW + 2) floats, in LDS (the first layer's weights, scale and
-    // shift of a stage's 16 channels travel in registers).  Two workgroups must share a CU: measured, two 80.6 KB allocations
-    // are both admitted and then CORRUPT each other's last kilobytes (one 80.6 KB workgroup per CU: correct; 76.8 KB x 2:
-    // correct), so this variant drops the A tile's 12 padding rows and stays below the 76.8 KB the plain kernel uses.
+    // shift of a stage's 16 channels travel in registers): 77.8 KB, two workgroups per CU.  (r03 dropped the A tile's 12 padding
+    // rows here on the reading that "two 80.6 KB allocations are both admitted and then corrupt each other's last
+    // kilobytes".  tools/ubench/lds_oversubscribe.hip, r04: the hardware never co-schedules two workgroups whose LDS sums
+    // beyond 160 KiB - 2 x 81 912 B share a CU and keep their bytes, from 82 432 B on there is one workgroup per CU - so
+    // whatever corrupted that build was not the allocation; with the padding rows back the halo store is branch-free
+    // again, like every other instantiation's: no EXEC change inside the stage loop, tests/test_isa_invariants.py.)
     static constexpr int FP_W = HW + 2, FP_FLOATS = (HH + 2) * FP_W, FIRST_FLOATS = FIRST ? FP_FLOATS : 0;
     static_assert(!FIRST || (MODE == M2_CONV3 && TI == 1 && NT == 1), "FIRST: 3x3 mode, one image per tile");
     static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS + FIRST_FLOATS) * 4;
@@ -261,6 +269,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         if constexpr (FIRST) {
             // the halo tile's channels of vgg_layer(1, 64) from the frame patch: 9 taps per value, folded BatchNorm, LeakyReLU;
             // slots outside the image are the SECOND layer's zero padding
+#if DVG_FIRST_SELECTS == 2     // diagnostic: the select form behind a full drain of the memory counters
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif DVG_FIRST_SELECTS == 3   // diagnostic: the select form with the scheduler fenced off (no MFMA interleaved with it)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
                 const int hp = min((tid + i * 256) >> 2, HP - 1);
@@ -273,12 +286,21 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(fw[t][e], px, v[e]);
                 }
                 // LeakyReLU as max(a, slope a) (0 < slope < 1) and the padding as a multiply by 0 / 1: no lane masks in this block
+#if DVG_FIRST_SELECTS      // diagnostic build only (tools/ubench/first_pair_selects.md): the form that gave run-to-run different tiles
+                const bool okb = (okmask >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = v[e] * fw[9][e] + fw[10][e];
+                    v[e] = okb ? (a > 0.f ? a : a * p.first_slope) : 0.f;
+                }
+#else
                 const float okf = (float)((okmask >> i) & 1u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a = v[e] * fw[9][e] + fw[10][e];
                     v[e] = fmaxf(a, a * p.first_slope) * okf;
                 }
+#endif
                 ra[i] = v;
             }
         }
@@ -324,7 +346,6 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
             const int hp = idx >> 2, q = idx & 3;
-            if (FIRST && hp >= HP) continue;        // (FIRST: the A region has no padding rows)
             // halo / out-of-image slots already hold zeros (gload_a read dvg_zero_slot for them); rows >= HP: padding
             if constexpr (X3) {
                 // the thread's four k-values as three bf16 quadruples, 8 bytes into each plane of the row
@@ -390,9 +411,9 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         constexpr int ngrp = (grp + 1) % NG;
         constexpr bool next_a = has_next && ngrp == 0;
         const int nchunk = nchunk_override >= 0 ? nchunk_override : chunk + (ngrp == 0 ? CPS : 0);
-        if (DVG_ABLATE < 1) {
-            if constexpr (next_a) gload_a(nchunk * C::KC, ra);
-            if constexpr (has_next) gload_b(nchunk, ngrp, rb);
+        if (DVG_ABLATE < 1 || DVG_ABLATE >= 6) {        // 6: the weight tile stays what the prologue loaded, 7: the A tile
+            if constexpr (next_a) { if (DVG_ABLATE != 7) gload_a(nchunk * C::KC, ra); }
+            if constexpr (has_next) { if (DVG_ABLATE != 6) gload_b(nchunk, ngrp, rb); }
         }
 
         // ---- all taps of this stage from LDS; fragments double-buffered across taps ----
@@ -447,8 +468,8 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 // forming an MFMA-less pass between two barriers.
                 if (DVG_ABLATE < 3) __syncthreads();
                 if (DVG_ABLATE < 2 || DVG_ABLATE >= 4) {      // 4: no B stores, 5: no A stores (timing only)
-                    if constexpr (next_a) { if (DVG_ABLATE != 5) lds_store_a(ra); }
-                    if (DVG_ABLATE != 4) lds_store_b(rb);
+                    if constexpr (next_a) { if (DVG_ABLATE != 5 && DVG_ABLATE != 7) lds_store_a(ra); }
+                    if (DVG_ABLATE != 4 && DVG_ABLATE != 6) lds_store_b(rb);
                 }
             }
             if constexpr (X3) {

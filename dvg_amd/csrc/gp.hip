@@ -478,6 +478,7 @@ struct GpBwdParams {
     const float* gmean; const float* gvar; const float* gkl;   // upstream gradients (any may be nullptr)
     float* dh; float* dz; float* dm; float* dls; float* dc; float* ds; float* dell;
     int B, D, M;
+    int Bc;                   // data points per chunk (gp_bwd_chunk): B when the whole fp64 working set fits the LDS
     float jitter;
     unsigned long long* clk;  // debug only (dvg_debug_set_gp_clockbuf): 12 x u64 phase stamps per workgroup
     unsigned clk_cap;
@@ -485,17 +486,24 @@ struct GpBwdParams {
 
 #define GP_STAMP(k) if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + (k)] = clock64();
 
+// Data points in CHUNKS of Bc (r04): everything that has a B-wide row - Kzx, W / GW, G2 and the solved columns P = K^-1 Kzx - is
+// held for Bc points at a time, so that the fp64 working set fits the 160 KB of LDS up to B = 128 (M = 40: two chunks of 64,
+// 155.6 KB; until r03 B > 71 fell back to fp32 arithmetic and a 5e-4 / 2e-3 bar).  What couples the points of a latent dim
+// is small and is kept whole: tt = Kzx gm (a first pass over the chunks), alpha, tau, K^-1 (solved once from the columns
+// [m - c | tt | I]), and the running sums GK (LDS), dL_S (accumulated in the output buffer by the thread that owns the entry),
+// dz / ds / dell (registers).  With one chunk (B <= 71 at M = 40) the arithmetic is the r03 kernel's.
 template <int NT, typename T>
 __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* sm = reinterpret_cast<T*>(gp_lds_raw);
     const int d = blockIdx.x, tid = threadIdx.x;
-    const int M = p.M, B = p.B, LM = M + 1, LB = B + 2;
-    const int NP = B + 2 + M, LP = NP + 1;   // P = K^-1 [Kzx | m-c | Kzx gm | I]
+    const int M = p.M, B = p.B, Bc = p.Bc, LM = M + 1, LB = Bc + 2;
+    const int LP = (Bc > M + 2 ? Bc : M + 2) + 1;   // P holds K^-1 [m-c | Kzx gm | I] first, then K^-1 Kzx of a chunk
     T* Kj = sm;               // [M][LM] K with jitter
     T* L = Kj + M * LM;       // chol(K)
     T* Ls = L + M * LM;       // variational factor
     T* GK = Ls + M * LM;      // dL/dK
-    T* Kzx = GK + M * LM;     // [M][LB]
+    T* Ki = GK + M * LM;      // K^-1
+    T* Kzx = Ki + M * LM;     // [M][LB]  (one chunk)
     T* Wm = Kzx + M * LB;     // W, then GW
     T* G2 = Wm + M * LB;      // dL/dKzx
     T* P = G2 + M * LB;       // [M][LP]
@@ -509,16 +517,17 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* gv = gm + B;
     T* gq = gv + B;
     T* red = gq + B;          // [16]
-    const T* Ki = P + B + 2;  // K^-1 = the last M columns of P (row stride LP)
 
     const T s = p.outputscale[d], ell = p.lengthscale[d];
     const T ninv = -T(0.5) / (ell * ell), c0 = p.mean_const[d];
     const T gk = p.gkl ? p.gkl[d] : T(0.);
+    const int nchunk = (B + Bc - 1) / Bc;
 
     GP_STAMP(0)
     for (int i = tid; i < M; i += NT) {
         zs[i] = p.z[(size_t)d * M + i];
         rr[i] = p.var_mean[(size_t)d * M + i] - c0;
+        tt[i] = T(0.);
     }
     for (int b = tid; b < B; b += NT) {
         xs[b] = p.h[(size_t)b * p.D + d];
@@ -534,85 +543,154 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         L[r * LM + q] = v;
         Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : T(0.);
     }
-    for (int i = tid; i < M * B; i += NT) {
-        const int r = i / B, b = i % B;
-        const T dx = zs[r] - xs[b];
-        Kzx[r * LB + b] = s * exp_t(dx * dx * ninv);
+    auto build_kzx = [&](int b0, int bc) {       // Kzx of the chunk [b0, b0 + bc)
+        for (int i = tid; i < M * bc; i += NT) {
+            const int r = i / bc, b = i % bc;
+            const T dx = zs[r] - xs[b0 + b];
+            Kzx[r * LB + b] = s * exp_t(dx * dx * ninv);
+        }
+    };
+    // tt = Kzx gm over ALL points (the last chunk's Kzx stays in LDS: with one chunk nothing is built twice)
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int b0 = ch * Bc, bc = min(Bc, B - b0);
+        __syncthreads();
+        build_kzx(b0, bc);
+        __syncthreads();
+        for (int i = tid; i < M; i += NT) {
+            T acc = tt[i];
+            for (int b = 0; b < bc; ++b) acc = fma_t(Kzx[i * LB + b], gm[b0 + b], acc);
+            tt[i] = acc;
+        }
     }
     __syncthreads();
     GP_STAMP(1)
-    // W = L_S^T Kzx and tt = Kzx gm by all threads, then chol(K) by the whole workgroup (8-column panels in registers,
-    // rank-8 trailing updates; the wave-serial left-looking factorisation this kernel used first took ~40 us of its 159)
-    for (int i = tid; i < M * B; i += NT) {
-        const int r = i / B, b = i % B;
-        T acc = T(0.);
-        for (int j = r; j < M; ++j) acc = fma_t(Ls[j * LM + r], Kzx[j * LB + b], acc);
-        Wm[r * LB + b] = acc;
-    }
-    for (int i = tid; i < M; i += NT) {
-        T acc = T(0.);
-        for (int b = 0; b < B; ++b) acc = fma_t(Kzx[i * LB + b], gm[b], acc);
-        tt[i] = acc;
-    }
     GP_STAMP(2)
     block_cholesky<NT, T>(L, M, LM, tid);   // ends with __syncthreads
     GP_STAMP(3)
-    // P <- [Kzx | m-c | Kzx gm | I]; then K^-1 applied column-wise by two blocked TRIANGULAR solves with L
+    // P <- [m-c | Kzx gm | I]; K^-1 applied column-wise by two blocked TRIANGULAR solves with L
     // (an explicit fp32 K^-1 from L^-1 loses ~cond(K)*eps = 1e-3 and the c / s gradients cancel to 1e-2 of it).  The
     // identity columns give K^-1 itself, which only the KL trace term -gk/2 K^-1 needs.
-    for (int i = tid; i < M * NP; i += NT) {
-        const int r = i / NP, b = i % NP;
-        P[r * LP + b] = b < B ? Kzx[r * LB + b] : (b == B ? rr[r] : (b == B + 1 ? tt[r] : (b - B - 2 == r ? T(1.) : T(0.))));
+    for (int i = tid; i < M * (M + 2); i += NT) {
+        const int r = i / (M + 2), b = i % (M + 2);
+        P[r * LP + b] = b == 0 ? rr[r] : (b == 1 ? tt[r] : (b - 2 == r ? T(1.) : T(0.)));
     }
     __syncthreads();
-    block_forward_subst<NT, T>(L, LM, P, LP, M, NP, tid);
-    GP_STAMP(4)
-    block_backward_subst<NT, T>(L, LM, P, LP, M, NP, tid);
-    GP_STAMP(5)
+    block_forward_subst<NT, T>(L, LM, P, LP, M, M + 2, tid);
+    block_backward_subst<NT, T>(L, LM, P, LP, M, M + 2, tid);
     for (int i = tid; i < M; i += NT) {
-        al[i] = P[i * LP + B];
-        tau[i] = P[i * LP + B + 1];
+        al[i] = P[i * LP];
+        tau[i] = P[i * LP + 1];
     }
+    for (int i = tid; i < M * M; i += NT) Ki[(i / M) * LM + i % M] = P[(i / M) * LP + 2 + i % M];
     __syncthreads();
-    T ds_part = T(0.);
-    for (int b = tid; b < B; b += NT) {
-        T q = T(0.);
-        for (int i = 0; i < M; ++i) q = fma_t(Kzx[i * LB + b], P[i * LP + b], q);
-        const T mask = (s - q > T(0.)) ? T(1.) : T(0.);
-        gq[b] = -gv[b] * mask;
-        ds_part += gv[b] * mask;
-    }
-    __syncthreads();
-    GP_STAMP(6)
-    for (int i = tid; i < M * B; i += NT) {   // GW = 2 gv W (in place)
-        const int r = i / B, b = i % B;
-        Wm[r * LB + b] *= T(2.) * gv[b];
-    }
-    __syncthreads();
-    for (int i = tid; i < M * B; i += NT) {
-        const int r = i / B, b = i % B;
-        T acc = gm[b] * al[r] + T(2.) * gq[b] * P[r * LP + b];
-        for (int k = 0; k <= r; ++k) acc = fma_t(Ls[r * LM + k], Wm[k * LB + b], acc);
-        G2[r * LB + b] = acc;
-    }
+    GP_STAMP(4)
+    // the parts of GK and dL_S that do not involve the data points
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
-        T acc = -tau[r] * al[q];
-        for (int b = 0; b < B; ++b) acc = fma_t(-gq[b] * P[r * LP + b], P[q * LP + b], acc);
         T sp = T(0.);
         const int kmax = r < q ? r : q;
         for (int k = 0; k <= kmax; ++k) sp = fma_t(Ls[r * LM + k], Ls[q * LM + k], sp);
-        acc += T(0.5) * gk * (-Ki[r * LP + q] + sp - al[r] * al[q]);
-        GK[r * LM + q] = acc;
-        // dL_S (lower part)
+        GK[r * LM + q] = -tau[r] * al[q] + T(0.5) * gk * (-Ki[r * LM + q] + sp - al[r] * al[q]);
+    }
+    // dL_S: entry (r, q) belongs to ONE thread (i = r M + q = tid + it NT), which keeps its running sum in a register
+    constexpr int EPT = (64 * 64 + NT - 1) / NT;      // entries per thread at the largest M
+    T dls_acc[EPT];
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int i = tid + it * NT;
         T g = T(0.);
-        if (q <= r) {
-            for (int b = 0; b < B; ++b) g = fma_t(Kzx[r * LB + b], Wm[q * LB + b], g);
-            T kl = (r == q) ? -T(1.) / Ls[r * LM + r] : T(0.);
-            for (int k = q; k < M; ++k) kl = fma_t(Kj[r * LM + k], Ls[k * LM + q], kl);
-            g = fma_t(gk, kl, g);
+        if (i < M * M) {
+            const int r = i / M, q = i % M;
+            if (q <= r) {
+                T kl = (r == q) ? -T(1.) / Ls[r * LM + r] : T(0.);
+                for (int k = q; k < M; ++k) kl = fma_t(Kj[r * LM + k], Ls[k * LM + q], kl);
+                g = gk * kl;
+            }
         }
-        p.dls[((size_t)d * M + r) * M + q] = g;
+        dls_acc[it] = g;
+    }
+    GP_STAMP(5)
+    T ds_part = T(0.), ds_acc = T(0.), dl_acc = T(0.), dz_acc = T(0.);
+    const T il2 = T(1.) / (ell * ell), il3 = il2 / ell;
+    for (int ch = nchunk - 1; ch >= 0; --ch) {      // the last chunk first: its Kzx is still in LDS
+        const int b0 = ch * Bc, bc = min(Bc, B - b0);
+        if (ch != nchunk - 1) {
+            __syncthreads();
+            build_kzx(b0, bc);
+        }
+        __syncthreads();
+        // W = L_S^T Kzx by all threads; P <- Kzx, then K^-1 Kzx by the two triangular solves
+        for (int i = tid; i < M * bc; i += NT) {
+            const int r = i / bc, b = i % bc;
+            T acc = T(0.);
+            for (int j = r; j < M; ++j) acc = fma_t(Ls[j * LM + r], Kzx[j * LB + b], acc);
+            Wm[r * LB + b] = acc;
+            P[r * LP + b] = Kzx[r * LB + b];
+        }
+        __syncthreads();
+        block_forward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
+        block_backward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
+        for (int b = tid; b < bc; b += NT) {
+            T q = T(0.);
+            for (int i = 0; i < M; ++i) q = fma_t(Kzx[i * LB + b], P[i * LP + b], q);
+            const T mask = (s - q > T(0.)) ? T(1.) : T(0.);
+            gq[b0 + b] = -gv[b0 + b] * mask;
+            ds_part += gv[b0 + b] * mask;
+        }
+        __syncthreads();
+        GP_STAMP(6)
+        for (int i = tid; i < M * bc; i += NT) {   // GW = 2 gv W (in place)
+            const int r = i / bc, b = i % bc;
+            Wm[r * LB + b] *= T(2.) * gv[b0 + b];
+        }
+        __syncthreads();
+        for (int i = tid; i < M * bc; i += NT) {
+            const int r = i / bc, b = i % bc;
+            T acc = gm[b0 + b] * al[r] + T(2.) * gq[b0 + b] * P[r * LP + b];
+            for (int k = 0; k <= r; ++k) acc = fma_t(Ls[r * LM + k], Wm[k * LB + b], acc);
+            G2[r * LB + b] = acc;
+        }
+        for (int i = tid; i < M * M; i += NT) {     // the same thread owns entry (r, q) in every chunk
+            const int r = i / M, q = i % M;
+            T acc = GK[r * LM + q];
+            for (int b = 0; b < bc; ++b) acc = fma_t(-gq[b0 + b] * P[r * LP + b], P[q * LP + b], acc);
+            GK[r * LM + q] = acc;
+        }
+#pragma unroll
+        for (int it = 0; it < EPT; ++it) {
+            const int i = tid + it * NT;
+            if (i < M * M && i % M <= i / M) {
+                const int r = i / M, q = i % M;
+                T g = dls_acc[it];
+                for (int b = 0; b < bc; ++b) g = fma_t(Kzx[r * LB + b], Wm[q * LB + b], g);
+                dls_acc[it] = g;
+            }
+        }
+        __syncthreads();
+        // RBF chain rule, the terms over this chunk's points
+        for (int i = tid; i < M * bc; i += NT) {
+            const int r = i / bc, b = i % bc;
+            const T dx = zs[r] - xs[b0 + b];
+            const T g = G2[r * LB + b] * Kzx[r * LB + b];
+            ds_acc += g;
+            dl_acc = fma_t(g, dx * dx, dl_acc);
+        }
+        for (int i = tid; i < M; i += NT) {
+            T acc = T(0.);
+            for (int b = 0; b < bc; ++b) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b0 + b]), acc);
+            dz_acc += acc;
+        }
+        for (int b = tid; b < bc; b += NT) {
+            T acc = T(0.);
+            for (int i = 0; i < M; ++i) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b0 + b], acc);
+            p.dh[(size_t)(b0 + b) * p.D + d] = acc * il2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int i = tid + it * NT;
+        if (i < M * M) p.dls[(size_t)d * M * M + i] = dls_acc[it];
     }
     T dc_part = T(0.);
     for (int i = tid; i < M; i += NT) {
@@ -621,11 +699,8 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         dc_part -= dr;
     }
     for (int b = tid; b < B; b += NT) dc_part += gm[b];
-    __syncthreads();
     GP_STAMP(7)
-    // RBF chain rule
-    T ds_acc = T(0.), dl_acc = T(0.);
-    const T il2 = T(1.) / (ell * ell), il3 = il2 / ell;
+    // RBF chain rule, the terms over the inducing points (GK is complete)
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         const T kp = Kj[r * LM + q] - (r == q ? p.jitter : T(0.));
@@ -634,26 +709,13 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         ds_acc += g;
         dl_acc = fma_t(g, dz * dz, dl_acc);
     }
-    for (int i = tid; i < M * B; i += NT) {
-        const int r = i / B, b = i % B;
-        const T dx = zs[r] - xs[b];
-        const T g = G2[r * LB + b] * Kzx[r * LB + b];
-        ds_acc += g;
-        dl_acc = fma_t(g, dx * dx, dl_acc);
-    }
     for (int i = tid; i < M; i += NT) {
-        T acc = T(0.);
+        T acc = dz_acc;
         for (int j = 0; j < M; ++j) {
             const T kp = Kj[i * LM + j] - (i == j ? p.jitter : T(0.));
             acc = fma_t((GK[i * LM + j] + GK[j * LM + i]) * kp, -(zs[i] - zs[j]), acc);
         }
-        for (int b = 0; b < B; ++b) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], -(zs[i] - xs[b]), acc);
         p.dz[(size_t)d * M + i] = acc * il2;
-    }
-    for (int b = tid; b < B; b += NT) {
-        T acc = T(0.);
-        for (int i = 0; i < M; ++i) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b], acc);
-        p.dh[(size_t)b * p.D + d] = acc * il2;
     }
     GP_STAMP(8)
     const T ds_tot = block_sum<NT, T>(ds_acc, red, tid);
@@ -756,8 +818,20 @@ static size_t gp_predict_elems(int B, int M, int need_cov) {
     if (need_cov) f += (size_t)B * (B + 1);
     return f;
 }
-static size_t gp_bwd_elems(int B, int M) {
-    return (size_t)4 * M * (M + 1) + (size_t)3 * M * (B + 2) + (size_t)M * (B + M + 3) + 5 * (size_t)M + 4 * (size_t)B + 16;
+// elements of gp_train_bwd_kernel's working set with the data points in chunks of Bc
+static size_t gp_bwd_elems(int B, int M, int Bc) {
+    const size_t lp = (size_t)(Bc > M + 2 ? Bc : M + 2) + 1;
+    return (size_t)5 * M * (M + 1) + (size_t)3 * M * (Bc + 2) + (size_t)M * lp + 5 * (size_t)M + 4 * (size_t)B + 16;
+}
+// points per chunk: all of them when that fits `bytes_per_elem`-wide arithmetic into the LDS, else the fewest equal chunks
+// that do (0: not even chunks of 8 points fit - M too large)
+static int gp_bwd_chunk(int B, int M, int bytes_per_elem) {
+    for (int n = 1; n <= 16; ++n) {
+        const int bc = (B + n - 1) / n;
+        if (gp_bwd_elems(B, M, bc) * bytes_per_elem <= 160 * 1024) return bc;
+        if (bc <= 8) break;
+    }
+    return 0;
 }
 
 // fp64 with the covariance's lower triangle overlaid on L / L_S (gp_predict_kernel<.., PACKED = true>)
@@ -773,9 +847,7 @@ static int gp_predict_variant(int B, int M, int need_cov) {
     return 0;
 }
 extern "C" int dvg_gp_precision(int B, int M, int need_cov) { return gp_predict_variant(B, M, need_cov) ? 64 : 32; }
-extern "C" int dvg_gp_bwd_precision(int B, int M) {
-    return (!gp_force_fp32() && gp_bwd_elems(B, M) * 8 <= GP_LDS_MAX) ? 64 : 32;
-}
+extern "C" int dvg_gp_bwd_precision(int B, int M) { return (!gp_force_fp32() && gp_bwd_chunk(B, M, 8) > 0) ? 64 : 32; }
 extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
     switch (gp_predict_variant(B, M, need_cov)) {
         case 1: return gp_predict_elems(B, M, need_cov) * 8;
@@ -783,7 +855,15 @@ extern "C" size_t dvg_gp_lds_bytes(int B, int M, int need_cov) {
         default: return gp_predict_elems(B, M, need_cov) * 4;
     }
 }
-extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) { return gp_bwd_elems(B, M) * (dvg_gp_bwd_precision(B, M) / 8); }
+extern "C" size_t dvg_gp_bwd_lds_bytes(int B, int M) {
+    const int bpe = dvg_gp_bwd_precision(B, M) / 8, bc = gp_bwd_chunk(B, M, bpe);
+    return gp_bwd_elems(B, M, bc > 0 ? bc : B) * bpe;
+}
+// data points per chunk of dvg_gp_train_bwd (== B: one pass)
+extern "C" int dvg_gp_bwd_chunk(int B, int M) {
+    const int bc = gp_bwd_chunk(B, M, dvg_gp_bwd_precision(B, M) / 8);
+    return bc > 0 ? bc : B;
+}
 
 extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_mean, const float* chol_var,
                               const float* mean_const, const float* outputscale, const float* lengthscale,
@@ -838,7 +918,7 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
     const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
     DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
-                  dh, dz, dm, dls, dc, ds, dell, B, D, M, jitter, g_gp_clk, g_gp_clk_cap};
+                  dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(B, M), jitter, g_gp_clk, g_gp_clk_cap};
     const int nt = gp_threads(GP_BWD_THREADS);
     const char* who = "dvg_gp_train_bwd";
     if (dvg_gp_bwd_precision(B, M) == 64) {

@@ -516,10 +516,13 @@ int dvg_lstm_gates_bwd(const float* dh, const float* dc, const float* gates, con
 /* Train-mode GP backward (gradients of dvg_gp_predict(train_mode=1) outputs mean / var
  * (without likelihood noise) / kl): upstream gmean [D][B], gvar [D][B], gkl [D] (any may
  * be NULL = zero) -> dh [B][D], dz [D][M], dm [D][M], dls [D][M][M] (lower), dc, ds, dell
- * [D] w.r.t. the soft-plus'ed hyper-parameters.  One workgroup per latent dim, all in LDS.  fp64 inside when the fp64
- * working set fits (M = 40: B <= 71; dvg_gp_bwd_precision returns 64 / 32), fp32 I/O either way (ABI 6). */
+ * [D] w.r.t. the soft-plus'ed hyper-parameters.  One workgroup per latent dim, all in LDS.  fp64 inside, fp32 I/O
+ * (ABI 6).  r04: the data points are processed in chunks of dvg_gp_bwd_chunk(B, M) so that the fp64 working set fits the
+ * 160 KB of LDS for every B <= 128 at M <= 40 (M = 40: one pass up to B = 71, two chunks of 64 at B = 128; until r03 B > 71
+ * fell back to fp32 arithmetic); dvg_gp_bwd_precision still returns 32 where not even small chunks fit (M = 64, B > 40). */
 int dvg_gp_bwd_precision(int B, int M);
 size_t dvg_gp_bwd_lds_bytes(int B, int M);
+int dvg_gp_bwd_chunk(int B, int M);
 int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, const float* chol_var,
                      const float* mean_const, const float* outputscale, const float* lengthscale,
                      const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,

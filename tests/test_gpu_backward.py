@@ -336,8 +336,14 @@ def test_lstm_bptt_backward():
         assert rel_err(xo[t].grad, xr[t].grad) < 1e-3
 
 
-@pytest.mark.parametrize("B,D,M", [(16, 12, 40), (64, 90, 40), (50, 7, 24)])
+@pytest.mark.parametrize("B,D,M", [(16, 12, 40), (64, 90, 40), (50, 7, 24), (128, 8, 40), (101, 5, 40), (72, 3, 40)])
 def test_gp_train_backward(B, D, M):
+    """dvg_gp_train_bwd through gp_autograd against fp64 autograd of the oracle, every gradient at 1e-4.  B = 128 / 101 / 72:
+    the data points in two chunks (64 + 64, 51 + 50, 36 + 36) - since r04 no shape reachable from `train.py --batch_size`
+    (<= 128) leaves the fp64 arithmetic at M = 40 (until r03: fp32 above B = 71, bars 5e-4 / 2e-3)."""
+    from dvg_amd import _lib
+    assert _lib.lib().dvg_gp_bwd_precision(B, M) == 64
+    assert (_lib.lib().dvg_gp_bwd_chunk(B, M) < B) == (B > 71)
     from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1, VariationalELBO
     sd, lik = params.gp_state(500, D=D, M=M)
     h = params.normal(501, B, D, scale=0.7).tanh()
