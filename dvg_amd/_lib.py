@@ -61,6 +61,8 @@ SIGNATURES = {
     "dvg_bn_act_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_gemm_nt_bias_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_lstm_cell": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "dvg_lstm_cell_pre": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "dvg_lstm_cell_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_lstm_cell_x": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_stem_gemm": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_gp_precision": (_i, [_i, _i, _i]),

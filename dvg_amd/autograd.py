@@ -777,6 +777,112 @@ def lstm_cell_autograd(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return _LSTMCell.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
 
 
+class _LSTMSequence(torch.autograd.Function):
+    """lstm.lstm (lstm.py:42-72) over a whole TEACHER-FORCED sequence (train.py:213-222,181-188: step i's input is the
+    encoding of the ground-truth frame x[i-1], never a prediction), from the zero state of `init_hidden()`:
+        e_t = W_e x_t + b_e;   per layer l: (h^l_t, c^l_t) = LSTMCell_l(h^{l-1}_t, (h^l_{t-1}, c^l_{t-1}));   y_t = tanh(W_o h^L_t + b_o)
+    Only W_hh h_{t-1} depends on the recurrence.  Everything else runs as ONE GEMM over the S x B rows of the sequence, layer
+    by layer (layer l's recurrence only needs its own past and layer l-1's complete output sequence): the embedding, every
+    cell's input half W_ih (.) + b_ih + b_hh, the output head - forward - and their data and weight gradients - backward;
+    per time step and layer one dvg_lstm_cell_pre launch forward and one dvg_lstm_cell_bwd launch backward (gate gradients
+    + the recurrent hand-over dG W_hh).  2 L S + 4 launches forward instead of (L + 2) S; per step results identical to the
+    step-by-step path up to fp32 summation order (the input half of the gates is added as one term).
+    x (S*B, in).  params = (W_e, b_e, [W_ih, W_hh, b_ih, b_hh] x L, W_o, b_o).  Returns y (S*B, out)."""
+
+    @staticmethod
+    def forward(ctx, x, S, *params):
+        L = (len(params) - 4) // 4
+        we, be, wo, bo = params[0], params[1], params[-2], params[-1]
+        x = _c(x)
+        rows, B = x.shape[0], x.shape[0] // S
+        H = we.shape[0]
+        dev = x.device
+        e = ops.gemm_nt(x, we.detach(), None, be.detach())
+        zero = torch.zeros((B, H), device=dev)
+        inp, saved = e, []
+        for l in range(L):
+            wih, whh, bih, bhh = params[2 + 4 * l: 6 + 4 * l]
+            pre = ops.gemm_nt(inp, wih.detach(), None, bih.detach() + bhh.detach())        # (S*B, 4H): input half + both biases
+            hs, cs = torch.empty((rows, H), device=dev), torch.empty((rows, H), device=dev)
+            gs = torch.empty((rows, 4 * H), device=dev)
+            hp, cp = zero, zero
+            for t in range(S):
+                sl = slice(t * B, (t + 1) * B)
+                ops.lstm_cell_pre(pre[sl], hp, cp, whh.detach(), hs[sl], cs[sl], gs[sl])
+                hp, cp = hs[sl], cs[sl]
+            saved += [inp, hs, cs, gs]
+            inp = hs
+        y = ops.gemm_nt(inp, wo.detach(), None, bo.detach(), act=ops.ACT_TANH)
+        ctx.save_for_backward(x, y, zero, *saved)
+        ctx.params, ctx.meta = params, (S, B, H, L)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, zero, *saved = ctx.saved_tensors
+        params = ctx.params
+        S, B, H, L = ctx.meta
+        ng = ctx.needs_input_grad            # (x, S, *params)
+        pg = list(ng[2:])
+        grads = [None] * len(params)
+
+        def acc_w(i, dyt, inp):              # dW_i = dy^T inp, into the parameter's .grad when that is an in-place sink
+            if not pg[i]:
+                return
+            s_ = _sink(params[i], True)
+            g = ops.gemm_nt(dyt, ops.transpose2d(inp), None, None, out=s_, accumulate=s_ is not None)
+            grads[i] = None if s_ is not None else g
+
+        def acc_b(idxs, d):                  # db_i = column sums of d
+            plain = None
+            for i in idxs:
+                if not pg[i]:
+                    continue
+                s_ = _sink(params[i], True)
+                if s_ is not None:
+                    ops.colsum(d, out=s_, accumulate=True)
+                else:
+                    plain = ops.colsum(d) if plain is None else plain
+                    grads[i] = plain
+        dpre = ops.act_bwd(_c(dy), y, ops.ACT_TANH)
+        top = saved[4 * (L - 1) + 1]
+        dpt = ops.transpose2d(dpre)
+        acc_w(len(params) - 2, dpt, top)
+        acc_b([len(params) - 1], dpre)
+        dh_all = ops.gemm_nt(dpre, _transposed(params[-2]), None, None)          # d h^L_t for every t, (S*B, H)
+        dev = x.device
+        for l in reversed(range(L)):
+            inp, hs, cs, gs = saved[4 * l: 4 * l + 4]
+            wih, whh = params[2 + 4 * l], params[3 + 4 * l]
+            whh_t = _transposed(whh)                                              # [H][4H]
+            dG = torch.empty((S * B, 4 * H), device=dev)
+            dcb = [torch.empty((B, H), device=dev), torch.empty((B, H), device=dev)]
+            dhb = [torch.empty((B, H), device=dev), torch.empty((B, H), device=dev)]
+            dh_rec = dc = None
+            for t in reversed(range(S)):
+                sl = slice(t * B, (t + 1) * B)
+                c_prev = cs[(t - 1) * B: t * B] if t > 0 else zero
+                dcp, dhp = dcb[t & 1], (dhb[t & 1] if t > 0 else None)
+                ops.lstm_cell_bwd(dh_all[sl], dh_rec, dc, gs[sl], c_prev, cs[sl], whh_t, dG[sl], dcp, dhp)
+                dh_rec, dc = dhp, dcp
+            dGt = ops.transpose2d(dG)
+            acc_w(2 + 4 * l, dGt, inp)
+            if S > 1:                           # h_{-1} = 0: the first step contributes nothing to dW_hh
+                acc_w(3 + 4 * l, ops.transpose2d(dG[B:]), hs[:(S - 1) * B])
+            acc_b([4 + 4 * l, 5 + 4 * l], dG)
+            if l > 0 or pg[0] or pg[1] or ng[0]:
+                dh_all = ops.gemm_nt(dG, _transposed(wih), None, None)          # gradient w.r.t. this layer's input sequence
+        de = dh_all
+        acc_w(0, ops.transpose2d(de), x)
+        acc_b([1], de)
+        dx = ops.gemm_nt(de, _transposed(params[0]), None, None) if ng[0] else None
+        return (dx, None) + tuple(grads)
+
+
+def lstm_sequence_autograd(x, S, params):
+    return _LSTMSequence.apply(x, S, *params)
+
+
 # --------------------------------------------------------------------------------------
 # GP (train mode).  Forward = dvg_gp_predict (mean, marginal variance, KL); backward = dvg_gp_train_bwd.
 # --------------------------------------------------------------------------------------

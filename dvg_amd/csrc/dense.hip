@@ -160,6 +160,10 @@ __device__ __forceinline__ void butterfly_step(float (&v)[64], int lane) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// PRE (r04, teacher-forced training, train.py:213-222): the input half of the gates - W_ih x + b_ih + b_hh - has been computed
+// for ALL time steps by one GEMM (the inputs of a teacher-forced sequence do not depend on the recurrence); `x` is then that
+// pre-activation [B][4H] and only the recurrent half W_hh h runs per step (w_ih, b_ih, b_hh unused).
+template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ x, const float* __restrict__ h,
                                                         const float* __restrict__ c,
                                                         const float* __restrict__ w_ih,
@@ -180,24 +184,24 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
     // epilogue operands of this lane's (batch, unit, gate), fetched with the first K slice instead of after the
     // butterfly (three more dependent round trips otherwise)
     const int eb = min(b0 + (lane >> 3), B - 1), ej = j0 + ((lane >> 2) & 1), eg = lane & 3;
-    const float e_bias = b_ih[eg * H + ej] + b_hh[eg * H + ej];
+    const float e_bias = PRE ? x[(size_t)eb * 4 * H + eg * H + ej] : b_ih[eg * H + ej] + b_hh[eg * H + ej];
     const float e_c = c[(size_t)eb * H + ej];
 
     // All 32 float4 loads of a 256-deep K slice are issued before the first FMA and none sits behind a branch
     // (rows past B are clamped to B-1 and their results dropped at the end): with `if (b < B)` guards hipcc put
     // each x/h pair in its own block behind a full vmcnt(0) - eight serialized memory round trips per slice.
     for (int k0 = lane * 4; k0 < H; k0 += 256) {
-        f32x4 xv[8], hv[8], wi[8], wh[8];
+        f32x4 xv[PRE ? 1 : 8], hv[8], wi[PRE ? 1 : 8], wh[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int bb = min(b0 + b, B - 1);
-            xv[b] = *reinterpret_cast<const f32x4*>(x + (size_t)bb * H + k0);
+            if constexpr (!PRE) xv[b] = *reinterpret_cast<const f32x4*>(x + (size_t)bb * H + k0);
             hv[b] = *reinterpret_cast<const f32x4*>(h + (size_t)bb * H + k0);
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = (r & 3) * H + j0 + (r >> 2);
-            wi[r] = *reinterpret_cast<const f32x4*>(w_ih + (size_t)row * H + k0);
+            if constexpr (!PRE) wi[r] = *reinterpret_cast<const f32x4*>(w_ih + (size_t)row * H + k0);
             wh[r] = *reinterpret_cast<const f32x4*>(w_hh + (size_t)row * H + k0);
         }
         __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise re-interleaves load / vmcnt(0) / FMA one load at a time
@@ -206,8 +210,10 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 float s = v[b * 8 + r];
+                if constexpr (!PRE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = fmaf(xv[b][e], wi[r][e], s);
+                    for (int e = 0; e < 4; ++e) s = fmaf(xv[b][e], wi[r][e], s);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s = fmaf(hv[b][e], wh[r][e], s);
                 v[b * 8 + r] = s;
@@ -458,6 +464,107 @@ __global__ __launch_bounds__(256) void gemm_dot_kernel(const GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// lstm_cell_bwd (r04): one BPTT step of one nn.LSTMCell in ONE launch - the gate pre-activation gradients dG_t [B][4H] and
+// dc_{t-1} (what dvg_lstm_gates_bwd computes) AND the recurrent hand-over dh_{t-1} = dG_t W_hh, which used to be a GEMM launch
+// of its own per step and layer.  A wave owns 8 batch rows x 4 columns of dh_{t-1}; K = 4H is spread over its lanes
+// with H = 256, so that lane l holds units 4l .. 4l+3 and the four 256-wide K slices ARE the four gates: the lane
+// derives the 16 gate gradients of each of its rows from the saved activations (recomputed by every wave of a row block:
+// 8 x 1024 elementwise values, nothing against a launch) and multiplies them with its 4 x 4 float4 of W_hh^T rows; the
+// 63-shuffle butterfly of the forward cell sums over the lanes.  The waves of column block 0 also write dG_t and dc_{t-1}.
+// dh = dh_a + dh_b (from the layer above / the output head, and from step t+1; either may be NULL), w_hh_t = W_hh^T [H][4H].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b,
+                                                            const float* __restrict__ dc, const float* __restrict__ gates,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                                                            const float* __restrict__ w_hh_t, float* __restrict__ dG,
+                                                            float* __restrict__ dc_prev, float* __restrict__ dh_prev,
+                                                            int B, int H, int nblk) {
+    const int lane = threadIdx.x & 63;
+    const long wid = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = (long)((B + 7) / 8) * nblk;
+    if (wid >= nwaves) return;   // wave-uniform; no barriers below
+    const int b0 = (int)(wid / nblk) * 8, n0 = (int)(wid % nblk) * 4;
+    const int j = lane * 4;       // this lane's four hidden units
+    // W_hh^T rows n0 .. n0+3, the lane's four k-values of each gate slice
+    f32x4 w[4][4];
+    if (dh_prev) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[n][g] = *reinterpret_cast<const f32x4*>(w_hh_t + (size_t)(n0 + n) * 4 * H + g * H + j);
+    }
+    float v[32];   // v[b * 4 + n]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int bb = min(b0 + b, B - 1);        // rows past B are clamped and dropped at the stores
+        const size_t o = (size_t)bb * H + j;
+        const float* gp = gates + (size_t)bb * 4 * H + j;
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(gp), gf = *reinterpret_cast<const f32x4*>(gp + H),
+                    gg = *reinterpret_cast<const f32x4*>(gp + 2 * H), go = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(c_new + o);
+        const f32x4 cp = c_prev ? *reinterpret_cast<const f32x4*>(c_prev + o) : zero4;      // NULL: the zero initial state
+        f32x4 dhv = dh_a ? *reinterpret_cast<const f32x4*>(dh_a + o) : zero4;
+        if (dh_b) dhv += *reinterpret_cast<const f32x4*>(dh_b + o);
+        const f32x4 dcin = dc ? *reinterpret_cast<const f32x4*>(dc + o) : zero4;
+        f32x4 d[4], dcp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float tc = tanhf(cn[e]);
+            const float dcv = dcin[e] + dhv[e] * go[e] * (1.f - tc * tc);
+            d[0][e] = dcv * gg[e] * gi[e] * (1.f - gi[e]);
+            d[1][e] = dcv * cp[e] * gf[e] * (1.f - gf[e]);
+            d[2][e] = dcv * gi[e] * (1.f - gg[e] * gg[e]);
+            d[3][e] = dhv[e] * tc * go[e] * (1.f - go[e]);
+            dcp[e] = dcv * gf[e];
+        }
+        if (n0 == 0 && b0 + b < B) {
+            float* og = dG + (size_t)bb * 4 * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(og + g * H) = d[g];
+            *reinterpret_cast<f32x4*>(dc_prev + o) = dcp;
+        }
+        if (dh_prev) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(d[g][e], w[n][g][e], s);
+                v[b * 4 + n] = s;
+            }
+        }
+    }
+    if (!dh_prev) return;
+    // 32 partial sums per lane -> lanes 0..31 hold one finished sum each (value index == lane & 31, both halves equal after the
+    // first step's exchange): the forward cell's butterfly on half the values
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] += __shfl_xor(v[i], 32);
+    {
+        const bool up16 = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float keep = up16 ? v[i + 16] : v[i], send = up16 ? v[i] : v[i + 16]; v[i] = keep + __shfl_xor(send, 16); }
+        const bool up8 = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float keep = up8 ? v[i + 8] : v[i], send = up8 ? v[i] : v[i + 8]; v[i] = keep + __shfl_xor(send, 8); }
+        const bool up4 = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float keep = up4 ? v[i + 4] : v[i], send = up4 ? v[i] : v[i + 4]; v[i] = keep + __shfl_xor(send, 4); }
+        const bool up2 = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const float keep = up2 ? v[i + 2] : v[i], send = up2 ? v[i] : v[i + 2]; v[i] = keep + __shfl_xor(send, 2); }
+        const bool up1 = (lane & 1) != 0;
+        { const float keep = up1 ? v[1] : v[0], send = up1 ? v[0] : v[1]; v[0] = keep + __shfl_xor(send, 1); }
+    }
+    // value index of lane l (< 32): bits (16, 8, 4, 2, 1) of l select the upper halves in that order = index l & 31
+    const int idx = lane & 31, b = idx >> 2, n = idx & 3;
+    if (lane < 32 && b0 + b < B) dh_prev[(size_t)(b0 + b) * H + n0 + n] = v[0];
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -515,9 +622,38 @@ extern "C" int dvg_lstm_cell(const float* x, const float* h, const float* c, con
     DVG_REQUIRE(aligned16(x) && aligned16(h) && aligned16(w_ih) && aligned16(w_hh), DVG_ERR_ALIGN,
                 "dvg_lstm_cell: alignment");
     dim3 grid(H / 2, (B + 31) / 32);
-    hipLaunchKernelGGL(lstm_cell_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, h, c, w_ih, w_hh, b_ih, b_hh,
+    hipLaunchKernelGGL(lstm_cell_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, h, c, w_ih, w_hh, b_ih, b_hh,
                        h_out, c_out, gates_out, B, H);
     return check_launch("dvg_lstm_cell");
+}
+
+extern "C" int dvg_lstm_cell_pre(const float* pre, const float* h, const float* c, const float* w_hh, float* h_out,
+                                 float* c_out, float* gates_out, int B, int H, void* stream) {
+    DVG_REQUIRE(pre && h && c && w_hh && h_out && c_out, DVG_ERR_NULL, "dvg_lstm_cell_pre: NULL pointer");
+    DVG_REQUIRE(B > 0 && H > 0 && H % 64 == 0, DVG_ERR_SHAPE, "dvg_lstm_cell_pre: H=%d must be a multiple of 64", H);
+    DVG_REQUIRE(h_out != h && c_out != c, DVG_ERR_SHAPE, "dvg_lstm_cell_pre: in-place state update");
+    DVG_REQUIRE(aligned16(h) && aligned16(w_hh), DVG_ERR_ALIGN, "dvg_lstm_cell_pre: alignment");
+    dim3 grid(H / 2, (B + 31) / 32);
+    hipLaunchKernelGGL(lstm_cell_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pre, h, c, nullptr, w_hh, nullptr,
+                       nullptr, h_out, c_out, gates_out, B, H);
+    return check_launch("dvg_lstm_cell_pre");
+}
+
+extern "C" int dvg_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc, const float* gates,
+                                 const float* c_prev, const float* c_new, const float* w_hh_t, float* dG, float* dc_prev,
+                                 float* dh_prev, int B, int H, void* stream) {
+    DVG_REQUIRE(gates && c_new && w_hh_t && dG && dc_prev, DVG_ERR_NULL, "dvg_lstm_cell_bwd: NULL pointer");
+    DVG_REQUIRE(dh_a || dh_b || dc, DVG_ERR_NULL, "dvg_lstm_cell_bwd: no incoming gradient");
+    DVG_REQUIRE(B > 0 && H == 256, DVG_ERR_SHAPE, "dvg_lstm_cell_bwd: H=%d (this kernel maps one gate to one 256-wide K slice)", H);
+    DVG_REQUIRE(aligned16(dh_a) && aligned16(dh_b) && aligned16(dc) && aligned16(gates) && aligned16(c_prev) &&
+                aligned16(c_new) && aligned16(w_hh_t) && aligned16(dG) && aligned16(dc_prev) && aligned16(dh_prev),
+                DVG_ERR_ALIGN, "dvg_lstm_cell_bwd: alignment");
+    // one wave = 8 batch rows x 4 columns of dh_prev; dh_prev == NULL (first time step): only dG and dc_prev
+    const int nblk = dh_prev ? H / 4 : 1;
+    const long waves = (long)((B + 7) / 8) * nblk;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dh_a, dh_b,
+                       dc, gates, c_prev, c_new, w_hh_t, dG, dc_prev, dh_prev, B, H, nblk);
+    return check_launch("dvg_lstm_cell_bwd");
 }
 
 extern "C" int dvg_lstm_cell_x(const float* x, int ldx, int Kx, const float* h, const float* c, const float* w_x,

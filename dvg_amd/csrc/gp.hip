@@ -497,13 +497,17 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* sm = reinterpret_cast<T*>(gp_lds_raw);
     const int d = blockIdx.x, tid = threadIdx.x;
     const int M = p.M, B = p.B, Bc = p.Bc, LM = M + 1, LB = Bc + 2;
-    const int LP = (Bc > M + 2 ? Bc : M + 2) + 1;   // P holds K^-1 [m-c | Kzx gm | I] first, then K^-1 Kzx of a chunk
+    // ONE chunk (Bc == B): P = K^-1 [Kzx | m-c | Kzx gm | I] comes out of one pair of triangular solves and K^-1 is read in
+    // place from its last M columns (the r03 layout and cost).  Several chunks: the M + 2 columns that couple the points are
+    // solved first, K^-1 is copied out to a buffer of its own, and P then holds K^-1 Kzx of one chunk at a time.
+    const bool single = Bc >= B;
+    const int LP = single ? B + M + 3 : (Bc > M + 2 ? Bc : M + 2) + 1;
     T* Kj = sm;               // [M][LM] K with jitter
     T* L = Kj + M * LM;       // chol(K)
     T* Ls = L + M * LM;       // variational factor
     T* GK = Ls + M * LM;      // dL/dK
-    T* Ki = GK + M * LM;      // K^-1
-    T* Kzx = Ki + M * LM;     // [M][LB]  (one chunk)
+    T* Kib = GK + M * LM;     // K^-1 (several chunks only)
+    T* Kzx = Kib + (single ? 0 : M * LM);     // [M][LB]  (one chunk)
     T* Wm = Kzx + M * LB;     // W, then GW
     T* G2 = Wm + M * LB;      // dL/dKzx
     T* P = G2 + M * LB;       // [M][LP]
@@ -550,6 +554,9 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
             Kzx[r * LB + b] = s * exp_t(dx * dx * ninv);
         }
     };
+    const int c_fix = single ? B : 0;               // first of the M + 2 coupling columns of P
+    const T* Ki = single ? P + B + 2 : Kib;         // K^-1 and its row stride
+    const int LKi = single ? LP : LM;
     // tt = Kzx gm over ALL points (the last chunk's Kzx stays in LDS: with one chunk nothing is built twice)
     for (int ch = 0; ch < nchunk; ++ch) {
         const int b0 = ch * Bc, bc = min(Bc, B - b0);
@@ -572,16 +579,19 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     // identity columns give K^-1 itself, which only the KL trace term -gk/2 K^-1 needs.
     for (int i = tid; i < M * (M + 2); i += NT) {
         const int r = i / (M + 2), b = i % (M + 2);
-        P[r * LP + b] = b == 0 ? rr[r] : (b == 1 ? tt[r] : (b - 2 == r ? T(1.) : T(0.)));
+        P[r * LP + c_fix + b] = b == 0 ? rr[r] : (b == 1 ? tt[r] : (b - 2 == r ? T(1.) : T(0.)));
     }
+    if (single)
+        for (int i = tid; i < M * B; i += NT) P[(i / B) * LP + i % B] = Kzx[(i / B) * LB + i % B];
     __syncthreads();
-    block_forward_subst<NT, T>(L, LM, P, LP, M, M + 2, tid);
-    block_backward_subst<NT, T>(L, LM, P, LP, M, M + 2, tid);
+    block_forward_subst<NT, T>(L, LM, P, LP, M, single ? B + M + 2 : M + 2, tid);
+    block_backward_subst<NT, T>(L, LM, P, LP, M, single ? B + M + 2 : M + 2, tid);
     for (int i = tid; i < M; i += NT) {
-        al[i] = P[i * LP];
-        tau[i] = P[i * LP + 1];
+        al[i] = P[i * LP + c_fix];
+        tau[i] = P[i * LP + c_fix + 1];
     }
-    for (int i = tid; i < M * M; i += NT) Ki[(i / M) * LM + i % M] = P[(i / M) * LP + 2 + i % M];
+    if (!single)
+        for (int i = tid; i < M * M; i += NT) Kib[(i / M) * LM + i % M] = P[(i / M) * LP + 2 + i % M];
     __syncthreads();
     GP_STAMP(4)
     // the parts of GK and dL_S that do not involve the data points
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         T sp = T(0.);
         const int kmax = r < q ? r : q;
         for (int k = 0; k <= kmax; ++k) sp = fma_t(Ls[r * LM + k], Ls[q * LM + k], sp);
-        GK[r * LM + q] = -tau[r] * al[q] + T(0.5) * gk * (-Ki[r * LM + q] + sp - al[r] * al[q]);
+        GK[r * LM + q] = -tau[r] * al[q] + T(0.5) * gk * (-Ki[r * LKi + q] + sp - al[r] * al[q]);
     }
     // dL_S: entry (r, q) belongs to ONE thread (i = r M + q = tid + it NT), which keeps its running sum in a register
     constexpr int EPT = (64 * 64 + NT - 1) / NT;      // entries per thread at the largest M
@@ -625,11 +635,13 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
             T acc = T(0.);
             for (int j = r; j < M; ++j) acc = fma_t(Ls[j * LM + r], Kzx[j * LB + b], acc);
             Wm[r * LB + b] = acc;
-            P[r * LP + b] = Kzx[r * LB + b];
+            if (!single) P[r * LP + b] = Kzx[r * LB + b];
         }
         __syncthreads();
-        block_forward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
-        block_backward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
+        if (!single) {       // (one chunk: P's first B columns already are K^-1 Kzx)
+            block_forward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
+            block_backward_subst<NT, T>(L, LM, P, LP, M, bc, tid);
+        }
         for (int b = tid; b < bc; b += NT) {
             T q = T(0.);
             for (int i = 0; i < M; ++i) q = fma_t(Kzx[i * LB + b], P[i * LP + b], q);
@@ -820,6 +832,8 @@ static size_t gp_predict_elems(int B, int M, int need_cov) {
 }
 // elements of gp_train_bwd_kernel's working set with the data points in chunks of Bc
 static size_t gp_bwd_elems(int B, int M, int Bc) {
+    if (Bc >= B)     // one chunk: K^-1 lives in P's last M columns
+        return (size_t)4 * M * (M + 1) + (size_t)3 * M * (B + 2) + (size_t)M * (B + M + 3) + 5 * (size_t)M + 4 * (size_t)B + 16;
     const size_t lp = (size_t)(Bc > M + 2 ? Bc : M + 2) + 1;
     return (size_t)5 * M * (M + 1) + (size_t)3 * M * (Bc + 2) + (size_t)M * lp + 5 * (size_t)M + 4 * (size_t)B + 16;
 }

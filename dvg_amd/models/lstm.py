@@ -132,6 +132,26 @@ class lstm(_Recurrent):
         return linear(self.output[0], self._trunk(input), ACT_TANH)
 
 
+def sequence_applies(mod) -> bool:
+    """forward_sequence's kernels: rnn_size 256 (train.py:37; dvg_lstm_cell_bwd maps one gate to one 256-wide K slice)."""
+    return isinstance(mod, lstm) and mod.hidden_size == 256 and mod.lstm[0].input_size == 256
+
+
+def forward_sequence(mod: "lstm", hseq: torch.Tensor) -> torch.Tensor:
+    """`[mod(h) for h in hseq]` for a TEACHER-FORCED sequence hseq (S, B, in) - the inputs of all steps exist up front
+    (train.py:181-188,213-222) - starting from the zero state of `init_hidden()`: (S, B, out).  One GEMM per non-recurrent
+    product over all S x B rows (autograd._LSTMSequence).  `mod.hidden` is NOT advanced: the closures that use this re-create
+    it per sequence (train.py:178,206) and never read it afterwards."""
+    from ..autograd import lstm_sequence_autograd
+    S, B = hseq.shape[0], hseq.shape[1]
+    params = [mod.embed.weight, mod.embed.bias]
+    for cell_ in mod.lstm:
+        params += [cell_.weight_ih, cell_.weight_hh, cell_.bias_ih, cell_.bias_hh]
+    params += [mod.output[0].weight, mod.output[0].bias]
+    y = lstm_sequence_autograd(hseq.reshape(S * B, -1), S, params)
+    return y.view(S, B, -1)
+
+
 class gaussian_lstm(_Recurrent):
     """lstm.gaussian_lstm (lstm.py:140-175): same trunk, mu / logvar heads, reparameterised z."""
 

@@ -664,6 +664,21 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=False):
     return (h_out, c_out, gates) if want_gates else (h_out, c_out)
 
 
+def lstm_cell_pre(pre, h, c, w_hh, h_out, c_out, gates_out):
+    """One LSTMCell step whose input half `pre` = W_ih x + b_ih + b_hh (B,4H) is given (dvg_lstm_cell_pre); writes into the
+    caller's h_out / c_out / gates_out (slices of the per-sequence buffers of autograd._LSTMSequence)."""
+    b, hid = h.shape
+    _run("lstm_cell", 2.0 * b * 4 * hid * hid, 4.0 * (4 * hid * hid + 9 * b * hid), lib().dvg_lstm_cell_pre, _p(pre), _p(h),
+         _p(c), _p(w_hh), _p(h_out), _p(c_out), _p(gates_out), b, hid, _stream())
+
+
+def lstm_cell_bwd(dh_a, dh_b, dc, gates, c_prev, c_new, w_hh_t, dG, dc_prev, dh_prev):
+    """One BPTT step of an LSTMCell in one launch (dvg_lstm_cell_bwd): dG, dc_prev and dh_prev = dG W_hh."""
+    b, hid = c_new.shape
+    _run("lstm_cell_bwd", 2.0 * b * 4 * hid * hid, 4.0 * (4 * hid * hid + 12 * b * hid), lib().dvg_lstm_cell_bwd, _p(dh_a),
+         _p(dh_b), _p(dc), _p(gates), _p(c_prev), _p(c_new), _p(w_hh_t), _p(dG), _p(dc_prev), _p(dh_prev), b, hid, _stream())
+
+
 def lstm_cell_x(x, h, c, w_x, w_hh, bias):
     """First cell of a time step with the embedding folded in (dvg_lstm_cell_x): x (B,Kx) raw LSTM input, w_x = W_ih W_e
     zero-padded to (4H,Kxp), bias = W_ih b_e + b_ih + b_hh.  Inference path."""

@@ -321,6 +321,23 @@ int dvg_lstm_cell(const float* x, const float* h, const float* c, const float* w
                   float* h_out, float* c_out, float* gates_out, int B, int H,
                   void* stream);
 
+/* Teacher-forced training (train.py:213-222: every step of a closure feeds the encoding of a GROUND-TRUTH frame to the
+ * predictor, so the inputs of all S steps exist before the recurrence starts).  r04: the input halves of both cells, the
+ * embedding and the output head run as ONE GEMM each over the S*B rows of a sequence (dvg_gemm_nt_bias_act) and only the
+ * recurrent half stays per step:
+ *   dvg_lstm_cell_pre: the nn.LSTMCell step of lstm.py:69 with `pre` [B][4H] = W_ih x + b_ih + b_hh given; h, c, h_out,
+ *     c_out [B][H], w_hh [4H][H], gates_out (optional) as in dvg_lstm_cell.
+ *   dvg_lstm_cell_bwd: one BPTT step of that cell in one launch (what `loss.backward()` of train.py:194,240 does per step
+ *     and layer): dh = dh_a + dh_b (from above and from step t+1; either may be NULL), dc (may be NULL), the saved
+ *     activated gates [B][4H], c_prev (NULL = the zero initial state of lstm.py:58-63) and c_new ->
+ *     dG [B][4H] (gate pre-activation gradients), dc_prev [B][H] and dh_prev [B][H] = dG W_hh (NULL: not needed at the
+ *     first step); w_hh_t = W_hh^T [H][4H].  H must be 256 (train.py:37 rnn_size; one gate per 256-wide K slice).     */
+int dvg_lstm_cell_pre(const float* pre, const float* h, const float* c, const float* w_hh, float* h_out,
+                      float* c_out, float* gates_out, int B, int H, void* stream);
+int dvg_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc, const float* gates,
+                      const float* c_prev, const float* c_new, const float* w_hh_t, float* dG, float* dc_prev,
+                      float* dh_prev, int B, int H, void* stream);
+
 /* The FIRST cell of a time step with the embedding folded in (lstm.py:50,66-70: `embed` is a plain nn.Linear, so
  * W_ih (W_e x + b_e) + b_ih + W_hh h + b_hh = (W_ih W_e) x + W_hh h + bias): x [B][Kx] (row stride ldx floats, 8-byte
  * aligned, Kx even and <= 128), w_x = W_ih W_e as [4H][Kxp] (Kxp % 4 == 0, zero padded), bias = W_ih b_e + b_ih + b_hh

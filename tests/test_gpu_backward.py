@@ -336,6 +336,69 @@ def test_lstm_bptt_backward():
         assert rel_err(xo[t].grad, xr[t].grad) < 1e-3
 
 
+@pytest.mark.parametrize("B,S", [(16, 4), (50, 14), (6, 3), (64, 19)])
+def test_lstm_sequence_matches_the_step_by_step_module(B, S):
+    """models.lstm.forward_sequence (autograd._LSTMSequence: a teacher-forced sequence with ONE GEMM per non-recurrent
+    product over all S x B rows - embedding, both cells' input halves, output head, their data and weight gradients - and
+    one dvg_lstm_cell_pre / dvg_lstm_cell_bwd launch per step and layer) against S calls of the module (the path that
+    tests/golden pins to the reference's own BPTT): outputs and every gradient - all 12 parameter tensors and the inputs -
+    under a per-step weighting, B = 50 / 6 (not multiples of 8: the clamped rows of both kernels), S up to 19 (C2)."""
+    import dvg_amd.models.lstm as ours
+    res = {}
+    for seq in (False, True):
+        net = ours.lstm(90, 90, 256, 2, B)
+        net.load_state_dict(params.fill_state_dict(net.state_dict(), 330))
+        net.to(dev())
+        assert ours.sequence_applies(net)
+        xs = torch.stack([params.normal(340 + t, B, 90, scale=0.5) for t in range(S)]).to(dev()).requires_grad_(True)
+        ws = torch.stack([params.normal(370 + t, B, 90) for t in range(S)]).to(dev())
+        net.hidden = net.init_hidden()
+        if seq:
+            y = ours.forward_sequence(net, xs)
+        else:
+            y = torch.stack([net(xs[t]) for t in range(S)])
+        (y * ws).sum().backward()
+        g = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        g["x"] = xs.grad.detach().clone()
+        res[seq] = (y.detach().clone(), g)
+    (ya, ga), (yb, gb) = res[False], res[True]
+    assert yb.shape == (S, B, 90) and rel_err(yb, ya) < 2e-6, rel_err(yb, ya)
+    assert len(gb) == 13
+    for k in ga:
+        assert rel_err(gb[k], ga[k]) < 2e-5, (k, rel_err(gb[k], ga[k]))
+
+
+def test_lstm_sequence_kernels_against_their_unfused_forms():
+    """dvg_lstm_cell_pre == dvg_lstm_cell with the input half handed over as a pre-activation; dvg_lstm_cell_bwd ==
+    dvg_lstm_gates_bwd followed by the dG W_hh GEMM, with both / one / none of (dh_b, dc), the zero initial state as a NULL
+    c_prev, no dh_prev at the first step, and a batch that is not a multiple of 8."""
+    from dvg_amd import ops
+    B, H = 21, 256
+    x, h, c = (params.normal(390 + i, B, H, scale=0.6).to(dev()) for i in range(3))
+    w_ih, w_hh = (params.normal(394 + i, 4 * H, H, scale=0.06).to(dev()) for i in range(2))
+    b_ih, b_hh = (params.normal(396 + i, 4 * H, scale=0.1).to(dev()) for i in range(2))
+    h2, c2, gates = ops.lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=True)
+    pre = ops.gemm_nt(x, w_ih, None, b_ih + b_hh)
+    h3, c3, g3 = torch.empty_like(h), torch.empty_like(c), torch.empty_like(gates)
+    ops.lstm_cell_pre(pre, h, c, w_hh, h3, c3, g3)
+    assert rel_err(h3, h2) < 2e-6 and rel_err(c3, c2) < 2e-6 and rel_err(g3, gates) < 2e-6
+    dh_a, dh_b, dc = (params.normal(400 + i, B, H).to(dev()) for i in range(3))
+    w_hh_t = w_hh.t().contiguous()
+    for use_b, use_dc, c_prev, want_dh in ((True, True, c, True), (False, True, c, True), (True, False, None, True),
+                                           (False, False, c, False)):
+        dh = dh_a + dh_b if use_b else dh_a
+        cp = c if c_prev is not None else torch.zeros_like(c)
+        _, c2z, gz = ops.lstm_cell(x, h, cp, w_ih, w_hh, b_ih, b_hh, want_gates=True)
+        dG_ref, dcp_ref = ops.lstm_gates_bwd(dh, dc if use_dc else None, gz, cp, c2z)
+        dhp_ref = ops.gemm_nt(dG_ref, w_hh_t, None, None)
+        dG, dcp = torch.empty_like(dG_ref), torch.empty_like(dcp_ref)
+        dhp = torch.empty_like(dhp_ref) if want_dh else None
+        ops.lstm_cell_bwd(dh_a, dh_b if use_b else None, dc if use_dc else None, gz, c_prev, c2z, w_hh_t, dG, dcp, dhp)
+        assert rel_err(dG, dG_ref) < 2e-6 and rel_err(dcp, dcp_ref) < 2e-6, (use_b, use_dc)
+        if want_dh:
+            assert rel_err(dhp, dhp_ref) < 5e-6, rel_err(dhp, dhp_ref)
+
+
 @pytest.mark.parametrize("B,D,M", [(16, 12, 40), (64, 90, 40), (50, 7, 24), (128, 8, 40), (101, 5, 40), (72, 3, 40)])
 def test_gp_train_backward(B, D, M):
     """dvg_gp_train_bwd through gp_autograd against fp64 autograd of the oracle, every gradient at 1e-4.  B = 128 / 101 / 72:

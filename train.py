@@ -128,6 +128,10 @@ class Trainer:
         # True (with time_batched) = train_model's 3 S decoder calls as one decoder pass with shared skip blocks
         # (_train_model_batched); DVG_TIME_BATCH=1: encoder only
         self.time_batched_decoder = os.environ.get("DVG_TIME_BATCH", "2") not in ("0", "1")
+        # True (with time_batched) = the LSTM of a teacher-forced closure over the whole sequence at once: one GEMM per
+        # non-recurrent product over all S x B rows, one launch per step and layer for the recurrence (models.lstm.
+        # forward_sequence); DVG_LSTM_SEQ=0: one module call per step
+        self.lstm_sequence = os.environ.get("DVG_LSTM_SEQ", "1") != "0"
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
         self.latent_stream = os.environ.get("DVG_LATENT_STREAM", "1") != "0"
         self._side_stream = None
@@ -223,6 +227,11 @@ class Trainer:
             from dvg_amd import autograd as _ag
             _ag.JOIN_STREAMS.append(self._side_stream)   # the end-of-backward weight-gradient flush waits for it
         return self._side_stream
+
+    def _lstm_seq_applies(self):
+        from dvg_amd.models.lstm import sequence_applies
+        return (self.lstm_sequence and self.time_batched and self.frame_predictor.training and torch.is_grad_enabled()
+                and sequence_applies(self.frame_predictor))
 
     def _gp_in(self, h):
         return h.transpose(0, 1).view(self.opt.g_dim, h.shape[0], 1)
@@ -345,11 +354,19 @@ class Trainer:
             self._ft_cache = (x, enc_all, trace.entries, tuple(p._version for p in self.encoder.parameters()))
         else:
             enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
-        for i in range(1, opt.n_past + opt.n_future):
-            h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
-            h_target = self._enc(enc_all, x, i, g)[0]
-            h_pred = self.frame_predictor(h)
-            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+        if self._lstm_seq_applies() and enc_all is not None and not g:
+            # teacher-forced: all S inputs exist before the recurrence starts - the sequence in one pass
+            from dvg_amd.models.lstm import forward_sequence
+            hcat = torch.stack([e[0].detach() for e in enc_all])              # (T, B, D)
+            pred = forward_sequence(self.frame_predictor, hcat[:-1])
+            d = pred - hcat[1:]
+            mse_latent = (d * d).sum() / float(hcat[0].numel())                # sum over the steps of nn.MSELoss (mean)
+        else:
+            for i in range(1, opt.n_past + opt.n_future):
+                h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
+                h_target = self._enc(enc_all, x, i, g)[0]
+                h_pred = self.frame_predictor(h)
+                mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
         self._ar(("reduce", self.rng_fp))
         self.frame_predictor_optimizer.step()
@@ -396,14 +413,22 @@ class Trainer:
         elbo, gp_means = gp_elbo_steps(self.gp_layer, self.mll, h_leaf[:S * B].view(S, B, D), h_leaf[B:].view(S, B, D))
         max_ll = -elbo
         # latent chain (the only recurrence): the LSTM steps
-        mse_latent = 0
-        vecs = []
-        for i in range(1, T):
-            h, h_target = hs[i - 1], hs[i]
-            h_pred = self.frame_predictor(h)
-            mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
-            vecs += [h_pred, h_target, gp_means[i - 1]]
-        vec_all = torch.cat(vecs, 0)                              # (3 S B, g_dim), reference call order
+        if self._lstm_seq_applies():
+            from dvg_amd.models.lstm import forward_sequence
+            tgt_h = h_leaf[B:].view(S, B, D)
+            pred = forward_sequence(self.frame_predictor, h_leaf[:S * B].view(S, B, D))      # (S, B, D)
+            dlat = pred - tgt_h
+            mse_latent = (dlat * dlat).sum() / float(B * D)                                      # sum over the steps of nn.MSELoss
+            vec_all = torch.stack([pred, tgt_h, gp_means], 1).reshape(3 * S * B, D)              # reference call order
+        else:
+            mse_latent = 0
+            vecs = []
+            for i in range(1, T):
+                h, h_target = hs[i - 1], hs[i]
+                h_pred = self.frame_predictor(h)
+                mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
+                vecs += [h_pred, h_target, gp_means[i - 1]]
+            vec_all = torch.cat(vecs, 0)                              # (3 S B, g_dim), reference call order
         # skip of step i: the encoder's skips of frame i-1 while i < n_past (or always with last_frame_skip), frozen after
         nblk = S if opt.last_frame_skip else max(1, opt.n_past - 1)
         gmap = tuple(min(g // 3, nblk - 1) for g in range(3 * S))
