@@ -41,10 +41,38 @@ F32MFMA_LIB = os.path.join(ROOT, "dvg_amd", "csrc", "libdvg_hip_f32mfma.so")
 # profiles/ (rocprofv3 cannot run inside bench.py); the JSON line says so in `traffic_source`.
 # direct-form FLOPs of one B = 64, 10-in/10-out rollout (19 encoder + 10 decoder passes + 19 LSTM steps)
 SURVEY_FLOPS_PER_ROLLOUT = {"vgg": 4.99e12, "dcgan": 0.51e12}
-TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "r03_conv3x3_traffic.json",
-                 ("vgg", "winograd_gemm"): "r03_winograd_gemm_traffic.json",
-                 ("dcgan", "conv4x4s2_igemm"): "r03_conv4x4s2_traffic.json",
-                 ("dcgan", "convT4x4s2_igemm"): "r03_convT4x4s2_traffic.json"}
+TRAFFIC_FILES = {("vgg", "conv3x3_igemm"): "conv3x3_traffic.json",
+                 ("vgg", "winograd_gemm"): "winograd_gemm_traffic.json",
+                 ("dcgan", "conv4x4s2_igemm"): "conv4x4s2_traffic.json",
+                 ("dcgan", "convT4x4s2_igemm"): "convT4x4s2_traffic.json"}
+# algorithmic bytes of one B = 64, 10-in/10-out rollout (every elementwise op fused)
+SURVEY_BYTES_PER_ROLLOUT = {"vgg": 15.7e9, "dcgan": 2.68e9}
+
+
+def profile_file(name: str):
+    """The newest committed profiles/rNN_<name> (rocprofv3 PMC passes cannot run inside bench.py: committed constants)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+    return hits[-1] if hits else None
+
+
+def rollout_traffic(model: str, args, ms_per_step: float):
+    """HBM-side bytes of ONE rollout from the committed per-kernel PMC sums (profiles/rNN_pmc_by_kernel.json: FETCH_SIZE
+    doubled per the gfx950 note + WRITE_SIZE, summed over every kernel of the rollouts profiled) against SURVEY 8(d)'s
+    algorithmic bytes; `counter_gbs` prices the counter bytes on THIS run's time per step."""
+    f = profile_file("pmc_by_kernel.json")
+    alg = SURVEY_BYTES_PER_ROLLOUT.get(model) if (args.batch, args.n_past, args.n_future) == (64, 10, 10) else None
+    if f is None or alg is None:
+        return None
+    d = (json.load(open(f)).get(model) or {}).get("_rollout")
+    if not d:
+        return None
+    cb = d["traffic_bytes_per_rollout"]
+    return {"counter_bytes_per_step": round(cb), "algorithmic_bytes_per_step": round(alg), "ratio": round(cb / alg, 3),
+            "counter_gbs": round(cb / (ms_per_step * 1e-3) / 1e9, 1),
+            "counter_frac_of_hbm_peak": round(cb / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "source": f"profiles/{os.path.basename(f)}: committed rocprofv3 PMC passes of this command (constant, NOT measured "
+                      "by this run; Infinity-Cache hits are counted, MI355X_MICROARCH.md)"}
 
 
 def parse_args(argv=None):
@@ -68,6 +96,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-f32mfma-leg", action="store_true",
                     help="skip the comparison run on the native f32-MFMA build of the library (a child process, N = 1 only)")
     ap.add_argument("--train-iters", type=int, default=6)
+    ap.add_argument("--no-train-shapes", action="store_true", help="skip the extra single-GPU training shapes (C2 / C4 vgg / C5)")
+    ap.add_argument("--no-make-gifs-leg", action="store_true", help="skip the make_gifs (C3) leg")
+    ap.add_argument("--nsample", type=int, default=12, help="sample rollouts per batch of the make_gifs leg")
     ap.add_argument("--train-full-graph", action="store_true",
                     help="with several ranks, also try the iteration as ONE hipGraph with the RCCL all-reduces captured "
                          "inside.  Off by default: on this stack (PyTorch 2.10 / ROCm 7) the c10d watchdog thread may query a "
@@ -324,18 +355,40 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     a = agg[dom]
     ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
     traffic, tsrc = None, None
-    tfile = TRAFFIC_FILES.get((model, dom))
-    if tfile and args.batch == 64 and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
-        traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["traffic_bytes_per_launch"]
-        tsrc = f"profiles/{tfile}: committed rocprofv3 PMC passes of this command (constant, NOT measured by this run)"
+    tname = TRAFFIC_FILES.get((model, dom))
+    tfile = profile_file(tname) if tname else None
+    if tfile and args.batch == 64:
+        traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
+        tsrc = f"profiles/{os.path.basename(tfile)}: committed rocprofv3 PMC passes of this command (constant, NOT measured by this run)"
     from dvg_amd import _lib
     x3 = _lib.lib().dvg_mfma_mode() == 1 and dom in ("winograd_gemm", "conv3x3_igemm", "conv4x4s2_igemm", "convT4x4s2_igemm")
-    peak = PEAK_F32_AS_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-    res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
-                       "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+    mfma_peak = PEAK_F32_AS_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    # WHICH roof binds follows from the kernel's own executed flops and algorithmic bytes: its HBM roof in TFLOP/s is
+    # intensity x 8 TB/s, and the lower of the two roofs is the bound (the Winograd GEMM's 45 FLOP/B put its
+    # HBM roof, 364 TF, below the 419 TF of the bf16-triple matrix pipe).  `achieved` / `peak` are in the binding roof's unit.
+    sec = a["ms"] * 1e-3
+    gbs = a["bytes"] / sec / 1e9
+    hbm_roof_tflops = a["flops"] / a["bytes"] * PEAK_HBM_GBS * 1e9 / 1e12
+    bound = "hbm" if hbm_roof_tflops < mfma_peak else "mfma"
+    if bound == "hbm":
+        r_ach, r_peak, r_unit = gbs, PEAK_HBM_GBS, "GB/s"
+    else:
+        r_ach, r_peak, r_unit = ach, mfma_peak, "TFLOP/s"
+    res["roofline"] = {"kernel": dom, "bound": bound, "achieved": round(r_ach, 2), "peak": round(r_peak, 1),
+                       "unit": r_unit, "frac": round(r_ach / r_peak, 4), "traffic": traffic,
                        "traffic_source": tsrc,
-                       "achieved_is": "EXECUTED fp32 flops of the kernel (2 x its multiply-adds, each counted once) / its HIP-event time",
-                       "peak_is": ("bf16 dense MFMA peak / 6: the kernel forms each fp32 product slab as six v_mfma_f32_32x32x16_bf16 "
+                       "bound_is": (f"the lower of the kernel's two roofs: intensity {a['flops'] / a['bytes']:.1f} FLOP/B x 8 TB/s = "
+                                    f"{hbm_roof_tflops:.0f} TFLOP/s (HBM) against {mfma_peak:.0f} TFLOP/s (matrix pipe)"),
+                       "mfma": {"achieved_tflops": round(ach, 2), "peak_tflops": round(mfma_peak, 1), "frac": round(ach / mfma_peak, 4)},
+                       "hbm": {"achieved_gbs": round(gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "bytes_are": "ALGORITHMIC (operands + result of a launch, each once)"},
+                       # the committed PMC traffic per launch over THIS run's event time per launch, against the 8 TB/s peak
+                       "hbm_frac_counter": None if traffic is None else
+                       round(traffic / (sec / a["launches"]) / 1e9 / PEAK_HBM_GBS, 4),
+                       "achieved_is": "EXECUTED fp32 flops of the kernel (2 x its multiply-adds, each counted once) / its HIP-event time"
+                                      if bound == "mfma" else "ALGORITHMIC bytes of the kernel's launches / their HIP-event time",
+                       "peak_is": ("HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, 6.3 achievable)" if bound == "hbm" else
+                                   "bf16 dense MFMA peak / 6: the kernel forms each fp32 product slab as six v_mfma_f32_32x32x16_bf16 "
                                    "on exact bf16 triples, so `frac` is also the busy fraction of the bf16 matrix pipe"
                                    if x3 else "f32-input dense MFMA peak (v_mfma_f32_32x32x2_f32)"),
                        # the same achieved rate against the NATIVE f32-MFMA roof (the peak r01 / r02 lines were priced on): above
@@ -381,6 +434,9 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
                             "algorithmic_tflops": None if alg_step is None else round(alg_step / sec / 1e12, 2),
                             "algorithmic_frac_of_fp32_mfma_peak": None if alg_step is None else
                             round(alg_step / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    rt = rollout_traffic(model, args, res["ms_per_step"])
+    if rt is not None:
+        res["rollout_traffic"] = rt
     res["kernels"] = {k: {"launches_per_step": v["launches"] // 3,
                           "avg_us": round(1000 * v["ms"] / v["launches"], 2),
                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
@@ -390,6 +446,42 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
                           "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
                       for k, v in agg.items()}
     return res
+
+
+def make_gifs_leg(ctx: Ctx, args, model: str, nsample: int) -> dict:
+    """BASELINE.json configs[2] (C3: "GP diverse sampling (generate_frames.py)"): `make_gifs` as generate_frames.py:107-189 runs it
+    for one batch - the posterior rollout (:110-134), `nsample` sample rollouts with a GP draw at the trigger steps (:143-177;
+    everything before the first predicted frame is the same for all samples of a batch and is computed once), utils.eval_seq's
+    SSIM / PSNR of every predicted frame (:178) and best-of-N by mean SSIM (:188-189) - through generate_frames.Generator
+    (rollout.GraphedSampler: the sample body as hipGraphs, `--inflight` samples at a time).  KTH frames are 64 x 64 x 1 like
+    Moving-MNIST (kth.py:54-55): same shapes, synthetic clips.  Predicted frames/s = B x n_future x nsample x ranks / wall time
+    of the whole call (conditioning, posterior rollout and metrics included)."""
+    import torch
+    import generate_frames
+    from dvg_amd.data import SyntheticMovingMNIST
+    n_eval = args.n_past + args.n_future
+    opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(args.batch), "--model", model,
+                                                     "--n_past", str(args.n_past), "--n_eval", str(n_eval),
+                                                     "--inflight", str(max(1, args.inflight))])
+    torch.manual_seed(args.seed + ctx.rank)
+    g = generate_frames.Generator(opt, generate_frames.synthetic_checkpoint(opt), ctx.dev)
+    x = SyntheticMovingMNIST(seq_len=n_eval, seed=args.seed + ctx.rank).batch_device(args.batch, ctx.dev)
+    calibrate_batchnorm(g.encoder, g.decoder, x[0])
+    g.make_gifs(x, 3)               # warm-up: weight packs, the capture of the sample body
+    reps = 2
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = g.make_gifs(x, nsample)
+    ctx.barrier()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0) / reps
+    assert bool(torch.isfinite(res["ssim"]).all()) and bool(torch.isfinite(res["psnr"]).all())
+    return {"workload": f"make_gifs on one batch: posterior rollout + {nsample} sample rollouts (GP draw at i % 15 == 0) + SSIM / "
+                        f"PSNR per predicted frame + best-of-N, {model}_64, batch {args.batch} per GPU, "
+                        f"{args.n_past}-in/{args.n_future}-out, 64x64x1 synthetic clips (KTH-shaped)",
+            "nsample": nsample, "samples_in_flight": max(1, args.inflight), "ms_per_batch": round(1e3 * dt, 2),
+            "predicted_frames_per_s": round(args.batch * args.n_future * nsample * ctx.world / dt, 1),
+            "mean_best_ssim": round(float(res["ssim"].mean(2).max(1).values.mean()), 4)}
 
 
 def f32mfma_leg(args) -> dict:
@@ -402,7 +494,7 @@ def f32mfma_leg(args) -> dict:
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--model", args.model, "--batch", str(args.batch), "--n_past", str(args.n_past), "--n_future", str(args.n_future),
            "--seed", str(args.seed), "--inflight", str(args.inflight), "--no-families", "--no-cpu-baseline", "--no-train-leg",
-           "--no-f32mfma-leg"] + (["--no-graph"] if args.no_graph else [])
+           "--no-f32mfma-leg", "--no-make-gifs-leg"] + (["--no-graph"] if args.no_graph else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["DVG_HIP_LIB"] = F32MFMA_LIB
     try:
@@ -420,17 +512,30 @@ def f32mfma_leg(args) -> dict:
                                                 "kernel_time_sum_ms", "transform_share")}}
 
 
-def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
-    """Data-parallel training at BASELINE.json configs[3]'s shape (BAIR-like: dcgan_64, nc=3, 16 clips per GPU,
+# training shapes: (model, image width, channels, clips per GPU, n_past, n_future)
+TRAIN_C4 = ("dcgan", 64, 3, 16, 2, 10)        # BASELINE.json configs[3]: BAIR 64x64 nc=3, batch 128 over 8 GPUs, 2-in/10-out
+TRAIN_EXTRA = {                                # measured at N = 1 only (one hipGraph per iteration), reported under train.shapes
+    "c2_vgg_64_b64": ("vgg", 64, 1, 64, 10, 10),      # configs[1]'s shape as a TRAINING iteration
+    "c2_dcgan_64_b64": ("dcgan", 64, 1, 64, 10, 10),
+    "c4_vgg_64": ("vgg", 64, 3, 16, 2, 10),
+    "c5_vgg_128": ("vgg", 128, 3, 4, 4, 12),          # configs[4]: UCF 128x128, batch 32 over 8 GPUs, 4-in/12-out
+    "c5_dcgan_128": ("dcgan", 128, 3, 4, 4, 12),
+}
+
+
+def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True, shape=TRAIN_C4, iters=None) -> dict:
+    """Data-parallel training at `shape` (default BASELINE.json configs[3]'s: BAIR-like dcgan_64, nc=3, 16 clips per GPU,
     2-in/10-out): train_model + both fine-tuning closures per iteration (train.py:354-361), gradients averaged over
-    RCCL (dvg_amd/parallel.py).  Weak scaling: the global batch is 16 x ranks."""
+    RCCL (dvg_amd/parallel.py).  Weak scaling: the global batch is clips per GPU x ranks."""
     import torch
     import train
     import utils
-    from dvg_amd.data import synthetic_video
-    per_gpu, n_past, n_future = 16, 2, 10
+    from dvg_amd.data import SyntheticMovingMNIST, synthetic_video
+    model, width, nc, per_gpu, n_past, n_future = shape
+    iters = iters or args.train_iters
     T = n_past + n_future
-    opt = train.build_parser().parse_args(["--model", "dcgan", "--channels", "3", "--image_width", "64", "--dataset", "bair",
+    opt = train.build_parser().parse_args(["--model", model, "--channels", str(nc), "--image_width", str(width), "--dataset",
+                                           "smmnist" if (nc, width) == (1, 64) else "bair",
                                            "--batch_size", str(per_gpu * ctx.world), "--n_past", str(n_past),
                                            "--n_future", str(n_future), "--no_save", "--synthetic_data"])
     opt.ft, opt.rank, opt.world, opt.local_batch = True, ctx.rank, ctx.world, per_gpu
@@ -438,8 +543,11 @@ def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
     tr = train.Trainer(opt, ctx.dev)
     tr.train_mode()
     tr.set_allreduce(allreduce)
-    x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor,
-                                synthetic_video(per_gpu, T, 3, 64, seed=args.seed + 31 * ctx.rank))
+    if (nc, width) == (1, 64):
+        seq = SyntheticMovingMNIST(seq_len=T, seed=args.seed + 31 * ctx.rank).batch(per_gpu)
+    else:
+        seq = synthetic_video(per_gpu, T, nc, width, seed=args.seed + 31 * ctx.rank)
+    x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
     # graphed: False = eager, True = ONE hipGraph (collectives captured inside), "segmented" = a chain of hipGraphs cut at
     # the all-reduces, which stay eager (train.SegmentedIteration: what train.py runs with several ranks)
     step = (train.SegmentedIteration(tr, warmup=2) if graphed == "segmented" else
@@ -449,10 +557,10 @@ def measure_train(ctx: Ctx, args, graphed, allreduce: bool = True) -> dict:
     tr.reset_allreduce_stats()
     ctx.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.train_iters):
+    for _ in range(iters):
         step(x)
     ctx.barrier()
-    per_rank = [t / args.train_iters for t in ctx.all_ranks(time.perf_counter() - t0)]
+    per_rank = [t / iters for t in ctx.all_ranks(time.perf_counter() - t0)]
     dt = max(per_rank)
     assert all(bool(torch.isfinite(p).all()) for p in tr.encoder.parameters())
     res = {"ms_per_iter": round(1e3 * dt, 2), "per_rank_ms_per_iter": [round(1e3 * t, 2) for t in per_rank],
@@ -524,6 +632,20 @@ def graphed_train_leg(ctx: Ctx, args, result: dict, emit) -> None:
     except Exception as e:   # noqa: BLE001 - reported, not fatal: the headline metric has been measured
         result["train"]["hipgraph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     done.set()
+    if ctx.world == 1 and not collectives and not args.no_train_shapes:
+        # the other BASELINE training shapes on one GPU, each as one hipGraph per iteration (per-GPU shapes of C4 / C5; the
+        # C2 shape trained): train frames/s = clips x (n_past + n_future - 1) / iteration
+        import torch
+        shapes = {}
+        for name, shape in TRAIN_EXTRA.items():
+            try:
+                g = measure_train(ctx, args, graphed=True, shape=shape, iters=3)
+                shapes[name] = {"shape": "%s_%d nc=%d, %d clips, %d-in/%d-out" % shape, "ms_per_iter": g["ms_per_iter"],
+                                "train_frames_per_s": g["train_frames_per_s"]}
+            except Exception as e:   # noqa: BLE001
+                shapes[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            torch.cuda.empty_cache()
+        result["train"]["shapes"] = shapes
 
 
 def main():
@@ -580,7 +702,7 @@ def main():
     if ctx.rehearsal:
         result["rehearsal"] = ("DVG_DP_SHARE_GPU=1: all ranks share GPU 0 (backend %s) - a rehearsal of the multi-rank "
                                "control flow, NOT a measurement" % getattr(ctx, "backend", "none"))
-    for k in ("roofline", "rollout_flops", "kernels"):
+    for k in ("roofline", "rollout_flops", "rollout_traffic", "kernels"):
         if k in main_res:
             result[k] = main_res[k]
 
@@ -593,6 +715,10 @@ def main():
         fam = measure_rollout(ctx, args, other, args.steps, args.warmup)
         fam["workload"] = result["config"]["workload"].replace(f"{args.model}_64", f"{other}_64")
         result["families"] = {other: fam}
+    if not args.no_make_gifs_leg and not args.no_graph:
+        ctx.barrier()
+        result["make_gifs"] = {m: make_gifs_leg(ctx, args, m, args.nsample)
+                               for m in ([args.model] if args.no_families else ["vgg", "dcgan"])}
     n_eval = args.n_past + args.n_future
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)

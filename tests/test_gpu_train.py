@@ -83,6 +83,9 @@ def test_finetune_closures_without_encoder_autograd_match_reference_structure():
         tr = train.Trainer(opt, torch.device("cuda:0"))
         tr.train_mode()
         tr.finetune_encoder_grad = with_grad
+        tr.lstm_sequence = False     # the same LSTM path on both sides (with encoder autograd the closure runs step by step): this
+        #                              test is about the ENCODER's structure; one Adam step is lr * sign(g), so a different
+        #                              summation order of the LSTM's weight gradients would flip elements with g ~ 0
         seq = SyntheticMovingMNIST(seq_len=4, seed=5).batch(4)
         x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, seq)
         v = tr.finetune_temporal_encoders(x)
