@@ -42,7 +42,8 @@
 //  DVG_ABLATE (timing experiments only, WRONG results): 1 = the stage loop issues no global loads (the next stage's LDS
 //  stores write stale registers), 2 = and no LDS stores, 3 = and no workgroup barriers - what the staging costs the loop;
 //  4 / 5 = no weight / activation LDS stores; 6 / 7 = neither loads nor stores of the weight / activation tile in the loop
-//  (6: what a weight-stationary workgroup would save at most)
+//  (6: what a weight-stationary workgroup would save at most); 8 = 2 + the GEMM mode stores one product value per lane
+//  instead of 16; 9 = 8 without the workgroup barriers: the bare fragment-read + MFMA loop
 #ifndef DVG_ABLATE
 #define DVG_ABLATE 0
 #endif
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         constexpr int ngrp = (grp + 1) % NG;
         constexpr bool next_a = has_next && ngrp == 0;
         const int nchunk = nchunk_override >= 0 ? nchunk_override : chunk + (ngrp == 0 ? CPS : 0);
-        if (DVG_ABLATE < 1 || DVG_ABLATE >= 6) {        // 6: the weight tile stays what the prologue loaded, 7: the A tile
+        if (DVG_ABLATE < 1 || DVG_ABLATE == 6 || DVG_ABLATE == 7) {        // 6: the weight tile stays what the prologue loaded, 7: the A tile
             if constexpr (next_a) { if (DVG_ABLATE != 7) gload_a(nchunk * C::KC, ra); }
             if constexpr (has_next) { if (DVG_ABLATE != 6) gload_b(nchunk, ngrp, rb); }
         }
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 // The last tap's fragments are in registers: every wave is done reading this stage's tiles after
                 // this barrier, and the next stage's ds_writes interleave with the last tap's MFMAs instead of
                 // forming an MFMA-less pass between two barriers.
-                if (DVG_ABLATE < 3) __syncthreads();
-                if (DVG_ABLATE < 2 || DVG_ABLATE >= 4) {      // 4: no B stores, 5: no A stores (timing only)
+                if (DVG_ABLATE < 3 || (DVG_ABLATE >= 4 && DVG_ABLATE != 9)) __syncthreads();
+                if (DVG_ABLATE < 2 || (DVG_ABLATE >= 4 && DVG_ABLATE < 8)) {      // 4: no B stores, 5: no A stores (timing only)
                     if constexpr (next_a) { if (DVG_ABLATE != 5 && DVG_ABLATE != 7) lds_store_a(ra); }
                     if (DVG_ABLATE != 4 && DVG_ABLATE != 6) lds_store_b(rb);
                 }
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 if constexpr (next_a) lds_store_a(ra);
                 lds_store_b(rb);
             }
-            if (DVG_ABLATE < 3) __syncthreads();
+            if (DVG_ABLATE < 3 || (DVG_ABLATE >= 4 && DVG_ABLATE != 9)) __syncthreads();
         }
     };
     using std::integral_constant;
@@ -626,7 +627,9 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                        yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout + nt * 32] = acc[mt * NT + nt][reg];
+                        // (DVG_ABLATE 8 / 9, timing only: one product value per lane instead of the tile's 16)
+                        if (DVG_ABLATE < 8 || reg == 0)
+                            yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout + nt * 32] = acc[mt * NT + nt][reg];
                         acc[mt * NT + nt][reg] = 0.f;
                     }
             }

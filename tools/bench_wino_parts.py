@@ -36,6 +36,8 @@ def main():
                 continue
             T = N * (H // 4) ** 2
             x = ops.nhwc_empty(N, C, H, H, dev).normal_()
+            # BENCH_V: what the GEMM's A operand holds - "input" (default: the real input transform of random data, written
+            # by the timed dvg_winograd_input call below), "zeros" or "randn" (DVFS: an MFMA loop on zeros holds a higher clock)
             v = torch.empty((36, T, C), device=dev)
             m = torch.empty((36, T, Cout), device=dev)
             u = ops.winograd_weight(torch.randn(Cout, C, 3, 3, device=dev) * 0.02, 4)
@@ -44,6 +46,12 @@ def main():
             yp = ops.nhwc_empty(N, Cout, H // 2, H // 2, dev) if pool else None
             s = ops._stream
             t_in = time_fn(lambda: lib().dvg_winograd_input(p(x), p(v), N, H, H, C, 4, 0, s()))
+            mode_v = os.environ.get("BENCH_V", "input")
+            if mode_v == "zeros":
+                v.zero_()
+                u.zero_()
+            elif mode_v == "randn":
+                v.normal_()
             t_g = time_fn(lambda: lib().dvg_gemm_batched_k16(p(v), p(u), p(m), 36, T // 16, 16, C, Cout, s()))
             t_out = time_fn(lambda: lib().dvg_winograd_output(p(m), p(sc), p(sh), p(y), p(yp), N, H, H, Cout, 1, 0.2, 4, None, s()))
             line = (f"{name:7s} {H:2d}x{H:<2d} {C:3d}->{Cout:3d}  in {t_in:7.1f} us {4e-6 * (x.numel() + v.numel()) / t_in:5.2f} TB/s | "
