@@ -280,7 +280,12 @@ def test_vgg_backward_free_running_noise_is_the_fp32_noise(golden):
                         sq_f = fingerprint_errors(g, golden[f"vgg_64/grad/{name}/{k}"])[2]
                         assert sq_f < 4e-2, (k, sq_f)
     cpu = np.array(cpu)
-    for wino, bar in ((0, 2.5), (4, 4.0)):
+    # the native f32-MFMA build (DVG_HIP_LIB=...f32mfma.so) rounds its running sum after every 2 products, the bf16-triple form
+    # after 16: its forward error is 1.3-3.2e-6 where the triples have 0.8-2.4e-6, measured 1.8-2.8 x the fp32
+    # oracle's noise in the direct form - proportionally wider bars there
+    from dvg_amd import _lib
+    bars = ((0, 2.5), (4, 4.0)) if _lib.lib().dvg_mfma_mode() == 1 else ((0, 3.5), (4, 5.0))
+    for wino, bar in bars:
         h = np.array(hip[wino])
         stats = {}
         for j, what in enumerate(("max", "l2")):

@@ -529,7 +529,10 @@ def test_shared_skip_halves_match_reference_structure(model):
                     continue
                 cos = float((da @ db) / (da.norm() * db.norm()))
                 agree = float(((da - db).abs() <= 1e-4).double().mean())
-                assert cos > 0.98 and agree > 0.97, (k, cos, agree)
+                # (as in test_shared_encoder_passes_match_reference_structure: every element of a first Adam step is +-lr, so
+                # ONE flipped sign in a tensor of n elements costs 2 / n of the cosine - 0.022 for the 90 entries of c5.1.weight)
+                n_el = da.numel()
+                assert cos > min(0.98, 1.0 - 2.2 * max(1, n_el // 100) / n_el) and agree > 0.97, (k, cos, agree)
             else:   # BatchNorm running statistics and other buffers
                 assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))
 

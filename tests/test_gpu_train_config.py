@@ -157,7 +157,11 @@ def test_time_batched_closures_equal_the_step_by_step_path_per_optimiser_range(m
     for name in ("model", "fp", "gp"):
         for u, v in zip(a[name][0], b[name][0]):
             assert abs(u - v) <= 1e-4 * max(1.0, abs(u)), (name, a[name][0], b[name][0])
-    bars = {"gp": 1e-3, "fp": 1e-3, "dec": 2e-3, "enc": 2e-3}
+    # vgg_64's 22 train-mode BatchNorm layers: a different summation order flips LeakyReLU branches of near-zero
+    # pre-activations (tests/test_gpu_backward.py measures that noise) - 1.5e-3 on the encoder range at B = 50 with the
+    # bf16-triple build, 2.6e-3 with the f32-MFMA build
+    bars = {"gp": 1e-3, "fp": 1e-3, "dec": 2e-3, "enc": 2e-3} if model == "dcgan" else \
+        {"gp": 1e-3, "fp": 1e-3, "dec": 4e-3, "enc": 4e-3}
     for name, which in (("model", ("gp", "fp", "dec", "enc")), ("fp", ("fp",)), ("gp", ("gp",))):
         errs = _range_errors(tra, a[name][1], b[name][1], which)
         for k, (e, norm) in errs.items():
