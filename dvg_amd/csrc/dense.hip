@@ -467,11 +467,11 @@ __global__ __launch_bounds__(256) void gemm_dot_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------
 // lstm_cell_bwd (r04): one BPTT step of one nn.LSTMCell in ONE launch - the gate pre-activation gradients dG_t [B][4H] and
 // dc_{t-1} (what dvg_lstm_gates_bwd computes) AND the recurrent hand-over dh_{t-1} = dG_t W_hh, which used to be a GEMM launch
-// of its own per step and layer.  A wave owns 8 batch rows x 4 columns of dh_{t-1}; K = 4H is spread over its lanes
+// of its own per step and layer.  A wave owns 8 batch rows x 2 columns of dh_{t-1}; K = 4H is spread over its lanes
 // with H = 256, so that lane l holds units 4l .. 4l+3 and the four 256-wide K slices ARE the four gates: the lane
 // derives the 16 gate gradients of each of its rows from the saved activations (recomputed by every wave of a row block:
-// 8 x 1024 elementwise values, nothing against a launch) and multiplies them with its 4 x 4 float4 of W_hh^T rows; the
-// 63-shuffle butterfly of the forward cell sums over the lanes.  The waves of column block 0 also write dG_t and dc_{t-1}.
+// 8 x 1024 elementwise values, nothing against a launch) and multiplies them with its 2 x 4 float4 of W_hh^T rows; the
+// forward cell's shuffle butterfly sums over the lanes.  The waves of column block 0 also write dG_t and dc_{t-1}.
 // dh = dh_a + dh_b (from the layer above / the output head, and from step t+1; either may be NULL), w_hh_t = W_hh^T [H][4H].
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b,
@@ -480,74 +480,90 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w_hh_t, float* __restrict__ dG,
                                                             float* __restrict__ dc_prev, float* __restrict__ dh_prev,
                                                             int B, int H, int nblk) {
+    constexpr int NC = 2;         // columns of dh_prev per wave (x 8 batch rows)
     const int lane = threadIdx.x & 63;
     const long wid = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const long nwaves = (long)((B + 7) / 8) * nblk;
     if (wid >= nwaves) return;   // wave-uniform; no barriers below
-    const int b0 = (int)(wid / nblk) * 8, n0 = (int)(wid % nblk) * 4;
+    const int b0 = (int)(wid / nblk) * 8, n0 = (int)(wid % nblk) * NC;
     const int j = lane * 4;       // this lane's four hidden units
-    // W_hh^T rows n0 .. n0+3, the lane's four k-values of each gate slice
-    f32x4 w[4][4];
+    // W_hh^T rows n0 .. n0 + NC - 1, the lane's four k-values of each gate slice
+    f32x4 w[NC][4];
     if (dh_prev) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NC; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[n][g] = *reinterpret_cast<const f32x4*>(w_hh_t + (size_t)(n0 + n) * 4 * H + g * H + j);
     }
-    float v[32];   // v[b * 4 + n]
+    float v[8 * NC];   // v[b * NC + n]
 #pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+    for (int i = 0; i < 8 * NC; ++i) v[i] = 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // rows in two batches of four: ALL loads of a batch are issued before its first FMA (left to hipcc, every row's loads sit
+    // behind their own vmcnt(0): eight serialized round trips, the lstm_cell_kernel lesson); rows past B are clamped and
+    // dropped at the stores
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const int bb = min(b0 + b, B - 1);        // rows past B are clamped and dropped at the stores
-        const size_t o = (size_t)bb * H + j;
-        const float* gp = gates + (size_t)bb * 4 * H + j;
-        const f32x4 gi = *reinterpret_cast<const f32x4*>(gp), gf = *reinterpret_cast<const f32x4*>(gp + H),
-                    gg = *reinterpret_cast<const f32x4*>(gp + 2 * H), go = *reinterpret_cast<const f32x4*>(gp + 3 * H);
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(c_new + o);
-        const f32x4 cp = c_prev ? *reinterpret_cast<const f32x4*>(c_prev + o) : zero4;      // NULL: the zero initial state
-        f32x4 dhv = dh_a ? *reinterpret_cast<const f32x4*>(dh_a + o) : zero4;
-        if (dh_b) dhv += *reinterpret_cast<const f32x4*>(dh_b + o);
-        const f32x4 dcin = dc ? *reinterpret_cast<const f32x4*>(dc + o) : zero4;
-        f32x4 d[4], dcp;
+    for (int half = 0; half < 2; ++half) {
+        f32x4 gi[4], gf[4], gg[4], go[4], cn[4], cp[4], dhv[4], dhw[4], dcin[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float tc = tanhf(cn[e]);
-            const float dcv = dcin[e] + dhv[e] * go[e] * (1.f - tc * tc);
-            d[0][e] = dcv * gg[e] * gi[e] * (1.f - gi[e]);
-            d[1][e] = dcv * cp[e] * gf[e] * (1.f - gf[e]);
-            d[2][e] = dcv * gi[e] * (1.f - gg[e] * gg[e]);
-            d[3][e] = dhv[e] * tc * go[e] * (1.f - go[e]);
-            dcp[e] = dcv * gf[e];
+        for (int r = 0; r < 4; ++r) {
+            const int bb = min(b0 + half * 4 + r, B - 1);
+            const size_t o = (size_t)bb * H + j;
+            const float* gp = gates + (size_t)bb * 4 * H + j;
+            gi[r] = *reinterpret_cast<const f32x4*>(gp);
+            gf[r] = *reinterpret_cast<const f32x4*>(gp + H);
+            gg[r] = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+            go[r] = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+            cn[r] = *reinterpret_cast<const f32x4*>(c_new + o);
+            cp[r] = c_prev ? *reinterpret_cast<const f32x4*>(c_prev + o) : zero4;      // NULL: the zero initial state
+            dhv[r] = dh_a ? *reinterpret_cast<const f32x4*>(dh_a + o) : zero4;
+            dhw[r] = dh_b ? *reinterpret_cast<const f32x4*>(dh_b + o) : zero4;
+            dcin[r] = dc ? *reinterpret_cast<const f32x4*>(dc + o) : zero4;
         }
-        if (n0 == 0 && b0 + b < B) {
-            float* og = dG + (size_t)bb * 4 * H + j;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(og + g * H) = d[g];
-            *reinterpret_cast<f32x4*>(dc_prev + o) = dcp;
-        }
-        if (dh_prev) {
+        for (int r = 0; r < 4; ++r) {
+            const int b = half * 4 + r;
+            const f32x4 dht = dhv[r] + dhw[r];
+            f32x4 d[4], dcp;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float s = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const float tc = tanhf(cn[r][e]);
+                const float dcv = dcin[r][e] + dht[e] * go[r][e] * (1.f - tc * tc);
+                d[0][e] = dcv * gg[r][e] * gi[r][e] * (1.f - gi[r][e]);
+                d[1][e] = dcv * cp[r][e] * gf[r][e] * (1.f - gf[r][e]);
+                d[2][e] = dcv * gi[r][e] * (1.f - gg[r][e] * gg[r][e]);
+                d[3][e] = dht[e] * tc * go[r][e] * (1.f - go[r][e]);
+                dcp[e] = dcv * gf[r][e];
+            }
+            if (n0 == 0 && b0 + b < B) {
+                const size_t o = (size_t)(b0 + b) * H + j;
+                float* og = dG + (size_t)(b0 + b) * 4 * H + j;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(og + g * H) = d[g];
+                *reinterpret_cast<f32x4*>(dc_prev + o) = dcp;
+            }
+            if (dh_prev) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s = fmaf(d[g][e], w[n][g][e], s);
-                v[b * 4 + n] = s;
+                for (int n = 0; n < NC; ++n) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s = fmaf(d[g][e], w[n][g][e], s);
+                    v[b * NC + n] = s;
+                }
             }
         }
     }
     if (!dh_prev) return;
-    // 32 partial sums per lane -> lanes 0..31 hold one finished sum each (value index == lane & 31, both halves equal after the
-    // first step's exchange): the forward cell's butterfly on half the values
+    // 16 partial sums per lane -> lanes hold one finished sum each (value index == lane & 15): two plain exchanges, then the
+    // forward cell's halving butterfly on 16 values
 #pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] += __shfl_xor(v[i], 32);
+    for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 32);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] += __shfl_xor(v[i], 16);
     {
-        const bool up16 = (lane & 16) != 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float keep = up16 ? v[i + 16] : v[i], send = up16 ? v[i] : v[i + 16]; v[i] = keep + __shfl_xor(send, 16); }
         const bool up8 = (lane & 8) != 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float keep = up8 ? v[i + 8] : v[i], send = up8 ? v[i] : v[i + 8]; v[i] = keep + __shfl_xor(send, 8); }
@@ -560,9 +576,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
         const bool up1 = (lane & 1) != 0;
         { const float keep = up1 ? v[1] : v[0], send = up1 ? v[0] : v[1]; v[0] = keep + __shfl_xor(send, 1); }
     }
-    // value index of lane l (< 32): bits (16, 8, 4, 2, 1) of l select the upper halves in that order = index l & 31
-    const int idx = lane & 31, b = idx >> 2, n = idx & 3;
-    if (lane < 32 && b0 + b < B) dh_prev[(size_t)(b0 + b) * H + n0 + n] = v[0];
+    // value index of lane l: bits (8, 4, 2, 1) of l select the upper halves in that order = l & 15 = b * NC + n
+    const int idx = lane & 15, b = idx / NC, n = idx % NC;
+    if (lane < 16 && b0 + b < B) dh_prev[(size_t)(b0 + b) * H + n0 + n] = v[0];
 }
 
 }  // namespace dvg
@@ -648,8 +664,8 @@ extern "C" int dvg_lstm_cell_bwd(const float* dh_a, const float* dh_b, const flo
     DVG_REQUIRE(aligned16(dh_a) && aligned16(dh_b) && aligned16(dc) && aligned16(gates) && aligned16(c_prev) &&
                 aligned16(c_new) && aligned16(w_hh_t) && aligned16(dG) && aligned16(dc_prev) && aligned16(dh_prev),
                 DVG_ERR_ALIGN, "dvg_lstm_cell_bwd: alignment");
-    // one wave = 8 batch rows x 4 columns of dh_prev; dh_prev == NULL (first time step): only dG and dc_prev
-    const int nblk = dh_prev ? H / 4 : 1;
+    // one wave = 8 batch rows x 2 columns of dh_prev; dh_prev == NULL (first time step): only dG and dc_prev
+    const int nblk = dh_prev ? H / 2 : 1;
     const long waves = (long)((B + 7) / 8) * nblk;
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dh_a, dh_b,
                        dc, gates, c_prev, c_new, w_hh_t, dG, dc_prev, dh_prev, B, H, nblk);
