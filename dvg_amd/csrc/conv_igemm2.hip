@@ -54,6 +54,18 @@
 #ifndef DVG_GEMM_WGS_PER_CU
 #define DVG_GEMM_WGS_PER_CU (DVG_BF16X3 ? 3 : 4)
 #endif
+//  DVG_GEMM128_WGS / _GT / _LEAN: the 128-row GEMM-mode tile.  bf16 triples: 3 workgroups per CU with K = 32 per stage (37 KB
+//  of LDS) and the LEAN fragment schedule (158 VGPRs) - what the transposed-conv mode's best tile runs at; r04 same-box A/B at
+//  the conditioning batch: 2077 us per pass against 2246 (2 per CU, K = 64) and 2267 (the 64-row tile).  f32 MFMA: as before.
+#ifndef DVG_GEMM128_WGS
+#define DVG_GEMM128_WGS (DVG_BF16X3 ? 3 : 2)
+#endif
+#ifndef DVG_GEMM128_GT
+#define DVG_GEMM128_GT (DVG_BF16X3 ? 2 : 4)
+#endif
+#ifndef DVG_GEMM128_LEAN
+#define DVG_GEMM128_LEAN 1
+#endif
 
 namespace dvg {
 
@@ -138,7 +150,7 @@ struct Cfg2 {
 #ifndef DVG_CONV4S2_GT
 #define DVG_CONV4S2_GT (DVG_BF16X3 ? 4 : 8)
 #endif
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? DVG_CONV4S2_GT : (GEMM ? (NT == 2 ? 2 : DVG_GEMM_GT) : 4));  // taps (GEMM: 16-channel slabs) per stage
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? DVG_CONV4S2_GT : (GEMM ? (NT == 2 ? 2 : (BM == 128 ? DVG_GEMM128_GT : DVG_GEMM_GT)) : 4));  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 16 / GT : 1;                     // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr bool X3 = DVG_BF16X3 != 0;
@@ -171,7 +183,7 @@ struct Cfg2 {
 };
 
 template <int MODE, int TI, int TH, int TW, int NT = 1, bool FIRST = false>
-__global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : 2) void conv_igemm2_kernel(const Igemm2Params p) {
+__global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PER_CU : ((MODE == M2_GEMM && NT == 1) ? DVG_GEMM128_WGS : 2)) void conv_igemm2_kernel(const Igemm2Params p) {
     using C = Cfg2<MODE, TI, TH, TW, NT, FIRST>;
     constexpr int S = C::S, HH = C::HH, HW = C::HW, HP = C::HP, LD = C::LD, MT = C::MT, GT = C::GT, NG = C::NG,
                   BN = C::BN, NLA = C::NLA, NLA1 = C::NLA1, LDB = C::LDB, NP = C::NP, PSTEP = C::PSTEP, NLB = C::NLB;
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             // LEAN (the 64 x 64 wave tile): the next tap's planes are read when the current tap no longer needs the plane -
             // h up front into a second buffer, l after the two groups that use l, m after the three that use m - so that 16
             // instead of 48 VGPRs double-buffer the fragments (the whole set twice does not fit 256 registers)
-            constexpr bool LEAN = X3 && NT == 2;
+            constexpr bool LEAN = X3 && (NT == 2 || (GEMM && MT == 2 && DVG_GEMM128_LEAN));
             auto read_plane = [&](int j) {
                 const int ao = tap_lds(grp, tt + 1);
 #pragma unroll
@@ -607,7 +619,14 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         // GEMMs have K = 128 ... 512, i.e. only 2 ... 8 stages per image.
         const int spi = (chunk_end - chunk_begin) / CPS;
         const long a_img = (long)p.H * p.W * p.C1;
-        float* const yimg = p.y + (size_t)n0 * p.H * p.W * p.Cout + nb0 + wn * 32 * NT + l31;
+        // Store addressing of the products: ONE lane-dependent 32-bit offset (the lane's pixel part x Cout + its column) and a
+        // wave-uniform base per accumulator register, so that the stores are `global_store saddr + voffset` and no 64-bit
+        // per-register address stays live across the stage loop (with a divergent base pointer hipcc kept 2 x 16 MT VGPRs of
+        // addresses alive through the kernel).  pixel(m) = (y0 + m / TW) W + x0 + m % TW with m = mbase + (reg & 3) + 8 (reg >> 2)
+        // + 4 hh: the (reg, mt, wm) part is uniform, 4 hh is the lane's.
+        const unsigned lane_off = (unsigned)(4 * hh * p.Cout + l31);
+        float* const ybase = p.y + (size_t)n0 * p.H * p.W * p.Cout + nb0 + __builtin_amdgcn_readfirstlane(wn) * 32 * NT;
+        const int wm_u = __builtin_amdgcn_readfirstlane(wm);
         for (int img = 0; img < p.gemm_ni; ++img) {
             for (int sg = 0; sg < spi; ++sg) {
                 const bool wrap = sg == spi - 1, last = wrap && img == p.gemm_ni - 1;
@@ -618,18 +637,18 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 if (last) stage(chunk_begin + sg * CPS, integral_constant<int, 0>{}, integral_constant<bool, false>{});
                 else stage(chunk_begin + sg * CPS, integral_constant<int, 0>{}, integral_constant<bool, true>{}, nchunk);
             }
-            float* const yb = yimg + (size_t)img * p.H * p.W * p.Cout;      // raw products: M[n0 + img][pixel][co]
+            float* const yb = ybase + (size_t)img * p.H * p.W * p.Cout;      // raw products: M[n0 + img][pixel][co]
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int mbase = wm * (C::BM / 2) + mt * 32;
+                const int mbase = wm_u * (C::BM / 2) + mt * 32;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        const int mu = mbase + (reg & 3) + 8 * (reg >> 2);       // the uniform part of m (4 hh is in lane_off)
                         // (DVG_ABLATE 8 / 9, timing only: one product value per lane instead of the tile's 16)
                         if (DVG_ABLATE < 8 || reg == 0)
-                            yb[((y0 + m / TW) * p.W + x0 + m % TW) * p.Cout + nt * 32] = acc[mt * NT + nt][reg];
+                            (yb + (size_t)((y0 + mu / TW) * p.W + x0 + mu % TW) * p.Cout + nt * 32)[lane_off] = acc[mt * NT + nt][reg];
                         acc[mt * NT + nt][reg] = 0.f;
                     }
             }
@@ -1042,11 +1061,11 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
         const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
         if (wgs >= 512) *tw = 16;
         if (mode == M2_GEMM && *tw == 16) {
-            // batched GEMM: a launch is rounds of 512 resident workgroups; 576 big tiles are 2 rounds for 1.1 rounds of work -
-            // take the half-size tile when its round count x size is smaller (the 8x8-map Winograd GEMMs at B = 64)
-            // (the 128-row tile runs 2 per CU - 219 VGPRs, 60 KB of LDS -, the 64-row tile 4 per CU)
-            const long r16 = (wgs + 511) / 512, r8 = (2 * wgs + 1023) / 1024;
-            if (r8 * 64 < r16 * 128) *tw = 8;
+            // batched GEMM.  The 64-row tile (K = 64 per stage, 3 workgroups per CU) is faster on every launch of a B = 64 step
+            // (r04 same-box: 365 us per pass against 381), the 128-row tile (K = 32, LEAN, 3 per CU: twice the weight-fragment
+            // reuse) from about four residency rounds on (the conditioning batch: 2077 us per pass against 2267)
+            // (f32 MFMA build: the 64-row tile at 4 per CU throughout, as measured in r03)
+            if (!DVG_BF16X3 || wgs < 4 * 768) *tw = 8;
             static const char* force = getenv("DVG_GEMM_TW");   // A/B runs only
             if (force) *tw = atoi(force);
         }

@@ -686,10 +686,13 @@ def test_concurrent_rollouts_equal_the_serial_chain():
 
 
 @pytest.mark.parametrize("N,H,C,Cout,pool", [(8, 8, 64, 64, False), (8, 8, 512, 256, True), (8, 16, 256, 256, False),
-                                             (64, 8, 256, 512, True), (2, 32, 128, 64, False), (32, 8, 512, 512, True)])
+                                             (64, 8, 256, 512, True), (2, 32, 128, 64, False), (32, 8, 512, 512, True),
+                                             (96, 32, 128, 128, True)])
 def test_winograd_conv3x3_matches_direct_and_fp64(N, H, C, Cout, pool):
     """Winograd F(2x2,3x3) path (input transform -> 16 batched GEMMs in the igemm kernel's GEMM mode -> output transform with
-    scale / shift / activation / 2x2 max-pool) against the fp64 reference and the direct implicit-GEMM kernel."""
+    scale / shift / activation / 2x2 max-pool) against the fp64 reference and the direct implicit-GEMM kernel.  The last case is
+    large enough (3456 workgroups of the 128-row tile) that the bf16-triple build runs its F(4x4) GEMMs on the 128-row tile
+    (K = 32 per stage, LEAN fragments, three workgroups per CU); the others run the 64-row tile."""
     from dvg_amd import ops
     x = params.normal(2300, N, C, H, H)
     w = params.normal(2301, Cout, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
