@@ -25,6 +25,7 @@ _l = C.c_long
 SIGNATURES = {
     "dvg_abi_version": (_i, []),
     "dvg_last_error": (C.c_char_p, []),
+    "dvg_stream_capture_id": (_l, [_p]),
     "dvg_mfma_mode": (_i, []),
     "dvg_packed_row_floats": (_i, []),
     "dvg_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -373,6 +373,16 @@ using namespace dvg;
 extern "C" int dvg_abi_version(void) { return 7; }  // 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
 extern "C" const char* dvg_last_error(void) { return err_buf(); }
 
+extern "C" long dvg_stream_capture_id(void* stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &st, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return st == hipStreamCaptureStatusActive ? (long)(id + 1) : 0;
+}
+
 #define PACK_ENTRY(NAME, TR, UN, A0, A1)                                                                        \
     extern "C" int NAME(const float* src, float* dst, int A0, int A1, int kh, int kw, void* stream) {          \
         DVG_REQUIRE(src && dst, DVG_ERR_NULL, #NAME ": NULL pointer");                                          \

@@ -38,6 +38,7 @@ def drop_version_keyed_caches() -> None:
         slot.clear()
     ops._WMAT_CACHE.clear()
     ops._MAP_CACHE.clear()
+    ops._SPLITK_WS.clear()
     ops.clear_skip_proj_cache()
     fused.clear_skip_hoist_cache()
     lstm_mod._FOLD_CACHE.clear()

@@ -148,3 +148,82 @@ def test_rollout_chains_in_flight_reproduce_the_single_chain_bit_for_bit():
             for o in outs:
                 for t in range(n_past, 15):
                     assert torch.equal(o[t], ref[t]), (family, t, int((o[t] != ref[t]).sum()))
+
+
+def test_splitk_one_launch_equals_the_two_launch_form_and_leaves_its_counters_zero():
+    """Split K combined inside the convolution kernel (the last-arriving split of a tile sums the partial tiles in split order
+    and runs the ordinary epilogue; conv_igemm2.hip, dvg_hip.h DVG_SPLITK_COUNTER_FLOATS) against the two-launch form
+    (partials + splitk_finish_kernel): every output bit for bit - with pool, with a raw addend, with fused upsample + skip, on
+    4x4x4-image tiles with a ragged last tile, on the transposed conv's four parities - over REPS launches on three streams
+    at once (arrival order varies; each stream has its own workspace), and every workspace's counter tail zero afterwards."""
+    from dvg_amd import ops
+    from dvg_amd._lib import lib
+
+    def nhwc(seed, *shape, scale=1.0):
+        return ops.to_nhwc(params.normal(seed, *shape, scale=scale).to(DEV))
+
+    def conv3(n, c1, c2, hw, cout, up, pool, add, seed):
+        hx = hw // 2 if up else hw
+        x = nhwc(seed, n, c1, hx, hx)
+        sk = nhwc(seed + 1, n, c2, hw, hw) if c2 else None
+        wp = ops.pack_igemm_weight(params.normal(seed + 2, cout, c1 + c2, 3, 3, scale=0.05).to(DEV))
+        sc, sh = _aff(cout, seed + 3)
+        ad = nhwc(seed + 5, n, cout, hw, hw, scale=0.3) if add else None
+        assert lib().dvg_conv_splitk_v2(ops.MODE_CONV3, n, hw, hw, c1 + c2, cout) > 1
+        return lambda: ops.conv3x3(x, sk, wp, sc, sh, upsample=up, pool=pool, addend=ad)
+
+    def conv4s2(n, cin, hw, cout, seed):
+        x = nhwc(seed, n, cin, hw, hw)
+        wp = ops.pack_igemm_weight(params.normal(seed + 1, cout, cin, 4, 4, scale=0.05).to(DEV))
+        sc, sh = _aff(cout, seed + 2)
+        assert lib().dvg_conv_splitk_v2(ops.MODE_CONV4S2, n, hw, hw, cin, cout) > 1
+        return lambda: ops.conv4x4s2(x, wp, sc, sh)
+
+    def convT(n, c1, c2, hw, cout, add, seed):
+        x = nhwc(seed, n, c1, hw, hw)
+        sk = nhwc(seed + 1, n, c2, hw, hw) if c2 else None
+        wp = ops.pack_igemm_weight(params.normal(seed + 2, c1 + c2, cout, 4, 4, scale=0.05).to(DEV), transposed=True)
+        sc, sh = _aff(cout, seed + 3)
+        ad = nhwc(seed + 5, n, cout, 2 * hw, 2 * hw, scale=0.3) if add else None
+        assert lib().dvg_conv_splitk_v2(ops.MODE_CONVT4S2, n, hw, hw, c1 + c2, cout) > 1
+        return lambda: ops.convT4x4s2(x, sk, wp, sc, sh, addend=ad)
+
+    cases = {
+        "conv3 8x8 up+skip 512+512->512": conv3(16, 512, 512, 8, 512, True, False, False, 5300),
+        "conv3 8x8 512->256 pool (x8)": conv3(8, 512, 0, 8, 256, False, True, False, 5310),
+        "conv3 16x16 128->128 addend": conv3(8, 128, 0, 16, 128, False, False, True, 5320),
+        "conv4s2 16x16 128->256 (x2)": conv4s2(64, 128, 16, 256, 5330),
+        "conv4s2 8x8 256->512 (x4)": conv4s2(64, 256, 8, 512, 5340),
+        "conv4s2 8x8 256->512 B=6 (ragged 4-image tile)": conv4s2(6, 256, 8, 512, 5350),
+        "convT 4x4 512+512->256": convT(64, 512, 512, 4, 256, False, 5360),
+        "convT 8x8 256->128 +addend B=16": convT(16, 256, 0, 8, 128, True, 5370),
+    }
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    saved = ops.SPLITK_ONE_LAUNCH
+    bad = []
+    try:
+        with torch.no_grad():
+            for name, launch in cases.items():
+                ops.SPLITK_ONE_LAUNCH = False
+                ref = [t.clone() for t in _flat(launch())]
+                torch.cuda.synchronize()
+                ops.SPLITK_ONE_LAUNCH = True
+                ndiff = 0
+                for rep in range(0, REPS, 3):
+                    outs = []
+                    for s in streams:
+                        s.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(s):
+                            outs.append(_flat(launch()))
+                    for s in streams:
+                        torch.cuda.current_stream().wait_stream(s)
+                    torch.cuda.synchronize()
+                    for o in outs:
+                        ndiff += sum(int((a != b).sum()) for a, b in zip(o, ref))
+                if ndiff:
+                    bad.append((name, ndiff))
+    finally:
+        ops.SPLITK_ONE_LAUNCH = saved
+    assert not bad, f"one-launch split-K differs from the two-launch form (name, elements over all launches): {bad}"
+    tails = [ws[-ops.SPLITK_COUNTER_FLOATS:] for key, ws in ops._SPLITK_WS.items() if key[3]]
+    assert len(tails) >= 3 and all(int((t.view(torch.int32) != 0).sum()) == 0 for t in tails)

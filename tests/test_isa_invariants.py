@@ -36,14 +36,26 @@ def kernel_bodies(asm: str):
 
 
 def loop_census(lines):
-    """Counts over the basic blocks hipcc annotates as `in Loop:` / loop headers."""
-    c = {"mfma": 0, "exec_change": 0, "exec_branch": 0, "mask_produced": 0, "cndmask": 0}
-    inloop = False
+    """Counts over the basic blocks hipcc annotates as loop headers / `in Loop: Header=...`, per loop (keyed by the block's
+    IMMEDIATE loop header), summed over the loops that contain MFMAs: the stage loops.  Loops without an MFMA (the split-K
+    epilogue's wait for the other splits' partial tiles and its sum over them, which run after the last MFMA has retired) are
+    counted under "other_loops" only."""
+    zero = {"mfma": 0, "exec_change": 0, "exec_branch": 0, "mask_produced": 0, "cndmask": 0}
+    loops = {}
+    cur = None
     for ln in lines:
-        if re.match(r"^\.LBB\d+_\d+:", ln) or ln.startswith("; %bb."):
-            inloop = "in Loop" in ln
-        if not inloop:
+        m = re.match(r"^\.L(BB\d+_\d+):", ln)
+        if m or ln.startswith("; %bb."):
+            h = re.search(r"in Loop: Header=(BB\d+_\d+)", ln)
+            if h:
+                cur = h.group(1)
+            elif "Loop Header" in ln and m:
+                cur = m.group(1)
+            else:
+                cur = None
+        if cur is None:
             continue
+        c = loops.setdefault(cur, dict(zero))
         op = ln.strip().split(" ")[0] if ln.strip() else ""
         if op.startswith("v_mfma"):
             c["mfma"] += 1
@@ -55,7 +67,15 @@ def loop_census(lines):
             c["mask_produced"] += 1
         if op.startswith("v_cndmask"):
             c["cndmask"] += 1
-    return c
+    out = dict(zero)
+    out["other_loops"] = 0
+    for c in loops.values():
+        if c["mfma"]:
+            for k in zero:
+                out[k] += c[k]
+        else:
+            out["other_loops"] += 1
+    return out
 
 
 @pytest.mark.parametrize("x3", [1, 0])
