@@ -453,7 +453,8 @@ def make_gifs_leg(ctx: Ctx, args, model: str, nsample: int) -> dict:
     for one batch - the posterior rollout (:110-134), `nsample` sample rollouts with a GP draw at the trigger steps (:143-177;
     everything before the first predicted frame is the same for all samples of a batch and is computed once), utils.eval_seq's
     SSIM / PSNR of every predicted frame (:178) and best-of-N by mean SSIM (:188-189) - through generate_frames.Generator
-    (rollout.GraphedSampler: the sample body as hipGraphs, `--inflight` samples at a time).  KTH frames are 64 x 64 x 1 like
+    (rollout.GraphedSampler: the sample body as hipGraphs, `--inflight` samples at a time; the prediction steps before the first
+    GP trigger step are sample-independent too and run once per batch - `per_sample_prediction` times the call without that).  KTH frames are 64 x 64 x 1 like
     Moving-MNIST (kth.py:54-55): same shapes, synthetic clips.  Predicted frames/s = B x n_future x nsample x ranks / wall time
     of the whole call (conditioning, posterior rollout and metrics included)."""
     import torch
@@ -467,20 +468,42 @@ def make_gifs_leg(ctx: Ctx, args, model: str, nsample: int) -> dict:
     g = generate_frames.Generator(opt, generate_frames.synthetic_checkpoint(opt), ctx.dev)
     x = SyntheticMovingMNIST(seq_len=n_eval, seed=args.seed + ctx.rank).batch_device(args.batch, ctx.dev)
     calibrate_batchnorm(g.encoder, g.decoder, x[0])
-    g.make_gifs(x, 3)               # warm-up: weight packs, the capture of the sample body
     reps = 2
-    ctx.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        res = g.make_gifs(x, nsample)
-    ctx.barrier()
-    dt = ctx.max_over_ranks(time.perf_counter() - t0) / reps
-    assert bool(torch.isfinite(res["ssim"]).all()) and bool(torch.isfinite(res["psnr"]).all())
+
+    def timed():
+        g.make_gifs(x, 3)           # warm-up: weight packs, the capture of the sample body
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = g.make_gifs(x, nsample)
+        ctx.barrier()
+        dt = ctx.max_over_ranks(time.perf_counter() - t0) / reps
+        assert bool(torch.isfinite(res["ssim"]).all()) and bool(torch.isfinite(res["psnr"]).all())
+        return dt, res
+
+    dt, res = timed()
+    first = [i for i in range(args.n_past, n_eval) if i % 15 == 0]
+    shared = (min(first) if first else n_eval) - args.n_past
+    # the same call with the reference loop's schedule: every sample runs all n_future prediction steps itself
+    g.opt.no_share_prefix = True
+    dt_ps, res_ps = timed()
+    g.opt.no_share_prefix = False
+    # (the GP draws of the two calls differ, so only the sample-independent part can be compared here)
+    same = bool(torch.equal(res["posterior"], res_ps["posterior"])) and \
+        bool(torch.equal(res["samples"][:, :args.n_past + shared], res_ps["samples"][:, :args.n_past + shared]))
+    fps = lambda t: round(args.batch * args.n_future * nsample * ctx.world / t, 1)  # noqa: E731
     return {"workload": f"make_gifs on one batch: posterior rollout + {nsample} sample rollouts (GP draw at i % 15 == 0) + SSIM / "
                         f"PSNR per predicted frame + best-of-N, {model}_64, batch {args.batch} per GPU, "
                         f"{args.n_past}-in/{args.n_future}-out, 64x64x1 synthetic clips (KTH-shaped)",
             "nsample": nsample, "samples_in_flight": max(1, args.inflight), "ms_per_batch": round(1e3 * dt, 2),
-            "predicted_frames_per_s": round(args.batch * args.n_future * nsample * ctx.world / dt, 1),
+            "predicted_frames_per_s": fps(dt),
+            "schedule": f"conditioning and the {shared} prediction steps before the first GP trigger step run once per batch (they "
+                        f"are the same kernels on the same inputs for every sample: bit-identical frames, tests/test_gpu_rollouts.py), "
+                        f"the remaining {args.n_future - shared} steps once per sample",
+            "per_sample_prediction": {"what": "the same call with every sample running all prediction steps itself (the "
+                                              "reference loop's schedule, --no_share_prefix); conditioning still once per batch",
+                                      "ms_per_batch": round(1e3 * dt_ps, 2), "predicted_frames_per_s": fps(dt_ps),
+                                      "shared_part_bit_identical": same},
             "mean_best_ssim": round(float(res["ssim"].mean(2).max(1).values.mean()), 4)}
 
 

@@ -16,6 +16,8 @@ Index bookkeeping (row K of SURVEY.md §8) is integer logic kept in `trigger_ste
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -43,6 +45,10 @@ def drop_version_keyed_caches() -> None:
     fused.clear_skip_hoist_cache()
     lstm_mod._FOLD_CACHE.clear()
     _ZERO_STATE.clear()
+
+
+# make_gifs: the prediction steps before the first GP trigger step once per batch instead of once per sample (GraphedSampler)
+SHARE_PREFIX = os.environ.get("DVG_SHARE_PREFIX", "1") != "0"
 
 
 def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
@@ -344,13 +350,20 @@ class GraphedSampler:
     hipGraphs and replayed once per sample, `inflight` samples at a time (one graph + one stream each, see
     ConcurrentRollouts).  The conditioning state (LSTM state, frozen skip tensors, last conditioning frame) and the ground
     truth live in static buffers shared by all chains (read-only during replays); GP base samples eps (D,B) per trigger step,
-    predicted frames and metrics are per chain.  `set_batch()` installs a new batch, `run()` draws the samples."""
+    predicted frames and metrics are per chain.  `set_batch()` installs a new batch, `run()` draws the samples.
+
+    `share_prefix` (default: DVG_SHARE_PREFIX != 0): the samples of a batch differ only from the first GP trigger step t0 on
+    (generate_frames.py:166-171: the draw at i % 15 == 0 is the loop's only source of randomness), so the prediction steps
+    n_past ... t0 - 1 - the same kernels on the same inputs for every sample, like the conditioning frames - run ONCE per
+    batch in a prefix graph (with the decoder's loop-invariant skip halves and the SSIM / PSNR of those frames) and every
+    sample graph continues from the state it leaves behind.  Results are bit-identical to the per-sample loop
+    (tests/test_gpu_rollouts.py); with no trigger step inside the rollout all samples are the prefix."""
 
     def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, state: dict, x, n_past, n_eval,
-                 last_frame_skip=False, period=15, inflight=3):
+                 last_frame_skip=False, period=15, inflight=3, share_prefix=None):
         self._mods = (encoder, decoder, frame_predictor, gp_layer, likelihood)
         self.n_past, self.n_eval, self.period = n_past, n_eval, period
-        self._kw = dict(n_past=n_past, n_eval=n_eval, last_frame_skip=last_frame_skip, period=period)
+        self._kw = dict(last_frame_skip=last_frame_skip, period=period)
         dev = x[0].device
         B, D = x[0].shape[0], gp_layer.num_dims
         # static state shared by all chains
@@ -358,6 +371,13 @@ class GraphedSampler:
         self.skip = None if state["skip"] is None else [s.clone(memory_format=torch.preserve_format) for s in state["skip"]]
         self.x = torch.stack([t.contiguous() for t in x])            # conditioning frames + ground truth of the metrics
         self.steps = [i for i in range(n_past, n_eval) if period and i % period == 0]
+        if share_prefix is None:
+            share_prefix = SHARE_PREFIX
+        self.t0 = min(self.steps) if self.steps else n_eval          # first step whose outcome depends on the sample
+        self.share = bool(share_prefix) and self.t0 > n_past and not last_frame_skip and self.skip is not None
+        if not self.share:
+            self.t0 = n_past
+        self.pre = None
         self.chains = []
         for _ in range(max(1, inflight)):
             self.chains.append({"eps": {i: torch.zeros(D, B, device=dev) for i in self.steps},
@@ -365,26 +385,65 @@ class GraphedSampler:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
+            if self.share:
+                self.pre = self._prefix()
             self._body(self.chains[0])
+            self.pre = None
         torch.cuda.current_stream().wait_stream(side)
-        for ch in self.chains:
+        ops.clear_skip_proj_cache()
+        fused.clear_skip_hoist_cache()
+        shared_keys = None
+        if self.share:
+            # The prefix graph first: the skip-dependent tensors its first decoder call creates (hoisted skip halves, the skip's
+            # share of the last projection) stay in the caches while the sample graphs are captured, so those read the prefix
+            # graph's buffers (written once per batch, before any sample replays) instead of recomputing them per sample.
+            self.pre_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.pre_graph, **CAPTURE_KW):
+                self.pre = self._prefix()
+            self.pre_keepalive = snapshot_eager_caches()
+            shared_keys = (set(fused._skip_seen), set(fused._frozen), set(ops._SKIP_PROJ_CACHE))
+        for ch in (() if self.share and self.t0 == n_eval else self.chains):
             ch["graph"] = torch.cuda.CUDAGraph()
-            ops.clear_skip_proj_cache()
-            fused.clear_skip_hoist_cache()
+            if shared_keys is None:
+                ops.clear_skip_proj_cache()
+                fused.clear_skip_hoist_cache()
             with torch.cuda.graph(ch["graph"], **CAPTURE_KW):
                 ch["frames"], ch["ssim"], ch["psnr"] = self._body(ch)
             ch["keepalive"] = snapshot_eager_caches()
-            ops.clear_skip_proj_cache()
-            fused.clear_skip_hoist_cache()
+            if shared_keys is not None:
+                # anything a sample graph added belongs to THAT graph's pool and replays: not for the next capture
+                for cache, keep in zip((fused._skip_seen, fused._frozen, ops._SKIP_PROJ_CACHE), shared_keys):
+                    for k in [k for k in cache if k not in keep]:
+                        del cache[k]
+        ops.clear_skip_proj_cache()
+        fused.clear_skip_hoist_cache()
 
     def _state(self):
         return {"hidden": list(self.hidden), "skip": self.skip, "frames": [self.x[i] for i in range(self.n_past)]}
 
+    def _metrics(self, frames, lo, hi):
+        m = [ops.eval_frames(self.x[t], frames[t]) for t in range(lo, hi)]
+        return torch.stack([a for a, _ in m], 1), torch.stack([b for _, b in m], 1)
+
+    def _prefix(self) -> dict:
+        """Steps n_past ... t0 - 1 from the conditioning state: frames, their metrics and the LSTM state after them."""
+        fp = self._mods[2]
+        frames = sample_from(self._state(), *self._mods, n_past=self.n_past, n_eval=self.t0, **self._kw)
+        ssim, psnr = self._metrics(frames, self.n_past, self.t0)
+        return {"hidden": list(fp.hidden), "frames": frames, "stack": torch.stack(frames), "ssim": ssim, "psnr": psnr}
+
     def _body(self, ch):
-        frames = sample_from(self._state(), *self._mods, eps_by_step=ch["eps"], **self._kw)
-        T = self.n_eval - self.n_past
-        m = [ops.eval_frames(self.x[self.n_past + t], frames[self.n_past + t]) for t in range(T)]
-        return torch.stack(frames), torch.stack([a for a, _ in m], 1), torch.stack([b for _, b in m], 1)
+        """One sample from step t0 on: (frames t0 ... n_eval - 1 stacked - with the conditioning frames in front when there is
+        no shared prefix -, SSIM, PSNR of the predicted ones among them)."""
+        if self.pre is not None:
+            state = {"hidden": list(self.pre["hidden"]), "skip": self.skip, "frames": list(self.pre["frames"])}
+        else:
+            state = self._state()
+        frames = sample_from(state, *self._mods, eps_by_step=ch["eps"], n_past=self.t0, n_eval=self.n_eval, **self._kw)
+        if self.t0 == self.n_eval:       # no trigger step inside the rollout: every sample IS the prefix
+            return None, None, None
+        ssim, psnr = self._metrics(frames, self.t0, self.n_eval)
+        return torch.stack(frames[self.t0 if self.pre is not None else 0:]), ssim, psnr
 
     def set_batch(self, state: dict, x) -> None:
         """New conditioning state (rollout.condition) and frames, copied into the static buffers on the current stream."""
@@ -402,8 +461,17 @@ class GraphedSampler:
         """Draws `nsample` samples: samples[s] <- the n_eval frames (n_eval,B,C,H,W), ssim[:, s] / psnr[:, s] <- (B,T).
         eps_by_sample[s][i]: base sample of sample s at trigger step i (parity runs); None = torch's generator."""
         cur = torch.cuda.current_stream()
+        P = self.t0 - self.n_past
+        if self.share:
+            self.pre_graph.replay()          # on the current stream: the sample chains below wait for it
+            samples[:, :self.t0].copy_(self.pre["stack"].unsqueeze(0).expand(nsample, *self.pre["stack"].shape))
+            ssim[:, :, :P].copy_(self.pre["ssim"].unsqueeze(1).expand(-1, nsample, -1))
+            psnr[:, :, :P].copy_(self.pre["psnr"].unsqueeze(1).expand(-1, nsample, -1))
+            if self.t0 == self.n_eval:
+                return
         for ch in self.chains:
             ch["stream"].wait_stream(cur)
+        lo = self.t0 if self.share else 0
         for s in range(nsample):
             ch = self.chains[s % len(self.chains)]
             with torch.cuda.stream(ch["stream"]):
@@ -413,8 +481,8 @@ class GraphedSampler:
                     else:
                         ch["eps"][i].copy_(eps_by_sample[s][i])
                 ch["graph"].replay()
-                samples[s].copy_(ch["frames"])
-                ssim[:, s].copy_(ch["ssim"])
-                psnr[:, s].copy_(ch["psnr"])
+                samples[s, lo:].copy_(ch["frames"])
+                ssim[:, s, P:].copy_(ch["ssim"])
+                psnr[:, s, P:].copy_(ch["psnr"])
         for ch in self.chains:
             cur.wait_stream(ch["stream"])

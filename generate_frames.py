@@ -62,6 +62,9 @@ def build_parser():
     p.add_argument('--synthetic_ckpt', action='store_true')
     p.add_argument('--inflight', type=int, default=3,
                    help='make_gifs: samples of a batch drawn at once (one hipGraph + stream each); 0 = eager loop, one at a time')
+    p.add_argument('--no_share_prefix', action='store_true',
+                   help='make_gifs: run the prediction steps before the first GP trigger step once per SAMPLE, like the reference '
+                        'loop (default: once per batch - they are the same for every sample; identical results)')
     p.add_argument('--synthetic_data', action='store_true',
                    help='datasets other than smmnist: synthetic clips of the right shape (--data_root is not read)')
     return p
@@ -103,11 +106,12 @@ class Generator:
             # the versions they were captured with, so a weight change (load_state_dict, an optimiser step) re-captures
             vers = tuple(t._version for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood)
                          for t in list(m.parameters()) + list(m.buffers()))
-            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight, vers)
+            share = not getattr(opt, 'no_share_prefix', False)
+            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight, share, vers)
             if self._sampler_key != key:
                 self._sampler = GraphedSampler(self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
                                                self.likelihood, state, x, opt.n_past, opt.n_eval, opt.last_frame_skip,
-                                               inflight=inflight)
+                                               inflight=inflight, share_prefix=None if share else False)
                 self._sampler_key = key
             self._sampler.set_batch(state, x)
             samples = torch.empty((nsample, opt.n_eval) + tuple(x[0].shape), device=self.dev)

@@ -144,16 +144,17 @@ def test_gp_trigger_generation_matches_oracle(depth, index):
         g.gp_trigger_gen([xs[0][:2].to(DEV)], n_index=1, total=14)
 
 
-@pytest.mark.parametrize("inflight", [0, 2])
-def test_make_gifs_best_ssim_matches_oracle(inflight):
+@pytest.mark.parametrize("inflight,share", [(0, True), (2, True), (2, False)])
+def test_make_gifs_best_ssim_matches_oracle(inflight, share):
     """generate_frames.py:143-189,207: nsample rollouts with GP samples at i % 15 == 0, SSIM / PSNR per frame
     (utils.eval_seq), best sample per row = np.argsort(mean SSIM)[-1] - exact index match.  inflight = 0: the eager sample
-    loop; 2: the sample body replayed as hipGraphs, two samples at a time (rollout.GraphedSampler)."""
+    loop; 2: the sample body replayed as hipGraphs, two samples at a time (rollout.GraphedSampler) - with the prediction steps
+    before the first trigger step run once per batch (share, the default) or once per sample."""
     import generate_frames
     B, n_past, n_eval, S = 3, 3, 20, 3
     opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", "dcgan",
                                                      "--n_past", str(n_past), "--n_eval", str(n_eval),
-                                                     "--inflight", str(inflight)])
+                                                     "--inflight", str(inflight)] + ([] if share else ["--no_share_prefix"]))
     mods, (esd, dsd, lsd, gsd, lik) = _build("dcgan", 64, 1, B, 1800)
     ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
     g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
@@ -198,6 +199,35 @@ def test_make_gifs_best_ssim_matches_oracle(inflight):
         for i in range(4):
             for j in range(i + 1, 4):
                 assert torch.equal(r[i, :15], r[j, :15]) and not torch.equal(r[i, 15], r[j, 15]), (i, j)
+        assert g._sampler.share == share and g._sampler.t0 == (15 if share else n_past)
+
+
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_make_gifs_shared_prefix_equals_the_per_sample_loop(family):
+    """GraphedSampler's shared prefix (the prediction steps before the first GP trigger step once per batch) against the eager
+    per-sample loop AND the per-sample graphs, bit for bit: frames, SSIM, PSNR, best index - at the bench's own step layout
+    (10-in / 10-out: trigger at 15), for two batches through one sampler, and for a rollout that ends before the first
+    trigger step (n_eval = 14: every sample is the prefix)."""
+    import generate_frames
+    B, S = 8, 4
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1900)
+    ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
+    for n_past, n_eval in ((10, 20), (10, 14)):
+        eps = [{i: params.normal(1940 + 7 * s + i, 90, B).to(DEV) for i in range(n_past, n_eval) if i % 15 == 0} for s in range(S)]
+        out = {}
+        for name, extra in (("shared", ["--inflight", "3"]), ("per_sample", ["--inflight", "3", "--no_share_prefix"]),
+                            ("eager", ["--inflight", "0"])):
+            opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", family,
+                                                             "--n_past", str(n_past), "--n_eval", str(n_eval)] + extra)
+            g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
+            out[name] = [g.make_gifs([params.frames(1910 + 40 * b + t, B, 1, 64).to(DEV) for t in range(n_eval)], S,
+                                     eps_by_sample=eps) for b in range(2)]
+            if name == "shared":
+                assert g._sampler.share and g._sampler.t0 == min(15, n_eval)
+        for name in ("per_sample", "eager"):
+            for a, b in zip(out["shared"], out[name]):
+                for k in ("samples", "ssim", "psnr", "best", "posterior"):
+                    assert torch.equal(a[k], b[k]), (family, n_past, n_eval, name, k)
 
 
 def test_gaussian_encoder_matches_reference_golden(golden):
