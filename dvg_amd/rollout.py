@@ -258,6 +258,30 @@ def posterior_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x
     return frames
 
 
+@torch.no_grad()
+def posterior_from(state: dict, encoder, decoder, frame_predictor, gp_layer, likelihood, n_past: int, n_eval: int,
+                   last_frame_skip: bool = False) -> List[torch.Tensor]:
+    """`posterior_rollout`'s prediction steps n_past ... n_eval - 1 from a `condition()` state.  Its conditioning phase
+    (generate_frames.py:113-121 for i < n_past: the encoder on x[i-1], the LSTM stepped with the output discarded, the skip
+    tensors of the last such frame, x[i] handed on) is the same computation as the samples' (:147-162), so `make_gifs` runs it
+    once for both."""
+    frame_predictor.hidden = list(state["hidden"])
+    frames = list(state["frames"])
+    skip = state["skip"]
+    x_in = frames[n_past - 1]
+    for i in range(n_past, n_eval):
+        h, sk = encoder(x_in)
+        if last_frame_skip or skip is None:
+            skip = sk
+        if i == n_past and not last_frame_skip and not decoder.training:
+            fused.declare_frozen_skips(skip)
+        h_pred = frame_predictor(h)
+        pred = likelihood(gp_layer(h_pred.transpose(0, 1).view(gp_layer.num_dims, h_pred.shape[0], 1)))
+        x_in = decoder([pred.mean.transpose(0, 1), skip])
+        frames.append(x_in)
+    return frames
+
+
 class GraphedRollout:
     """`sample_rollout` captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~500 launches of
     a rollout (19 encoder + 10 decoder passes, 38 LSTM cells, GEMMs, the GP sample) are launch-latency-bound at
@@ -345,130 +369,148 @@ class ConcurrentRollouts:
 
 
 class GraphedSampler:
-    """The `for s in range(nsample)` body of make_gifs (generate_frames.py:163-178: the prediction phase of one sample from
-    the state the conditioning frames left behind, then utils.eval_seq's SSIM / PSNR per predicted frame) captured as
-    hipGraphs and replayed once per sample, `inflight` samples at a time (one graph + one stream each, see
-    ConcurrentRollouts).  The conditioning state (LSTM state, frozen skip tensors, last conditioning frame) and the ground
-    truth live in static buffers shared by all chains (read-only during replays); GP base samples eps (D,B) per trigger step,
-    predicted frames and metrics are per chain.  `set_batch()` installs a new batch, `run()` draws the samples.
+    """`make_gifs` for one batch (generate_frames.py:107-178) as hipGraphs.  Everything that does not depend on the sample is
+    replayed once per batch (three graphs: the conditioning, then side by side the other two): the conditioning (`condition`: the past frames encoded as one batch, the LSTM warmed up,
+    the decoder's loop-invariant skip halves), the posterior rollout's prediction steps (`posterior_from`, :110-134 - its
+    conditioning phase is the same computation as the samples') and, with `share_prefix`, the samples' prediction steps before
+    the first GP trigger step with their SSIM / PSNR.  The body of the `for s in range(nsample)` loop (:163-178) - the remaining
+    steps of one sample and utils.eval_seq's metrics - is one graph per chain, replayed once per sample, `inflight` samples at
+    a time (one graph + one stream each, see ConcurrentRollouts); the sample graphs read the batch graph's state and
+    skip-dependent tensors (read-only during their replays); GP base samples eps (D,B) per trigger step, predicted frames
+    and metrics are per chain.  `set_batch()` installs a new batch, `run()` replays.
 
     `share_prefix` (default: DVG_SHARE_PREFIX != 0): the samples of a batch differ only from the first GP trigger step t0 on
     (generate_frames.py:166-171: the draw at i % 15 == 0 is the loop's only source of randomness), so the prediction steps
     n_past ... t0 - 1 - the same kernels on the same inputs for every sample, like the conditioning frames - run ONCE per
-    batch in a prefix graph (with the decoder's loop-invariant skip halves and the SSIM / PSNR of those frames) and every
-    sample graph continues from the state it leaves behind.  Results are bit-identical to the per-sample loop
-    (tests/test_gpu_rollouts.py); with no trigger step inside the rollout all samples are the prefix."""
+    batch and every sample graph continues from the state they leave behind.  Results are bit-identical to the per-sample
+    loop (tests/test_gpu_rollouts.py); with no trigger step inside the rollout all samples are the prefix."""
 
-    def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, state: dict, x, n_past, n_eval,
+    def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
                  last_frame_skip=False, period=15, inflight=3, share_prefix=None):
         self._mods = (encoder, decoder, frame_predictor, gp_layer, likelihood)
         self.n_past, self.n_eval, self.period = n_past, n_eval, period
+        self.last_frame_skip = last_frame_skip
         self._kw = dict(last_frame_skip=last_frame_skip, period=period)
         dev = x[0].device
         B, D = x[0].shape[0], gp_layer.num_dims
-        # static state shared by all chains
-        self.hidden = [(h.clone(), c.clone()) for h, c in state["hidden"]]
-        self.skip = None if state["skip"] is None else [s.clone(memory_format=torch.preserve_format) for s in state["skip"]]
         self.x = torch.stack([t.contiguous() for t in x])            # conditioning frames + ground truth of the metrics
         self.steps = [i for i in range(n_past, n_eval) if period and i % period == 0]
         if share_prefix is None:
             share_prefix = SHARE_PREFIX
         self.t0 = min(self.steps) if self.steps else n_eval          # first step whose outcome depends on the sample
-        self.share = bool(share_prefix) and self.t0 > n_past and not last_frame_skip and self.skip is not None
+        self.share = bool(share_prefix) and self.t0 > n_past and not last_frame_skip and n_past >= 2
         if not self.share:
             self.t0 = n_past
-        self.pre = None
+        self.b = None
         self.chains = []
         for _ in range(max(1, inflight)):
             self.chains.append({"eps": {i: torch.zeros(D, B, device=dev) for i in self.steps},
                                 "stream": torch.cuda.Stream()})
+        self.post_stream = torch.cuda.Stream()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
-            if self.share:
-                self.pre = self._prefix()
+            self.b = {"state": self._condition()}
+            self.b["post"] = self._posterior()
+            self.b["pre"] = self._prefix() if self.share else None
             self._body(self.chains[0])
-            self.pre = None
+            self.b = None
         torch.cuda.current_stream().wait_stream(side)
         ops.clear_skip_proj_cache()
         fused.clear_skip_hoist_cache()
-        shared_keys = None
+        # Three graphs for the sample-independent part: the conditioning, then - independent of each other, replayed on two
+        # streams - the posterior rollout's prediction steps and the samples' shared prefix.  The conditioning graph comes
+        # first: the skip-dependent tensors it creates (hoisted skip halves) and those of the first decoder call after it (the
+        # skip's share of the last projection) stay in the caches while the later graphs are captured, so those read buffers
+        # written once per batch, before they replay, instead of recomputing them per sample.
+        shared = (fused._skip_seen, fused._frozen, ops._SKIP_PROJ_CACHE)
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **CAPTURE_KW):
+                out = fn()
+            return g, out, snapshot_eager_caches()
+
+        def keys():
+            return [set(c) for c in shared]
+
+        def drop_new(keep):     # what a graph added belongs to THAT graph's pool and replays: not for the next capture
+            for cache, k0 in zip(shared, keep):
+                for k in [k for k in cache if k not in k0]:
+                    del cache[k]
+
+        self.b = {}
+        self.cond_graph, self.b["state"], self._keep_c = capture(self._condition)
+        after_cond = keys()
+        # the posterior graph replays BESIDE the prefix graph (another stream): it may read what the conditioning graph wrote,
+        # never what the prefix graph writes
+        self.post_graph, self.b["post"], self._keep_o = capture(self._posterior)
+        drop_new(after_cond)
+        self.pre_graph, self.b["pre"] = None, None
         if self.share:
-            # The prefix graph first: the skip-dependent tensors its first decoder call creates (hoisted skip halves, the skip's
-            # share of the last projection) stay in the caches while the sample graphs are captured, so those read the prefix
-            # graph's buffers (written once per batch, before any sample replays) instead of recomputing them per sample.
-            self.pre_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.pre_graph, **CAPTURE_KW):
-                self.pre = self._prefix()
-            self.pre_keepalive = snapshot_eager_caches()
-            shared_keys = (set(fused._skip_seen), set(fused._frozen), set(ops._SKIP_PROJ_CACHE))
-        for ch in (() if self.share and self.t0 == n_eval else self.chains):
-            ch["graph"] = torch.cuda.CUDAGraph()
-            if shared_keys is None:
-                ops.clear_skip_proj_cache()
-                fused.clear_skip_hoist_cache()
-            with torch.cuda.graph(ch["graph"], **CAPTURE_KW):
-                ch["frames"], ch["ssim"], ch["psnr"] = self._body(ch)
-            ch["keepalive"] = snapshot_eager_caches()
-            if shared_keys is not None:
-                # anything a sample graph added belongs to THAT graph's pool and replays: not for the next capture
-                for cache, keep in zip((fused._skip_seen, fused._frozen, ops._SKIP_PROJ_CACHE), shared_keys):
-                    for k in [k for k in cache if k not in keep]:
-                        del cache[k]
+            self.pre_graph, self.b["pre"], self._keep_p = capture(self._prefix)
+        main_stream = keys()    # written by graphs that replay on the main stream before any sample graph
+        for ch in (() if self.t0 == n_eval else self.chains):
+            ch["graph"], (ch["frames"], ch["ssim"], ch["psnr"]), ch["keepalive"] = capture(lambda: self._body(ch))
+            drop_new(main_stream)
         ops.clear_skip_proj_cache()
         fused.clear_skip_hoist_cache()
-
-    def _state(self):
-        return {"hidden": list(self.hidden), "skip": self.skip, "frames": [self.x[i] for i in range(self.n_past)]}
 
     def _metrics(self, frames, lo, hi):
         m = [ops.eval_frames(self.x[t], frames[t]) for t in range(lo, hi)]
         return torch.stack([a for a, _ in m], 1), torch.stack([b for _, b in m], 1)
 
+    def _condition(self) -> dict:
+        """The conditioning state (rollout.condition) of the frames in self.x."""
+        enc, dec, fp, gp, lik = self._mods
+        return condition(enc, fp, [self.x[i] for i in range(self.x.shape[0])], self.n_past, self.last_frame_skip, decoder=dec)
+
+    def _posterior(self) -> torch.Tensor:
+        return torch.stack(posterior_from(self.b["state"], *self._mods, self.n_past, self.n_eval, self.last_frame_skip))
+
     def _prefix(self) -> dict:
-        """Steps n_past ... t0 - 1 from the conditioning state: frames, their metrics and the LSTM state after them."""
-        fp = self._mods[2]
-        frames = sample_from(self._state(), *self._mods, n_past=self.n_past, n_eval=self.t0, **self._kw)
+        """The samples' steps n_past ... t0 - 1 from the conditioning state: frames, their metrics, the LSTM state after them."""
+        st = self.b["state"]
+        frames = sample_from(st, *self._mods, n_past=self.n_past, n_eval=self.t0, **self._kw)
         ssim, psnr = self._metrics(frames, self.n_past, self.t0)
-        return {"hidden": list(fp.hidden), "frames": frames, "stack": torch.stack(frames), "ssim": ssim, "psnr": psnr}
+        return {"hidden": list(self._mods[2].hidden), "skip": st["skip"], "frames": frames, "stack": torch.stack(frames),
+                "ssim": ssim, "psnr": psnr}
 
     def _body(self, ch):
         """One sample from step t0 on: (frames t0 ... n_eval - 1 stacked - with the conditioning frames in front when there is
         no shared prefix -, SSIM, PSNR of the predicted ones among them)."""
-        if self.pre is not None:
-            state = {"hidden": list(self.pre["hidden"]), "skip": self.skip, "frames": list(self.pre["frames"])}
-        else:
-            state = self._state()
-        frames = sample_from(state, *self._mods, eps_by_step=ch["eps"], n_past=self.t0, n_eval=self.n_eval, **self._kw)
         if self.t0 == self.n_eval:       # no trigger step inside the rollout: every sample IS the prefix
             return None, None, None
+        state = self.b["pre"] if self.share else self.b["state"]
+        frames = sample_from(state, *self._mods, eps_by_step=ch["eps"], n_past=self.t0, n_eval=self.n_eval, **self._kw)
         ssim, psnr = self._metrics(frames, self.t0, self.n_eval)
-        return torch.stack(frames[self.t0 if self.pre is not None else 0:]), ssim, psnr
+        return torch.stack(frames[self.t0 if self.share else 0:]), ssim, psnr
 
-    def set_batch(self, state: dict, x) -> None:
-        """New conditioning state (rollout.condition) and frames, copied into the static buffers on the current stream."""
-        for (h, c), (h2, c2) in zip(self.hidden, state["hidden"]):
-            h.copy_(h2)
-            c.copy_(c2)
-        if self.skip is not None:
-            for s, s2 in zip(self.skip, state["skip"]):
-                s.copy_(s2)
+    def set_batch(self, x) -> None:
+        """New frames (conditioning + ground truth), copied into the static buffer on the current stream."""
         for i, t in enumerate(x):
             self.x[i].copy_(t)
 
     def run(self, nsample: int, samples: torch.Tensor, ssim: torch.Tensor, psnr: torch.Tensor,
-            eps_by_sample: Optional[Sequence[Dict[int, torch.Tensor]]] = None) -> None:
-        """Draws `nsample` samples: samples[s] <- the n_eval frames (n_eval,B,C,H,W), ssim[:, s] / psnr[:, s] <- (B,T).
+            eps_by_sample: Optional[Sequence[Dict[int, torch.Tensor]]] = None) -> torch.Tensor:
+        """Draws `nsample` samples: samples[s] <- the n_eval frames (n_eval,B,C,H,W), ssim[:, s] / psnr[:, s] <- (B,T); returns
+        the posterior rollout's frames (n_eval,B,C,H,W) - a static buffer the next run() overwrites.
         eps_by_sample[s][i]: base sample of sample s at trigger step i (parity runs); None = torch's generator."""
         cur = torch.cuda.current_stream()
         P = self.t0 - self.n_past
+        self.cond_graph.replay()             # on the current stream: everything below waits for it
+        self.post_stream.wait_stream(cur)
+        with torch.cuda.stream(self.post_stream):
+            self.post_graph.replay()         # beside the prefix and the samples (it only reads the conditioning state)
         if self.share:
-            self.pre_graph.replay()          # on the current stream: the sample chains below wait for it
-            samples[:, :self.t0].copy_(self.pre["stack"].unsqueeze(0).expand(nsample, *self.pre["stack"].shape))
-            ssim[:, :, :P].copy_(self.pre["ssim"].unsqueeze(1).expand(-1, nsample, -1))
-            psnr[:, :, :P].copy_(self.pre["psnr"].unsqueeze(1).expand(-1, nsample, -1))
+            self.pre_graph.replay()
+            pre = self.b["pre"]
+            samples[:, :self.t0].copy_(pre["stack"].unsqueeze(0).expand(nsample, *pre["stack"].shape))
+            ssim[:, :, :P].copy_(pre["ssim"].unsqueeze(1).expand(-1, nsample, -1))
+            psnr[:, :, :P].copy_(pre["psnr"].unsqueeze(1).expand(-1, nsample, -1))
             if self.t0 == self.n_eval:
-                return
+                cur.wait_stream(self.post_stream)
+                return self.b["post"]
         for ch in self.chains:
             ch["stream"].wait_stream(cur)
         lo = self.t0 if self.share else 0
@@ -486,3 +528,5 @@ class GraphedSampler:
                 psnr[:, s, P:].copy_(ch["psnr"])
         for ch in self.chains:
             cur.wait_stream(ch["stream"])
+        cur.wait_stream(self.post_stream)
+        return self.b["post"]

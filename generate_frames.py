@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import utils  # noqa: E402
 from dvg_amd import ops  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
-from dvg_amd.rollout import GraphedSampler, condition, posterior_rollout, sample_from, sample_rollout  # noqa: E402
+from dvg_amd.rollout import GraphedSampler, condition, posterior_from, sample_from, sample_rollout  # noqa: E402
 from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
 
 
@@ -91,33 +91,40 @@ class Generator:
     def make_gifs(self, x, nsample, eps_by_sample=None):
         """`eps_by_sample[s][i]`: the N(0,1) base sample (D,B) of sample s at trigger step i (parity runs); None = torch RNG."""
         opt = self.opt
-        post = posterior_rollout(self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood, x,
-                                 opt.n_past, opt.n_eval, opt.last_frame_skip)
         B, T = x[0].shape[0], opt.n_eval - opt.n_past
         ssim = torch.zeros(B, nsample, T, device=self.dev)
         psnr = torch.zeros(B, nsample, T, device=self.dev)
         all_gen = []
-        # everything before the first predicted frame is the same for all nsample rollouts of this batch: once per batch
-        state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip, decoder=self.decoder)
         inflight = getattr(opt, 'inflight', 3)
         if inflight > 0:
-            # the nsample rollouts are independent: each is a replay of the captured sample body, `inflight` at a time
-            # parameter / buffer versions are part of the key: the captured graphs read packed weights and BatchNorm folds of
+            # One graph per batch for everything the samples share (conditioning, the posterior rollout's prediction steps, the
+            # samples' steps before the first GP trigger step) and one per chain for the sample body: rollout.GraphedSampler.
+            # Parameter / buffer versions are part of the key: the captured graphs read packed weights and BatchNorm folds of
             # the versions they were captured with, so a weight change (load_state_dict, an optimiser step) re-captures
-            vers = tuple(t._version for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood)
-                         for t in list(m.parameters()) + list(m.buffers()))
             share = not getattr(opt, 'no_share_prefix', False)
-            key = (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight, share, vers)
-            if self._sampler_key != key:
+
+            def key():
+                vers = tuple(t._version for m in (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood)
+                             for t in list(m.parameters()) + list(m.buffers()))
+                return (tuple(x[0].shape), len(x), opt.n_past, opt.n_eval, bool(opt.last_frame_skip), inflight, share, vers)
+            if self._sampler_key != key():
                 self._sampler = GraphedSampler(self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
-                                               self.likelihood, state, x, opt.n_past, opt.n_eval, opt.last_frame_skip,
+                                               self.likelihood, x, opt.n_past, opt.n_eval, opt.last_frame_skip,
                                                inflight=inflight, share_prefix=None if share else False)
-                self._sampler_key = key
-            self._sampler.set_batch(state, x)
+                # the key AFTER the construction: the sampler's eager warm-up pass may be the GP layer's first call, which
+                # initialises its variational parameters in place (gp_models: variational_params_initialized); the graphs are
+                # captured after that pass, i.e. with the versions read here
+                self._sampler_key = key()
+            self._sampler.set_batch(x)
             samples = torch.empty((nsample, opt.n_eval) + tuple(x[0].shape), device=self.dev)
-            self._sampler.run(nsample, samples, ssim, psnr, eps_by_sample)
+            post = self._sampler.run(nsample, samples, ssim, psnr, eps_by_sample).clone()
             best = ssim.mean(2).argsort(1)[:, -1]
-            return {'posterior': torch.stack(post), 'samples': samples, 'ssim': ssim, 'psnr': psnr, 'best': best}
+            return {'posterior': post, 'samples': samples, 'ssim': ssim, 'psnr': psnr, 'best': best}
+        # everything before the first predicted frame is the same for the posterior rollout and all nsample rollouts of this
+        # batch (generate_frames.py:113-121 and :147-162 are the same computation): once per batch
+        state = condition(self.encoder, self.frame_predictor, x, opt.n_past, opt.last_frame_skip, decoder=self.decoder)
+        post = posterior_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood,
+                              opt.n_past, opt.n_eval, opt.last_frame_skip)
         for s in range(nsample):
             frames = sample_from(state, self.encoder, self.decoder, self.frame_predictor, self.gp_layer,
                                  self.likelihood, opt.n_past, opt.n_eval, opt.last_frame_skip,

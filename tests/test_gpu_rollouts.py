@@ -93,8 +93,10 @@ def test_plot_rollout_and_best_of_n_match_oracle():
 
 @pytest.mark.parametrize("family", ["dcgan", "vgg"])
 def test_posterior_rollout_matches_oracle(family):
-    """generate_frames.py:110-134: the GP is fed the LSTM output and its predictive MEAN is decoded at every step."""
-    from dvg_amd.rollout import posterior_rollout
+    """generate_frames.py:110-134: the GP is fed the LSTM output and its predictive MEAN is decoded at every step.  Both forms:
+    `posterior_rollout` (the reference's loop) and `posterior_from(condition())` (what make_gifs runs: the conditioning phase
+    shared with the samples, its frames encoded as one batch)."""
+    from dvg_amd.rollout import condition, posterior_from, posterior_rollout
     B, n_past, n_eval = 4, 3, 8
     mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1400)
     xs = [params.frames(1410 + t, B, 1, 64) for t in range(n_eval)]
@@ -107,6 +109,14 @@ def test_posterior_rollout_matches_oracle(family):
     assert len(ours) == len(ref) == n_eval
     for t in range(n_eval):
         assert rel_err(ours[t], ref[t]) < 1e-4, (t, rel_err(ours[t], ref[t]))
+    xd = [t.to(DEV) for t in xs]
+    with torch.no_grad():
+        st = condition(mods[0], mods[2], xd, n_past, decoder=mods[1])
+        shared = posterior_from(st, *mods, n_past, n_eval)
+    assert len(shared) == n_eval
+    for t in range(n_eval):
+        assert rel_err(shared[t], ref[t]) < 1e-4, (t, rel_err(shared[t], ref[t]))
+        assert rel_err(shared[t], ours[t]) < 2e-5       # same arithmetic per image; tile choices may differ with the batch
 
 
 @pytest.mark.parametrize("depth,index", [(1, 0), (1, 2), (-250, 1)])
