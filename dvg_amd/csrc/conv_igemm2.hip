@@ -1043,6 +1043,8 @@ static int finish_units_per_block(long units) {
     return (int)upb;
 }
 
+static int g_last_splitk_form = 0;   // dvg_debug_last_splitk_form: 0 no split, 1 partials + finish launch, 2 combined in the kernel
+
 // number of K splits for a v2 launch: only when the grid would leave CUs idle and K is deep enough
 static int choose_splitk(long wgs, int nchunks) {
     if (wgs >= 384 || nchunks < 8) return 1;
@@ -1110,6 +1112,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     const long out_floats = (long)p.N * Ho * Wo * p.Cout;
     int S = (ws != nullptr && C::CAN_SPLIT) ? choose_splitk(wgs, nchunks) : 1;
     if (S > 1 && (long)S * out_floats > ws_floats) return fail(DVG_ERR_SHAPE, "conv_igemm2: split-K workspace too small");
+    const int S_asked = S;      // what dvg_conv_splitk_v2 told the caller to size the workspace for
     p.cps = (nchunks + S - 1) / S;
     p.cps = (p.cps + C::CHUNKS_PER_STAGE - 1) / C::CHUNKS_PER_STAGE * C::CHUNKS_PER_STAGE;   // whole stages per split
     S = (nchunks + p.cps - 1) / p.cps;  // no empty split: the kernel's peeled stage loop needs >= 1 chunk per workgroup
@@ -1117,9 +1120,12 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     p.ws = ws;
     // in-kernel finish: launches without statistics whose workspace carries the counter tail (dvg_hip.h: DVG_SPLITK_COUNTER_FLOATS)
     static const char* sk_launch = getenv("DVG_SPLITK_FINISH_LAUNCH");   // A/B runs: "1" keeps the two-launch form
-    const bool sk_inkernel = S > 1 && p.stats == nullptr && (long)S * out_floats + DVG_SPLITK_COUNTER_FLOATS <= ws_floats &&
+    // (EXACTLY the documented size: a caller of the two-launch form that merely over-allocates must not have the end of its
+    // buffer read as counters)
+    const bool sk_inkernel = S > 1 && p.stats == nullptr && (long)S_asked * out_floats + DVG_SPLITK_COUNTER_FLOATS == ws_floats &&
                              wgs * 2 <= DVG_SPLITK_COUNTER_FLOATS && !(sk_launch && sk_launch[0] == '1');
     p.sk_cnt = sk_inkernel ? reinterpret_cast<int*>(ws + ws_floats - DVG_SPLITK_COUNTER_FLOATS) : nullptr;
+    g_last_splitk_form = S <= 1 ? 0 : (sk_inkernel ? 2 : 1);
     float* y_pool = p.y_pool;
     float* stats = p.stats;
     const unsigned grid = (unsigned)(wgs * S);
@@ -1233,6 +1239,8 @@ static long v2_wgs(int mode, int N, int Hg, int Wg, int Cout, int ti, int th, in
 }
 
 // K splits the v2 launch of this shape will use when a workspace is supplied (1 = no split)
+extern "C" int dvg_debug_last_splitk_form(void) { return g_last_splitk_form; }
+
 extern "C" int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout) {
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }

@@ -210,7 +210,10 @@ def test_splitk_one_launch_equals_the_two_launch_form_and_leaves_its_counters_ze
                 ops.SPLITK_ONE_LAUNCH = False
                 ref = [t.clone() for t in _flat(launch())]
                 torch.cuda.synchronize()
+                assert lib().dvg_debug_last_splitk_form() == 1, name       # partial tiles + splitk_finish launch
                 ops.SPLITK_ONE_LAUNCH = True
+                launch()
+                assert lib().dvg_debug_last_splitk_form() == 2, name       # combined inside the convolution kernel
                 ndiff = 0
                 for rep in range(0, REPS, 3):
                     outs = []
