@@ -412,7 +412,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     # The 3x3 layers as a whole (SURVEY 8(d) counts a layer's direct-form FLOPs): direct implicit-GEMM launches plus, for the
     # layers that run as Winograd F(4x4) / F(2x2), their transform + batched-GEMM launches.  Can exceed the fp32 MFMA peak:
     # Winograd executes 1/4 (1/2.25) of the direct form's multiplies.
-    fam = [k for k in agg if k in ("conv3x3_igemm", "winograd_input", "winograd_gemm", "winograd_output", "winograd_output_input")]
+    fam = [k for k in agg if k == "conv3x3_igemm" or k.startswith("winograd_")]     # (r04 left the pool hand-over out)
     if any(k.startswith("winograd") for k in fam):
         ms = sum(agg[k]["ms"] for k in fam)
         alg = sum(agg[k]["alg_flops"] for k in ("conv3x3_igemm", "winograd_gemm") if k in agg)
@@ -492,11 +492,17 @@ def make_gifs_leg(ctx: Ctx, args, model: str, nsample: int) -> dict:
     same = bool(torch.equal(res["posterior"], res_ps["posterior"])) and \
         bool(torch.equal(res["samples"][:, :args.n_past + shared], res_ps["samples"][:, :args.n_past + shared]))
     fps = lambda t: round(args.batch * args.n_future * nsample * ctx.world / t, 1)  # noqa: E731
+    # frames the kernels actually produced per batch: the shared prediction steps once, the rest once per sample (ADVICE r04:
+    # `predicted_frames_per_s` counts every DELIVERED sample frame, also those that are one computation shared by all samples)
+    fps_computed = lambda t: round(args.batch * (shared + nsample * (args.n_future - shared)) * ctx.world / t, 1)  # noqa: E731
     return {"workload": f"make_gifs on one batch: posterior rollout + {nsample} sample rollouts (GP draw at i % 15 == 0) + SSIM / "
                         f"PSNR per predicted frame + best-of-N, {model}_64, batch {args.batch} per GPU, "
                         f"{args.n_past}-in/{args.n_future}-out, 64x64x1 synthetic clips (KTH-shaped)",
             "nsample": nsample, "samples_in_flight": max(1, args.inflight), "ms_per_batch": round(1e3 * dt, 2),
             "predicted_frames_per_s": fps(dt),
+            "predicted_frames_per_s_is": "DELIVERED sample frames (B x n_future x nsample) / wall time; `computed_frames_per_s` "
+                                         "counts the shared prediction steps once per batch",
+            "computed_frames_per_s": fps_computed(dt),
             "schedule": f"conditioning and the {shared} prediction steps before the first GP trigger step run once per batch (they "
                         f"are the same kernels on the same inputs for every sample: bit-identical frames, tests/test_gpu_rollouts.py), "
                         f"the remaining {args.n_future - shared} steps once per sample",

@@ -38,15 +38,17 @@ SIGNATURES = {
     "dvg_debug_last_splitk_form": (_i, []),
     "dvg_conv_stats_rows_v2": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dvg_conv3x3_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
-    "dvg_conv3x3_first_pair": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_conv3x3_first_pair": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_conv4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p]),
     "dvg_convT4x4s2_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "dvg_winograd_input": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_gemm_batched_k16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "dvg_winograd_output": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
+    "dvg_winograd_output": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _i, _p]),
     "dvg_winograd_output_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
-    "dvg_winograd_output_pool_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_stem_up_winograd_input": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "dvg_winograd_output_up_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dvg_winograd_output_pool_input": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_conv3x3_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "dvg_convT3x3_last": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvg_conv4x4s2_first": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     "dvg_lstm_gates_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_gp_var_norms": (_i, [_p, _p, _i, _i, _p]),
+    "dvg_gp_trigger_step": (_i, [_p, _i, _i, _i, _p, _i, _f, _p, _p, _p, _p, _i, _p]),
+    "dvg_gp_trigger_select": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p, _p, _p]),
     # debug hooks (tools/diag_*.py)
     "dvg_debug_set_clockbuf": (None, [_p, C.c_uint]),
     "dvg_debug_set_gp_clockbuf": (None, [_p, C.c_uint]),

@@ -132,6 +132,16 @@ def flush_wgrads():
         _flush_dense(key)
 
 
+def drop_deferred_wgrads() -> None:
+    """Forget every queued weight-gradient operand WITHOUT flushing it (rollout.drop_version_keyed_caches: after a hipGraph
+    capture that raised inside backward() the queued (dY, X, V) tensors point into the freed graph pool and were never
+    written; the engine skipped its end-of-backward callback, so the queues and the flag would otherwise survive)."""
+    global _wgrad_flush_queued
+    _wgrad_queues.clear()
+    _dense_queues.clear()
+    _wgrad_flush_queued = False
+
+
 def _wgrad(mode, x, skip, du, up, sink, finish, tag, v=None):
     """Weight gradient of one use: queued for a batched launch when it accumulates in place into `sink`, immediate
     otherwise.  finish(partial) reduces the partial slabs into the destination.  v: the forward's Winograd input transform of
@@ -815,12 +825,18 @@ class _LSTMSequence(torch.autograd.Function):
         y = ops.gemm_nt(inp, wo.detach(), None, bo.detach(), act=ops.ACT_TANH)
         ctx.save_for_backward(x, y, zero, *saved)
         ctx.params, ctx.meta = params, (S, B, H, L)
+        ctx.param_versions = tuple(p._version for p in params)   # backward re-reads the weights: see the check there
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, zero, *saved = ctx.saved_tensors
         params = ctx.params
+        # The parameters are kept as objects (their .grad buffers are the in-place sinks), not through save_for_backward, so
+        # autograd's own version check does not cover them: an optimiser step between this node's forward and backward
+        # would make the transposed weights below the NEW ones.
+        if tuple(p._version for p in params) != ctx.param_versions:
+            raise RuntimeError("_LSTMSequence.backward: an LSTM parameter was modified in place after the forward pass")
         S, B, H, L = ctx.meta
         ng = ctx.needs_input_grad            # (x, S, *params)
         pg = list(ng[2:])

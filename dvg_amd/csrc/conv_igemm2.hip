@@ -110,6 +110,10 @@ struct Igemm2Params {
     const float* first_scale;   // folded BatchNorm of the first layer, 64 each
     const float* first_shift;
     float first_slope;
+    // FIRST: images n < y_from do not store the full-resolution output (only y_pool): a rollout discards the encoder's skip
+    // tensors once the skip is frozen (generate_frames.py:154-157), and of the conditioning batch only the last frame's are
+    // kept.  y is biased by -y_from images on the host, so image y_from lands at the start of the caller's buffer.
+    int y_from;
 };
 
 // image of `addend` that output image n adds (see Igemm2Params::add_map)
@@ -824,6 +828,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     // The activation is dispatched ONCE (it used to be a runtime switch per value, tanh/exp code inlined 32 times),
     // and addresses are a per-workgroup 64-bit base plus 32-bit per-value offsets.
     float* const yb = p.y + (size_t)n0 * Ho * Wo * p.Cout + c;
+    const bool want_y = !FIRST || n0 >= p.y_from;      // workgroup-uniform (FIRST tiles hold one image)
     float* const pb = p.y_pool ? p.y_pool + (size_t)n0 * (Ho >> 1) * (Wo >> 1) * p.Cout + c : nullptr;
     const float* const ab = p.addend ? p.addend + (size_t)n0 * Ho * Wo * p.Cout + c : nullptr;
     // shared addend blocks (add_map): per image of the tile, the distance (floats) from "addend image n" to the image its
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     int oy, ox;
                     if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
                     else { oy = y0 + ty; ox = x0 + tx; }
-                    yb[((tii * Ho + oy) * Wo + ox) * p.Cout] = o;
+                    if (!FIRST || want_y) yb[((tii * Ho + oy) * Wo + ox) * p.Cout] = o;
                 }
             }
             if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
@@ -1313,13 +1318,20 @@ extern "C" int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const fl
 // layer's (64,1,3,3) weight TRANSPOSED to [9 taps][64 channels];
 // scale0 / shift0 the first layer's folded BatchNorm (64 each); the rest as dvg_conv3x3_bn_act_v2 with C1 = 64, no skip,
 // no split-K.  H % 8 == 0, W % 16 == 0, at least 512 workgroups (the 8 x 16 tile).
+// y_from (ABI 8): y holds the images [y_from, N) only - the full-resolution output (the stage's skip tensor) of the images
+// before is not stored (y may be NULL when y_from == N); y_pool always covers all N images.
 extern "C" int dvg_conv3x3_first_pair(const float* frame, const float* w0, const float* scale0, const float* shift0,
                                       const float* w1_k16, const float* scale1, const float* shift1, float* y, float* y_pool,
-                                      int N, int H, int W, int Cout, int act, float slope, void* stream) {
+                                      int N, int H, int W, int Cout, int act, float slope, int y_from, void* stream) {
     DVG_REQUIRE(frame && w0 && scale0 && shift0, DVG_ERR_NULL, "dvg_conv3x3_first_pair: NULL pointer");
-    Igemm2Params p{frame /* never read as an activation */, nullptr, w1_k16, scale1, shift1, y, y_pool, nullptr, N, H, W, 64, 0, Cout, 0,
+    DVG_REQUIRE(y_from >= 0 && y_from <= N && (y_from == 0 || y_pool != nullptr) && (y != nullptr || y_from == N), DVG_ERR_SHAPE,
+                "dvg_conv3x3_first_pair: y_from=%d needs 0 <= y_from <= N, a pooled output when > 0, y unless == N", y_from);
+    // y holds the images [y_from, N): biased so that the kernel's image index applies (never dereferenced below y_from)
+    float* const y_biased = y ? y - (size_t)y_from * H * W * Cout : y_pool;
+    Igemm2Params p{frame /* never read as an activation */, nullptr, w1_k16, scale1, shift1, y_biased, y_pool, nullptr, N, H, W, 64, 0, Cout, 0,
                    act, slope, 0, 0, 0, 0, 0, 1, 0, nullptr};
     p.first_frame = frame; p.first_w = w0; p.first_scale = scale0; p.first_shift = shift0; p.first_slope = 0.2f;
+    p.y_from = y_from;
     if (int e = checks2(p, "dvg_conv3x3_first_pair")) return e;
     DVG_REQUIRE(H % 8 == 0 && W % 16 == 0 && (long)N * (H / 8) * (W / 16) * (Cout / 64) >= 512, DVG_ERR_SHAPE,
                 "dvg_conv3x3_first_pair: H %% 8, W %% 16 and >= 512 workgroups needed (N=%d H=%d W=%d Cout=%d)", N, H, W, Cout);

@@ -1,5 +1,7 @@
 // Weight re-layout, layout converters, train-mode BatchNorm helpers.
 // All HBM-bound elementwise / reduction kernels: 16-byte accesses, grid-stride.
+#include <algorithm>
+
 #include "dvg_common.h"
 
 namespace dvg {
@@ -366,11 +368,97 @@ __global__ void moving_mnist_compose_kernel(const float* __restrict__ sprites, c
     }
 }
 
+
+// ---- GPtrigger_gen's bookkeeping on the device (generate_frames.py:227-232,283-296) ---------------------------------------------
+// norms[b] = || var[:, b] ||_2 over the D latent dims (`np.linalg.norm(variance.numpy().transpose(), axis = 1)`, :230,275), the
+// sum of squares in fp64, rounded to float32 like the reference's float32 array.  One wave per sample.
+__global__ __launch_bounds__(64) void gp_var_norms_kernel(const float* __restrict__ var, float* __restrict__ norms, int D, int B) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = (double)var[(size_t)d * B + b];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) norms[b] = (float)sqrt(s);
+}
+
+// One step of the main loop's decision (:285-289): value = norm of sample `col`'s variance; the 12-long context window slides
+// (`np.concatenate([ctx[1:], [value]])`); threshold = mean + coef * std (numpy population std) with float32 results at the
+// points where the reference's float32 arrays round (mean, std, coef * std, the sum); flag = value > threshold.  ctx (W floats)
+// is updated in place; value / threshold / flag are logged at `slot` for ONE read-back after the rollout.  One wave.
+__global__ __launch_bounds__(64) void gp_trigger_step_kernel(const float* __restrict__ var, int D, int B, int col, float* __restrict__ ctx,
+                                                             int W, float coef, int* __restrict__ flag, float* __restrict__ values,
+                                                             float* __restrict__ thresholds, int* __restrict__ flags, int slot) {
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = (double)var[(size_t)d * B + col];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float value = (float)sqrt(s);
+    // the slid window: lane i holds element i
+    float w = 0.f;
+    if (lane < W) w = lane + 1 < W ? ctx[lane + 1] : value;
+    double m = lane < W ? (double)w : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
+    const float mean = (float)(m / W);
+    double q = 0.0;
+    if (lane < W) {
+        const float dlt = w - mean;                      // float32 like `x - x.mean()` on a float32 array
+        q = (double)dlt * (double)dlt;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float sd = (float)sqrt((double)(float)(q / W));
+    const float thr = mean + coef * sd;                  // float32 product, float32 sum (NumPy 2 scalar promotion)
+    __syncthreads();                                     // every lane has read its ctx[lane + 1]
+    if (lane < W) ctx[lane] = w;
+    if (lane == 0) {
+        const int f = value > thr ? 1 : 0;
+        *flag = f;
+        values[slot] = value;
+        thresholds[slot] = thr;
+        flags[slot] = f;
+    }
+}
+
+// What the step decodes and which recurrent state survives it (:289-296): a triggered step decodes the GP sample and does
+// NOT step the LSTM, otherwise `generation` steps it and decodes its output.  vec[b][d] = flag ? sample[d][b] : h_pred[b][d];
+// state_out[k] = flag ? state_old[k] : state_new[k] for the n_state tensors of `elems` floats each.
+struct TriggerSelectParams {
+    const int* flag;
+    const float* sample;   // (D, B)
+    const float* h_pred;   // (B, D)
+    float* vec;            // (B, D)
+    int D, B, n_state;
+    long elems;
+    const float* s_old[8];
+    const float* s_new[8];
+    float* s_out[8];
+};
+
+__global__ __launch_bounds__(256) void gp_trigger_select_kernel(const TriggerSelectParams p) {
+    const bool trig = *p.flag != 0;
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    const long nv = (long)p.B * p.D;
+    if (i < nv) {
+        const int b = (int)(i / p.D), d = (int)(i % p.D);
+        p.vec[i] = trig ? p.sample[(size_t)d * p.B + b] : p.h_pred[i];
+    }
+    for (int k = 0; k < p.n_state; ++k)
+        if (i < p.elems) p.s_out[k][i] = trig ? p.s_old[k][i] : p.s_new[k][i];
+}
+
 }  // namespace dvg
 
 using namespace dvg;
 
-extern "C" int dvg_abi_version(void) { return 7; }  // 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
+extern "C" int dvg_abi_version(void) { return 8; }  // 8: y_from (skip tensors of part of a batch), r05 entry points; 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
 extern "C" const char* dvg_last_error(void) { return err_buf(); }
 
 extern "C" long dvg_stream_capture_id(void* stream) {
@@ -514,4 +602,39 @@ extern "C" int dvg_moving_mnist_compose(const float* sprites, const int* ids, co
     hipLaunchKernelGGL(moving_mnist_compose_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                        sprites, ids, pos, out, T, B, num_digits, image_size, digit_size, n_sprites);
     return check_launch("dvg_moving_mnist_compose");
+}
+
+// GPtrigger_gen's variance norms / threshold decision / branch select on the device (generate_frames.py:227-232,275,283-296):
+// no host round trip per step, the 93-step loop is capturable as a hipGraph.
+extern "C" int dvg_gp_var_norms(const float* var, float* norms, int D, int B, void* stream) {
+    DVG_REQUIRE(var && norms, DVG_ERR_NULL, "dvg_gp_var_norms: NULL pointer");
+    DVG_REQUIRE(D > 0 && B > 0, DVG_ERR_SHAPE, "dvg_gp_var_norms: empty shape");
+    hipLaunchKernelGGL(gp_var_norms_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, var, norms, D, B);
+    return check_launch("dvg_gp_var_norms");
+}
+
+extern "C" int dvg_gp_trigger_step(const float* var, int D, int B, int col, float* ctx, int window, float coef, int* flag,
+                                   float* values, float* thresholds, int* flags, int slot, void* stream) {
+    DVG_REQUIRE(var && ctx && flag && values && thresholds && flags, DVG_ERR_NULL, "dvg_gp_trigger_step: NULL pointer");
+    DVG_REQUIRE(D > 0 && B > 0 && col >= 0 && col < B && window > 0 && window <= 64 && slot >= 0, DVG_ERR_SHAPE,
+                "dvg_gp_trigger_step: col=%d must index the batch of %d, window=%d in [1, 64]", col, B, window);
+    hipLaunchKernelGGL(gp_trigger_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, var, D, B, col, ctx, window, coef, flag,
+                       values, thresholds, flags, slot);
+    return check_launch("dvg_gp_trigger_step");
+}
+
+extern "C" int dvg_gp_trigger_select(const int* flag, const float* sample_db, const float* h_pred, float* vec, int D, int B,
+                                     int n_state, long state_elems, const float* const* state_old,
+                                     const float* const* state_new, float* const* state_out, void* stream) {
+    DVG_REQUIRE(flag && sample_db && h_pred && vec, DVG_ERR_NULL, "dvg_gp_trigger_select: NULL pointer");
+    DVG_REQUIRE(D > 0 && B > 0 && n_state >= 0 && n_state <= 8 && state_elems >= 0, DVG_ERR_SHAPE,
+                "dvg_gp_trigger_select: at most 8 state tensors");
+    TriggerSelectParams p{flag, sample_db, h_pred, vec, D, B, n_state, state_elems, {}, {}, {}};
+    for (int k = 0; k < n_state; ++k) {
+        DVG_REQUIRE(state_old[k] && state_new[k] && state_out[k], DVG_ERR_NULL, "dvg_gp_trigger_select: NULL state pointer");
+        p.s_old[k] = state_old[k]; p.s_new[k] = state_new[k]; p.s_out[k] = state_out[k];
+    }
+    const long n = std::max((long)B * D, state_elems);
+    hipLaunchKernelGGL(gp_trigger_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dvg_gp_trigger_select");
 }

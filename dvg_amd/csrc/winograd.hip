@@ -89,7 +89,8 @@ template <bool POOL>
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ y,
                                                               float* __restrict__ y_pool, int N, int H, int W, int C4,
-                                                              int act, float slope) {
+                                                              int act, float slope, int y_from) {
+    // y_from: y holds the images [y_from, N) (POOL only; see dvg_winograd_output)
     const int Ht = H >> 1, Wt = W >> 1;
     const long T = (long)N * Ht * Wt, total = T * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
                 f32x4 val;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) val[k] = apply_act(o[pp][qq][k] * sc[k] + sf[k], act, slope);
-                reinterpret_cast<f32x4*>(y)[(((size_t)n * H + 2 * ty + pp) * W + 2 * tx + qq) * C4 + c4] = val;
+                if (!POOL || n >= y_from)
+                    reinterpret_cast<f32x4*>(y)[(((size_t)(n - y_from) * H + 2 * ty + pp) * W + 2 * tx + qq) * C4 + c4] = val;
                 if (POOL) {
                     if (pp == 0 && qq == 0) mx = val;
                     else
@@ -286,7 +288,9 @@ template <bool POOL, typename V>
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                float* __restrict__ y_pool, int N, int H, int W, int C4,
-                                                               int act, float slope, const float* __restrict__ addend) {
+                                                               int act, float slope, const float* __restrict__ addend,
+                                                               int y_from) {
+    // y_from (POOL only, else 0): y holds the images [y_from, N); the images before store only their pooled output
     // addend (optional): raw partial sums in y's shape, y = act((A^T M A + addend) * scale + shift) - the hoisted skip half
     // of a decoder block's first conv (the same role as the igemm kernels' addend)
     constexpr int VN = VecN<V>::N;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
 #pragma unroll
                 for (int k = 0; k < VN; ++k)
                     vset(val[pp][qq], k, apply_act((vget(o[qq], k) + vget(ad, k)) * vget(sc, k) + vget(sf, k), act, slope));
-                reinterpret_cast<V*>(y)[px] = val[pp][qq];
+                if (!POOL || n >= y_from) reinterpret_cast<V*>(y)[px - (size_t)y_from * H * W * C4] = val[pp][qq];
             }
         }
         if (POOL) {
@@ -421,17 +425,24 @@ __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __re
 //                 pooled tensor is never written or re-read and one launch disappears.
 // Arithmetic per element is exactly that of the separate kernels (at4 / scale, shift, activation / max / bt4 in the same
 // order): results are bit-identical to winograd4_output_kernel followed by winograd4_input_kernel.
-template <int HW, int CS, typename V, bool POOL, int NT>
+//   UP = true   : the LAST layer of a decoder block hands over to the first conv of the NEXT block through nearest-x2
+//                 upsampling (vgg_64.py:93,98-105, the x half of the concat conv in Winograd form): y (HW x HW) is staged in
+//                 LDS and leaves as the input transform of up2(y) (2 HW x 2 HW, 4 x the tiles); neither y nor its upsampled
+//                 form is written.  Bit-identical to winograd4_output_kernel followed by winograd4_input_kernel<up = 1>.
+template <int HW, int CS, typename V, bool POOL, int NT, bool UP = false>
 __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __restrict__ m, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ y,
                                                              float* __restrict__ v, int N, int C, int act, float slope,
-                                                             const float* __restrict__ addend) {
+                                                             const float* __restrict__ addend, int y_from) {
+    // y_from (POOL only): y holds the images [y_from, N) - the skip tensor of the images before is not stored
     constexpr int VN = VecN<V>::N;
     constexpr int WT = HW / 4, TI = WT * WT;         // tiles per image side / per image of layer L
-    constexpr int S2 = POOL ? HW / 2 : HW;           // side of the map layer L + 1 reads
+    static_assert(!(POOL && UP), "pool and upsample exclude each other");
+    constexpr int SS = POOL ? HW / 2 : HW;           // side of the map staged in LDS
+    constexpr int S2 = UP ? 2 * HW : SS;             // side of the map layer L + 1 reads (UP: through the upsampling)
     constexpr int WT2 = S2 / 4, TI2 = WT2 * WT2;
     constexpr int CV = CS / VN;                      // channel vectors per workgroup
-    extern __shared__ __attribute__((aligned(16))) float chain_ys[];   // [S2 * S2][CS]
+    extern __shared__ __attribute__((aligned(16))) float chain_ys[];   // [SS * SS][CS]
     float* const ys = chain_ys;
     const int cblocks = C / CS;
     const int n = blockIdx.x / cblocks, c0 = (blockIdx.x % cblocks) * CS;
@@ -470,9 +481,10 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
 #pragma unroll
                 for (int k = 0; k < VN; ++k)
                     vset(val[pp][qq], k, apply_act((vget(o[qq], k) + vget(ad, k)) * vget(sc, k) + vget(sf, k), act, slope));
-                if (POOL)
-                    reinterpret_cast<V*>(y)[(((size_t)n * HW + 4 * ty + pp) * HW + 4 * tx + qq) * CVg + cg] = val[pp][qq];
-                else
+                if (POOL) {
+                    if (n >= y_from)       // workgroup-uniform
+                        reinterpret_cast<V*>(y)[(((size_t)(n - y_from) * HW + 4 * ty + pp) * HW + 4 * tx + qq) * CVg + cg] = val[pp][qq];
+                } else
                     *reinterpret_cast<V*>(&ys[((4 * ty + pp) * HW + 4 * tx + qq) * CS + cv * VN]) = val[pp][qq];
             }
         }
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
                     for (int k = 0; k < VN; ++k)
                         vset(mx, k, fmaxf(fmaxf(vget(val[2 * pp][2 * qq], k), vget(val[2 * pp][2 * qq + 1], k)),
                                           fmaxf(vget(val[2 * pp + 1][2 * qq], k), vget(val[2 * pp + 1][2 * qq + 1], k))));
-                    *reinterpret_cast<V*>(&ys[((2 * ty + pp) * S2 + 2 * tx + qq) * CS + cv * VN]) = mx;
+                    *reinterpret_cast<V*>(&ys[((2 * ty + pp) * SS + 2 * tx + qq) * CS + cv * VN]) = mx;
                 }
         }
     }
@@ -505,7 +517,8 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
             for (int a = 0; a < 6; ++a) {
                 const int yy = 4 * ty - 1 + a;
                 d[a] = ((unsigned)yy < (unsigned)S2 && (unsigned)xx < (unsigned)S2)
-                           ? *reinterpret_cast<const V*>(&ys[(yy * S2 + xx) * CS + cv * VN]) : vzero<V>();
+                           ? *reinterpret_cast<const V*>(&ys[((yy >> (UP ? 1 : 0)) * SS + (xx >> (UP ? 1 : 0))) * CS + cv * VN])
+                           : vzero<V>();
             }
             V col[6];
             bt4(d, col);
@@ -522,12 +535,12 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
     }
 }
 
-template <int HW, int CS, typename V, bool POOL, int NT>
+template <int HW, int CS, typename V, bool POOL, int NT, bool UP = false>
 static int launch_chain(const float* mm, const float* scale, const float* shift, float* y, float* v, int N, int C, int act,
-                        float slope, hipStream_t st, const float* addend = nullptr) {
+                        float slope, hipStream_t st, const float* addend = nullptr, int y_from = 0) {
     constexpr int S2 = POOL ? HW / 2 : HW;
     constexpr size_t lds = (size_t)S2 * S2 * CS * 4;
-    auto kern = winograd4_chain_kernel<HW, CS, V, POOL, NT>;
+    auto kern = winograd4_chain_kernel<HW, CS, V, POOL, NT, UP>;
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -535,8 +548,82 @@ static int launch_chain(const float* mm, const float* scale, const float* shift,
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)N * (C / CS))), dim3(NT), lds, st, mm, scale, shift, y, v, N, C, act, slope,
-                       addend);
+                       addend, y_from);
     return check_launch("winograd4_chain");
+}
+
+// Decoder stem -> first conv of the first block (vgg_64.py:65-69 then :93,98-99): ConvTranspose2d(dim,C,4,1,0) on a 1x1 map +
+// BN + LeakyReLU gives a 4 x 4 x C map per sample (a GEMM with K = dim: dense.hip's stem_kernel), which upc2 reads through `up`
+// and the x half of its concat conv in Winograd form.  One kernel: a workgroup computes the 4 x 4 map of BR samples x 16
+// channels into LDS (thread = one output column (pixel, channel), its K weights in registers, the latent vectors broadcast from
+// LDS - the arithmetic of stem_kernel, bit for bit) and writes the input transform of the UPSAMPLED 8 x 8 map (the arithmetic
+// of winograd4_input_kernel<up = 1>): the 4 x 4 map never travels.  wt: the weight transposed to [KP][16 C], rows K..KP-1 zero.
+template <int KP>
+__global__ __launch_bounds__(256) void stem_up_input_kernel(const float* __restrict__ vec, int ldv, const float* __restrict__ wt,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ v, int M, int C, int K, int act, float slope) {
+    constexpr int BR = 8;
+    __shared__ float vs[BR * KP];
+    __shared__ float ys[BR * 16 * 16];     // [sample][pixel][channel]
+    const int tid = threadIdx.x, cl = tid & 15, hw = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const size_t N = (size_t)16 * C, n = (size_t)hw * C + c;
+    const int m0 = blockIdx.y * BR, mrows = min(BR, M - m0);
+    for (int i = tid; i < BR * KP; i += 256) {
+        const int r = i / KP, k = i % KP;
+        vs[i] = (r < mrows && k < K) ? vec[(size_t)(m0 + r) * ldv + k] : 0.f;
+    }
+    float w[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w[k] = wt[(size_t)k * N + n];
+    __syncthreads();
+    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
+#pragma unroll
+    for (int bb = 0; bb < BR; ++bb) {
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vs + bb * KP);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const f32x4 v4 = vr[k4];
+            s0 = fmaf(v4[0], w[4 * k4], s0);
+            s1 = fmaf(v4[1], w[4 * k4 + 1], s1);
+            s0 = fmaf(v4[2], w[4 * k4 + 2], s0);
+            s1 = fmaf(v4[3], w[4 * k4 + 3], s1);
+        }
+        ys[(bb * 16 + hw) * 16 + cl] = apply_act((s0 + s1) * sc + sf, act, slope);
+    }
+    __syncthreads();
+    const long T = (long)M * 4;
+    for (int u = tid; u < BR * 64; u += 256) {
+        const int ucl = u & 15, tile = (u >> 4) & 3, bb = u >> 6;
+        if (bb >= mrows) continue;
+        const int ty = tile >> 1, tx = tile & 1;
+        const float* src = ys + bb * 256 + ucl;
+        float e[6][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int xx = 4 * tx - 1 + b;
+            float d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int yy = 4 * ty - 1 + a;
+                d[a] = ((unsigned)yy < 8u && (unsigned)xx < 8u) ? src[((yy >> 1) * 4 + (xx >> 1)) * 16] : 0.f;
+            }
+            float col[6];
+            bt4(d, col);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) e[a][b] = col[a];
+        }
+        const long t = (long)(m0 + bb) * 4 + tile;
+        float* dst = v + t * C + blockIdx.x * 16 + ucl;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float o[6];
+            bt4(e[a], o);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) dst[(size_t)(a * 6 + b) * T * C] = o[b];
+        }
+    }
 }
 
 static int chain_variant() {
@@ -661,12 +748,50 @@ extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, co
     return check_launch("dvg_winograd_output_input");
 }
 
+// stem_up_input_kernel: vec (M, K) row stride ldv; w_kn the stem weight as [KP][16 C] (dvg_stem_gemm's operand: column
+// (h * 4 + w) * C + c, rows K..KP-1 zero); v_next (36, 4 M, C) = the F(4x4,3x3) input transform of
+// UpsamplingNearest2d(2)(act(scale * convT(vec) + shift)).  C % 16 == 0, KP in {96, 128}.
+extern "C" int dvg_stem_up_winograd_input(const float* vec, int ldv, const float* w_kn, int KP, const float* scale,
+                                          const float* shift, float* v_next, int M, int C, int K, int act, float slope,
+                                          void* stream) {
+    DVG_REQUIRE(vec && w_kn && v_next, DVG_ERR_NULL, "dvg_stem_up_winograd_input: NULL pointer");
+    DVG_REQUIRE(M > 0 && C > 0 && C % 16 == 0 && K > 0 && K <= KP && (KP == 96 || KP == 128) && ldv >= K, DVG_ERR_SHAPE,
+                "dvg_stem_up_winograd_input: bad shape M=%d C=%d K=%d KP=%d (C %% 16 == 0, KP 96 or 128)", M, C, K, KP);
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_stem_up_winograd_input: bad act");
+    DVG_REQUIRE(aligned16(v_next), DVG_ERR_ALIGN, "dvg_stem_up_winograd_input: alignment");
+    const dim3 grid(C / 16, (M + 7) / 8);
+    if (KP == 96)
+        hipLaunchKernelGGL(stem_up_input_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, vec, ldv, w_kn, scale, shift, v_next,
+                           M, C, K, act, slope);
+    else
+        hipLaunchKernelGGL(stem_up_input_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, vec, ldv, w_kn, scale, shift, v_next,
+                           M, C, K, act, slope);
+    return check_launch("dvg_stem_up_winograd_input");
+}
+
+// Last layer of a decoder block -> first conv of the next block (vgg_64.py:98-105): M (36, T, C) of an H x H layer ->
+// V' (36, 4 T, C), the F(4x4,3x3) input transform of UpsamplingNearest2d(2)(act(scale * A^T M A + shift)) (winograd4_chain_kernel
+// <UP>); neither the activation nor its upsampled form is written.  H == W == 8 (the next block works at 16 x 16).
+extern "C" int dvg_winograd_output_up_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H,
+                                            int W, int C, int act, float slope, void* stream) {
+    DVG_REQUIRE(mm && v_next, DVG_ERR_NULL, "dvg_winograd_output_up_input: NULL pointer");
+    DVG_REQUIRE(N > 0 && H == W && H == 8 && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
+                "dvg_winograd_output_up_input: 8x8 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
+    DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_up_input: bad act");
+    DVG_REQUIRE(aligned16(mm) && aligned16(v_next), DVG_ERR_ALIGN, "dvg_winograd_output_up_input: alignment");
+    const hipStream_t st = (hipStream_t)stream;
+    return launch_chain<8, 32, float, false, 512, true>(mm, scale, shift, nullptr, v_next, N, C, act, slope, st);
+}
+
 // Last layer of an encoder stage (vgg_64.py:51-56): M (36, T, C) -> y = act(scale * A^T M A + shift) (N,H,W,C) NHWC, the
 // skip tensor, AND V' (36, T / 4, C), the F(4x4,3x3) input transform of maxpool2x2(y) for the first layer of the next stage
 // (winograd4_chain_kernel<POOL>).  H == W in {16, 32}, C % 64 == 0.  The pooled tensor itself is not written.
+// y_from (ABI 8): y holds the images [y_from, N) only (NULL allowed when y_from == N): a rollout keeps the skip tensors of the
+// last conditioning frame alone (generate_frames.py:154-157).
 extern "C" int dvg_winograd_output_pool_input(const float* mm, const float* scale, const float* shift, float* y, float* v_next,
-                                              int N, int H, int W, int C, int act, float slope, void* stream) {
-    DVG_REQUIRE(mm && y && v_next, DVG_ERR_NULL, "dvg_winograd_output_pool_input: NULL pointer");
+                                              int N, int H, int W, int C, int act, float slope, int y_from, void* stream) {
+    DVG_REQUIRE(mm && v_next && (y || y_from == N), DVG_ERR_NULL, "dvg_winograd_output_pool_input: NULL pointer");
+    DVG_REQUIRE(y_from >= 0 && y_from <= N, DVG_ERR_SHAPE, "dvg_winograd_output_pool_input: y_from=%d outside [0, N]", y_from);
     DVG_REQUIRE(N > 0 && H == W && (H == 16 || H == 32) && C > 0 && C % 64 == 0, DVG_ERR_SHAPE,
                 "dvg_winograd_output_pool_input: 16x16 or 32x32 maps, C %% 64 == 0 needed (got %dx%d, C=%d)", H, W, C);
     DVG_REQUIRE(act >= 0 && act <= 3, DVG_ERR_SHAPE, "dvg_winograd_output_pool_input: bad act");
@@ -676,14 +801,18 @@ extern "C" int dvg_winograd_output_pool_input(const float* mm, const float* scal
     // us at B = 64 / 576 against output(+pool) followed by input: 16 -> 8 (256 ch) 12.2 / 120 vs 18.3 / 124; 32 -> 16 (128 ch)
     // 21.7 / 244 vs 30.0 / 247 (the 16-channel variant: 33.5 / 324)
     (void)var;
-    if (H == 16) return launch_chain<16, 64, f32x2, true, 512>(mm, scale, shift, y, v_next, N, C, act, slope, st);
-    return launch_chain<32, 32, f32x2, true, 1024>(mm, scale, shift, y, v_next, N, C, act, slope, st);
+    if (H == 16) return launch_chain<16, 64, f32x2, true, 512>(mm, scale, shift, y, v_next, N, C, act, slope, st, nullptr, y_from);
+    return launch_chain<32, 32, f32x2, true, 1024>(mm, scale, shift, y, v_next, N, C, act, slope, st, nullptr, y_from);
 }
 
-extern "C" int dvg_winograd_output(
-const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
-                                   int H, int W, int C, int act, float slope, int mt, const float* addend, void* stream) {
-    DVG_REQUIRE(m && y, DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
+// y_from (ABI 8; 0 unless y_pool is given): y holds the images [y_from, N) only, the images before store only y_pool
+// (NULL y allowed when y_from == N).
+extern "C" int dvg_winograd_output(const float* m, const float* scale, const float* shift, float* y, float* y_pool, int N,
+                                   int H, int W, int C, int act, float slope, int mt, const float* addend, int y_from,
+                                   void* stream) {
+    DVG_REQUIRE(m && (y || (y_pool && y_from == N)), DVG_ERR_NULL, "dvg_winograd_output: NULL pointer");
+    DVG_REQUIRE(y_from >= 0 && y_from <= N && (y_from == 0 || y_pool != nullptr), DVG_ERR_SHAPE,
+                "dvg_winograd_output: y_from=%d needs 0 <= y_from <= N and a pooled output", y_from);
     DVG_REQUIRE(addend == nullptr || (mt == 4 && y_pool == nullptr && aligned16(addend)), DVG_ERR_SHAPE,
                 "dvg_winograd_output: addend needs m = 4, no pooled output, 16-byte alignment");
     DVG_REQUIRE((mt == 2 || mt == 4) && N > 0 && H > 0 && W > 0 && H % mt == 0 && W % mt == 0 && C > 0 && C % 4 == 0,
@@ -694,14 +823,14 @@ const float* m, const float* scale, const float* shift, float* y, float* y_pool,
     const unsigned g = wgrid((long)N * (H / mt) * (W / mt) * (C / 4));
     const hipStream_t st = (hipStream_t)stream;
     if (mt == 2 && y_pool)
-        hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+        hipLaunchKernelGGL(winograd_output_kernel<true>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope, y_from);
     else if (mt == 2)
-        hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope);
+        hipLaunchKernelGGL(winograd_output_kernel<false>, dim3(g), dim3(256), 0, st, m, scale, shift, y, y_pool, N, H, W, C / 4, act, slope, 0);
     else {
         const long tiles = (long)N * (H / 4) * (W / 4);
 #define W4OUT(POOL_, V_, CW_)                                                                                             \
     hipLaunchKernelGGL((winograd4_output_kernel<POOL_, V_>), dim3(wgrid(tiles * (C / CW_))), dim3(256), 0, st, m, scale, shift, \
-                       y, y_pool, N, H, W, C / CW_, act, slope, addend)
+                       y, y_pool, N, H, W, C / CW_, act, slope, addend, y_from)
         if (tiles * (C / 4) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x4, 4); else W4OUT(false, f32x4, 4); }
         else if (tiles * (C / 2) >= 1024L * 256) { if (y_pool) W4OUT(true, f32x2, 2); else W4OUT(false, f32x2, 2); }
         else { if (y_pool) W4OUT(true, float, 1); else W4OUT(false, float, 1); }

@@ -446,9 +446,10 @@ WINOGRAD_CHAIN = os.environ.get("DVG_WINOGRAD_CHAIN", "1") != "0"
 
 
 # DVG_WINOGRAD_CHAIN: 0 = every layer writes its activation; 1 = hand-overs inside a block at 8x8 / 16x16 (the r02 set);
-# 2 (default) = also at 32x32 and from the last layer of an encoder stage, through its 2x2 max-pool, to the first layer of the
-# next stage (dvg_winograd_output_pool_input).
-_CHAIN_LEVEL = int(os.environ.get("DVG_WINOGRAD_CHAIN", "2"))
+# 2 = also at 32x32 and from the last layer of an encoder stage, through its 2x2 max-pool, to the first layer of the
+# next stage (dvg_winograd_output_pool_input); 3 (default) = also from the last layer of a decoder block, through the
+# nearest-x2 upsampling, to the x half of the next block's concat conv (dvg_winograd_output_up_input).
+_CHAIN_LEVEL = int(os.environ.get("DVG_WINOGRAD_CHAIN", "3"))
 
 
 def _chain_to(conv_next, n, c, h, w, pool=False):
@@ -465,11 +466,66 @@ def _chain_to(conv_next, n, c, h, w, pool=False):
     return winograd_tile(n, c, h, w, conv_next.weight.shape[0]) == 4 and ops.winograd_chain_ok(n, c, h, w)
 
 
-def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2, next_conv=None):
+def _from(res, y_from):
+    """(y, pooled) of a path that stored every image -> the `y_from` convention (y covers the images [y_from, N), None if empty)."""
+    if not y_from:
+        return res
+    y, yp = res
+    return (y[y_from:] if y_from < y.shape[0] else None), yp
+
+
+def _hoist_ready(conv, skip) -> bool:
+    """True when _hoisted_skip(conv, ., skip, .) will hand out the skip half on its next call (no side effects)."""
+    if not SKIP_HOIST or skip is None:
+        return False
+    ent = _skip_seen.get((id(conv), id(skip)))
+    if ent is not None and ent[0]() is skip and ent[1] == skip._version and ent[2] == _ver(conv.weight):
+        return True
+    fz = _frozen.get(id(skip))
+    return fz is not None and fz[0]() is skip and fz[1] == skip._version
+
+
+def _chain_up_to(next_up, n, c, h, w, stem=False) -> bool:
+    """True when the first conv of the NEXT decoder block - next_up = (conv, bn, skip): conv(cat([up2(this output), skip])) -
+    will take this layer's (n,c,h,w) output as an ops.WinoV through the upsampling: eval mode, its skip half hoisted (so the
+    x half runs alone, in Winograd form), shapes dvg_winograd_output_up_input takes."""
+    if next_up is None or torch.is_grad_enabled():
+        return False
+    conv_n, bn_n, skip_n = next_up
+    if not (WINOGRAD_CHAIN and _CHAIN_LEVEL >= 3 and WINOGRAD >= 4 and UPCONV_WINOGRAD and isinstance(conv_n, nn.Conv2d)
+            and tuple(conv_n.kernel_size) == (3, 3) and not conv_n.training and not bn_n.training and skip_n is not None
+            and not isinstance(skip_n, ops.SharedBlocks)):
+        return False
+    if conv_n.weight.shape[1] - skip_n.shape[1] != c or tuple(skip_n.shape) != (n, skip_n.shape[1], 2 * h, 2 * w):
+        return False
+    return (2 * h <= _UPCONV_WINO_MAX and winograd_tile(n, c, 2 * h, 2 * w, conv_n.weight.shape[0]) == 4
+            and ((h, w) == (4, 4) if stem else ops.winograd_up_chain_ok(n, c, h, w)) and _hoist_ready(conv_n, skip_n))
+
+
+def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_LRELU, slope=0.2, next_conv=None, y_from=0,
+                 next_up=None):
     """vgg_layer (vgg_64.py:5-15) with optional fused cat/upsample on the input and
     fused 2x2 max-pool on the output.  next_conv: the Conv2d of the vgg_layer that consumes this layer's output and is its
     ONLY consumer - in eval mode the result may then be an ops.WinoV (that layer's Winograd input transform) instead of the
-    activation; pass it on as `x` unchanged."""
+    activation; pass it on as `x` unchanged.
+    y_from (pool=True only, eval mode): of the (y, pooled) pair, y - an encoder stage's skip tensor - is wanted for the images
+    [y_from, N) only: the Winograd paths then do not store the rest (ops.conv3x3_winograd), the others slice.
+    next_up = (conv, bn, skip) of the NEXT decoder block's first layer when this is a block's last layer and that layer is
+    the only consumer: in eval mode the result may be the input transform of the upsampled output (an ops.WinoV with .up)."""
+    if y_from and (not pool or bn.training or _needs_grad(x, skip, conv.weight, bn.weight)):
+        raise RuntimeError("conv3_bn_act: y_from is an eval-mode, no-grad option of the pooled form")
+    if isinstance(x, ops.WinoV) and x.up:
+        # first conv of a decoder block fed by the previous block's last layer through the upsampling (_chain_up_to held there)
+        hs = None if (bn.training or not upsample or pool) else \
+            _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE))
+        if hs is None:
+            raise RuntimeError("conv3_bn_act: an upsampled WinoV needs the eval-mode concat conv with its skip half hoisted")
+        sc, sh = folded_affine(conv, bn)
+        n, c1, h, w = x.shape
+        cout = conv.weight.shape[0]
+        to_v = _chain_to(next_conv, n, cout, h, w)
+        return ops.conv3x3_winograd(x, _winograd_weight_x(conv, c1), sc, sh, act=act, slope=slope, upsample=True,
+                                    addend=hs[1], to_v=to_v)
     if isinstance(x, ops.WinoV):
         if bn.training or skip is not None or upsample:
             raise RuntimeError("conv3_bn_act: a WinoV input needs an eval-mode plain 3x3 layer")
@@ -479,7 +535,10 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
         if winograd_tile(n, c, h, w, cout) != 4:
             raise RuntimeError("conv3_bn_act: WinoV handed to a layer that is not F(4x4,3x3)")
         to_v = _chain_to(next_conv, n, cout, h, w, pool)
-        return ops.conv3x3_winograd(x, winograd_weight(conv, 4), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
+        if not to_v and not pool and _chain_up_to(next_up, n, cout, h, w):
+            to_v = "up"
+        return ops.conv3x3_winograd(x, winograd_weight(conv, 4), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v,
+                                    y_from=y_from)
     if _needs_grad(x, skip, conv.weight, bn.weight):
         from .autograd import conv_block_autograd
         return conv_block_autograd("conv3", conv, bn, x, skip, upsample=upsample, pool=pool, act=act, slope=slope)
@@ -511,8 +570,11 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
             if m:
                 to_v = m == 4 and not torch.is_grad_enabled() and \
                     _chain_to(next_conv, x.shape[0], conv.weight.shape[0], x.shape[2], x.shape[3], pool)
-                return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v)
-        return ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool)
+                if m == 4 and not to_v and not pool and _chain_up_to(next_up, x.shape[0], conv.weight.shape[0], x.shape[2], x.shape[3]):
+                    to_v = "up"
+                return ops.conv3x3_winograd(x, winograd_weight(conv, m), sc, sh, act=act, slope=slope, pool=pool, to_v=to_v,
+                                            y_from=y_from)
+        return _from(ops.conv3x3(x, skip, packed_weight(conv), sc, sh, upsample=upsample, act=act, slope=slope, pool=pool), y_from)
     wp = packed_weight(conv)
     u, st = ops.conv3x3(x, skip, wp, None, conv.bias.detach() if conv.bias is not None else None, upsample=upsample,
                         act=ACT_NONE, stats=True)
@@ -547,8 +609,9 @@ def first_pair_applies(conv0, bn0, conv1, bn1, x_nchw) -> bool:
     return conv0.out_channels == 64 and conv1.in_channels == 64 and ops.first_pair_ok(n, nc, h, w, conv1.out_channels)
 
 
-def conv3_first_pair(conv0, bn0, conv1, bn1, x_nchw, *, pool=False, slope=0.2):
-    """vgg_64.py:23-26 (+ :49): c1 on the raw frame, both layers in one kernel (eval mode, one input channel)."""
+def conv3_first_pair(conv0, bn0, conv1, bn1, x_nchw, *, pool=False, slope=0.2, y_from=0):
+    """vgg_64.py:23-26 (+ :49): c1 on the raw frame, both layers in one kernel (eval mode, one input channel).
+    y_from: as conv3_bn_act."""
     sc0, sh0 = folded_affine(conv0, bn0)
     sc1, sh1 = folded_affine(conv1, bn1)
     slot, key = _slot(conv0), _ver(conv0.weight)
@@ -556,7 +619,7 @@ def conv3_first_pair(conv0, bn0, conv1, bn1, x_nchw, *, pool=False, slope=0.2):
     if hit is None or hit[0] != key:
         hit = (key, conv0.weight.detach().reshape(64, 9).t().contiguous())      # [tap][channel]
         slot["w_t9x64"] = hit
-    return ops.conv3x3_first_pair(x_nchw, hit[1], sc0, sh0, packed_weight(conv1), sc1, sh1, slope=slope, pool=pool)
+    return ops.conv3x3_first_pair(x_nchw, hit[1], sc0, sh0, packed_weight(conv1), sc1, sh1, slope=slope, pool=pool, y_from=y_from)
 
 
 def conv4s2_bn_act(conv, bn, x, *, act=ACT_LRELU, slope=0.2):
@@ -631,8 +694,10 @@ def head_bn_tanh(conv, bn, x):
     return ops.bn_act_apply(_as_nhwc_vec(u), sc, sh, act=ACT_TANH, inplace=True).reshape(n, u.shape[1])
 
 
-def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2):
-    """Decoder stem ConvTranspose2d(dim,512,4,1,0)+BN+LReLU (vgg_64.py:65-69): (N,dim) -> NHWC (N,512,4,4)."""
+def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2, next_up=None):
+    """Decoder stem ConvTranspose2d(dim,512,4,1,0)+BN+LReLU (vgg_64.py:65-69): (N,dim) -> NHWC (N,512,4,4).
+    next_up = (conv, bn, skip) of the first decoder block's first layer (the stem's only consumer, through `up`): in eval
+    rollouts the result may be that layer's Winograd input transform instead (an ops.WinoV with .up; see _chain_up_to)."""
     if _needs_grad(vec, conv.weight, bn.weight):
         from .autograd import dense_block_autograd
         return dense_block_autograd("stem", conv, bn, vec, act=act, slope=slope)
@@ -640,11 +705,14 @@ def stem_bn_act(conv, bn, vec, *, act=ACT_LRELU, slope=0.2):
     vec = vec.reshape(-1, dim)
     n = vec.shape[0]
     gw = gemm_weight(conv, "stem")
-    out = ops.nhwc_empty(n, cout, kh, kw, vec.device)
-    out2d = out.permute(0, 2, 3, 1).reshape(n, kh * kw * cout)
     if not bn.training:
         sc, sh = folded_affine(conv, bn)
         wt = gemm_weight(conv, "stem_t")
+        if wt is not None and (kh, kw) == (4, 4) and cout % 16 == 0 and _chain_up_to(next_up, n, cout, 4, 4, stem=True):
+            return ops.stem_up_winograd_input(vec, wt, dim, sc, sh, cout, act=act, slope=slope)
+    out = ops.nhwc_empty(n, cout, kh, kw, vec.device)
+    out2d = out.permute(0, 2, 3, 1).reshape(n, kh * kw * cout)
+    if not bn.training:
         if wt is not None:
             ops.stem_gemm(vec, wt, dim, sc, sh, out2d, period=cout, act=act, slope=slope)
         else:

@@ -127,17 +127,24 @@ class VggEncoder(nn.Module):
             n += 1
         return [getattr(self, f"c{s}") for s in range(1, n)], getattr(self, f"c{n}")
 
-    def features(self, input):
+    def features(self, input, skips_from=0):
+        """(head output, skip tensors).  skips_from = k (eval mode, no grad): the skip tensors are wanted for the images
+        [k, N) only - they come back with N - k images (None each when k == N) and the kernels that can do not store the
+        rest: a rollout keeps the skips of the last conditioning frame and discards those of every predicted frame
+        (generate_frames.py:154-157), and the full-resolution stage outputs are 126 MB per 64 frames."""
         stages, head = self._stages()
         skips = []
         h = _frame(input)
+        k = int(skips_from)
+        if k and (self.training or torch.is_grad_enabled()):
+            raise RuntimeError("encoder: skips_from is an eval-mode, no-grad option")
         for si, stage in enumerate(stages):
             layers = list(stage)
             if si == 0 and len(layers) == 2 and fused.first_pair_applies(layers[0].main[0], layers[0].main[1],
                                                                          layers[1].main[0], layers[1].main[1], h):
                 # eval mode, one input channel: both layers of c1 in one launch (the 64-channel map between them stays on chip)
                 full, h = fused.conv3_first_pair(layers[0].main[0], layers[0].main[1], layers[1].main[0], layers[1].main[1], h,
-                                                 pool=True)
+                                                 pool=True, y_from=k)
                 skips.append(full)
                 continue
             for li, layer in enumerate(layers):
@@ -148,7 +155,7 @@ class VggEncoder(nn.Module):
                 elif last:  # stage output = skip tensor; its 2x2 max-pool feeds the next stage and nothing else (eval: the
                     # pooled map may be handed over as the next stage's Winograd input transform, an ops.WinoV)
                     nxt = stages[si + 1][0].main[0] if si + 1 < len(stages) else None
-                    full, h = fused.conv3_bn_act(conv, bn, h, pool=True, next_conv=nxt)
+                    full, h = fused.conv3_bn_act(conv, bn, h, pool=True, next_conv=nxt, y_from=k)
                     skips.append(full)
                 else:       # inner layer: its output has one consumer, the next layer (eval: may hand over an ops.WinoV)
                     h = fused.conv3_bn_act(conv, bn, h, next_conv=layers[li + 1].main[0])
@@ -156,6 +163,11 @@ class VggEncoder(nn.Module):
 
     def forward(self, input):
         h, skips = self.features(input)
+        return h.view(-1, self.dim), skips
+
+    def encode(self, input, skips_from=0):
+        """forward() with the skip tensors of the images [skips_from, N) only (see features)."""
+        h, skips = self.features(input, skips_from)
         return h.view(-1, self.dim), skips
 
 
@@ -181,22 +193,31 @@ class VggDecoder(nn.Module):
         n = 1
         while hasattr(self, f"upc{n + 1}"):
             n += 1
-        d = fused.stem_bn_act(self.upc1[0], self.upc1[1], vec)
+        sks = {s: _skip_nhwc(skip[n - s]) for s in range(2, n + 1)}
+        fl = self.upc2[0]
+        d = fused.stem_bn_act(self.upc1[0], self.upc1[1], vec,
+                              next_up=(fl.main[0], fl.main[1], sks[2]) if isinstance(fl, vgg_layer) and n > 2 else None)
         for s in range(2, n + 1):
-            sk = _skip_nhwc(skip[n - s])
+            sk = sks[s]
             first = True
             mods = list(getattr(self, f"upc{s}"))
             for li, layer in enumerate(mods):
                 if isinstance(layer, vgg_layer):
+                    # the layer after this one when it is a vgg_layer of the same block (eval: may take an ops.WinoV) ...
+                    nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None
+                    # ... or, for a block's last layer, the first layer of the NEXT block, which reads this output through `up`
+                    # and cat(skip) and nothing else does (vgg_64.py:98-105; eval rollouts: an ops.WinoV through the upsampling)
+                    nup = None
+                    if nxt is None and li == len(mods) - 1 and s < n:
+                        fl = getattr(self, f"upc{s + 1}")[0]
+                        nup = (fl.main[0], fl.main[1], sks[s + 1])
                     if first:  # nearest x2 + cat(skip) fused into the tile loader (eval rollouts: x half in Winograd form)
-                        nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None
                         d = fused.conv3_bn_act(layer.main[0], layer.main[1], d, sk, upsample=True,
-                                               next_conv=None if nxt is None else nxt.main[0])
+                                               next_conv=None if nxt is None else nxt.main[0], next_up=nup)
                         first = False
                     else:      # an inner layer followed by another vgg_layer of the block may hand over an ops.WinoV
-                        nxt = mods[li + 1] if li + 1 < len(mods) and isinstance(mods[li + 1], vgg_layer) and s < n else None
                         d = fused.conv3_bn_act(layer.main[0], layer.main[1], d,
-                                               next_conv=None if nxt is None else nxt.main[0])
+                                               next_conv=None if nxt is None else nxt.main[0], next_up=nup)
                 elif isinstance(layer, nn.ConvTranspose2d):
                     d = fused.convT3_last(layer, d, act=ACT_SIGMOID)
         return d
@@ -252,16 +273,22 @@ class DcganEncoder(nn.Module):
         setattr(self, f"c{len(plan) + 1}", _head(dim))
 
     def forward(self, input):
+        return self.encode(input)
+
+    def encode(self, input, skips_from=0):
+        """forward() with the skip tensors of the images [skips_from, N) only (same convention as VggEncoder.encode; here every
+        skip is also the next layer's input, so nothing is saved - the skips are views)."""
         n = 1
         while hasattr(self, f"c{n + 1}"):
             n += 1
         h = _frame(input)
+        k = int(skips_from)
         skips = []
         for s in range(1, n):
             layer = getattr(self, f"c{s}")
             conv, bn = layer.main[0], layer.main[1]
             h = fused.conv4s2_first_bn_act(conv, bn, h) if conv.in_channels % 32 else fused.conv4s2_bn_act(conv, bn, h)
-            skips.append(h)
+            skips.append(h if not k else (h[k:] if k < h.shape[0] else None))
         head = getattr(self, f"c{n}")
         return fused.head_bn_tanh(head[0], head[1], h).view(-1, self.dim), skips
 

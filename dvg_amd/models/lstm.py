@@ -140,8 +140,10 @@ def sequence_applies(mod) -> bool:
 def forward_sequence(mod: "lstm", hseq: torch.Tensor) -> torch.Tensor:
     """`[mod(h) for h in hseq]` for a TEACHER-FORCED sequence hseq (S, B, in) - the inputs of all steps exist up front
     (train.py:181-188,213-222) - starting from the zero state of `init_hidden()`: (S, B, out).  One GEMM per non-recurrent
-    product over all S x B rows (autograd._LSTMSequence).  `mod.hidden` is NOT advanced: the closures that use this re-create
-    it per sequence (train.py:178,206) and never read it afterwards."""
+    product over all S x B rows (autograd._LSTMSequence).
+    REQUIREMENT ON CALLERS: `mod.hidden` is NOT advanced (the step-by-step module leaves the state after step S there) - a
+    caller must not read `mod.hidden` after this call; it is set to None so that such a read fails instead of returning the
+    stale pre-sequence state.  The closures that use this re-create it per sequence (train.py:178,206) and never read it."""
     from ..autograd import lstm_sequence_autograd
     S, B = hseq.shape[0], hseq.shape[1]
     params = [mod.embed.weight, mod.embed.bias]
@@ -149,6 +151,7 @@ def forward_sequence(mod: "lstm", hseq: torch.Tensor) -> torch.Tensor:
         params += [cell_.weight_ih, cell_.weight_hh, cell_.bias_ih, cell_.bias_hh]
     params += [mod.output[0].weight, mod.output[0].bias]
     y = lstm_sequence_autograd(hseq.reshape(S * B, -1), S, params)
+    mod.hidden = None
     return y.view(S, B, -1)
 
 

@@ -211,6 +211,16 @@ SPLITK_ONE_LAUNCH = os.environ.get("DVG_SPLITK_ONE_LAUNCH", "0") == "1"
 _SPLITK_WS = {}
 
 
+def evict_captured_workspaces() -> None:
+    """Drop the split-K workspaces that were allocated from a hipGraph's private pool (capture id != 0).  Called by
+    rollout.snapshot_eager_caches right after a capture has ended: the graph replays through raw pointers and its pool
+    keeps the memory, so the tensor objects are only needed WHILE the capture runs (later launches of the same size reuse
+    them) - kept afterwards they would pin segments of a pool that GraphedIteration._release() / a sampler rebuild wants
+    to free."""
+    for k in [k for k in _SPLITK_WS if k[-1] != 0]:
+        del _SPLITK_WS[k]
+
+
 def _stats_buf(rows: int, cout: int, device, tile_images: int = 0):
     """tile_images > 0: the rows are per-TILE partial sums in image-major order, a tile spanning `tile_images` consecutive
     images (recorded on the tensor: fused.group_stats may then cut the rows into per-group runs without another pass);
@@ -361,10 +371,12 @@ def winograd_ok(n, c, h, w, cout, m: int = 2) -> bool:
 class WinoV:
     """The Winograd F(4x4,3x3) input transform V (36, T, C) of an activation (N,C,H,W) that was never materialised: what
     conv3x3_winograd(..., to_v=True) hands to the next layer's conv3x3_winograd instead of y."""
-    __slots__ = ("v", "shape")
+    __slots__ = ("v", "shape", "up")
 
-    def __init__(self, v, shape):
-        self.v, self.shape = v, tuple(shape)
+    def __init__(self, v, shape, up=False):
+        # up: `shape` is the UPSAMPLED map the transform was taken of (conv3x3_winograd(to_v="up")): only a layer called with
+        # upsample=True may consume it
+        self.v, self.shape, self.up = v, tuple(shape), bool(up)
 
     @property
     def device(self):
@@ -380,23 +392,33 @@ def winograd_chain_ok(n, c, h, w):
     return h == w and h in (8, 16, 32) and c % 64 == 0 and n > 0
 
 
+def winograd_up_chain_ok(n, c, h, w):
+    """Shapes dvg_winograd_output_up_input takes (last layer of a decoder block -> upsample -> first conv of the next)."""
+    return h == w and h == 8 and c % 64 == 0 and n > 0
+
+
 def winograd_pool_chain_ok(n, c, h, w):
     """Shapes dvg_winograd_output_pool_input takes (last layer of an encoder stage -> first layer of the next stage)."""
     return h == w and h in (16, 32) and c % 64 == 0 and n > 0
 
 
 def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False, return_v=False, to_v=False,
-                     upsample=False, addend=None):
+                     upsample=False, addend=None, y_from=0):
     """y = act(conv3x3(x) * scale + shift) (+ pooled y) through input transform -> (m+2)^2 batched GEMMs -> output
     transform; m (2 or 4) follows from u's leading dimension (16 or 36).  x may be a WinoV (the previous layer's to_v=True
     result: no input transform); to_v=True returns the NEXT layer's input transform as a WinoV instead of y (m = 4,
     winograd_chain_ok shapes: dvg_winograd_output_input); pool=True with to_v=True returns (y, WinoV of maxpool2x2(y)): the
     last layer of an encoder stage handing over to the first layer of the next (dvg_winograd_output_pool_input).
+    to_v="up": the WinoV is the input transform of nearest_up2(y) (dvg_winograd_output_up_input; the consumer is a layer called
+    with upsample=True, which then skips its own input transform).
     upsample (m = 4): x is read through nearest-x2 upsampling (output 2H x 2W).  addend (m = 4, no pool): raw partial sums
-    in the output's shape, y = act((conv + addend) * scale + shift) - the hoisted skip half of a decoder block's first conv."""
+    in the output's shape, y = act((conv + addend) * scale + shift) - the hoisted skip half of a decoder block's first conv.
+    y_from (pool only): y is stored for the images [y_from, N) only (N - y_from images; None when y_from == N)."""
     from_v = isinstance(x, WinoV)
     if from_v:
         n, c, h, w = x.shape
+        if x.up != bool(upsample):
+            raise RuntimeError("conv3x3_winograd: a WinoV taken through the upsampling needs upsample=True (and only then)")
     else:
         _dev_f32(x, "conv3x3_winograd.x")
         assert is_nhwc(x), "conv3x3_winograd: x must be NHWC in memory"
@@ -409,13 +431,15 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
     if (from_v or to_v or upsample or addend is not None) and (mt != 4 or return_v):
         raise RuntimeError("conv3x3_winograd: WinoV hand-over / upsample / addend need F(4x4,3x3) and no return_v")
-    if (upsample and from_v) or (addend is not None and pool):
-        raise RuntimeError("conv3x3_winograd: upsample excludes a WinoV input, addend excludes the pooled output")
+    if addend is not None and pool:
+        raise RuntimeError("conv3x3_winograd: addend excludes the pooled output")
+    if to_v == "up" and (pool or addend is not None or not winograd_up_chain_ok(n, cout, h, w)):
+        raise RuntimeError(f"conv3x3_winograd: to_v='up' unsupported for output {(n, cout, h, w)} pool={pool}")
     if addend is not None:
         _dev_f32(addend, "conv3x3_winograd.addend")
         if tuple(addend.shape) != (n, cout, h, w) or not is_nhwc(addend):
             raise RuntimeError(f"conv3x3_winograd: addend {tuple(addend.shape)} must be NHWC {(n, cout, h, w)}")
-    if to_v and not (winograd_pool_chain_ok(n, cout, h, w) if pool else winograd_chain_ok(n, cout, h, w)):
+    if to_v and to_v != "up" and not (winograd_pool_chain_ok(n, cout, h, w) if pool else winograd_chain_ok(n, cout, h, w)):
         raise RuntimeError(f"conv3x3_winograd: to_v unsupported for output {(n, cout, h, w)} pool={pool}")
     t = n * (h // mt) * (w // mt)
     dev = x.device
@@ -430,21 +454,30 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
              int(upsample), _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
+    if not 0 <= y_from <= n or (y_from and not pool):
+        raise RuntimeError("conv3x3_winograd: y_from needs the pooled output and 0 <= y_from <= N")
     if to_v and pool:
-        y = nhwc_empty(n, cout, h, w, dev)
+        y = nhwc_empty(n - y_from, cout, h, w, dev) if y_from < n else None
         vn = torch.empty((npos, t // 4, cout), device=dev, dtype=torch.float32)
-        _run("winograd_output_pool_input", 0.0, 4.0 * (m.numel() + y.numel() + vn.numel()), lib().dvg_winograd_output_pool_input,
-             _p(m), _p(scale), _p(shift), _p(y), _p(vn), n, h, w, cout, act, slope, _stream())
+        _run("winograd_output_pool_input", 0.0, 4.0 * (m.numel() + (0 if y is None else y.numel()) + vn.numel()),
+             lib().dvg_winograd_output_pool_input, _p(m), _p(scale), _p(shift), _p(y), _p(vn), n, h, w, cout, act, slope, y_from,
+             _stream())
         return y, WinoV(vn, (n, cout, h // 2, w // 2))
+    if to_v == "up":
+        vn = torch.empty((npos, 4 * t, cout), device=dev, dtype=torch.float32)
+        _run("winograd_output_up_input", 0.0, 4.0 * (m.numel() + vn.numel()), lib().dvg_winograd_output_up_input, _p(m), _p(scale),
+             _p(shift), _p(vn), n, h, w, cout, act, slope, _stream())
+        return WinoV(vn, (n, cout, 2 * h, 2 * w), up=True)
     if to_v:
         vn = torch.empty((npos, t, cout), device=dev, dtype=torch.float32)
         _run("winograd_output_input", 0.0, 4.0 * (m.numel() + vn.numel()), lib().dvg_winograd_output_input, _p(m), _p(scale),
              _p(shift), _p(vn), n, h, w, cout, act, slope, _p(addend), _stream())
         return WinoV(vn, (n, cout, h, w))
-    y = nhwc_empty(n, cout, h, w, dev)
+    y = nhwc_empty(n - y_from, cout, h, w, dev) if y_from < n else None
     yp = nhwc_empty(n, cout, h // 2, w // 2, dev) if pool else None
-    _run("winograd_output", 0.0, 4.0 * (m.numel() + y.numel()), lib().dvg_winograd_output, _p(m), _p(scale), _p(shift),
-         _p(y), _p(yp), n, h, w, cout, act, slope, mt, _p(addend), _stream())
+    _run("winograd_output", 0.0, 4.0 * (m.numel() + (0 if y is None else y.numel()) + (0 if yp is None else yp.numel())),
+         lib().dvg_winograd_output, _p(m), _p(scale), _p(shift), _p(y), _p(yp), n, h, w, cout, act, slope, mt, _p(addend), y_from,
+         _stream())
     if return_v:   # the input transform (P, T, C): the Winograd-form weight gradient's second operand (training)
         return ((y, yp) if pool else y), v
     return (y, yp) if pool else y
@@ -471,10 +504,12 @@ def first_pair_ok(n, nc, h, w, cout) -> bool:
     return nc == 1 and h % 8 == 0 and w % 16 == 0 and cout % 64 == 0 and n * (h // 8) * (w // 16) * (cout // 64) >= 512
 
 
-def conv3x3_first_pair(x_nchw, w0, scale0, shift0, wp1, scale1, shift1, *, act=ACT_LRELU, slope=0.2, pool=False):
+def conv3x3_first_pair(x_nchw, w0, scale0, shift0, wp1, scale1, shift1, *, act=ACT_LRELU, slope=0.2, pool=False, y_from=0):
     """vgg_layer(1, 64) -> vgg_layer(64, Cout) (+ 2x2 max-pool) of the encoder's first stage in eval mode as ONE launch
     (dvg_conv3x3_first_pair): the 64-channel activation between the two layers is never materialised.
-    w0: the first layer's (64,1,3,3) weight as a contiguous (9, 64) tensor [tap][channel]."""
+    w0: the first layer's (64,1,3,3) weight as a contiguous (9, 64) tensor [tap][channel].
+    y_from (pool only): the full-resolution output is stored for the images [y_from, N) only - y has N - y_from images, None
+    when y_from == N (a rollout discards the skip tensors of every frame but the last conditioning one)."""
     _dev_f32(x_nchw, "conv3x3_first_pair.x")
     x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
     n, nc, h, wd = x.shape
@@ -483,12 +518,14 @@ def conv3x3_first_pair(x_nchw, w0, scale0, shift0, wp1, scale1, shift1, *, act=A
     if nc != 1 or tuple(w0.shape) != (9, 64) or not w0.is_contiguous() or (taps, cin) != (9, 64) or \
             not first_pair_ok(n, nc, h, wd, cout):
         raise RuntimeError(f"conv3x3_first_pair: unsupported shapes x {tuple(x.shape)} w0 {tuple(w0.shape)} wp1 {tuple(wp1.shape)}")
-    y = nhwc_empty(n, cout, h, wd, x.device)
+    if not 0 <= y_from <= n or (y_from and not pool):
+        raise RuntimeError("conv3x3_first_pair: y_from needs the pooled output and 0 <= y_from <= N")
+    y = nhwc_empty(n - y_from, cout, h, wd, x.device) if y_from < n else None
     yp = nhwc_empty(n, cout, h // 2, wd // 2, x.device) if pool else None
     flops = 2.0 * n * h * wd * (64 * 9 + cout * 9 * 64)
-    _run("conv3x3_igemm", flops, 4.0 * (x.numel() + y.numel() * (1.25 if pool else 1.0) + wp1.numel()),
+    _run("conv3x3_igemm", flops, 4.0 * (x.numel() + (0 if y is None else y.numel()) + (0 if yp is None else yp.numel()) + wp1.numel()),
          lib().dvg_conv3x3_first_pair, _p(x), _p(w0), _p(scale0), _p(shift0), _p(wp1), _p(scale1), _p(shift1), _p(y), _p(yp),
-         n, h, wd, cout, act, slope, _stream(), alg_flops=flops)
+         n, h, wd, cout, act, slope, y_from, _stream(), alg_flops=flops)
     return (y, yp) if pool else y
 
 
@@ -740,6 +777,23 @@ def stem_gemm(vec, w_kn, k, scale, shift, out, *, period, act=ACT_LRELU, slope=0
     return out
 
 
+def stem_up_winograd_input(vec, w_kn, k, scale, shift, cout, *, act=ACT_LRELU, slope=0.2):
+    """Decoder stem + BN + activation, nearest-x2 upsampling and the F(4x4,3x3) input transform of the result in one launch
+    (dvg_stem_up_winograd_input): a WinoV (.up) of shape (M, cout, 8, 8) for the x half of the first decoder block's concat
+    conv; the 4 x 4 map is never written.  w_kn as stem_gemm takes it."""
+    _dev_f32(vec, "stem_up_winograd_input.vec")
+    if vec.dim() != 2 or vec.stride(1) != 1:
+        vec = vec.contiguous().view(vec.shape[0], -1)
+    m = vec.shape[0]
+    kp, n = w_kn.shape
+    if vec.shape[1] != k or n != 16 * cout or cout % 16:
+        raise RuntimeError("stem_up_winograd_input: shape mismatch")
+    v = torch.empty((36, 4 * m, cout), device=vec.device, dtype=torch.float32)
+    _run("stem_up_winograd_input", 2.0 * m * n * k, 4.0 * (m * k + n * k + v.numel()), lib().dvg_stem_up_winograd_input, _p(vec),
+         vec.stride(0), _p(w_kn), kp, _p(scale), _p(shift), _p(v), m, cout, k, act, slope, _stream())
+    return WinoV(v, (m, cout, 8, 8), up=True)
+
+
 # ----------------------------------------------------------------------------------
 # GP
 # ----------------------------------------------------------------------------------
@@ -774,6 +828,52 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
 # ----------------------------------------------------------------------------------
 # backward (training) wrappers
 # ----------------------------------------------------------------------------------
+def gp_var_norms(var: torch.Tensor) -> torch.Tensor:
+    """(B,) L2 norm over the latent dims of a predictive variance (D,B): generate_frames.py:230,275's
+    `np.linalg.norm(variance.cpu().numpy().transpose(), axis=1)` without the host round trip (dvg_gp_var_norms)."""
+    _dev_f32(var, "gp_var_norms.var")
+    var = var.contiguous()
+    d, b = var.shape
+    out = torch.empty(b, device=var.device, dtype=torch.float32)
+    check(lib().dvg_gp_var_norms(_p(var), _p(out), d, b, _stream()), "gp_var_norms")
+    return out
+
+
+def gp_trigger_step(var, col, ctx, coef, flag, values, thresholds, flags, slot) -> None:
+    """One decision of GPtrigger_gen's main loop on the device (dvg_gp_trigger_step; generate_frames.py:227-232,285-289): ctx
+    (window floats) slides in place, flag (1 int32) = value > threshold, logs at `slot`."""
+    _dev_f32(var, "gp_trigger_step.var")
+    d, b = var.shape
+    if not var.is_contiguous() or ctx.dtype != torch.float32 or flag.dtype != torch.int32 or flags.dtype != torch.int32:
+        raise RuntimeError("gp_trigger_step: contiguous (D,B) variance, float32 window, int32 flags expected")
+    if not 0 <= slot < min(values.numel(), thresholds.numel(), flags.numel()):
+        raise RuntimeError("gp_trigger_step: log slot out of range")
+    check(lib().dvg_gp_trigger_step(_p(var), d, b, int(col), _p(ctx), ctx.numel(), float(coef), _p(flag), _p(values),
+                                    _p(thresholds), _p(flags), int(slot), _stream()), "gp_trigger_step")
+
+
+def gp_trigger_select(flag, sample_db, h_pred, states_old, states_new):
+    """(vec (B,D), [state tensors]) of a GPtrigger_gen step (dvg_gp_trigger_select): the GP sample (D,B), transposed, and the
+    OLD recurrent state when the device flag is set, the LSTM output and the NEW state otherwise (generate_frames.py:289-296)."""
+    import ctypes as C
+    _dev_f32(sample_db, "gp_trigger_select.sample")
+    _dev_f32(h_pred, "gp_trigger_select.h_pred")
+    d, b = sample_db.shape
+    if tuple(h_pred.shape) != (b, d) or not sample_db.is_contiguous() or not h_pred.is_contiguous():
+        raise RuntimeError("gp_trigger_select: sample (D,B) and h_pred (B,D), both contiguous, expected")
+    n = len(states_old)
+    if n != len(states_new) or n > 8 or any(a.shape != c.shape or not a.is_contiguous() or not c.is_contiguous()
+                                             or a.numel() != states_old[0].numel() for a, c in zip(states_old, states_new)):
+        raise RuntimeError("gp_trigger_select: up to 8 contiguous state tensors of one size, old and new alike")
+    vec = torch.empty((b, d), device=h_pred.device, dtype=torch.float32)
+    outs = [torch.empty_like(a) for a in states_old]
+    arr = lambda ts: (C.c_void_p * max(1, n))(*[t.data_ptr() for t in ts])   # noqa: E731
+    check(lib().dvg_gp_trigger_select(_p(flag), _p(sample_db), _p(h_pred), _p(vec), d, b, n,
+                                      states_old[0].numel() if n else 0, arr(states_old), arr(states_new), arr(outs), _stream()),
+          "gp_trigger_select")
+    return vec, outs
+
+
 def transpose2d(a: torch.Tensor) -> torch.Tensor:
     """[R][C] -> contiguous [C][R] with the LDS-tiled layout kernel (a (1,R,C) 'NCHW' -> 'NHWC' pass)."""
     _dev_f32(a, "transpose2d")

@@ -32,9 +32,13 @@ def drop_version_keyed_caches() -> None:
     raised part-way.  During a capture a cache miss allocates from the graph's private pool and records the kernels that
     would fill the tensor - nothing executes - and the entry is stored under the current parameter version; when the
     capture is abandoned the pool is freed, but the entry would still be hit by the next eager call, which would read
-    never-written (and freed) memory.  Everything here is rebuilt on demand from the parameters."""
+    never-written (and freed) memory.  Everything here is rebuilt on demand from the parameters.
+    The deferred weight-gradient queues go with them: a capture that dies INSIDE backward() skips autograd's
+    end-of-backward callback, so operands queued during it - pointers into the freed pool, never written - would be
+    flushed into .grad by the next eager backward (or block its flush: the `flush queued` flag stays set)."""
     from . import autograd as ag
     from .models import lstm as lstm_mod
+    ag.drop_deferred_wgrads()
     ag._pack_cache.clear()
     for slot in list(fused._cache.values()):
         slot.clear()
@@ -106,6 +110,8 @@ def snapshot_eager_caches() -> list:
     walk(list(lstm_mod._FOLD_CACHE.values()))
     walk(list(ag._pack_cache.values()))
     walk([dict(d) for d in list(fused._cache.values())])
+    if not torch.cuda.is_current_stream_capturing():
+        ops.evict_captured_workspaces()      # the capture that just ended no longer needs its split-K workspace OBJECTS
     return keep
 
 
@@ -127,6 +133,22 @@ def _zero_hidden(frame_predictor):
     return [(z, z) for _ in range(frame_predictor.n_layers)]
 
 
+# Skip tensors the rollout never reads are not stored (encoder.encode(x, skips_from), VggEncoder.features): of the conditioning
+# batch only the LAST frame's skips survive, and once the skip is frozen (generate_frames.py:154-157) the encoder's skips of
+# every predicted frame are discarded by the caller (`h, _ = h`).  DVG_ELIDE_SKIPS=0: every call stores all of them.
+ELIDE_SKIPS = os.environ.get("DVG_ELIDE_SKIPS", "1") != "0"
+
+
+def _encode(encoder, x, skips_from=0):
+    """encoder(x) -> (h, skips); with skips_from = k > 0 the skips hold the images [k, N) only (None when k == N)."""
+    if skips_from and ELIDE_SKIPS and hasattr(encoder, "encode") and not encoder.training and not torch.is_grad_enabled():
+        return encoder.encode(x, skips_from)
+    h, skips = encoder(x)
+    if skips_from:
+        skips = [s[skips_from:] if skips_from < s.shape[0] else None for s in skips]
+    return h, skips
+
+
 def _encode_conditioning(encoder, x, n_past, last_frame_skip):
     """Eval-mode only: BatchNorm uses running statistics, so encoder outputs are independent across samples and the
     n_past-1 conditioning frames x[0..n_past-2] (all known before the rollout starts) can go through the encoder as
@@ -136,10 +158,9 @@ def _encode_conditioning(encoder, x, n_past, last_frame_skip):
     frames = _adjacent_view(x[:n_past - 1])
     if frames is None:
         frames = torch.cat([x[i] for i in range(n_past - 1)], 0)
-    h_all, skips = encoder(frames)
-    hs = [h_all[i * b:(i + 1) * b] for i in range(n_past - 1)]
     last = n_past - 2
-    skip = [s[last * b:(last + 1) * b] for s in skips]   # batch is the outermost NHWC dim: plain views
+    h_all, skip = _encode(encoder, frames, last * b)      # the skips of the last frame x[n_past-2] alone (b images each)
+    hs = [h_all[i * b:(i + 1) * b] for i in range(n_past - 1)]
     return hs, skip
 
 
@@ -205,8 +226,9 @@ def sample_from(state: dict, encoder, decoder, frame_predictor, gp_layer, likeli
     skip = state["skip"]
     x_in = frames[n_past - 1]
     for i in range(n_past, n_eval):
-        h, sk = encoder(x_in)
-        if last_frame_skip or skip is None:
+        keep = last_frame_skip or skip is None
+        h, sk = _encode(encoder, x_in, 0 if keep else x_in.shape[0])   # frozen skip: this frame's skips are discarded (:157)
+        if keep:
             skip = sk
         if i == n_past and not last_frame_skip and not decoder.training:
             fused.declare_frozen_skips(skip)    # frozen from here on: decoder blocks hoist their skip halves now
@@ -242,8 +264,9 @@ def posterior_rollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x
     x_in = x[0]
     skip = None
     for i in range(1, n_eval):
-        h, sk = encoder(x_in)
-        if last_frame_skip or i < n_past:
+        keep = last_frame_skip or i < n_past
+        h, sk = _encode(encoder, x_in, 0 if keep else x_in.shape[0])
+        if keep:
             skip = sk
         if i == n_past and not last_frame_skip and not decoder.training:
             fused.declare_frozen_skips(skip)
@@ -270,8 +293,9 @@ def posterior_from(state: dict, encoder, decoder, frame_predictor, gp_layer, lik
     skip = state["skip"]
     x_in = frames[n_past - 1]
     for i in range(n_past, n_eval):
-        h, sk = encoder(x_in)
-        if last_frame_skip or skip is None:
+        keep = last_frame_skip or skip is None
+        h, sk = _encode(encoder, x_in, 0 if keep else x_in.shape[0])
+        if keep:
             skip = sk
         if i == n_past and not last_frame_skip and not decoder.training:
             fused.declare_frozen_skips(skip)
@@ -280,6 +304,134 @@ def posterior_from(state: dict, encoder, decoder, frame_predictor, gp_layer, lik
         x_in = decoder([pred.mean.transpose(0, 1), skip])
         frames.append(x_in)
     return frames
+
+
+# ---- GPtrigger_gen (generate_frames.py:220-298) without a host round trip per step --------------------------------------------
+# The reference pulls the predictive variance to the host at every step, slides the 12-long window in numpy and branches in
+# Python; it re-runs the 12 warm-up steps for every batch index although only the COLUMN of the variance norms they record
+# depends on the index (:275), and it encodes x_in two or three times per step (`var_value`, then `generation` or the trigger
+# branch: the same eval-mode encoder on the same frame).  Here: the warm-up once per batch with the norms of every sample
+# (`trigger_warmup`), one encoder call per step, the decision and the branch select on the device (ops.gp_trigger_step /
+# gp_trigger_select: both branches' cheap parts - the GP sample, the LSTM step - are computed, the flag picks the latent to
+# decode and the recurrent state that survives), so that the main loop is capturable (`GraphedTrigger`) and the value /
+# threshold / trigger logs are read back once per index.
+@torch.no_grad()
+def trigger_warmup(encoder, decoder, frame_predictor, gp_layer, likelihood, x0, warmup: int = 12, skip_steps: int = 5) -> dict:
+    """Loop steps 0 .. warmup-1 of GPtrigger_gen (:266-280) for the whole batch: autoregressive from x0, skip tensors of the steps
+    i < skip_steps (:268-269), every step `generation` (:220-224).  norms[i, b] = the value the reference records at step i
+    for batch index b (:275)."""
+    b = x0.shape[0]
+    frame_predictor.hidden = _zero_hidden(frame_predictor)
+    x_in, skip, norms, frames = x0, None, [], []
+    for i in range(warmup):
+        keep = i < skip_steps
+        h, sk = _encode(encoder, x_in, 0 if keep else b)
+        if keep:
+            skip = sk
+        if i == skip_steps - 1 and not decoder.training:
+            fused.declare_frozen_skips(skip)            # final from here on (:268-271)
+        pred = likelihood(gp_layer(h.transpose(0, 1).view(gp_layer.num_dims, b, 1)))
+        norms.append(ops.gp_var_norms(pred.variance))
+        x_in = decoder([frame_predictor(h), skip])      # generation(): its encoder call is the one above (eval mode)
+        frames.append(x_in)
+    return {"x_in": x_in, "skip": skip, "hidden": list(frame_predictor.hidden), "norms": torch.stack(norms), "frames": frames}
+
+
+@torch.no_grad()
+def trigger_body(state: dict, encoder, decoder, frame_predictor, gp_layer, likelihood, ctx, coef: float, eps_all, log: dict,
+                 warmup: int = 12, total: int = 105, probe: int = 3) -> List[torch.Tensor]:
+    """Loop steps warmup .. total-1 (:285-297) from a `trigger_warmup` state.  ctx: the window (float32, device), initialised
+    by the caller to norms[:, index] and slid in place; eps_all[i - warmup]: the base sample (D,B) of step i; log: device
+    tensors `flag` (1 int32), `values` / `thresholds` (total float32), `flags` (total int32).  Nothing here syncs."""
+    b = state["x_in"].shape[0]
+    if b <= probe:
+        raise IndexError(f"GPtrigger_gen reads sample [{probe}] of the batch (generate_frames.py:230): batch_size must be > {probe}")
+    frame_predictor.hidden = list(state["hidden"])
+    x_in, skip, frames = state["x_in"], state["skip"], []
+    for i in range(warmup, total):
+        h, _ = _encode(encoder, x_in, b)
+        pred = likelihood(gp_layer(h.transpose(0, 1).view(gp_layer.num_dims, b, 1)))
+        z = pred.rsample(eps_all[i - warmup])                       # (D,B); the same launch leaves the variance
+        ops.gp_trigger_step(pred.variance, probe, ctx, coef, log["flag"], log["values"], log["thresholds"], log["flags"], i)
+        old = [t for hc in frame_predictor.hidden for t in hc]
+        h_pred = frame_predictor(h)
+        new = [t for hc in frame_predictor.hidden for t in hc]
+        vec, st = ops.gp_trigger_select(log["flag"], z, h_pred, old, new)
+        frame_predictor.hidden = [(st[2 * l], st[2 * l + 1]) for l in range(len(st) // 2)]
+        x_in = decoder([vec, skip])
+        frames.append(x_in)
+    return frames
+
+
+def trigger_log(total: int, device) -> dict:
+    return {"flag": torch.zeros(1, dtype=torch.int32, device=device), "values": torch.zeros(total, device=device),
+            "thresholds": torch.zeros(total, device=device), "flags": torch.zeros(total, dtype=torch.int32, device=device)}
+
+
+class GraphedTrigger:
+    """GPtrigger_gen for one batch as two hipGraphs: the warm-up (once per batch) and the main loop (once per batch index; it
+    reads the warm-up graph's state - frames, LSTM state, skip tensors and the decoder's hoisted skip halves - and its own
+    static window / base samples / logs).  `warm(x0)` then `run(index)`; one device-to-host copy of the logs per index."""
+
+    def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x0, warmup=12, total=105, depth=1,
+                 skip_steps=5, probe=3):
+        self._mods = (encoder, decoder, frame_predictor, gp_layer, likelihood)
+        self.warmup, self.total, self.probe, self.skip_steps = warmup, total, probe, skip_steps
+        self.coef = 2 + 0.01 * depth
+        dev, b, d = x0.device, x0.shape[0], gp_layer.num_dims
+        self.x0 = x0.contiguous().clone()
+        self.eps = torch.zeros(max(1, total - warmup), d, b, device=dev)
+        self.ctx = torch.zeros(warmup, device=dev)
+        self.log = trigger_log(total, dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
+            st = self._warm()
+            self._body(st)
+        torch.cuda.current_stream().wait_stream(side)
+        ops.clear_skip_proj_cache()
+        fused.clear_skip_hoist_cache()
+        self.warm_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.warm_graph, **CAPTURE_KW):
+            self.state = self._warm()
+            self.warm_stack = torch.stack(self.state["frames"])
+        self._keep_w = snapshot_eager_caches()
+        # (the skip-dependent cache entries the warm-up graph created stay while the body is captured: it reads those buffers)
+        self.body_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.body_graph, **CAPTURE_KW):
+            fr = self._body(self.state)
+            self.body_stack = torch.stack(fr) if fr else None
+        self._keep_b = snapshot_eager_caches()
+        ops.clear_skip_proj_cache()
+        fused.clear_skip_hoist_cache()
+
+    def _warm(self):
+        return trigger_warmup(*self._mods, self.x0, self.warmup, self.skip_steps)
+
+    def _body(self, st):
+        return trigger_body(st, *self._mods, self.ctx, self.coef, self.eps, self.log, self.warmup, self.total, self.probe)
+
+    def warm(self, x0) -> None:
+        self.x0.copy_(x0)
+        self.warm_graph.replay()
+
+    def run(self, index: int, eps_by_step: Optional[Dict[int, torch.Tensor]] = None) -> dict:
+        """One batch index: frames (total,B,C,H,W) (static buffers: clone to keep), and on the host the trigger steps, the
+        recorded values (total) and the thresholds (total - warmup)."""
+        self.ctx.copy_(self.state["norms"][:, index])
+        if eps_by_step is None:
+            self.eps.normal_()
+        else:
+            for i in range(self.warmup, self.total):
+                self.eps[i - self.warmup].copy_(eps_by_step[i])
+        if self.body_stack is not None:
+            self.body_graph.replay()
+        values = torch.cat([self.state["norms"][:, index], self.log["values"][self.warmup:]]).cpu()
+        thresholds = self.log["thresholds"][self.warmup:].cpu()
+        flags = self.log["flags"][self.warmup:].cpu()
+        frames = self.warm_stack if self.body_stack is None else torch.cat([self.warm_stack, self.body_stack])
+        return {"frames": frames, "triggers": [self.warmup + int(i) for i in torch.nonzero(flags).flatten()],
+                "values": [float(v) for v in values], "thresholds": [float(v) for v in thresholds]}
 
 
 class GraphedRollout:

@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 import utils  # noqa: E402
 from dvg_amd import ops  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
-from dvg_amd.rollout import GraphedSampler, condition, posterior_from, sample_from, sample_rollout  # noqa: E402
+from dvg_amd.rollout import (GraphedSampler, GraphedTrigger, condition, posterior_from, sample_from, sample_rollout,  # noqa: E402
+                             trigger_body, trigger_log, trigger_warmup)
 from gp_models import GaussianLikelihood, GPRegressionLayer1  # noqa: E402
 
 
@@ -148,17 +149,68 @@ class Generator:
         return np.linalg.norm(pred.variance.cpu().numpy().transpose(), axis=1)
 
     @torch.no_grad()
-    def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1, eps_by_step=None, keep_batch=False):
+    def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1, eps_by_step=None, keep_batch=False,
+                       indices=None, graph=True, host_loop=False):
         """generate_frames.py:249-298.  Keeps the reference's bookkeeping verbatim: the warm-up records the
         variance norm of sample `index` (:275) while `var_value` reads sample [3] (:230 - a batch smaller than 4 is an
         IndexError there and an error here); the skip tensors are those of loop steps `i < 5` (:268-269); the rollout is
         autoregressive from x[0]; a triggered step decodes a GP sample and does NOT step the LSTM (:289-292).
-        `eps_by_step[i]`: base sample (D,B) for a trigger at step i (parity runs); None = torch RNG."""
+        `eps_by_step[i]`: base sample (D,B) for a trigger at step i (parity runs); None = torch RNG.
+        indices: the batch indices to run (default range(n_index or B), the reference's `for index in range(batch_size)`).
+        Default schedule (rollout.trigger_warmup / trigger_body): the warm-up once per BATCH, one encoder call per step,
+        decision and branch select on the device, the main loop a hipGraph (`graph`), logs read back once per index;
+        host_loop=True: the reference's own schedule (per index: warm-up, a host round trip and 2-3 encoder calls per step)."""
         B = x[0].shape[0]
         if B < 4:
             raise IndexError("GPtrigger_gen reads sample [3] of the batch (generate_frames.py:230): batch_size must be >= 4")
+        if indices is None:
+            indices = range(B if n_index is None else n_index)
+        if host_loop:
+            return self._gp_trigger_gen_host(x, indices, warmup, total, depth, eps_by_step, keep_batch)
+        mods = (self.encoder, self.decoder, self.frame_predictor, self.gp_layer, self.likelihood)
         out = []
-        for index in range(B if n_index is None else n_index):
+        if graph:
+            def key():     # parameter / buffer versions: the graphs read packed weights and folds of the versions they captured
+                return (tuple(x[0].shape), warmup, total, depth,
+                        tuple(t._version for m in mods for t in list(m.parameters()) + list(m.buffers())))
+            if getattr(self, "_trigger_key", None) != key():
+                self._trigger = GraphedTrigger(*mods, x[0], warmup, total, depth)
+                self._trigger_key = key()      # AFTER the construction: its eager pass may initialise the GP in place (make_gifs)
+            self._trigger.warm(x[0])
+            run = lambda index: self._trigger.run(index, eps_by_step)   # noqa: E731
+        else:
+            dev = x[0].device
+            state = trigger_warmup(*mods, x[0], warmup)
+            warm_stack = torch.stack(state["frames"])
+            eps = torch.zeros(max(1, total - warmup), self.opt.g_dim, B, device=dev)
+
+            def run(index):
+                log, ctx = trigger_log(total, dev), state["norms"][:, index].clone()
+                if eps_by_step is None:
+                    eps.normal_()
+                else:
+                    for i in range(warmup, total):
+                        eps[i - warmup].copy_(eps_by_step[i])
+                fr = trigger_body(state, *mods, ctx, 2 + 0.01 * depth, eps, log, warmup, total)
+                flags = log["flags"][warmup:].cpu()
+                return {"frames": torch.cat([warm_stack, torch.stack(fr)]) if fr else warm_stack,
+                        "triggers": [warmup + int(i) for i in torch.nonzero(flags).flatten()],
+                        "values": [float(v) for v in torch.cat([state["norms"][:, index], log["values"][warmup:]]).cpu()],
+                        "thresholds": [float(v) for v in log["thresholds"][warmup:].cpu()]}
+        for index in indices:
+            r = run(index)
+            out.append({'index': index, 'frames': r["frames"][:, index].cpu(), 'triggers': r["triggers"],
+                        'values': r["values"], 'thresholds': r["thresholds"]})
+            if keep_batch:        # parity tests compare the whole batch's frames, not only row `index`
+                out[-1]['batch_frames'] = [t.clone() for t in r["frames"]]
+        return out
+
+    @torch.no_grad()
+    def _gp_trigger_gen_host(self, x, indices, warmup, total, depth, eps_by_step, keep_batch):
+        """The reference's schedule, statement for statement (see gp_trigger_gen): kept as the timing baseline of the device
+        schedule and as its cross-check (tests/test_gpu_rollouts.py)."""
+        out = []
+        for index in indices:
             self.frame_predictor.hidden = self.frame_predictor.init_hidden()
             ctx, triggers, gen_seq, values, thresholds = [], [], [], [], []
             x_in, skip = x[0], None
@@ -189,7 +241,7 @@ class Generator:
                 gen_seq.append(x_in)
             out.append({'index': index, 'frames': torch.stack(gen_seq)[:, index].cpu(), 'triggers': triggers,
                         'values': values, 'thresholds': thresholds})
-            if keep_batch:        # parity tests compare the whole batch's frames, not only row `index`
+            if keep_batch:
                 out[-1]['batch_frames'] = gen_seq
         return out
 

@@ -171,7 +171,9 @@ int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,
  * dvg_conv3x3_bn_act_v2 with C1 = 64.  H % 8 == 0, W % 16 == 0, N * H/8 * W/16 * Cout/64 >= 512.                          */
 int dvg_conv3x3_first_pair(const float* frame, const float* w0, const float* scale0, const float* shift0,
                            const float* w1_k16, const float* scale1, const float* shift1, float* y, float* y_pool,
-                           int N, int H, int W, int Cout, int act, float slope, void* stream);
+                           int N, int H, int W, int Cout, int act, float slope,
+                           int y_from /* ABI 8: y holds the images [y_from, N) only - see dvg_winograd_output_pool_input */,
+                           void* stream);
 int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const float* scale,
                             const float* shift, float* y, float* stats, int N, int H, int W,
                             int Cin, int Cout, int act, float slope, float* workspace,
@@ -203,19 +205,35 @@ int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y, int NB, i
 /* addend (ABI 6; optional, m = 4, no y_pool): raw partial sums (N,H,W,Cout) NHWC added before scale / shift / activation -
  * the hoisted skip half of a decoder block's first conv, as in dvg_conv3x3_bn_act_v2.                                  */
 int dvg_winograd_output(const float* mm, const float* scale, const float* shift, float* y, float* y_pool, int N, int H,
-                        int W, int C, int act, float slope, int m, const float* addend, void* stream);
+                        int W, int C, int act, float slope, int m, const float* addend,
+                        int y_from /* ABI 8; 0 unless y_pool is given: as dvg_winograd_output_pool_input */, void* stream);
 /* dvg_winograd_output of layer L and dvg_winograd_input of layer L+1 in one pass (m = 4, H == W in {8, 16, 32}, C % 64 == 0) for
  * two consecutive eval-mode vgg_layers at one resolution whose intermediate activation has no other consumer (the inner
  * layers of a vgg block, vgg_64.py:24-43,70-87): mm (36, T, C) -> v_next (36, T, C); the activation is not written.     */
 int dvg_winograd_output_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H, int W,
                               int C, int act, float slope, const float* addend /* as dvg_winograd_output; may be NULL */,
                               void* stream);
+/* Decoder stem -> first conv of the first decoder block (vgg_64.py:65-69 then :93,98-99): ConvTranspose2d(dim,C,4,1,0) on the
+ * 1x1 latent + BN + LeakyReLU, `up`, and the Winograd input transform of the x half of upc2's concat conv in ONE launch - the
+ * 4 x 4 x C map is never written.  vec (M, K), row stride ldv; w_kn as dvg_stem_gemm takes it ([KP][16 C], KP in {96, 128});
+ * v_next (36, 4 M, C).  Bit-identical to dvg_stem_gemm followed by dvg_winograd_input(upsample = 1).  C % 16 == 0.  ABI 8.  */
+int dvg_stem_up_winograd_input(const float* vec, int ldv, const float* w_kn, int KP, const float* scale, const float* shift,
+                               float* v_next, int M, int C, int K, int act, float slope, void* stream);
+/* Last layer of a decoder block -> first conv of the next block (vgg_64.py:93,98-105: `up` + the x half of the concat conv in
+ * Winograd form): mm (36, T, C) of an 8 x 8 layer -> v_next (36, 4 T, C), the input transform of
+ * UpsamplingNearest2d(2)(act(scale * A^T M A + shift)); neither the activation nor its upsampled form is written.  Bit-identical
+ * to dvg_winograd_output followed by dvg_winograd_input(upsample = 1).  H == W == 8, C % 64 == 0.  ABI 8.               */
+int dvg_winograd_output_up_input(const float* mm, const float* scale, const float* shift, float* v_next, int N, int H, int W,
+                                 int C, int act, float slope, void* stream);
 /* Last layer of an encoder stage (vgg_64.py:51-56, `mp` :49): M (36, T, C) -> the stage's skip tensor y = act(scale * A^T M A
  * + shift) (N,H,W,C) NHWC AND V' (36, T / 4, C), the F(4x4,3x3) input transform of maxpool2x2(y) for the first layer of the
  * next stage.  The pooled tensor itself is never written.  H == W in {16, 32}, C % 64 == 0.  Bit-identical to
- * dvg_winograd_output(+pool) followed by dvg_winograd_input.  ABI 6. */
+ * dvg_winograd_output(+pool) followed by dvg_winograd_input.  ABI 6.
+ * y_from (ABI 8): y holds the images [y_from, N) only; the skip tensor of the images before is not stored (y may be NULL when
+ * y_from == N).  A rollout keeps the skip tensors of the last conditioning frame alone and discards those of every predicted
+ * frame (generate_frames.py:154-157: `h, skip = h` only while i < n_past); v_next always covers all N images.            */
 int dvg_winograd_output_pool_input(const float* m, const float* scale, const float* shift, float* y, float* v_next, int N,
-                                   int H, int W, int C, int act, float slope, void* stream);
+                                   int H, int W, int C, int act, float slope, int y_from, void* stream);
 
 /* First encoder layer: Conv2d(nc,Cout,3,1,1)+BN+LReLU with nc in {1..4}
  * (vgg_64.py:23 `vgg_layer(nc, 64)`).  HBM-bound direct convolution.
@@ -592,6 +610,24 @@ int dvg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void*
 void dvg_debug_set_clockbuf(void* buf, unsigned records);        /* conv_igemm2 kernels: 8 x u64 per workgroup */
 void dvg_debug_set_gp_clockbuf(void* buf, unsigned records);     /* gp_predict_kernel: 12 x u64 per workgroup  */
 void dvg_debug_set_wgrad_clockbuf(void* buf, unsigned records);  /* wgrad_igemm_kernel: 4 x u64 per workgroup  */
+
+/* ---- GPtrigger_gen's bookkeeping on the device (generate_frames.py:220-232,275,283-296; ABI 8) ------------------------------
+ * The reference pulls the predictive variance to the host at every step (`.cpu().numpy()` + np.linalg.norm), slides a 12-long
+ * window in numpy and branches in Python.  Here the norm, the window statistics, the decision and the branch select are three
+ * tiny kernels, so the loop has no host round trip and can be captured as a hipGraph; the logs are read back once.
+ *   dvg_gp_var_norms      norms[b] = || var[:, b] ||_2, var (D,B): the warm-up's recorded values for every sample (:275)
+ *   dvg_gp_trigger_step   value = norm of sample `col` (:230 reads sample [3]); ctx (window floats) <- [ctx[1:], value] (:231);
+ *                         threshold = mean(ctx) + coef * std(ctx) (population std, float32 like the reference's arrays; :288);
+ *                         *flag = flags[slot] = value > threshold; values[slot], thresholds[slot] logged
+ *   dvg_gp_trigger_select vec (B,D) = *flag ? sample_db^T : h_pred; state_out[k] = *flag ? state_old[k] : state_new[k] - a
+ *                         triggered step decodes the GP sample and does NOT step the LSTM (:289-296); n_state <= 8 tensors of
+ *                         state_elems floats (host arrays of device pointers)                                            */
+int dvg_gp_var_norms(const float* var, float* norms, int D, int B, void* stream);
+int dvg_gp_trigger_step(const float* var, int D, int B, int col, float* ctx, int window, float coef, int* flag, float* values,
+                        float* thresholds, int* flags, int slot, void* stream);
+int dvg_gp_trigger_select(const int* flag, const float* sample_db, const float* h_pred, float* vec, int D, int B, int n_state,
+                          long state_elems, const float* const* state_old, const float* const* state_new,
+                          float* const* state_out, void* stream);
 
 #ifdef __cplusplus
 }

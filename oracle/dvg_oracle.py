@@ -33,7 +33,7 @@ Pinning:
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -604,7 +604,8 @@ def best_ssim(ssim) -> List[int]:
 
 def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, eps_by_step: Dict[int, torch.Tensor],
                    warmup: int = 12, total: int = 105, depth: int = 1, skip_steps: int = 5, probe: int = 3,
-                   rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float64) -> dict:
+                   rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float64,
+                   decisions: Optional[Dict[int, bool]] = None, guard: float = 0.0) -> dict:
     """ONE pass of the `for index in range(batch_size)` body of GPtrigger_gen (generate_frames.py:249-298) with
     `generation` (:220-224) and `var_value` (:227-232) inlined.  The reference's bookkeeping, kept verbatim:
       * the rollout is autoregressive from x[0] alone (x_in = x_out, :280,297) - no ground-truth frame after the first;
@@ -615,7 +616,12 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
       * threshold = mean + (2 + 0.01*depth) * std of the window, numpy population std (:288); `value > threshold`
         decodes a GP sample of the encoder output (:290-292) WITHOUT stepping the LSTM, otherwise `generation` steps it.
     Values are float32 like the reference's `.cpu().numpy()` arrays; the window statistics use numpy on that dtype.
-    Returns dict(frames, triggers, values, thresholds)."""
+    decisions / guard (parity tests; the analogue of `forced_kinks`): `value > threshold` is a discontinuity - two
+    implementations that agree to 1e-7 on both sides can still branch differently when the margin |value - threshold| /
+    |threshold| is of that size, and untrained networks roll out towards a fixed point where it is.  With `decisions`
+    ({step: bool}, the branches another implementation took) a step whose OWN margin is below `guard` follows that implementation's
+    branch and is reported in `forced`; every other step decides for itself.  All arithmetic stays this function's.
+    Returns dict(frames, triggers, values, thresholds, margins, forced)."""
     import numpy as np
     hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
     noise = likelihood_noise(lik_sd)
@@ -628,7 +634,7 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
         p = gp_predict(h, gp_sd, training=False, noise=noise, dtype=gp_dtype)
         return np.linalg.norm(p["var"].to(torch.float32).numpy().transpose(), axis=1), p
 
-    context, values, thresholds, triggers, gen_seq = [], [], [], [], []
+    context, values, thresholds, triggers, gen_seq, margins, forced = [], [], [], [], [], [], []
     x_in, skip = x[0], None
     for i in range(warmup):                                                # :266-280
         h, sk = enc(x_in)
@@ -646,7 +652,12 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
         value = norms[probe]                                               # :230 - sample 3, not `index`
         context = np.concatenate([context[1:], [value]])                   # :231
         threshold = np.mean(context) + (2 + 0.01 * depth) * np.std(context)   # :288
-        if value > threshold:                                              # :289-292
+        take = bool(value > threshold)
+        margins.append(float(abs(value - threshold) / abs(threshold)))
+        if decisions is not None and margins[-1] < guard:
+            take = bool(decisions[i])
+            forced.append(i)
+        if take:                                                           # :289-292
             x_in = dec(gp_rsample(p["mean"], p["cov"], eps_by_step[i]).t().to(h.dtype), skip)
             triggers.append(i)
         else:
@@ -654,4 +665,5 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
         values.append(float(value))
         thresholds.append(float(threshold))
         gen_seq.append(x_in)
-    return {"frames": gen_seq, "triggers": triggers, "values": values, "thresholds": thresholds}
+    return {"frames": gen_seq, "triggers": triggers, "values": values, "thresholds": thresholds, "margins": margins,
+            "forced": forced}

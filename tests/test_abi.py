@@ -33,7 +33,7 @@ def test_binding_table_covers_header():
     from dvg_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dvg_abi_version() == 7
+    assert lib.dvg_abi_version() == 8
 
 
 def test_both_builds_of_the_library_load_and_say_which_arithmetic_they_run():
@@ -47,7 +47,7 @@ def test_both_builds_of_the_library_load_and_say_which_arithmetic_they_run():
     h = ctypes.CDLL(native)
     for s in header_symbols():
         assert hasattr(h, s), f"{s} missing from the f32-MFMA build"
-    assert h.dvg_abi_version() == 7 and h.dvg_mfma_mode() == 0 and h.dvg_packed_row_floats() == 16
+    assert h.dvg_abi_version() == 8 and h.dvg_mfma_mode() == 0 and h.dvg_packed_row_floats() == 16
 
 
 def test_host_side_checks_reject_bad_shapes_without_gpu():

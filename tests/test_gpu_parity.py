@@ -934,6 +934,155 @@ def test_first_stage_as_one_launch_matches_two_launches_and_fp64(N):
             assert torch.equal(fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)[0], y)
 
 
+@pytest.mark.parametrize("N,C,Cmid,Cout", [(32, 512, 256, 256), (64, 256, 128, 128)])
+def test_winograd_chain_through_the_upsampling(N, C, Cmid, Cout):
+    """dvg_winograd_output_up_input: the last layer of a decoder block (8 x 8) hands the input transform of its UPSAMPLED output to
+    the x half of the next block's concat conv (vgg_64.py:93,98-105) - bit-identical to writing the activation and letting
+    that conv transform it through the upsampling (dvg_winograd_output + dvg_winograd_input(upsample = 1)), and both match fp64."""
+    from dvg_amd import ops
+    H = 8
+    x = params.normal(2800, N, C, H, H)
+    w1 = params.normal(2801, Cmid, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
+    w2 = params.normal(2802, Cout, Cmid, 3, 3, scale=1.2 / (3 * Cmid ** 0.5))     # the x half of the next block's concat conv
+    s1, b1 = 1 + 0.1 * params.normal(2803, Cmid), 0.1 * params.normal(2804, Cmid)
+    s2, b2 = 1 + 0.1 * params.normal(2805, Cout), 0.1 * params.normal(2806, Cout)
+    add = params.normal(2807, N, Cout, 2 * H, 2 * H, scale=0.3)                    # the hoisted skip half (raw sums)
+    f64 = lambda t: t.double()   # noqa: E731
+    mid = F.leaky_relu(F.conv2d(f64(x), f64(w1), padding=1) * f64(s1).view(1, -1, 1, 1) + f64(b1).view(1, -1, 1, 1), 0.2)
+    up = F.interpolate(mid, scale_factor=2, mode="nearest")
+    ref = F.leaky_relu((F.conv2d(up, f64(w2), padding=1) + f64(add)) * f64(s2).view(1, -1, 1, 1) + f64(b2).view(1, -1, 1, 1), 0.2)
+    d = lambda t: t.to(dev())   # noqa: E731
+    u1, u2 = ops.winograd_weight(d(w1), 4), ops.winograd_weight(d(w2), 4)
+    assert ops.winograd_up_chain_ok(N, Cmid, H, H)
+    y1 = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1))
+    y2 = ops.conv3x3_winograd(y1, u2, d(s2), d(b2), upsample=True, addend=nhwc(add))
+    v = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1), to_v="up")
+    assert isinstance(v, ops.WinoV) and v.up and v.shape == (N, Cmid, 2 * H, 2 * H)
+    y2c = ops.conv3x3_winograd(v, u2, d(s2), d(b2), upsample=True, addend=nhwc(add))
+    assert torch.equal(y2c, y2)
+    assert rel_err(y2c, ref) < 1e-4, rel_err(y2c, ref)
+    with pytest.raises(RuntimeError):      # an upsampled WinoV is not a same-resolution input transform
+        ops.conv3x3_winograd(v, u2, d(s2), d(b2))
+
+
+@pytest.mark.parametrize("M,K", [(64, 90), (50, 90), (3, 128)])
+def test_stem_hands_over_through_the_upsampling(M, K):
+    """dvg_stem_up_winograd_input == dvg_stem_gemm followed by dvg_winograd_input(upsample = 1), bit for bit (ragged batch, both
+    K paddings), and the stem map it stands for matches an fp64 composition."""
+    from dvg_amd import ops
+    C = 512
+    KP = 96 if K <= 96 else 128
+    vec = params.normal(2820, M, K, scale=0.5).tanh().to(dev())
+    w = params.normal(2821, K, C, 4, 4, scale=0.05)                      # ConvTranspose2d(K, C, 4, 1, 0).weight
+    wt = torch.zeros(KP, 16 * C)
+    wt[:K] = w.permute(0, 2, 3, 1).reshape(K, 16 * C)
+    wt = wt.to(dev())
+    sc, sh = (1 + 0.1 * params.normal(2822, C)).to(dev()), (0.1 * params.normal(2823, C)).to(dev())
+    out = ops.nhwc_empty(M, C, 4, 4, dev())
+    ops.stem_gemm(vec, wt, K, sc, sh, out.permute(0, 2, 3, 1).reshape(M, 16 * C), period=C)
+    ref = F.leaky_relu(torch.einsum("mk,kchw->mchw", vec.double().cpu(), w.double()) * sc.double().cpu().view(1, -1, 1, 1)
+                       + sh.double().cpu().view(1, -1, 1, 1), 0.2)
+    assert rel_err(out, ref) < 1e-5
+    v_ref = torch.empty(36, 4 * M, C, device=dev())
+    from dvg_amd._lib import check, lib
+    check(lib().dvg_winograd_input(out.data_ptr(), v_ref.data_ptr(), M, 8, 8, C, 4, 1, torch.cuda.current_stream().cuda_stream), "in")
+    wv = ops.stem_up_winograd_input(vec, wt, K, sc, sh, C)
+    assert wv.up and wv.shape == (M, C, 8, 8) and torch.equal(wv.v, v_ref)
+
+
+def test_decoder_blocks_hand_over_through_the_upsampling():
+    """vgg_64 decoder in eval mode with frozen skips (a rollout's prediction steps): with DVG_WINOGRAD_CHAIN >= 3 the last layer of
+    upc2 hands upc3's first conv its input transform through `up` (one launch instead of dvg_winograd_output +
+    dvg_winograd_input), and the stem hands upc2's first conv its own (dvg_stem_up_winograd_input instead of dvg_stem_gemm +
+    dvg_winograd_input); frames bit-identical to the level-2 run."""
+    from dvg_amd import fused, ops
+    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
+    enc.to(dev()).eval(), dec.to(dev()).eval()
+    x = params.frames(2810, 32, 1, 64).to(dev())
+    out = {}
+    for level in (3, 2):
+        old = fused._CHAIN_LEVEL
+        fused._CHAIN_LEVEL = level
+        fused.clear_skip_hoist_cache()
+        ops.clear_skip_proj_cache()
+        try:
+            with torch.no_grad():
+                h, skips = enc(x)
+                fused.declare_frozen_skips(skips)
+                dec([h, skips])                     # (the first call computes the hoisted skip halves)
+                timer = ops.KernelTimer()
+                ops.set_timer(timer)
+                y = dec([h, skips])
+                ops.set_timer(None)
+        finally:
+            ops.set_timer(None)
+            fused._CHAIN_LEVEL = old
+        out[level] = (y, timer.summary())
+    fused.clear_skip_hoist_cache()
+    ops.clear_skip_proj_cache()
+    assert torch.equal(out[3][0], out[2][0])
+    if fused.WINOGRAD == 4 and fused.WINOGRAD_CHAIN and fused.SKIP_HOIST and fused.UPCONV_WINOGRAD:
+        assert out[3][1].get("winograd_output_up_input", {}).get("launches", 0) == 1, list(out[3][1])
+        assert out[3][1].get("stem_up_winograd_input", {}).get("launches", 0) == 1, list(out[3][1])    # stem -> upc2 likewise
+        assert "winograd_output_up_input" not in out[2][1] and "stem_up_winograd_input" not in out[2][1]
+        n3 = sum(v["launches"] for v in out[3][1].values())
+        n2 = sum(v["launches"] for v in out[2][1].values())
+        assert n3 == n2 - 2, (n3, n2)
+
+
+def test_skip_tensors_of_part_of_a_batch_are_not_stored():
+    """ABI 8 `y_from` / encoder.encode(x, skips_from=k): a rollout reads the skip tensors of ONE conditioning frame
+    (generate_frames.py:154-157), so the kernels that write an encoder stage's full-resolution output beside its pooled map
+    store it for the images [k, N) only.  Everything that IS returned - latent, the skips of the images [k, N), and through them
+    the decoder's frames - is bit-identical to the call that stores everything, for k = 0 (all), a middle k and k = N (none);
+    memory in front of / behind the shortened skip buffers is untouched (canary)."""
+    from dvg_amd import fused, ops
+    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
+    enc.to(dev()).eval(), dec.to(dev()).eval()
+    N = 32
+    x = params.frames(2700, N, 1, 64).to(dev())
+    with torch.no_grad():
+        h_all, skips_all = enc(x)
+        for k in (0, 8, 24, N):
+            timer = ops.KernelTimer()
+            ops.set_timer(timer)
+            try:
+                h, skips = enc.encode(x, skips_from=k)
+            finally:
+                ops.set_timer(None)
+            assert torch.equal(h, h_all)
+            for a, b in zip(skips, skips_all):
+                if k == N:
+                    assert a is None
+                else:
+                    assert a.shape[0] == N - k and ops.is_nhwc(a) and torch.equal(a, b[k:])
+            if fused.WINOGRAD == 4 and fused.FIRST_PAIR and fused._CHAIN_LEVEL >= 2:
+                # the kernels really skipped the stores: algorithmic bytes of the launches shrink by the elided images
+                by = sum(v["bytes"] for v in timer.summary().values())
+                if k == 0:
+                    by0 = by
+                else:
+                    assert by < by0 - 0.9 * 4 * k * sum(s_.numel() // N for s_ in skips_all), (k, by, by0)
+        # op level with canaries around the shortened buffer (a store with the wrong image offset would hit them)
+        m = params.normal(2701, 36, N * 16, 128).to(dev())
+        sc, sh = (1 + 0.1 * params.normal(2702, 128)).to(dev()), (0.1 * params.normal(2703, 128)).to(dev())
+        from dvg_amd._lib import check, lib
+        full = ops.nhwc_empty(N, 128, 16, 16, dev())
+        v_full = torch.empty(36, N * 4, 128, device=dev())
+        check(lib().dvg_winograd_output_pool_input(m.data_ptr(), sc.data_ptr(), sh.data_ptr(), full.data_ptr(), v_full.data_ptr(),
+                                                   N, 16, 16, 128, 1, 0.2, 0, torch.cuda.current_stream().cuda_stream), "full")
+        k = 20
+        per = 16 * 16 * 128
+        buf = torch.full(((N - k + 2) * per,), 7.25, device=dev())
+        v_part = torch.empty_like(v_full)
+        check(lib().dvg_winograd_output_pool_input(m.data_ptr(), sc.data_ptr(), sh.data_ptr(), buf.data_ptr() + 4 * per,
+                                                   v_part.data_ptr(), N, 16, 16, 128, 1, 0.2, k,
+                                                   torch.cuda.current_stream().cuda_stream), "part")
+        assert torch.equal(v_part, v_full)
+        assert bool((buf[:per] == 7.25).all()) and bool((buf[-per:] == 7.25).all())
+        assert torch.equal(buf[per:-per], full.permute(0, 2, 3, 1).reshape(-1)[k * per:])
+
+
 @pytest.mark.parametrize("N,C,H,Cout", [(4, 64, 16, 128), (3, 128, 8, 64)])
 def test_integration_snippet_runs_verbatim(N, C, H, Cout):
     """The binding example of INTEGRATION.md ("What a maintainer of the reference would add"), extracted from the document

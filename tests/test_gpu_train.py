@@ -562,16 +562,22 @@ def test_gp_closure_reuses_lstm_closure_encodings_exactly(model):
             assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("where", ["between_closures", "inside_backward"])
 @pytest.mark.parametrize("model", ["dcgan", "vgg"])
-def test_capture_failure_falls_back_to_eager_without_stale_caches(model):
+def test_capture_failure_falls_back_to_eager_without_stale_caches(model, where):
     """a hipGraph capture that raises part-way leaves cache entries (packed / Winograd-domain weights,
     BatchNorm folds, ...) that were allocated from the graph's pool under the CURRENT parameter versions and never written
     - the capture executes nothing.  GraphedIteration's fallback must not read them: the eager iterations after a failed
     capture equal a pure-eager run from the same seed (losses, parameters, BatchNorm buffers).  The failure is forced after
     train_model's forward, backward and Adam steps have been recorded (all weight packs of the iteration missed: the
-    warm-up iteration's optimiser step had bumped every parameter version)."""
+    warm-up iteration's optimiser step had bumped every parameter version).
+    `inside_backward`: the failure is raised by a backward NODE in the middle of train_model's backward pass,
+    after weight-gradient operands have been queued - the engine then skips its end-of-backward callback and the fallback
+    itself has to drop the queues (autograd.drop_deferred_wgrads), or the next eager backward flushes operands that live in
+    the freed pool and were never written."""
     import train
     import utils
+    from dvg_amd import autograd as ag
     from dvg_amd.data import SyntheticMovingMNIST
     res = []
     for broken in (False, True):
@@ -588,7 +594,19 @@ def test_capture_failure_falls_back_to_eager_without_stale_caches(model):
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("forced capture failure")
                 return real(x)
-            tr._train_fp_dev = failing
+            if where == "between_closures":
+                tr._train_fp_dev = failing
+            else:
+                real_bwd, seen = ag.ops.bn_act_bwd, {"n": 0, "queued": False}
+
+                def failing_bwd(*a, real_bwd=real_bwd, seen=seen, **kw):
+                    if torch.cuda.is_current_stream_capturing():
+                        seen["n"] += 1
+                        if seen["n"] == 4:      # a few layers into the backward pass: their weight gradients are queued
+                            seen["queued"] = bool(ag._wgrad_queues or ag._dense_queues)
+                            raise RuntimeError("forced capture failure inside backward")
+                    return real_bwd(*a, **kw)
+                ag.ops.bn_act_bwd = failing_bwd
         else:
             step = tr.iteration
         losses = []
@@ -597,6 +615,10 @@ def test_capture_failure_falls_back_to_eager_without_stale_caches(model):
             losses.append(step(x) + (tr.last_loss,))
         if broken:
             assert step.failed and step.graph is None
+            if where == "inside_backward":
+                ag.ops.bn_act_bwd = real_bwd
+                assert seen["queued"], "the forced failure must leave queued weight-gradient operands behind"
+            assert not ag._wgrad_queues and not ag._dense_queues and not ag._wgrad_flush_queued
         res.append((losses, [copy.deepcopy(m.state_dict()) for m in tr.modules]))
     (la, sa), (lb, sb) = res
     for a, b in zip(la, lb):

@@ -53,7 +53,7 @@ def main():
             elif mode_v == "randn":
                 v.normal_()
             t_g = time_fn(lambda: lib().dvg_gemm_batched_k16(p(v), p(u), p(m), 36, T // 16, 16, C, Cout, s()))
-            t_out = time_fn(lambda: lib().dvg_winograd_output(p(m), p(sc), p(sh), p(y), p(yp), N, H, H, Cout, 1, 0.2, 4, None, s()))
+            t_out = time_fn(lambda: lib().dvg_winograd_output(p(m), p(sc), p(sh), p(y), p(yp), N, H, H, Cout, 1, 0.2, 4, None, 0, s()))
             line = (f"{name:7s} {H:2d}x{H:<2d} {C:3d}->{Cout:3d}  in {t_in:7.1f} us {4e-6 * (x.numel() + v.numel()) / t_in:5.2f} TB/s | "
                     f"gemm {t_g:7.1f} us {2e-6 * 36 * T * C * Cout / t_g:6.1f} TF ({4e-6 * (v.numel() + m.numel() + u.numel()) / t_g:5.2f} TB/s) | "
                     f"out {t_out:7.1f} us {4e-6 * (m.numel() + y.numel() * (1.25 if pool else 1)) / t_out:5.2f} TB/s")
@@ -66,7 +66,7 @@ def main():
                 t_f = None
             if pool and ops.winograd_pool_chain_ok(N, Cout, H, H):
                 vp = torch.empty((36, T // 4, Cout), device=dev)
-                t_p = time_fn(lambda: lib().dvg_winograd_output_pool_input(p(m), p(sc), p(sh), p(y), p(vp), N, H, H, Cout, 1, 0.2, s()))
+                t_p = time_fn(lambda: lib().dvg_winograd_output_pool_input(p(m), p(sc), p(sh), p(y), p(vp), N, H, H, Cout, 1, 0.2, 0, s()))
                 line += f" | out+pool+in {t_p:7.1f} us {4e-6 * (m.numel() + y.numel() + vp.numel()) / t_p:5.2f} TB/s"
             # what the rollout runs today for this layer
             first = name.endswith(".0") or name.endswith("c2.1") or name in ("upc2.1", "upc3.1", "upc4.1")
