@@ -98,6 +98,8 @@ def parse_args(argv=None):
     ap.add_argument("--train-iters", type=int, default=6)
     ap.add_argument("--no-train-shapes", action="store_true", help="skip the extra single-GPU training shapes (C2 / C4 vgg / C5)")
     ap.add_argument("--no-make-gifs-leg", action="store_true", help="skip the make_gifs (C3) leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the C1 (batch 8, 5-in/5-out) leg, the GPtrigger_gen leg and the isolated HBM-bound layers")
     ap.add_argument("--nsample", type=int, default=12, help="sample rollouts per batch of the make_gifs leg")
     ap.add_argument("--train-full-graph", action="store_true",
                     help="with several ranks, also try the iteration as ONE hipGraph with the RCCL all-reduces captured "
@@ -513,6 +515,136 @@ def make_gifs_leg(ctx: Ctx, args, model: str, nsample: int) -> dict:
             "mean_best_ssim": round(float(res["ssim"].mean(2).max(1).values.mean()), 4)}
 
 
+def c1_leg(ctx: Ctx, args) -> dict:
+    """BASELINE.json configs[0] (C1): Moving-MNIST 64x64, batch 8, 5-in/5-out, vgg_64 + lstm - the configuration BASELINE.md names
+    as the reference's CPU-runnable case.  The same rollout measurement as the headline at that shape (hipGraph replay, three
+    rollouts in flight and one serial chain) and, on rank 0 at N = 1, the CPU oracle at the SAME configuration on this box."""
+    import copy
+    a = copy.copy(args)
+    a.batch, a.n_past, a.n_future = 8, 5, 5
+    a.no_roofline = True
+    r = measure_rollout(ctx, a, "vgg", max(20, args.steps), args.warmup)
+    out = {"workload": "Moving-MNIST 64x64 rollout, vgg_64 + lstm + GP (no trigger step inside 5 + 5), batch 8 per GPU, 5-in/5-out "
+                       "(BASELINE.json configs[0])",
+           "value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "single_chain": r.get("single_chain"),
+           "rollouts_in_flight": r["rollouts_in_flight"]}
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline("vgg", 8, 5, 10, args.seed, budget_s=4.0)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    return out
+
+
+def hbm_bound_layers(ctx: Ctx, args) -> dict:
+    """north_star's ">= 40 % HBM roofline on the encoder": the layers of the path whose roof IS the HBM (AI 4.4-19
+    FLOP/B) are fused into or hidden behind other kernels in the timed rollout, so each is timed here in isolation at B = 64 -
+    back-to-back launches between two HIP events on the launch stream, ALGORITHMIC bytes (operands + result, each once) over
+    that time against the 8 TB/s peak.  first_conv: vgg_layer(1, 64) on the frame (vgg_64.py:23); last_projection: the decoder's
+    ConvTranspose2d(64,1,3,1,1) + Sigmoid (vgg_64.py:88-92; projection + gather launches); lstm_step: embed + 2 cells + output
+    (lstm.py:65-72; 3 launches, 4.4 MB of weights: latency-bound, reported in us); gp_sample: one sampling call of the GP
+    trigger (gp_models.py:10-24)."""
+    import torch
+    from dvg_amd import fused, ops
+    B = args.batch
+    enc, dec, fp, gp, lik = build_models("vgg", B, 1, ctx.dev, args.seed)
+    x = torch.rand(B, 1, 64, 64, device=ctx.dev)
+
+    def timed(fn, iters=100):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3      # us per call
+
+    def row(us, nbytes, launches, what):
+        gbs = nbytes / (us * 1e-6) / 1e9
+        return {"us": round(us, 2), "launches": launches, "algorithmic_bytes": int(nbytes), "gbs": round(gbs, 1),
+                "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "what": what}
+    out = {}
+    with torch.no_grad():
+        c0 = enc.c1[0].main
+        us = timed(lambda: fused.conv3_first_bn_act(c0[0], c0[1], x))
+        out["first_conv"] = row(us, 4.0 * (x.numel() + B * 64 * 64 * 64 + 64 * 9), 1,
+                                "conv_first_kernel<3,1>: (B,1,64,64) frame -> (B,64,64,64) NHWC, BN + LeakyReLU fused")
+        d = ops.nhwc_empty(B, 64, 64, 64, ctx.dev).normal_()
+        last = dec.upc5[1]
+        us = timed(lambda: fused.convT3_last(last, d))
+        out["last_projection"] = row(us, 4.0 * (d.numel() + B * 64 * 64 + 64 * 9), 2,
+                                     "pixel_proj_kernel + convT_gather_kernel: (B,64,64,64) NHWC -> (B,1,64,64) frame, Sigmoid fused")
+        h = torch.randn(B, 90, device=ctx.dev).tanh()
+        h0 = fp.init_hidden()
+
+        def lstm_step():
+            fp.hidden = h0          # (the cells return new state tensors: h0 is never written)
+            return fp(h)
+        us = timed(lstm_step)
+        nparam = sum(p.numel() for p in fp.parameters())
+        out["lstm_step"] = row(us, 4.0 * (nparam + 6 * B * 256 + 2 * B * 90), 3,
+                               "lstm_cell_x + lstm_cell + output GEMV: latency-bound (4.4 MB of weights from L2 / Infinity Cache)")
+        eps = torch.randn(90, B, device=ctx.dev)
+
+        def gp_sample():
+            return lik(gp(h.transpose(0, 1).view(90, B, 1))).rsample(eps)
+        gp_sample()
+        us = timed(gp_sample, iters=30)
+        out["gp_sample"] = row(us, 4.0 * (B * 90 * 4 + 90 * 40 * 43), 1,
+                               "gp_predict_kernel (sampling): one 1024-thread workgroup per latent dim, fp64 inside: a serial "
+                               "dependency chain in LDS, not a streaming kernel")
+    return out
+
+
+def gp_trigger_leg(ctx: Ctx, args, model: str, n_index: int = 8) -> dict:
+    """generate_frames.py:249-298 (`--gp_trigger`, the other generate mode of BASELINE.json configs[2]) at the reference's own
+    configuration: B = 50, 105 steps, per batch index.  ms per index of (a) the device schedule as generate_frames.py runs it
+    (warm-up once per batch, decision and branch select on the device, the 93-step loop one hipGraph replay, logs read back
+    once; an index whose decisions on an already computed trigger-free rollout are that rollout's decisions reuses it),
+    (b) the same with every index running its own rollout, (c) the reference's schedule (`host_loop`: per index the warm-up,
+    a `.cpu().numpy()` round trip and 2-3 encoder calls per step, eager launches: the r04 path)."""
+    import torch
+    import generate_frames
+    from dvg_amd.data import SyntheticMovingMNIST
+    B, total = 50, 105
+    opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", model,
+                                                     "--n_eval", str(total)])
+    torch.manual_seed(args.seed + ctx.rank)
+    g = generate_frames.Generator(opt, generate_frames.synthetic_checkpoint(opt), ctx.dev)
+    x = SyntheticMovingMNIST(seq_len=2, seed=args.seed + ctx.rank).batch_device(B, ctx.dev)
+    calibrate_batchnorm(g.encoder, g.decoder, x[0])
+    g.gp_trigger_gen(x, indices=[0], total=total)            # capture
+
+    def timed(indices, **kw):
+        ctx.barrier()
+        t0 = time.perf_counter()
+        res = g.gp_trigger_gen(x, indices=indices, total=total, **kw)
+        ctx.barrier()
+        return ctx.max_over_ranks(time.perf_counter() - t0) / len(indices), res
+    dt, res = timed(list(range(n_index)))
+    computed = g.trigger_rollouts_run
+    dt_own, _ = timed([0, 1], share_paths=False)
+    g.gp_trigger_gen(x, indices=[0], total=24, host_loop=True)      # warm the eager path
+    dt_host, _ = timed([0], host_loop=True)
+    assert all(bool(torch.isfinite(r["frames"]).all()) for r in res)
+    return {"workload": f"GPtrigger_gen, {model}_64, batch {B}, {total} steps (12 warm-up + 93 with the variance-threshold "
+                        "decision), per batch index", "indices_timed": n_index,
+            "ms_per_index": round(1e3 * dt, 2), "rollouts_computed": computed,
+            "ms_per_index_is": f"wall time of gp_trigger_gen over {n_index} batch indices / {n_index}: the batch's warm-up graph once, "
+                               f"{computed} main-loop graph replay(s) - indices whose decisions on a computed trigger-free rollout "
+                               "equal its decisions reuse its frames (their rollout is that rollout) -, one log read-back per index",
+            "own_rollout_per_index": {"ms_per_index": round(1e3 * dt_own, 2),
+                                      "batch_frames_per_s": round(B * total * ctx.world / dt_own, 1),
+                                      "what": "share_paths=False: every index replays the main-loop graph"},
+            "reference_schedule": {"what": "host_loop=True: the reference's statement order - warm-up per index, host round trip "
+                                           "and 2-3 encoder calls per step, eager launches (the r04 path)",
+                                   "ms_per_index": round(1e3 * dt_host, 2)},
+            "speedup_over_reference_schedule": round(dt_host / dt, 2),
+            "speedup_own_rollout_over_reference_schedule": round(dt_host / dt_own, 2),
+            "triggers_index0": res[0]["triggers"][:12]}
+
+
 def f32mfma_leg(args) -> dict:
     """The SAME rollout measurement on the native f32-MFMA build of the library (libdvg_hip_f32mfma.so, `make f32mfma`),
     in a child process (one process holds one build of the library), after this process's own timed region: what the bf16-triple
@@ -748,6 +880,12 @@ def main():
         ctx.barrier()
         result["make_gifs"] = {m: make_gifs_leg(ctx, args, m, args.nsample)
                                for m in ([args.model] if args.no_families else ["vgg", "dcgan"])}
+    if not args.no_extra_legs and not args.no_graph:
+        ctx.barrier()
+        result["c1"] = c1_leg(ctx, args)
+        result["gp_trigger_gen"] = {m: gp_trigger_leg(ctx, args, m) for m in ([args.model] if args.no_families else ["vgg", "dcgan"])}
+        if ctx.rank == 0 and "roofline" in result:
+            result["roofline"]["hbm_bound_layers"] = hbm_bound_layers(ctx, args)
     n_eval = args.n_past + args.n_future
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_gp_var_norms": (_i, [_p, _p, _i, _i, _p]),
     "dvg_gp_trigger_step": (_i, [_p, _i, _i, _i, _p, _i, _f, _p, _p, _p, _p, _i, _p]),
+    "dvg_gp_trigger_replay": (_i, [_p, _i, _p, _i, _f, _p, _p, _p]),
     "dvg_gp_trigger_select": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p, _p, _p]),
     # debug hooks (tools/diag_*.py)
     "dvg_debug_set_clockbuf": (None, [_p, C.c_uint]),

@@ -388,6 +388,24 @@ __global__ __launch_bounds__(64) void gp_var_norms_kernel(const float* __restric
 // (`np.concatenate([ctx[1:], [value]])`); threshold = mean + coef * std (numpy population std) with float32 results at the
 // points where the reference's float32 arrays round (mean, std, coef * std, the sum); flag = value > threshold.  ctx (W floats)
 // is updated in place; value / threshold / flag are logged at `slot` for ONE read-back after the rollout.  One wave.
+// the slid window's statistics and the decision, one wave: lane i < W holds window element w; returns value > threshold
+__device__ __forceinline__ bool trigger_window_decide(int lane, float w, int W, float coef, float value, float& thr_out) {
+    double m = lane < W ? (double)w : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
+    const float mean = (float)(m / W);
+    double q = 0.0;
+    if (lane < W) {
+        const float dlt = w - mean;                      // float32 like `x - x.mean()` on a float32 array
+        q = (double)dlt * (double)dlt;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float sd = (float)sqrt((double)(float)(q / W));
+    thr_out = mean + coef * sd;                          // float32 product, float32 sum (NumPy 2 scalar promotion)
+    return value > thr_out;
+}
+
 __global__ __launch_bounds__(64) void gp_trigger_step_kernel(const float* __restrict__ var, int D, int B, int col, float* __restrict__ ctx,
                                                              int W, float coef, int* __restrict__ flag, float* __restrict__ values,
                                                              float* __restrict__ thresholds, int* __restrict__ flags, int slot) {
@@ -403,27 +421,38 @@ __global__ __launch_bounds__(64) void gp_trigger_step_kernel(const float* __rest
     // the slid window: lane i holds element i
     float w = 0.f;
     if (lane < W) w = lane + 1 < W ? ctx[lane + 1] : value;
-    double m = lane < W ? (double)w : 0.0;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
-    const float mean = (float)(m / W);
-    double q = 0.0;
-    if (lane < W) {
-        const float dlt = w - mean;                      // float32 like `x - x.mean()` on a float32 array
-        q = (double)dlt * (double)dlt;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-    const float sd = (float)sqrt((double)(float)(q / W));
-    const float thr = mean + coef * sd;                  // float32 product, float32 sum (NumPy 2 scalar promotion)
+    float thr;
+    const bool trig = trigger_window_decide(lane, w, W, coef, value, thr);
     __syncthreads();                                     // every lane has read its ctx[lane + 1]
     if (lane < W) ctx[lane] = w;
     if (lane == 0) {
-        const int f = value > thr ? 1 : 0;
+        const int f = trig ? 1 : 0;
         *flag = f;
         values[slot] = value;
         thresholds[slot] = thr;
         flags[slot] = f;
+    }
+}
+
+// The decisions another batch index WOULD take on a recorded sequence of values (the main loop's value is that of sample
+// [3] whatever the index, :230; only the window's first entries - the warm-up norms of the index's own column, :275 - differ):
+// the same arithmetic as gp_trigger_step_kernel, n steps in one launch.  Valid as long as the decisions it returns equal the
+// recorded rollout's (then the index's rollout IS that rollout).
+__global__ __launch_bounds__(64) void gp_trigger_replay_kernel(const float* __restrict__ values, int n, const float* __restrict__ ctx0,
+                                                               int W, float coef, int* __restrict__ flags,
+                                                               float* __restrict__ thresholds) {
+    const int lane = threadIdx.x;
+    float w = lane < W ? ctx0[lane] : 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float value = values[i];
+        const float up = __shfl_down(w, 1);
+        if (lane < W) w = lane + 1 < W ? up : value;
+        float thr;
+        const bool trig = trigger_window_decide(lane, w, W, coef, value, thr);
+        if (lane == 0) {
+            flags[i] = trig ? 1 : 0;
+            thresholds[i] = thr;
+        }
     }
 }
 
@@ -621,6 +650,15 @@ extern "C" int dvg_gp_trigger_step(const float* var, int D, int B, int col, floa
     hipLaunchKernelGGL(gp_trigger_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, var, D, B, col, ctx, window, coef, flag,
                        values, thresholds, flags, slot);
     return check_launch("dvg_gp_trigger_step");
+}
+
+extern "C" int dvg_gp_trigger_replay(const float* values, int n, const float* ctx0, int window, float coef, int* flags,
+                                     float* thresholds, void* stream) {
+    DVG_REQUIRE(values && ctx0 && flags && thresholds, DVG_ERR_NULL, "dvg_gp_trigger_replay: NULL pointer");
+    DVG_REQUIRE(n > 0 && window > 0 && window <= 64, DVG_ERR_SHAPE, "dvg_gp_trigger_replay: n > 0, window in [1, 64]");
+    hipLaunchKernelGGL(gp_trigger_replay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, ctx0, window, coef, flags,
+                       thresholds);
+    return check_launch("dvg_gp_trigger_replay");
 }
 
 extern "C" int dvg_gp_trigger_select(const int* flag, const float* sample_db, const float* h_pred, float* vec, int D, int B,

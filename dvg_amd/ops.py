@@ -852,6 +852,20 @@ def gp_trigger_step(var, col, ctx, coef, flag, values, thresholds, flags, slot) 
                                     _p(thresholds), _p(flags), int(slot), _stream()), "gp_trigger_step")
 
 
+def gp_trigger_replay(values, ctx0, coef):
+    """(flags int32 (n,), thresholds (n,)): the decisions another batch index would take on the recorded main-loop values
+    from its own initial window (dvg_gp_trigger_replay)."""
+    _dev_f32(values, "gp_trigger_replay.values")
+    _dev_f32(ctx0, "gp_trigger_replay.ctx0")
+    values, ctx0 = values.contiguous(), ctx0.contiguous()
+    n = values.numel()
+    flags = torch.empty(n, dtype=torch.int32, device=values.device)
+    thr = torch.empty(n, dtype=torch.float32, device=values.device)
+    check(lib().dvg_gp_trigger_replay(_p(values), n, _p(ctx0), ctx0.numel(), float(coef), _p(flags), _p(thr), _stream()),
+          "gp_trigger_replay")
+    return flags, thr
+
+
 def gp_trigger_select(flag, sample_db, h_pred, states_old, states_new):
     """(vec (B,D), [state tensors]) of a GPtrigger_gen step (dvg_gp_trigger_select): the GP sample (D,B), transposed, and the
     OLD recurrent state when the device flag is set, the LSTM output and the NEW state otherwise (generate_frames.py:289-296)."""

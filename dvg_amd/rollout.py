@@ -431,7 +431,8 @@ class GraphedTrigger:
         flags = self.log["flags"][self.warmup:].cpu()
         frames = self.warm_stack if self.body_stack is None else torch.cat([self.warm_stack, self.body_stack])
         return {"frames": frames, "triggers": [self.warmup + int(i) for i in torch.nonzero(flags).flatten()],
-                "values": [float(v) for v in values], "thresholds": [float(v) for v in thresholds]}
+                "values": [float(v) for v in values], "thresholds": [float(v) for v in thresholds],
+                "values_main": self.log["values"][self.warmup:].clone()}
 
 
 class GraphedRollout:

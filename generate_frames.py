@@ -150,7 +150,7 @@ class Generator:
 
     @torch.no_grad()
     def gp_trigger_gen(self, x, n_index=None, warmup=12, total=105, depth=1, eps_by_step=None, keep_batch=False,
-                       indices=None, graph=True, host_loop=False):
+                       indices=None, graph=True, host_loop=False, share_paths=True):
         """generate_frames.py:249-298.  Keeps the reference's bookkeeping verbatim: the warm-up records the
         variance norm of sample `index` (:275) while `var_value` reads sample [3] (:230 - a batch smaller than 4 is an
         IndexError there and an error here); the skip tensors are those of loop steps `i < 5` (:268-269); the rollout is
@@ -159,7 +159,12 @@ class Generator:
         indices: the batch indices to run (default range(n_index or B), the reference's `for index in range(batch_size)`).
         Default schedule (rollout.trigger_warmup / trigger_body): the warm-up once per BATCH, one encoder call per step,
         decision and branch select on the device, the main loop a hipGraph (`graph`), logs read back once per index;
-        host_loop=True: the reference's own schedule (per index: warm-up, a host round trip and 2-3 encoder calls per step)."""
+        host_loop=True: the reference's own schedule (per index: warm-up, a host round trip and 2-3 encoder calls per step).
+        share_paths: the main loop's value is that of sample [3] whatever the index (:230) - only the window's first entries (the
+        warm-up norms of the index's own column, :275) differ between indices - so an index whose decisions on an ALREADY
+        COMPUTED rollout's values (ops.gp_trigger_replay: the device decision's arithmetic) are that rollout's decisions IS that
+        rollout: same frames, no launches.  Applied to rollouts WITHOUT a trigger only: a triggered step draws a GP sample
+        from torch's generator, and the reference draws afresh for every index."""
         B = x[0].shape[0]
         if B < 4:
             raise IndexError("GPtrigger_gen reads sample [3] of the batch (generate_frames.py:230): batch_size must be >= 4")
@@ -196,9 +201,25 @@ class Generator:
                 return {"frames": torch.cat([warm_stack, torch.stack(fr)]) if fr else warm_stack,
                         "triggers": [warmup + int(i) for i in torch.nonzero(flags).flatten()],
                         "values": [float(v) for v in torch.cat([state["norms"][:, index], log["values"][warmup:]]).cpu()],
-                        "thresholds": [float(v) for v in log["thresholds"][warmup:].cpu()]}
+                        "thresholds": [float(v) for v in log["thresholds"][warmup:].cpu()],
+                        "values_main": log["values"][warmup:].clone()}
+        norms = (self._trigger.state if graph else state)["norms"]
+        quiet = []          # computed rollouts without a trigger: (frames (clone), main-loop values on the device)
+        self.trigger_rollouts_run = 0
         for index in indices:
-            r = run(index)
+            r = None
+            if share_paths and total > warmup:
+                for fr_q, vm_q in quiet:
+                    fl, th = ops.gp_trigger_replay(vm_q, norms[:, index], 2 + 0.01 * depth)
+                    if not bool(fl.any()):            # this index decides "no trigger" at every step of that rollout too
+                        r = {"frames": fr_q, "triggers": [], "thresholds": [float(v) for v in th.cpu()],
+                             "values": [float(v) for v in torch.cat([norms[:, index], vm_q]).cpu()]}
+                        break
+            if r is None:
+                r = run(index)
+                self.trigger_rollouts_run += 1
+                if share_paths and not r["triggers"] and total > warmup:
+                    quiet.append((r["frames"].clone(), r["values_main"]))
             out.append({'index': index, 'frames': r["frames"][:, index].cpu(), 'triggers': r["triggers"],
                         'values': r["values"], 'thresholds': r["thresholds"]})
             if keep_batch:        # parity tests compare the whole batch's frames, not only row `index`

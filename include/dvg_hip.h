@@ -619,12 +619,17 @@ void dvg_debug_set_wgrad_clockbuf(void* buf, unsigned records);  /* wgrad_igemm_
  *   dvg_gp_trigger_step   value = norm of sample `col` (:230 reads sample [3]); ctx (window floats) <- [ctx[1:], value] (:231);
  *                         threshold = mean(ctx) + coef * std(ctx) (population std, float32 like the reference's arrays; :288);
  *                         *flag = flags[slot] = value > threshold; values[slot], thresholds[slot] logged
+ *   dvg_gp_trigger_replay the decisions (and thresholds) ANOTHER batch index would take on a recorded sequence of n main-loop
+ *                         values from its own initial window ctx0 - the main loop's value is that of sample [3] whatever the
+ *                         index (:230), so an index whose decisions equal the recorded rollout's IS that rollout
  *   dvg_gp_trigger_select vec (B,D) = *flag ? sample_db^T : h_pred; state_out[k] = *flag ? state_old[k] : state_new[k] - a
  *                         triggered step decodes the GP sample and does NOT step the LSTM (:289-296); n_state <= 8 tensors of
  *                         state_elems floats (host arrays of device pointers)                                            */
 int dvg_gp_var_norms(const float* var, float* norms, int D, int B, void* stream);
 int dvg_gp_trigger_step(const float* var, int D, int B, int col, float* ctx, int window, float coef, int* flag, float* values,
                         float* thresholds, int* flags, int slot, void* stream);
+int dvg_gp_trigger_replay(const float* values, int n, const float* ctx0, int window, float coef, int* flags, float* thresholds,
+                          void* stream);
 int dvg_gp_trigger_select(const int* flag, const float* sample_db, const float* h_pred, float* vec, int D, int B, int n_state,
                           long state_elems, const float* const* state_old, const float* const* state_new,
                           float* const* state_out, void* stream);

@@ -388,7 +388,7 @@ def rollout(x: Sequence[torch.Tensor], enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd:
     mode.  enc(x)->(h,skips), dec(vec,skips)->frame are closures over the encoder/decoder
     restatements.  Returns the n_eval frames [x0, ...] (conditioning frames copied)."""
     B = x[0].shape[0]
-    hidden = lstm_init_hidden(B, rnn_size, n_layers)
+    hidden = lstm_init_hidden(B, rnn_size, n_layers, dtype=x[0].dtype)
     frames = [x[0]]
     x_in = x[0]
     skip = None
@@ -476,7 +476,7 @@ def eval_seq(gt: Sequence[torch.Tensor], pred: Sequence[torch.Tensor]):
 def train_model_loss(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n_future: int, num_data: int,
                      last_frame_skip: bool = False, rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float32):
     """train.py:200-239 up to the loss (no backward / optimiser): returns (loss, mse_latent)."""
-    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)
     noise = likelihood_noise(lik_sd)
     mse = mse_latent = mse_gp = ae_mse = 0
     max_ll = 0
@@ -501,7 +501,7 @@ def train_model_loss(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: in
 def train_frame_predictor_loss(x, enc, lstm_sd: SD, n_past: int, n_future: int, last_frame_skip: bool = False,
                                rnn_size: int = 256, n_layers: int = 2):
     """train.py:175-193: sum over steps of MSE(lstm(h_{i-1}), h_i)."""
-    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)
     mse_latent = 0
     for i in range(1, n_past + n_future):
         h = enc(x[i - 1])[0]
@@ -532,7 +532,7 @@ def plot_rollout(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: int, n
     noise = likelihood_noise(lik_sd)
     gen_seq = []
     for eps in eps_by_sample:
-        hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)      # :263
+        hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)      # :263
         seq = [x[0]]
         x_in = x[0]
         skip = None
@@ -577,7 +577,7 @@ def posterior_rollout(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, n_past: i
                       gp_dtype=torch.float64) -> List[torch.Tensor]:
     """generate_frames.py:110-134: after the conditioning frames EVERY step decodes the GP predictive MEAN, and the GP is
     fed the LSTM OUTPUT h_pred (:131), unlike the sample rollouts (:170) which feed it the encoder output."""
-    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)
     frames = [x[0]]
     x_in = x[0]
     skip = None
@@ -623,7 +623,7 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
     branch and is reported in `forced`; every other step decides for itself.  All arithmetic stays this function's.
     Returns dict(frames, triggers, values, thresholds, margins, forced)."""
     import numpy as np
-    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers)
+    hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)
     noise = likelihood_noise(lik_sd)
 
     def generation(x_in, skip):                                            # :220-224

@@ -130,3 +130,33 @@ def single_call_kinks(acts):
     """acts of record_hip_kinks when every module ran once: prefix -> tensor."""
     assert all(len(v) == 1 for v in acts.values()), {k: len(v) for k, v in acts.items() if len(v) != 1}
     return {k: v[0] for k, v in acts.items()}
+
+
+def to64(obj):
+    """A tensor / state dict / list of tensors in float64 (integer entries - num_batches_tracked - unchanged)."""
+    if torch.is_tensor(obj):
+        return obj.double() if obj.is_floating_point() else obj.clone()
+    if isinstance(obj, dict):
+        return {k: to64(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to64(v) for v in obj)
+    return obj
+
+
+def _err(a, b):
+    if torch.is_tensor(a) or torch.is_tensor(b):
+        return rel_err(a, b)
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+def yardstick(name, hip, ref32, ref64, *, ratio=1.5, slack=0.0):
+    """The fp64 yardstick of the GP tests for every parity bar above 1e-4: the oracle's arithmetic in fp64 is the
+    truth, the oracle's own fp32 run (torch-CPU: the reference's arithmetic) shows how far fp32 rounding alone moves the
+    quantity - train-mode BatchNorm divides by batch statistics and amplifies it - and the HIP result must not be further from
+    the truth than `ratio` x that (+ `slack`, an absolute rel-err allowance where the fp32 oracle happens to land within a few
+    ulps).  Prints all three; returns (HIP error, fp32-oracle error), both against fp64."""
+    e_hip, e_32, e_pair = _err(hip, ref64), _err(ref32, ref64), _err(hip, ref32)
+    print(f"yardstick {name}: HIP vs fp64 oracle {e_hip:.2e} | fp32 oracle vs fp64 oracle {e_32:.2e} | HIP vs fp32 oracle "
+          f"{e_pair:.2e} | ratio {e_hip / max(e_32, 1e-30):.2f}")
+    assert e_hip <= ratio * e_32 + slack, (name, e_hip, e_32, ratio)
+    return e_hip, e_32

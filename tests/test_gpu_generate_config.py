@@ -14,11 +14,12 @@ import torch
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import rel_err, rel_err_elem
+from tests.common import to64, rel_err, rel_err_elem
 from tests.test_gpu_configs import _build, _oracle_fns
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ELEM_BAR = 2e-3       # element-wise relative error (1 % floor) of eval-mode latents / frames; see the yardstick print
 FRAME_BAR = 1e-4      # BASELINE.json north_star: "within 1e-4 relative on fp32 frames" (rel_err: max |a - b| / max |b|)
 
 
@@ -39,8 +40,17 @@ def test_backbone_modules_at_the_reference_generate_batch(family):
         y = dec([vec.to(DEV), sk])
     assert h.shape == (B, 90) and y.shape == (B, 1, 64, 64)
     assert rel_err(h, h_ref) < FRAME_BAR and rel_err(y, y_ref) < FRAME_BAR, (rel_err(h, h_ref), rel_err(y, y_ref))
-    # element-wise as well (entries below 1 % of the largest magnitude are floored there): latents are not frames
-    assert rel_err_elem(h, h_ref) < 2e-3 and rel_err_elem(y, y_ref) < 2e-3, (rel_err_elem(h, h_ref), rel_err_elem(y, y_ref))
+    # element-wise as well (entries below 1 % of the largest magnitude are floored there): latents are not frames.  With the
+    # fp64 yardstick: truth = the oracle in fp64, the fp32 oracle's own element-wise deviation beside ours
+    enc_6, dec_6 = _oracle_fns(family, 64, to64(esd), to64(dsd))
+    with torch.no_grad():
+        h64, sk64 = enc_6(x.double())
+        y64 = dec_6(vec.double(), sk64)
+    for nm, a, r32, r64 in (("latent", h, h_ref, h64), ("frame", y, y_ref, y64)):
+        e_hip, e_32 = rel_err_elem(a, r64), rel_err_elem(r32, r64)
+        print(f"yardstick element-wise {family} B=50 {nm}: HIP vs fp64 {e_hip:.2e} | fp32 oracle vs fp64 {e_32:.2e}")
+        assert e_hip < ELEM_BAR, (nm, e_hip, e_32)
+    assert rel_err_elem(h, h_ref) < ELEM_BAR and rel_err_elem(y, y_ref) < ELEM_BAR, (rel_err_elem(h, h_ref), rel_err_elem(y, y_ref))
     for a, b in zip(sk, sk_ref):
         assert a.shape == b.shape and rel_err(a, b) < FRAME_BAR
     # the n_past - 1 = 4 conditioning frames as one batch of 200 (rollout._encode_conditioning): per-sample identical

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import BACKBONE_CASES, backbone_case, oracle_backbone, rel_err, summarize
+from tests.common import BACKBONE_CASES, backbone_case, oracle_backbone, rel_err, summarize, to64, yardstick
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -341,6 +341,9 @@ def test_gp_index_bookkeeping_is_exact():
 # ----------------------------------------------------------------------------------------
 # module level: HIP path vs oracle and vs the REFERENCE's golden vectors
 # ----------------------------------------------------------------------------------------
+TRAIN_BN_BAR = 1e-4      # train-mode module outputs against the fp32 references (see the yardstick in the test)
+
+
 @pytest.mark.parametrize("tag", list(BACKBONE_CASES))
 def test_backbone_modules(tag, golden):
     enc, dec, esd, dsd, x, vec = backbone_case(tag)
@@ -352,7 +355,20 @@ def test_backbone_modules(tag, golden):
         y = dec([vec.to(dev()), skips])
         y_h = dec([h, skips])
     assert h.shape == h_ref.shape and y.shape == y_ref.shape
-    tol = REL if not training else 5e-4  # batch statistics amplify rounding differences a little
+    tol = REL
+    if training:
+        # Train-mode BatchNorm divides by batch statistics of B = 2-4 images: fp32 rounding of the convolutions is amplified.
+        # By how much is MEASURED, not assumed: the oracle's arithmetic in fp64 is the truth, its fp32 run (and the
+        # reference's own fp32 outputs, the golden) show what fp32 costs; the HIP result may be no further from the truth
+        # than 1.5 x the fp32 oracle is (3e-6 of slack for cases where torch's blocked CPU sums land within an ulp), and the
+        # bar against the fp32 references below is 3 x the largest HIP error measured over the four train cases.
+        with torch.no_grad():
+            h64, skips64, y64, y_h64, _, _ = oracle_backbone(tag, to64(esd), to64(dsd), x.double(), vec.double())
+        for nm, a, r32, r64 in [("h", h, h_ref, h64), ("y", y, y_ref, y64), ("y_h", y_h, y_h_ref, y_h64)] + \
+                [(f"skip{i}", s_, sr, s6) for i, (s_, sr, s6) in enumerate(zip(skips, skips_ref, skips64))]:
+            yardstick(f"{tag}/{nm}", a, r32, r64, ratio=1.5, slack=3e-6)
+        yardstick(f"{tag}/y reference golden", y, torch.from_numpy(golden[f"{tag}/y"]), y64, ratio=1.5, slack=3e-6)
+        tol = TRAIN_BN_BAR
     assert rel_err(h, h_ref) < tol, rel_err(h, h_ref)
     for s, sr in zip(skips, skips_ref):
         assert s.shape == sr.shape and rel_err(s, sr) < tol

@@ -10,11 +10,13 @@ import torch
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import rel_err
+from tests.common import rel_err, to64, yardstick
 from tests.test_gpu_configs import _build, _oracle_fns
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+PLOT_BAR = 2e-3        # frames of train.py's `plot` rollout after n_past (train-mode BatchNorm at B = 4; see the yardstick there)
+CLOSURE_BAR = 1e-4     # fine-tuning closure VALUES against the oracle: 3 x the HIP deviation measured (yardstick prints, r05)
 
 
 def _cpu_state(m):
@@ -48,16 +50,23 @@ def test_finetuning_closure_values_match_oracle(model):
     tr, o = _trainer(model, 4, 2, 2, 4)
     x = [params.frames(1200 + t, 4, 1, 64) for t in range(4)]
     esd, lsd, gsd, lik = (_cpu_state(m) for m in (tr.encoder, tr.frame_predictor, tr.gp_layer, tr.likelihood))
+    e64, l64, g64, k64 = (to64(sd) for sd in (esd, lsd, gsd, lik))
     enc, _ = _train_mode_fns(model, 64, esd, None)
+    enc64, _ = _train_mode_fns(model, 64, e64, None)
+    x64 = [t.double() for t in x]
     T = o.n_past + o.n_future
     with torch.no_grad():
         ref_fp = float(orc.train_frame_predictor_loss(x, enc, lsd, o.n_past, o.n_future)) / T
         ref_gp = float(orc.train_gp_loss(x, enc, gsd, lik, o.n_past, o.n_future, num_data=o.batch_size)) / T
+        r64_fp = float(orc.train_frame_predictor_loss(x64, enc64, l64, o.n_past, o.n_future)) / T
+        r64_gp = float(orc.train_gp_loss(x64, enc64, g64, k64, o.n_past, o.n_future, num_data=o.batch_size)) / T
     xd = [t.to(DEV) for t in x]
     got_fp = tr.train_frame_predictor(xd)
     got_gp = tr.train_GP_Frame_predictor(xd)
-    assert abs(got_fp - ref_fp) < 1e-3 * abs(ref_fp), (got_fp, ref_fp)
-    assert abs(got_gp - ref_gp) < 2e-3 * abs(ref_gp), (got_gp, ref_gp)
+    yardstick(f"train_frame_predictor value {model}", got_fp, ref_fp, r64_fp, ratio=1.5, slack=CLOSURE_BAR)
+    yardstick(f"train_GP_Frame_predictor value {model}", got_gp, ref_gp, r64_gp, ratio=1.5, slack=CLOSURE_BAR)
+    assert abs(got_fp - ref_fp) < CLOSURE_BAR * abs(ref_fp), (got_fp, ref_fp)
+    assert abs(got_gp - ref_gp) < CLOSURE_BAR * abs(ref_gp), (got_gp, ref_gp)
 
 
 def test_plot_rollout_and_best_of_n_match_oracle():
@@ -70,16 +79,29 @@ def test_plot_rollout_and_best_of_n_match_oracle():
     eps = [params.normal(1320 + s, 90, B) for s in range(S)]
     esd, dsd, lsd, gsd, lik = (_cpu_state(m) for m in (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer,
                                                        tr.likelihood))
+    e64, d64, l64, g64, k64 = (to64(sd) for sd in (esd, dsd, lsd, gsd, lik))
     enc, dec = _train_mode_fns("dcgan", 64, esd, dsd)
+    enc64, dec64 = _train_mode_fns("dcgan", 64, e64, d64)
     with torch.no_grad():
         ref = orc.plot_rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps)
+        ref64 = orc.plot_rollout([t.double() for t in x], enc64, dec64, l64, g64, k64, n_past, n_eval, [e.double() for e in eps])
     ref_best = orc.best_of_n_sse(x, ref, B)
     gen, best = tr.plot([t.to(DEV) for t in x], 0, nsample=S, eps_by_sample=[e.to(DEV) for e in eps])
     assert gen.shape == (S, n_eval, B, 1, 64, 64)
+    # A 10-step autoregressive rollout through TRAIN-mode BatchNorm at B = 4: every step divides by batch statistics of four
+    # images, so fp32 rounding is amplified step by step - in the oracle's own fp32 run as much as in ours.  Measured, per
+    # step: truth = the oracle in fp64, yardstick = the oracle in fp32; HIP stays within 1.5 x that (+ 1e-5), and the bar
+    # against the fp32 oracle is 3 x the largest HIP deviation measured (r05).
+    worst = [0.0, 0.0]
     for s in range(S):
         for t in range(n_eval):
-            tol = 1e-4 if t < n_past else 2e-3   # train-mode BN at B=4 amplifies fp32 noise per step; no extra for the GP step
+            e_hip, e_32 = rel_err(gen[s, t], ref64[s][t]), rel_err(ref[s][t], ref64[s][t])
+            worst = [max(worst[0], e_hip), max(worst[1], e_32)]
+            assert e_hip <= 1.5 * e_32 + 1e-5, (s, t, e_hip, e_32)
+            tol = 1e-4 if t < n_past else PLOT_BAR
             assert rel_err(gen[s, t], ref[s][t]) < tol, (s, t, rel_err(gen[s, t], ref[s][t]))
+    print(f"yardstick plot rollout (train-mode BN, B=4, {n_eval - n_past} steps): worst HIP vs fp64 {worst[0]:.2e} | worst fp32 "
+          f"oracle vs fp64 {worst[1]:.2e}")
     assert best.tolist() == ref_best, (best.tolist(), ref_best)
     # the frames after i == 10 differ between samples (distinct eps), the frames before do not
     assert torch.equal(gen[0, 9], gen[1, 9]) and not torch.equal(gen[0, 10], gen[1, 10])
@@ -149,15 +171,20 @@ def test_gp_trigger_generation_matches_oracle(depth, index):
     for t in range(total):
         tol = 1e-4       # before AND after the first GP-sampled step
         assert rel_err(res["batch_frames"][t], ref["frames"][t]) < tol, (t, rel_err(res["batch_frames"][t], ref["frames"][t]))
-    # the reference's own schedule (a host round trip and 2-3 encoder calls per step, the warm-up per index) and the eager
-    # form of the device schedule: same decisions, same kernels on the same operands -> the same frames, bit for bit
+    # the eager form of the device schedule: the same kernels on the same operands -> the same frames, bit for bit; the
+    # reference's own schedule (a host round trip and 2-3 encoder calls per step, the warm-up per index): the same decisions
+    # and frames up to the summation order of the decoder's concat convs (the device schedule declares the skip frozen at step
+    # 4 and adds the hoisted skip half from then on, the host loop's decoder hoists from the second sighting)
     epd = {k: v.to(DEV) for k, v in eps.items()}
-    for kw in ({"host_loop": True}, {"graph": False}):
+    for kw in ({"graph": False}, {"host_loop": True}):
         alt = g.gp_trigger_gen([xs[0].to(DEV)], indices=[index], total=total, depth=depth, eps_by_step=epd, keep_batch=True, **kw)[0]
         assert alt["triggers"] == res["triggers"], kw
-        np.testing.assert_allclose(alt["values"], res["values"], rtol=1e-6)
+        np.testing.assert_allclose(alt["values"], res["values"], rtol=1e-5)
         for t in range(total):
-            assert torch.equal(alt["batch_frames"][t], res["batch_frames"][t]), (kw, t)
+            if "graph" in kw:
+                assert torch.equal(alt["batch_frames"][t], res["batch_frames"][t]), (kw, t)
+            else:
+                assert rel_err(alt["batch_frames"][t], res["batch_frames"][t]) < 1e-5, (kw, t)
     with pytest.raises(IndexError):
         g.frame_predictor.batch_size = 2
         g.gp_trigger_gen([xs[0][:2].to(DEV)], n_index=1, total=14)
@@ -205,6 +232,11 @@ def test_gp_trigger_generation_at_the_reference_batch(family, depth):
         assert worst < 1e-4, (index, worst)
     if depth != 1:
         assert unforced >= 0.5 * len(idx) * (total - 12) and min(both) >= 5, (unforced, both)
+    # indices whose decisions on an already computed trigger-free rollout are that rollout's decisions reused it (their
+    # frames / values / thresholds went through the same oracle comparison above)
+    assert 1 <= g.trigger_rollouts_run <= len(idx)
+    if all(not r["triggers"] for r in got):
+        assert g.trigger_rollouts_run == 1
 
 
 @pytest.mark.parametrize("inflight,share", [(0, True), (2, True), (2, False)])

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import dvg_oracle as orc
+from tests.common import to64, yardstick
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,9 @@ def _opt(model, extra=()):
     o.ft = True
     o.rank, o.world, o.local_batch = 0, 1, o.batch_size
     return o
+
+
+LOSS_BAR = 1e-4        # closure VALUES against the oracle (see the yardstick prints)
 
 
 def _oracle_loss(model, esd, dsd, lsd, gsd, lik, x, opt):
@@ -50,11 +54,16 @@ def test_train_model_loss_matches_oracle(model):
     cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}  # noqa: E731
     esd, dsd, lsd, gsd, lik = cpu(tr.encoder), cpu(tr.decoder), cpu(tr.frame_predictor), cpu(tr.gp_layer), \
         cpu(tr.likelihood)
+    sds64 = [to64(sd) for sd in (esd, dsd, lsd, gsd, lik)]           # (the oracle advances the running statistics in place)
     ref = float(_oracle_loss(model, esd, dsd, lsd, gsd, lik, [t.cpu() for t in x], opt))
+    ref64 = float(_oracle_loss(model, *sds64, [t.cpu().double() for t in x], opt))
     before = [p.detach().clone() for p in tr.encoder.parameters()]
     tr.train_model(x)
     assert math.isfinite(tr.last_loss)
-    assert abs(tr.last_loss - ref) < 2e-3 * abs(ref), (tr.last_loss, ref)
+    # the loss value is a mean over ~1e5 terms: fp32 rounding of either side averages out to ~1e-7; the bar is 3 x the HIP
+    # deviation measured (r05) and the yardstick prints all three
+    yardstick(f"train_model loss {model} B=4", tr.last_loss, ref, ref64, ratio=1.5, slack=LOSS_BAR)
+    assert abs(tr.last_loss - ref) < LOSS_BAR * abs(ref), (tr.last_loss, ref)
     assert any(not torch.equal(a, b) for a, b in zip(before, tr.encoder.parameters())), "optimizer must step"
     # BatchNorm running statistics saw the same number of train-mode calls as the reference would issue
     assert int(tr.encoder.c1.main[1].num_batches_tracked if model == "dcgan" else
@@ -190,7 +199,7 @@ def test_rollout_matches_oracle_rollout():
     from dvg_amd.models.lstm import lstm
     from dvg_amd.rollout import sample_rollout
     from oracle import params
-    from tests.common import backbone_case, rel_err
+    from tests.common import backbone_case, rel_err, to64, yardstick
     dev = torch.device("cuda:0")
     enc, dec, esd, dsd, x0, _ = backbone_case("dcgan_64/eval")
     B, n_past, n_eval = 2, 3, 17

@@ -9,5 +9,5 @@ for spec in "$@"; do
   if [ "$tw" != "-" ]; then export DVG_GEMM_TW=$tw; else unset DVG_GEMM_TW; fi
   echo "=== lib=$l TW=$tw" | tee -a $out/parts.txt
   BENCH_BATCHES=64,576 timeout -k 10 200 python3 tools/bench_wino_parts.py 2>&1 | grep -v amdgpu.ids | sed -E 's/\| out .*//' | grep "gemm\|---" | tee -a $out/parts.txt || exit 1
-  timeout -k 10 300 python3 bench.py --no-families --no-train-leg --no-cpu-baseline --no-f32mfma-leg --no-make-gifs-leg --no-roofline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('    rollout', d['value'], d['ms_per_step'])" | tee -a $out/parts.txt || exit 1
+  timeout -k 10 300 python3 bench.py --no-families --no-train-leg --no-cpu-baseline --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --no-roofline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('    rollout', d['value'], d['ms_per_step'])" | tee -a $out/parts.txt || exit 1
 done

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_splitk
 rm -rf $out; mkdir -p $out
-P="--steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg"
+P="--steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs"
 export DVG_SPLITK_ONE_LAUNCH=1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_dcgan_$c -o pmc -- python3 bench.py --model dcgan $P > $out/pmc_$c.log 2>&1 < /dev/null || exit 1
