@@ -35,7 +35,6 @@ SIGNATURES = {
     "dvg_conv_first_stats_rows": (_i, [_i, _i, _i, _i]),
     "dvg_pack_conv_weight_k16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dvg_conv_splitk_v2": (_i, [_i, _i, _i, _i, _i, _i]),
-    "dvg_debug_last_splitk_form": (_i, []),
     "dvg_conv_stats_rows_v2": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dvg_conv3x3_bn_act_v2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _i, _p]),
     "dvg_conv3x3_first_pair": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),

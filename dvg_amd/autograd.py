@@ -27,7 +27,7 @@ import torch
 from . import fused, ops
 from .ops import ACT_NONE, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2
 
-DIRECT_PARAM_GRADS = os.environ.get("DVG_DIRECT_GRADS", "1") != "0"
+DIRECT_PARAM_GRADS = True      # the backward kernels add parameter gradients straight into `.grad` (tests toggle it)
 
 
 def _c(t):
@@ -41,8 +41,8 @@ def _c(t):
 # WGRAD_BATCH of them (dvg_conv_wgrad_multi: K grows, the slabs do not), flushed when a queue is full and, through the
 # autograd engine's end-of-backward callback, when the backward pass that queued them completes - `.grad` is final when
 # `loss.backward()` returns, as always.  Only with in-place gradients (the finish kernel accumulates into `.grad`).
-WGRAD_BATCH = int(os.environ.get("DVG_WGRAD_BATCH", "8"))
-DENSE_BATCH = int(os.environ.get("DVG_DENSE_BATCH", "64"))   # uses of a Linear / LSTMCell per batched dW GEMM (1: per use)
+WGRAD_BATCH = 8
+DENSE_BATCH = 64   # uses of a Linear / LSTMCell per batched dW GEMM (1: per use)
 _wgrad_queues = {}
 _wgrad_flush_queued = False
 
@@ -232,8 +232,8 @@ def _wino(weight, m, lo=None, hi=None, dgrad=False):
 
 # Keep the forward's Winograd input transform V (2.25 x the layer input) for the weight gradient instead of recomputing it in
 # the backward pass: ~17 GB more live memory in a vgg_64 iteration at B = 64 (of 288), half of the weight gradient's operand
-# passes gone.  DVG_SAVE_WINO_V=0: recompute.
-SAVE_WINO_V = os.environ.get("DVG_SAVE_WINO_V", "1") != "0"
+# passes gone.  False: recompute.
+SAVE_WINO_V = True
 
 
 def _conv3_raw(x, weight, b, need_stats, lo=None, hi=None, keep_v=None):

@@ -89,7 +89,6 @@ struct Igemm2Params {
     int splitk;  // K split across workgroups (v2 only): raw partial tiles go to `ws`, dvg finishes with splitk_finish
     int cps;     // K chunks (of 16 channels) per split
     float* ws;   // [splitk][N*Ho*Wo][Cout]
-    int* sk_cnt; // in-kernel finish (else nullptr): per output tile {arrival tickets, partials written}, zero between launches
     const float* addend;  // optional raw (pre-scale) partial sums, NHWC like y: y = act((acc + addend) * scale + shift)
     unsigned long long* clk;  // debug only (dvg_debug_set_clockbuf): per-workgroup {clock64, wall_clock64} at entry/exit
     unsigned clk_cap;         // records the buffer holds (workgroups beyond it do not stamp)
@@ -209,10 +208,6 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     if (MODE == M2_CONVT4S2) { par = lid & 3; lid >>= 2; }
     const int split = lid % p.splitk;
     lid /= p.splitk;
-    const unsigned sk_unit = (MODE == M2_CONVT4S2) ? lid * 4 + par : lid;   // the output tile the splits of a K share
-    // one-launch split K (see the epilogue): the arrival ticket is drawn HERE, its round trip hidden behind the stage loop
-    int sk_ticket = -1;
-    if (C::CAN_SPLIT && p.splitk > 1 && p.sk_cnt != nullptr && tid == 0) sk_ticket = atomicAdd(&p.sk_cnt[2 * sk_unit], 1);
     // Order: Cout-block-within-group fastest, then pixel tile, then group.  xcd_remap hands each XCD a contiguous lid
     // range, i.e. nb_group Cout blocks x (range / nb_group) pixel tiles: the host picks nb_group so that the weight
     // slabs plus the input tiles an XCD's L2 has to fetch are smallest (with all Cout blocks per XCD every L2 pulled
@@ -715,113 +710,28 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     else { Ho = p.H * 2; Wo = p.W * 2; }
     const int c = nb0 + wn * 32 + l31;
     if (C::CAN_SPLIT && p.splitk > 1) {
-        // Split K.  Two ways to combine the partial tiles:
-        //  - p.sk_cnt == nullptr: every split writes its raw partial tile to `ws`; splitk_finish_kernel (a second launch) sums
-        //    them and does scale / activation / pool / statistics.
-        //  - p.sk_cnt != nullptr (launches without statistics): the splits of a tile draw tickets as they START (top of the
-        //    kernel); all but the LAST starter write their partials, the last one - which knows the others are resident, so
-        //    the wait below cannot deadlock - waits for those S - 1 writes, sums the S partials IN SPLIT ORDER (its own from
-        //    registers: the result does not depend on who holds the last ticket) and falls through to the ordinary epilogue.  The
-        //    splits of a tile are consecutive remapped workgroup ids, i.e. on one XCD: the exchange stays in that L2.  One
-        //    launch, (S - 1) instead of S partial tiles written and read, no raw-sum read-back.
+        // Split K: every split writes its raw partial tile to `ws`; splitk_finish_kernel (a second launch) sums them in split
+        // order and does scale / activation / pool / statistics.  (r04 also built the combination INSIDE this kernel - tickets,
+        // device-scope relaxed atomics on the partial tiles, the last starter sums: bit-equal, 11 % less traffic, 2.5 % slower on
+        // the dcgan_64 rollout because the finisher's wait sits on every tile's critical path; removed in r05, numbers in
+        // docs/DESIGN_NOTES_r04.md.)
         const size_t slab = (size_t)p.N * Ho * Wo * p.Cout;
-        auto ws_index = [&](int mt, int reg, bool& ok) -> size_t {
-            const int m = wm * (C::BM / 2) + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            const int tii = m / (TH * TW), r = m % (TH * TW);
-            const int ty = r / TW, tx = r % TW;
-            const int n = n0 + tii;
-            int oy, ox;
-            if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
-            else { oy = y0 + ty; ox = x0 + tx; }
-            ok = n < p.N;
-            return (((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c;
-        };
-        int ticket = -1;
-        if (p.sk_cnt != nullptr) {
-            int* const flag = reinterpret_cast<int*>(smem);
-            __syncthreads();                     // every wave is done with the LDS tiles
-            if (tid == 0) flag[0] = sk_ticket;
-            __syncthreads();
-            ticket = flag[0];
-        }
-        // Coherence of the exchange without whole-cache maintenance: a device-scope release / acquire FENCE on gfx950 is a
-        // write-back plus an invalidate of the XCD's entire L2 (buffer_wbl2 / buffer_inv sc1) - measured: dcgan_64 single
-        // chain 3.94 -> 5.59 ms with `__threadfence()` here, every finishing workgroup throwing away the weights its
-        // neighbours had cached.  Instead the partial tiles and the counters are accessed with device-scope RELAXED atomics
-        // (sc1 stores write through to the device's point of coherence, sc1 loads miss non-coherent lines), ordered by
-        // s_waitcnt vmcnt(0) + the workgroup barrier on the writer's side (the count is bumped after every wave's stores have
-        // been acknowledged) and by the barrier after the wait on the reader's side.
-        if (ticket != p.splitk - 1) {
-            float* const wsp = p.ws + (size_t)split * slab;
-            if (p.sk_cnt == nullptr) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        bool ok;
-                        const size_t i = ws_index(mt, reg, ok);
-                        if (ok) wsp[i] = acc[mt][reg];
-                    }
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        bool ok;
-                        const size_t i = ws_index(mt, reg, ok);
-                        if (ok) __hip_atomic_store(wsp + i, acc[mt][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's stores have been acknowledged
-                __syncthreads();
-                if (tid == 0) atomicAdd(&p.sk_cnt[2 * sk_unit + 1], 1);
-            }
-            clk_exit();
-            return;
-        }
-        if (tid == 0) {
-            while (__hip_atomic_load(&p.sk_cnt[2 * sk_unit + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.splitk - 1)
-                __builtin_amdgcn_s_sleep(2);
-            // both counters back to zero for the next launch that uses this workspace
-            __hip_atomic_store(&p.sk_cnt[2 * sk_unit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&p.sk_cnt[2 * sk_unit + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        // the S partial tiles in split order, each tile's loads issued together (one wait per tile, not per value)
-        unsigned idx[MT][16];
+        float* const wsp = p.ws + (size_t)split * slab;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                bool ok;
-                const size_t i = ws_index(mt, reg, ok);
-                idx[mt][reg] = ok ? (unsigned)i : 0xffffffffu;
+                const int m = wm * (C::BM / 2) + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int tii = m / (TH * TW), r = m % (TH * TW);
+                const int ty = r / TW, tx = r % TW;
+                const int n = n0 + tii;
+                int oy, ox;
+                if (MODE == M2_CONVT4S2) { oy = 2 * (y0 + ty) + py; ox = 2 * (x0 + tx) + px; }
+                else { oy = y0 + ty; ox = x0 + tx; }
+                if (n < p.N) wsp[(((size_t)n * Ho + oy) * Wo + ox) * p.Cout + c] = acc[mt][reg];
             }
-        float tot[MT][16];
-        for (int s_ = 0; s_ < p.splitk; ++s_) {
-            float v[MT][16];
-            if (s_ == split) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) v[mt][reg] = acc[mt][reg];
-            } else {
-                const float* const src = p.ws + (size_t)s_ * slab;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        v[mt][reg] = idx[mt][reg] != 0xffffffffu
-                                         ? __hip_atomic_load(src + idx[mt][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) tot[mt][reg] = s_ ? tot[mt][reg] + v[mt][reg] : v[mt][reg];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][reg] = tot[mt][reg];
+        clk_exit();
+        return;
     }
     const float sc = p.scale ? p.scale[c] : 1.f, sf = p.shift ? p.shift[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -1048,8 +958,6 @@ static int finish_units_per_block(long units) {
     return (int)upb;
 }
 
-static int g_last_splitk_form = 0;   // dvg_debug_last_splitk_form: 0 no split, 1 partials + finish launch, 2 combined in the kernel
-
 // number of K splits for a v2 launch: only when the grid would leave CUs idle and K is deep enough
 static int choose_splitk(long wgs, int nchunks) {
     if (wgs >= 384 || nchunks < 8) return 1;
@@ -1083,8 +991,6 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
             if (w1 % slots == 0 && w1 / slots >= 2 && w1 / slots <= 6 && p.N % (w1 / slots) == 0) ni = (int)(w1 / slots);
         }
 #endif
-        static const char* force_ni = getenv("DVG_GEMM_NI");   // A/B runs only
-        if (force_ni && p.N % atoi(force_ni) == 0) ni = atoi(force_ni);
         p.gemm_ni = ni;
         p.tiles_n = p.N / ni;
     }
@@ -1117,20 +1023,11 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     const long out_floats = (long)p.N * Ho * Wo * p.Cout;
     int S = (ws != nullptr && C::CAN_SPLIT) ? choose_splitk(wgs, nchunks) : 1;
     if (S > 1 && (long)S * out_floats > ws_floats) return fail(DVG_ERR_SHAPE, "conv_igemm2: split-K workspace too small");
-    const int S_asked = S;      // what dvg_conv_splitk_v2 told the caller to size the workspace for
     p.cps = (nchunks + S - 1) / S;
     p.cps = (p.cps + C::CHUNKS_PER_STAGE - 1) / C::CHUNKS_PER_STAGE * C::CHUNKS_PER_STAGE;   // whole stages per split
     S = (nchunks + p.cps - 1) / p.cps;  // no empty split: the kernel's peeled stage loop needs >= 1 chunk per workgroup
     p.splitk = S;
     p.ws = ws;
-    // in-kernel finish: launches without statistics whose workspace carries the counter tail (dvg_hip.h: DVG_SPLITK_COUNTER_FLOATS)
-    static const char* sk_launch = getenv("DVG_SPLITK_FINISH_LAUNCH");   // A/B runs: "1" keeps the two-launch form
-    // (EXACTLY the documented size: a caller of the two-launch form that merely over-allocates must not have the end of its
-    // buffer read as counters)
-    const bool sk_inkernel = S > 1 && p.stats == nullptr && (long)S_asked * out_floats + DVG_SPLITK_COUNTER_FLOATS == ws_floats &&
-                             wgs * 2 <= DVG_SPLITK_COUNTER_FLOATS && !(sk_launch && sk_launch[0] == '1');
-    p.sk_cnt = sk_inkernel ? reinterpret_cast<int*>(ws + ws_floats - DVG_SPLITK_COUNTER_FLOATS) : nullptr;
-    g_last_splitk_form = S <= 1 ? 0 : (sk_inkernel ? 2 : 1);
     float* y_pool = p.y_pool;
     float* stats = p.stats;
     const unsigned grid = (unsigned)(wgs * S);
@@ -1147,7 +1044,7 @@ static int launch2(Igemm2Params p, int Hg, int Wg, float* ws, long ws_floats, hi
     }
     hipLaunchKernelGGL((conv_igemm2_kernel<MODE, TI, TH, TW, NT, FIRST>), dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
     if (int e = check_launch("conv_igemm2")) return e;
-    if (S > 1 && !sk_inkernel) {
+    if (S > 1) {
         const bool pool = y_pool != nullptr;
         const long units = pool ? (long)p.N * (Ho / 2) * (Wo / 2) : (long)p.N * Ho * Wo;
         const int upb = finish_units_per_block(units);
@@ -1179,8 +1076,6 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
             // reuse) from about four residency rounds on (the conditioning batch: 2077 us per pass against 2267)
             // (f32 MFMA build: the 64-row tile at 4 per CU throughout, as measured in r03)
             if (!DVG_BF16X3 || wgs < 4 * 768) *tw = 8;
-            static const char* force = getenv("DVG_GEMM_TW");   // A/B runs only
-            if (force) *tw = atoi(force);
         }
     }
     return 0;
@@ -1244,8 +1139,6 @@ static long v2_wgs(int mode, int N, int Hg, int Wg, int Cout, int ti, int th, in
 }
 
 // K splits the v2 launch of this shape will use when a workspace is supplied (1 = no split)
-extern "C" int dvg_debug_last_splitk_form(void) { return g_last_splitk_form; }
-
 extern "C" int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout) {
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
@@ -1393,16 +1286,6 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_GEMM, NB, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
                 "dvg_gemm_batched_k16: no tile for %dx%d", H, W);
-#if DVG_BF16X3
-    {
-        // 128 x 128 workgroup tile (64 x 64 per wave, K = 32 stages): measured, NOT the default.  At B = 576 it ties the
-        // 64-row tile (16x16 256->256: 341 vs 349 us), at B = 64 it loses 15-25 % (576 workgroups on 512 slots; 50 spilled
-        // registers around the per-image epilogue).  DVG_GEMM_NT=2 selects it for A/B runs.
-        static const char* force_nt = getenv("DVG_GEMM_NT");
-        const bool wide = Cout % 128 == 0 && Wg % 16 == 0 && Cin % 32 == 0 && force_nt && atoi(force_nt) == 2;
-        if (wide) return launch2<M2_GEMM, 1, 8, 16, 2>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
-    }
-#endif
     D2(M2_GEMM, 1, 8, 16)
     D2(M2_GEMM, 1, 8, 8)
     return fail(DVG_ERR_SHAPE, "dvg_gemm_batched_k16: no kernel");

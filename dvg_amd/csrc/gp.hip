@@ -804,15 +804,8 @@ using namespace dvg;
 #ifndef GP_BWD_THREADS
 #define GP_BWD_THREADS 1024
 #endif
-static int gp_threads(int dflt) {
-    static const char* e = getenv("DVG_GP_THREADS");
-    const int n = e ? atoi(e) : dflt;
-    return (n == 256 || n == 512 || n == 1024) ? n : dflt;
-}
-static bool gp_force_fp32() {
-    static const char* e = getenv("DVG_GP_FP32");   // A/B switch: the r02 all-fp32 arithmetic
-    return e && atoi(e) != 0;
-}
+static int gp_threads(int dflt) { return dflt; }      // (256 / 512-thread instantiations exist: see the dispatch below)
+static bool gp_force_fp32() { return false; }        // fp32 variants only run where the fp64 working set does not fit the LDS
 static constexpr size_t GP_LDS_MAX = 160 * 1024;
 
 template <typename K, typename P>

@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WW_BM = 128;                // Cout rows / Cin columns of a workgroup's output block
-// Variants (template parameters; the host picks WW_DEFAULT_*, DVG_WW_DB overrides for A/B runs):
+// Variants (template parameters; the host picks WW_DEFAULT_*):
 //   KS  tiles (K rows) per stage: 32 (64 measured 2-4 % slower in the single-buffer form and is not instantiated)
 //   DB  true: two LDS stages, one barrier per stage; false: one LDS stage, the next stage's ds_writes behind a barrier
 //       under the last k group's MFMAs (as the forward igemm does)
@@ -403,8 +403,6 @@ static void ww_plan(long Tp, int Cin, int Cout, long* q_out, long* w_out, int* s
     // ONE round of resident workgroups, two per CU.  (Compiled for three per CU - 168 VGPRs, 9 of them spilled - and split 768
     // ways the single-buffer variant measured 107-112 TF against 115-123.)
     long wgs = 512;
-    static const char* env = getenv("DVG_WW_WGS");     // A/B runs only
-    if (env && atoi(env) > 0) wgs = atoi(env);
     if (wgs * min_st > total) wgs = (total + min_st - 1) / min_st;
     const long q = (total + wgs - 1) / wgs;
     wgs = (total + q - 1) / q;
@@ -478,8 +476,7 @@ static int ww_gemm(const float* dm, const float* const* v_items, int items, long
     DVG_REQUIRE(q > 0, DVG_ERR_SHAPE, "dvg_winograd_wgrad_gemm: too many tiles (%ld)", tiles_padded);
     p.q = (int)q;
     p.total = 36 * p.nbi * p.nbj * p.nst;
-    static const char* env = getenv("DVG_WW_DB");   // A/B runs only
-    const bool db = env ? atoi(env) != 0 : WW_DEFAULT_DB;
+    const bool db = WW_DEFAULT_DB;
     const hipStream_t st = (hipStream_t)stream;
 #if DVG_BF16X3
     {

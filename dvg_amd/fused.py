@@ -64,9 +64,9 @@ if WINOGRAD not in (0, 2, 4):
 
 # F(4x4) eligibility: input channels >= 64 (the 64 -> 128 layer at 32x32 included: -1.2 % per vgg_64 rollout, alone and with
 # rollouts in flight; it lost against the direct form before the chained transforms existed), maps up to 32x32 (at 64x64 the
-# HBM-bound transform passes cost what the GEMM saves: 17.89 vs 17.79 ms).  Environment overrides for A/B runs only.
-_WINO_MIN_C = int(os.environ.get("DVG_WINO_MIN_C", "64"))
-_WINO_MAX_HW = int(os.environ.get("DVG_WINO_MAX_HW", "32"))
+# HBM-bound transform passes cost what the GEMM saves: 17.89 vs 17.79 ms).
+_WINO_MIN_C = 64
+_WINO_MAX_HW = 32
 
 
 def winograd_tile(n, c, h, w, cout) -> int:
@@ -94,7 +94,7 @@ def winograd_weight(conv: nn.Module, m: int) -> torch.Tensor:
 # x half of a decoder block's upsample + concat conv in Winograd F(4x4) form when the skip half is hoisted (eval-mode
 # rollouts); DVG_UPCONV_WINOGRAD=0: the transposed-conv (K4) form
 UPCONV_WINOGRAD = os.environ.get("DVG_UPCONV_WINOGRAD", "1") != "0"
-_UPCONV_WINO_MAX = int(os.environ.get("DVG_UPCONV_WINO_MAX", "16"))     # largest output map side that takes this form
+_UPCONV_WINO_MAX = 16     # largest output map side that takes this form (32 x 32 measured slower than the K4 transposed form)
 
 
 def _winograd_weight_x(conv: nn.Module, c1: int) -> torch.Tensor:
@@ -206,7 +206,7 @@ def bn_passes_now() -> int:
 # and how many reference passes the first / a middle / the last group stands for (see bn_passes: a middle frame of a
 # sequence is encoded twice per closure).  Inside it `bn_passes` must be 1.
 _BN_GROUPS = None
-_GROUP_STATS_RECOMPUTE = os.environ.get("DVG_GROUP_STATS_RECOMPUTE", "0") == "1"
+_GROUP_STATS_RECOMPUTE = False      # tests set it: always take the dvg_channel_stats pass
 
 
 class bn_groups:
@@ -230,7 +230,7 @@ def group_stats(st, u):
     """Partial statistics rows that respect the group boundaries: `st` itself with one group, or when its rows are per-tile
     sums in image-major order whose tiles do not straddle groups (ops._stats_buf records that: un-split igemm launches and
     the first-layer kernels), else a dvg_channel_stats pass over u (NHWC-in-memory (N,C,H,W) or [rows][C]) with per-group
-    slabs.  DVG_GROUP_STATS_RECOMPUTE=1 always takes the extra pass (A/B and tests)."""
+    slabs.  fused._GROUP_STATS_RECOMPUTE = True always takes the extra pass (tests)."""
     g = bn_groups_now()
     if g == 1:
         return st

@@ -26,9 +26,6 @@ import torch.nn.functional as F
 
 from .. import ops
 
-import os
-
-FUSED_ELBO = os.environ.get("DVG_FUSED_ELBO", "1") != "0"
 JITTER = 1e-3        # lazy_tensor.add_jitter() default of gpytorch 0.3.x
 NOISE_FLOOR = 1e-4   # GaussianLikelihood noise constraint GreaterThan(1e-4)
 
@@ -232,11 +229,13 @@ class VariationalELBO(nn.Module):
 
     def forward(self, pred: GPPrediction, target: torch.Tensor):
         b = target.shape[-1]
-        if (FUSED_ELBO and self.combine_terms and pred._training and pred._noise is None and pred._raw_noise is None and
+        if (self.combine_terms and pred._training and pred._noise is None and pred._raw_noise is None and
                 target.is_cuda and target.dim() == 2 and isinstance(self.likelihood, GaussianLikelihood)):
-            # one launch forward, one backward (dvg_gp_elbo) instead of ~25 torch launches per call; DVG_FUSED_ELBO=0: torch ops
+            # the reference's call sites (train.py:164-169,225-226): one launch forward, one backward (dvg_gp_elbo)
             from ..gp_autograd import gp_elbo
             return gp_elbo(pred.mean, pred.variance, pred.kl, target, self.likelihood.noise_covar.raw_noise, self.num_data)
+        # anything else gpytorch's API allows (combine_terms=False, a prediction that already carries noise): the definition,
+        # term by term
         ll = self.likelihood.expected_log_prob(target, pred) / b
         kl = pred.kl / self.num_data
         return ll - kl if self.combine_terms else (ll, kl)

@@ -181,33 +181,21 @@ def unpack_convT_weight(wp: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
 def _splitk_ws(mode, n, h, w, cin, cout, out_numel, device):
     """Workspace for the split-K path of the implicit GEMM (None when the launch fills the chip on its own)."""
     s = lib().dvg_conv_splitk_v2(mode, n, h, w, cin, cout)
-    if s <= 1 or os.environ.get("DVG_NO_SPLITK") == "1":     # (the switch: A/B runs)
+    if s <= 1:
         return None
-    # One buffer per (stream, size), reused by every launch of that size on that stream (launches on a stream are ordered):
-    # its last SPLITK_COUNTER_FLOATS floats are the arrival counters of the one-launch finish (dvg_hip.h), zero here and left
-    # zero by every launch.  Keyed by the hipGraph capture too: a buffer first touched during a capture is zeroed only when
-    # THAT graph replays, so neither eager calls nor another capture may pick it up.
-    tail = SPLITK_COUNTER_FLOATS if SPLITK_ONE_LAUNCH else 0      # no tail: the library keeps the two-launch form
+    # One buffer per (stream, size), reused by every launch of that size on that stream (launches on a stream are ordered).
+    # Keyed by the hipGraph capture too: a buffer allocated during a capture lives in that graph's private pool.
     stream = torch.cuda.current_stream(device).cuda_stream
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream, s * out_numel, tail,
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream, s * out_numel,
            lib().dvg_stream_capture_id(stream))
     ws = _SPLITK_WS.get(key)
     if ws is None:
         if len(_SPLITK_WS) > 256:
             _SPLITK_WS.clear()
-        ws = torch.empty(s * out_numel + tail, device=device, dtype=torch.float32)
-        if tail:
-            ws[-tail:].zero_()
-        _SPLITK_WS[key] = ws
+        ws = _SPLITK_WS[key] = torch.empty(s * out_numel, device=device, dtype=torch.float32)
     return ws
 
 
-SPLITK_COUNTER_FLOATS = 1024      # DVG_SPLITK_COUNTER_FLOATS of include/dvg_hip.h
-# The one-launch combine is built, bit-equal to the two-launch form (tests/test_gpu_determinism.py) and OFF by default: measured
-# r04 same box on the dcgan_64 rollout 4.00 ms single chain / 211 k frames/s in flight against 3.90 ms / 216 k with the
-# finish launch (profiles/r04_splitk_ab.txt) - the finisher's wait + device-scope loads sit on each tile's critical path,
-# while splitk_finish spreads the same sum over every CU in 5 us.  DVG_SPLITK_ONE_LAUNCH=1 selects it.
-SPLITK_ONE_LAUNCH = os.environ.get("DVG_SPLITK_ONE_LAUNCH", "0") == "1"
 _SPLITK_WS = {}
 
 

@@ -134,21 +134,11 @@ int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin,
  * supplies `workspace` (>= dvg_conv_splitk_v2(...) * N*Ho*Wo*Cout floats), K is split over workgroups, raw partial
  * tiles go to the workspace and a finish kernel applies scale/shift/act (+pool, +statistics).  workspace may be
  * NULL (no split).  `stats` then has dvg_conv_stats_rows_v2(..., pool, with_workspace) rows.
- * One-launch form (r04, additive): a workspace of EXACTLY dvg_conv_splitk_v2(...) * N*Ho*Wo*Cout + DVG_SPLITK_COUNTER_FLOATS floats
- * whose LAST DVG_SPLITK_COUNTER_FLOATS floats are zero before the first launch that uses the buffer lets a launch without
- * `stats` combine the partial tiles inside the convolution kernel (the last-arriving split of a tile sums them in split
- * order and runs the ordinary epilogue: same result bit for bit whichever split arrives last); every launch leaves that
- * tail zero again.  Launches that share such a workspace must be ordered (one stream); pass the same workspace_floats for
- * the same buffer every time (the tail is found from the end).  A workspace without the tail keeps the two-launch form.
  * `addend` (may be NULL): raw pre-scale partial sums in y's NHWC shape, y = act((conv + addend) * scale + shift).
  * It carries the skip half of a decoder block's first conv, cat([up(d), skip]) (vgg_64.py:98-105, dcgan_64.py:84-86),
  * when the skip tensor is loop-invariant over the steps of a rollout (generate_frames.py:154-157): the caller
  * computes conv(skip, W[:, C1:]) once with scale = shift = NULL, act = NONE and then runs only the x half per step.
  * Statistics (train-mode BatchNorm) are taken over conv + addend; excludes the pooled output.                 */
-#define DVG_SPLITK_COUNTER_FLOATS 1024
-/* tests only: how the calling thread's last *_v2 convolution launch combined its K splits - 0 no split, 1 partial tiles +
- * splitk_finish launch, 2 inside the convolution kernel (not thread-safe).                                         */
-int dvg_debug_last_splitk_form(void);
 int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout);
 int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, int Cout, int pool, int with_workspace);
 int dvg_conv3x3_bn_act_v2(const float* x, const float* skip, const float* w_k16,

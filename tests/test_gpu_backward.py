@@ -466,9 +466,10 @@ def test_gp_train_backward(B, D, M):
 
 
 def test_fused_elbo_equals_the_torch_composition():
-    """VariationalELBO.forward as dvg_gp_elbo / dvg_gp_elbo_bwd (one launch each way) against the same expression in torch
-    ops (DVG_FUSED_ELBO=0 path): values and every gradient - GP parameters and h through mean / variance / KL, the raw
-    noise through the soft-plus, and the TARGET handed over as the strided view h_target.transpose(0, 1) (train.py:226)."""
+    """VariationalELBO.forward as dvg_gp_elbo / dvg_gp_elbo_bwd (one launch each way) against the same expression composed term
+    by term in torch ops (likelihood.expected_log_prob / B - KL / num_data): values and every gradient - GP parameters and h
+    through mean / variance / KL, the raw noise through the soft-plus, and the TARGET handed over as the strided view
+    h_target.transpose(0, 1) (train.py:226)."""
     from dvg_amd.models import gp_models as gm
     B, D, M = 16, 90, 40
     sd, lik = params.gp_state(520, D=D, M=M)
@@ -477,22 +478,22 @@ def test_fused_elbo_equals_the_torch_composition():
     w = params.normal(523, D).to(dev())
     res = {}
     for fused_on in (True, False):
-        gm.FUSED_ELBO = fused_on
-        try:
-            gp, like = gm.GPRegressionLayer1(D, M), gm.GaussianLikelihood(batch_size=D)
-            gp.load_state_dict(sd)
-            like.load_state_dict(lik)
-            gp.to(dev()).train(), like.to(dev()).train()
-            mll = gm.VariationalELBO(like, gp, num_data=37)
-            ho = h.to(dev()).requires_grad_(True)
-            hto = ht.to(dev()).requires_grad_(True)
-            elbo = mll(gp(ho.transpose(0, 1).view(D, B, 1)), hto.transpose(0, 1))
-            (elbo * w).sum().backward()
-            g = {k: p.grad.clone() for k, p in gp.named_parameters()}
-            g.update(h=ho.grad.clone(), target=hto.grad.clone(), noise=like.noise_covar.raw_noise.grad.clone())
-            res[fused_on] = (elbo.detach().clone(), g)
-        finally:
-            gm.FUSED_ELBO = True
+        gp, like = gm.GPRegressionLayer1(D, M), gm.GaussianLikelihood(batch_size=D)
+        gp.load_state_dict(sd)
+        like.load_state_dict(lik)
+        gp.to(dev()).train(), like.to(dev()).train()
+        mll = gm.VariationalELBO(like, gp, num_data=37)
+        ho = h.to(dev()).requires_grad_(True)
+        hto = ht.to(dev()).requires_grad_(True)
+        pred = gp(ho.transpose(0, 1).view(D, B, 1))
+        if fused_on:
+            elbo = mll(pred, hto.transpose(0, 1))
+        else:
+            elbo = like.expected_log_prob(hto.transpose(0, 1), pred) / B - pred.kl / 37
+        (elbo * w).sum().backward()
+        g = {k: p.grad.clone() for k, p in gp.named_parameters()}
+        g.update(h=ho.grad.clone(), target=hto.grad.clone(), noise=like.noise_covar.raw_noise.grad.clone())
+        res[fused_on] = (elbo.detach().clone(), g)
     (ea, ga), (eb, gb) = res[True], res[False]
     assert ea.shape == (D,) and rel_err(ea, eb) < 1e-5
     for k in ga:

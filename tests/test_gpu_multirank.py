@@ -64,9 +64,9 @@ def test_train_py_ranks_end_with_identical_parameters(ranks):
     iterations (train_model + both fine-tuning closures each) every rank must hold bit-identical parameters, and they must
     differ from a single-rank run on rank 0's data alone (i.e. the other rank's gradients did arrive)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", DVG_PRINT_PARAM_CHECKSUM="1", OMP_NUM_THREADS="2")
+    env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
     args = ["--model", "dcgan", "--dataset", "smmnist", "--n_past", "2", "--n_future", "3", "--n_eval", "5", "--niter", "1",
-            "--epoch_size", "4", "--no_save", "--save_every", "1000"]
+            "--epoch_size", "4", "--no_save", "--save_every", "1000", "--print_param_checksum"]
 
     def run(cmd):
         r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -87,7 +87,7 @@ def test_library_loaded_before_torch_touches_the_gpu_still_launches():
     runtime; the library links the system runtime, and in that order every launch used to fail with "no ROCm-capable
     device is detected".  `_lib.lib()` now brings torch's runtime up first."""
     code = ("from dvg_amd import _lib\n"
-            "assert _lib.lib().dvg_abi_version() == 7\n"
+            "assert _lib.lib().dvg_abi_version() == 8\n"
             "import torch\n"
             "from dvg_amd import ops\n"
             "x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32, device='cuda').reshape(2, 3, 4, 5)\n"

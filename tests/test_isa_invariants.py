@@ -99,14 +99,7 @@ def test_no_exec_change_and_no_lane_mask_inside_any_stage_loop(x3, tmp_path):
     assert not bad, bad
     # the address-select path exists and is predication, not control flow: conv modes keep v_cndmask in their loops
     assert sum(loop_census(v)["cndmask"] for k, v in bodies.items() if "ILi3E" not in k) > 0
-    # Split K inside the kernel: the exchange of partial tiles uses device-scope relaxed accesses (sc1 stores and
-    # loads), never a device-scope FENCE - on gfx950 that is a write-back + invalidate of the XCD's whole L2 (measured: the
-    # dcgan_64 chain 3.94 -> 5.59 ms) - and only the tiles that can split carry the code (the 16-wide tiles, the first layer and
-    # the batched GEMM do not: it cost them 18-35 SGPR spills)
+    # no device-scope FENCE anywhere in these kernels: on gfx950 that is a write-back + invalidate of the XCD's whole L2
+    # (measured r04 with the in-kernel split-K exchange, removed in r05: the dcgan_64 chain 3.94 -> 5.59 ms)
     text = {k: "\n".join(v) for k, v in bodies.items()}
     assert not any("buffer_wbl2" in t or "buffer_inv" in t for t in text.values())
-    can_split = [k for k in text if "Lb1EEE" not in k and "ILi3E" not in k and "ELi16ELi" not in k]
-    assert len(can_split) >= 5, sorted(text)
-    for k, t in text.items():
-        has = bool(re.search(r"global_store_dword .* sc1", t)) and bool(re.search(r"global_load_dword .* sc1", t))
-        assert has == (k in can_split), (k, has)

@@ -83,6 +83,8 @@ def build_parser():
                         'parameters as the eager loop, tested; 1.5-2.7x the train frames/s); with more than one rank: as a '
                         'chain of hipGraphs cut at the gradient all-reduces, which stay eager (SegmentedIteration)')
     p.add_argument('--no_hip_graph', action='store_true', help='eager launches for every iteration')
+    p.add_argument('--print_param_checksum', action='store_true',
+                   help='print a checksum of all parameters per rank at the end (multi-rank tests: every rank must agree)')
     p.add_argument('--synthetic_data', action='store_true',
                    help='datasets other than smmnist: train on synthetic clips of the right shape (--data_root is not read)')
     return p
@@ -133,7 +135,7 @@ class Trainer:
         # forward_sequence); DVG_LSTM_SEQ=0: one module call per step
         self.lstm_sequence = os.environ.get("DVG_LSTM_SEQ", "1") != "0"
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
-        self.latent_stream = os.environ.get("DVG_LATENT_STREAM", "1") != "0"
+        self.latent_stream = True
         self._side_stream = None
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group.  All groups live in ONE
         # flat arena in the order [GP | likelihood | LSTM | decoder | encoder]: parameters, gradients (p.grad are views)
@@ -316,7 +318,7 @@ class Trainer:
             fused.replay_bn_trace(cache[2])          # ... and the BatchNorm side effects of re-encoding them, replayed
         else:
             enc_all = self._encode_sequence(x, g) if self.share_encoder_passes else None
-        if self.time_batched and enc_all is not None and not g and self.gp_layer.training and _fused_elbo():
+        if self.time_batched and enc_all is not None and not g and self.gp_layer.training:
             # no recurrence in this closure: all S GP posteriors + ELBO terms as one launch (gp_autograd.gp_elbo_steps)
             from dvg_amd.gp_autograd import gp_elbo_steps
             hcat = torch.stack([e[0].detach() for e in enc_all])          # (T, B, D)
@@ -463,7 +465,7 @@ class Trainer:
     def _train_model_dev(self, x):
         opt = self.opt
         if (self.time_batched and self.time_batched_decoder and self.share_encoder_passes and self.encoder.training
-                and self.decoder.training and opt.n_past >= 2 and opt.n_past + opt.n_future >= 3 and _fused_elbo()):
+                and self.decoder.training and opt.n_past >= 2 and opt.n_past + opt.n_future >= 3):
             return self._train_model_batched(x)
         self.encoder_optimizer.zero_grad()            # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203)
         self.decoder_optimizer.zero_grad()
@@ -609,13 +611,6 @@ class Trainer:
                     'frame_predictor': _detached_copy(self.frame_predictor),
                     'likelihood': own(self.likelihood.state_dict()), 'gp_layer': own(self.gp_layer.state_dict()),
                     'gp_layer_optimizer': self.optimizer.state_dict(), 'opt': self.opt}, path)
-
-
-def _fused_elbo() -> bool:
-    """DVG_FUSED_ELBO=0 (gp_models.FUSED_ELBO): the ELBO as the torch composition of the per-step `mll(...)` calls; the
-    closures then take their step-by-step GP path (gp_elbo_steps is built on the fused dvg_gp_elbo launch)."""
-    from dvg_amd.models import gp_models
-    return bool(gp_models.FUSED_ELBO)
 
 
 def _detached_copy(module):
@@ -901,12 +896,12 @@ def main(argv=None):
     train_gen = BatchPrefetcher(make_batch_generator(opt, opt.n_past + opt.n_future, opt.seed + 17 * rank, device))
     test_gen = make_batch_generator(opt, opt.n_eval, opt.seed + 7919 + 17 * rank, device)
     # One rank: the iteration as one hipGraph.  Several ranks: a chain of hipGraphs cut at the gradient all-reduces, which
-    # stay eager (SegmentedIteration).  DVG_HIP_GRAPH_DP=1 captures the RCCL collectives inside ONE graph instead - NOT safe
+    # stay eager (SegmentedIteration).  Capturing the RCCL collectives inside ONE graph instead is NOT safe
     # on this stack: the c10d watchdog thread may query a collective's event while it is "recorded in a capturing stream"
     # (hipErrorCapturedEvent) and terminate the process (1 of 5 runs with a one-rank RCCL group).
     if opt.no_hip_graph:
         step = tr.iteration
-    elif world == 1 or os.environ.get("DVG_HIP_GRAPH_DP") == "1":
+    elif world == 1:
         step = GraphedIteration(tr)
     else:
         step = SegmentedIteration(tr)
@@ -939,7 +934,7 @@ def main(argv=None):
                 tr.save('%s/model.pth' % opt.output_path)
         if epoch % 10 == 0 and rank == 0:
             print('log dir: %s' % opt.log_dir)
-    if os.environ.get("DVG_PRINT_PARAM_CHECKSUM") == "1":   # tests: every rank must end with the same parameters
+    if opt.print_param_checksum:   # tests: every rank must end with the same parameters
         mods = (tr.encoder, tr.decoder, tr.frame_predictor, tr.gp_layer, tr.likelihood)
         cs = sum(float(p.detach().double().sum()) for m in mods for p in m.parameters())
         ab = sum(float(p.detach().double().abs().sum()) for m in mods for p in m.parameters())
