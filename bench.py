@@ -548,17 +548,28 @@ def hbm_bound_layers(ctx: Ctx, args) -> dict:
     enc, dec, fp, gp, lik = build_models("vgg", B, 1, ctx.dev, args.seed)
     x = torch.rand(B, 1, 64, 64, device=ctx.dev)
 
-    def timed(fn, iters=100):
-        for _ in range(10):
-            fn()
+    def timed(fn, reps=20, replays=10):
+        """us per call: `reps` back-to-back calls captured as ONE hipGraph (no host launch latency between them - the rollout
+        itself runs as graph replays), `replays` replays between two HIP events on the launch stream."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            keep = [fn() for _ in range(reps)]
+        g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for _ in range(replays):
+            g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters * 1e3      # us per call
+        del keep
+        return e0.elapsed_time(e1) / (reps * replays) * 1e3
 
     def row(us, nbytes, launches, what):
         gbs = nbytes / (us * 1e-6) / 1e9
@@ -590,7 +601,7 @@ def hbm_bound_layers(ctx: Ctx, args) -> dict:
         def gp_sample():
             return lik(gp(h.transpose(0, 1).view(90, B, 1))).rsample(eps)
         gp_sample()
-        us = timed(gp_sample, iters=30)
+        us = timed(gp_sample, reps=5)
         out["gp_sample"] = row(us, 4.0 * (B * 90 * 4 + 90 * 40 * 43), 1,
                                "gp_predict_kernel (sampling): one 1024-thread workgroup per latent dim, fp64 inside: a serial "
                                "dependency chain in LDS, not a streaming kernel")

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-LOSS_BAR = 1e-4        # closure VALUES against the oracle: 3 x the HIP deviation measured (yardstick prints, r05)
+LOSS_BAR = 2e-6        # closure VALUES against the oracle: measured r05 <= 1.8e-7 (HIP) / 1.5e-7 (fp32 oracle) against fp64
 
 
 def _build(family, res, nc, batch, seed):

@@ -19,7 +19,8 @@ from tests.test_gpu_configs import _build, _oracle_fns
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ELEM_BAR = 2e-3       # element-wise relative error (1 % floor) of eval-mode latents / frames; see the yardstick print
+ELEM_BAR = 6e-4       # element-wise relative error (1 % floor) of eval-mode latents / frames at B = 50: measured r05 HIP vs fp64
+#                       1.9e-4 (vgg latent; the fp32 oracle: 8.3e-5), 1.0e-4 (dcgan frame; fp32 oracle 7.5e-5) - r04's bar was 2e-3
 FRAME_BAR = 1e-4      # BASELINE.json north_star: "within 1e-4 relative on fp32 frames" (rel_err: max |a - b| / max |b|)
 
 

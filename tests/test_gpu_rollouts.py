@@ -15,8 +15,10 @@ from tests.test_gpu_configs import _build, _oracle_fns
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-PLOT_BAR = 2e-3        # frames of train.py's `plot` rollout after n_past (train-mode BatchNorm at B = 4; see the yardstick there)
-CLOSURE_BAR = 1e-4     # fine-tuning closure VALUES against the oracle: 3 x the HIP deviation measured (yardstick prints, r05)
+PLOT_BAR = 1e-5        # frames of train.py's `plot` rollout after n_past (train-mode BatchNorm at B = 4): measured r05 worst
+#                        HIP vs fp64 1.2e-6, worst fp32 oracle vs fp64 2.0e-6 over the 10 predicted steps (r04's bar: 2e-3)
+CLOSURE_BAR = 1e-6     # LSTM fine-tuning closure VALUE against the oracle: measured r05 <= 1.8e-7
+GP_CLOSURE_BAR = 5e-5  # GP fine-tuning closure VALUE (-ELBO): measured r05 1.3e-5 at B = 4 (the oracle's GP is fp64 in both runs)
 
 
 def _cpu_state(m):
@@ -64,9 +66,9 @@ def test_finetuning_closure_values_match_oracle(model):
     got_fp = tr.train_frame_predictor(xd)
     got_gp = tr.train_GP_Frame_predictor(xd)
     yardstick(f"train_frame_predictor value {model}", got_fp, ref_fp, r64_fp, ratio=1.5, slack=CLOSURE_BAR)
-    yardstick(f"train_GP_Frame_predictor value {model}", got_gp, ref_gp, r64_gp, ratio=1.5, slack=CLOSURE_BAR)
+    yardstick(f"train_GP_Frame_predictor value {model}", got_gp, ref_gp, r64_gp, ratio=1.5, slack=GP_CLOSURE_BAR)
     assert abs(got_fp - ref_fp) < CLOSURE_BAR * abs(ref_fp), (got_fp, ref_fp)
-    assert abs(got_gp - ref_gp) < CLOSURE_BAR * abs(ref_gp), (got_gp, ref_gp)
+    assert abs(got_gp - ref_gp) < GP_CLOSURE_BAR * abs(ref_gp), (got_gp, ref_gp)
 
 
 def test_plot_rollout_and_best_of_n_match_oracle():
@@ -108,7 +110,8 @@ def test_plot_rollout_and_best_of_n_match_oracle():
     # BatchNorm side effects of plot(): the discarded encoder(x[i]) calls of train.py:273-274 count as well
     got = tr.encoder.state_dict()
     for k in ("c1.main.1.running_mean", "c1.main.1.running_var", "c5.1.running_mean"):
-        assert rel_err(got[k], esd[k]) < 2e-3, k
+        print(f"plot rollout BatchNorm buffer {k}: rel err {rel_err(got[k], esd[k]):.2e}")
+        assert rel_err(got[k], esd[k]) < 1e-4, k
     # per sample: 2 encoder calls per conditioning step (train.py:267,273), 1 per predicted step
     assert int(got["c1.main.1.num_batches_tracked"]) == S * (2 * (n_past - 1) + (n_eval - n_past))
 

@@ -26,7 +26,7 @@ def _opt(model, extra=()):
     return o
 
 
-LOSS_BAR = 1e-4        # closure VALUES against the oracle (see the yardstick prints)
+LOSS_BAR = 2e-6        # closure VALUES against the oracle: measured r05 <= 1.3e-7 (HIP) / 1.3e-7 (fp32 oracle) against fp64
 
 
 def _oracle_loss(model, esd, dsd, lsd, gsd, lik, x, opt):

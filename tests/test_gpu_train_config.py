@@ -28,8 +28,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-VALUE_BAR = 1e-4        # closure VALUES against the oracle: 3 x the HIP deviation measured (yardstick prints, r05)
-LSTM_GRAD_BAR = 1e-3    # LSTM parameter gradients at the real configuration (see the yardstick prints)
+VALUE_BAR = 1e-6        # closure VALUES against the oracle: measured r05 <= 2.1e-7 (HIP), <= 2.6e-7 (fp32 oracle) against fp64
+GP_VALUE_BAR = 5e-6     # the GP closure's value (-ELBO): measured r05 1.0e-6 / 7.1e-7 (the oracle's GP is fp64 in both runs)
+GP_GRAD_BAR = 5e-4      # GP / likelihood parameter gradients at the real configuration (r04's bar; see the yardstick prints)
+LSTM_GRAD_BAR = 5e-5    # LSTM parameter gradients at the real configuration: measured r05 HIP vs fp32 oracle <= 2.9e-6 (dcgan_64,
+#                         14 steps) / 1.5e-5 (vgg_64: its encodings carry the Winograd layers' ~1e-5 rounding), 1.1-2.5 x the fp32
+#                         oracle's own deviation from fp64 (r04's bar: 1e-3)
 
 
 def _zero_lrs(tr):
@@ -102,9 +106,10 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
     (v_fp,), _ = got["fp"]
     (v_gp,), _ = got["gp"]
     yardstick(f"train_frame_predictor value {tag}", v_fp, float(ref_fp) / T, float(r64_fp) / T, ratio=1.5, slack=VALUE_BAR)
-    yardstick(f"train_GP_Frame_predictor value {tag}", v_gp, float(ref_gp) / T, float(r64_gp) / T, ratio=1.5, slack=VALUE_BAR)
+    yardstick(f"train_GP_Frame_predictor value {tag}", v_gp, float(ref_gp) / T, float(r64_gp) / T, ratio=1.5, slack=GP_VALUE_BAR)
     assert abs(v_fp - float(ref_fp) / T) < VALUE_BAR * abs(float(ref_fp) / T), (v_fp, float(ref_fp) / T)
-    assert abs(v_gp - float(ref_gp) / T) < VALUE_BAR * abs(float(ref_gp) / T), (v_gp, float(ref_gp) / T)
+    assert abs(v_gp - float(ref_gp) / T) < GP_VALUE_BAR * abs(float(ref_gp) / T), (v_gp, float(ref_gp) / T)
+    worst_bn = 0.0
     for sd_ref, mod, calls in ((esd, tr.encoder, 6 * (T - 1)), (dsd, tr.decoder, 3 * (T - 1))):
         mine = mod.state_dict()
         n = 0
@@ -113,9 +118,11 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
                 assert int(mine[k]) == calls, (k, int(mine[k]), calls)       # the oracle's functional BN does not count
             elif "running" in k:
                 scale = max(float(r.abs().max()), 1e-3)
-                assert float((mine[k].cpu() - r).abs().max()) <= 2e-4 * scale + 1e-6, (k, float((mine[k].cpu() - r).abs().max()), scale)
+                worst_bn = max(worst_bn, float((mine[k].cpu() - r).abs().max()) / scale)
+                assert float((mine[k].cpu() - r).abs().max()) <= 1e-4 * scale + 1e-6, (k, float((mine[k].cpu() - r).abs().max()), scale)
                 n += 1
         assert n >= 8
+    print(f"BatchNorm running statistics {tag}: worst |diff| / max|ref| {worst_bn:.2e}")
     # (3) LSTM / GP parameter gradients of the fine-tuning closures vs autograd of the oracle on the same encodings
     # (the encoder runs in train mode on the frames again: statistics are batch statistics, weights unchanged)
     esd_g = {k: v.clone() for k, v in esd0.items()}
@@ -141,27 +148,39 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
         lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
         mine = g_fp[lo: lo + p.numel()].view_as(p).cpu()
         # BPTT over T - 1 steps on train-mode encodings: the fp32 oracle's own deviation from fp64 is the yardstick
-        e_hip, _ = yardstick(f"lstm grad {k} {tag}", mine, g32[k], g64_[k], ratio=1.5, slack=LSTM_GRAD_BAR / 3)
+        e_hip, _ = yardstick(f"lstm grad {k} {tag}", mine, g32[k], g64_[k], ratio=3.0, slack=2e-6)
         worst = max(worst, e_hip)
         assert rel_err(mine, g32[k]) < LSTM_GRAD_BAR, ("lstm", k, rel_err(mine, g32[k]))
-    g_leaf = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gsd.items()}
-    n_leaf = {k: v.double().clone().requires_grad_(True) for k, v in lik.items()}
-    noise = orc.likelihood_noise(n_leaf)
-    tot = 0
-    for i in range(1, T):
-        pr = orc.gp_predict(hs[i - 1].double(), g_leaf, training=True)
-        tot = tot - orc.variational_elbo(pr, hs[i].double().t(), noise, num_data=batch).sum()
-    tot.backward()
+    def gp_grads(dt):   # fp64 autograd of the oracle's GP + ELBO over the S steps, on encodings computed by the oracle in `dt`
+        e_ = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in esd0.items()}
+        enc_, _ = _train_mode_fns(model, 64, e_, None)
+        with torch.no_grad():
+            hs_ = [enc_(t.to(dt))[0].double() for t in x]
+        g_leaf = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gsd.items()}
+        n_leaf = {k: v.double().clone().requires_grad_(True) for k, v in lik.items()}
+        noise = orc.likelihood_noise(n_leaf)
+        tot = 0
+        for i in range(1, T):
+            pr = orc.gp_predict(hs_[i - 1], g_leaf, training=True)
+            tot = tot - orc.variational_elbo(pr, hs_[i].t(), noise, num_data=batch).sum()
+        tot.backward()
+        out = {("gp", k): v.grad for k, v in g_leaf.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+        out.update({("lik", k): v.grad for k, v in n_leaf.items()})
+        return out
+    # yardstick: the encodings are the only fp32 quantity on the oracle's side (its GP arithmetic is fp64 either way): what
+    # fp32 ROUNDING OF THE ENCODINGS does to these gradients (fp32-encodings run against the fp64-encodings run) beside what
+    # the HIP path's encodings + fp64-inside GP kernels do
+    gg32, gg64 = gp_grads(torch.float32), gp_grads(torch.float64)
     g_gp = got["gp"][1]
-    for mod, leaf in ((tr.gp_layer, g_leaf), (tr.likelihood, n_leaf)):
+    for who, mod in (("gp", tr.gp_layer), ("lik", tr.likelihood)):
         for k, p in mod.named_parameters():
             lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
             mine = g_gp[lo: lo + p.numel()].view_as(p).cpu().double()
-            ref = leaf[k].grad
+            r32, r64 = gg32[(who, k)], gg64[(who, k)]
             if k.endswith("chol_variational_covar"):
-                ref = torch.tril(ref)
-            err = float((mine - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
-            assert err < 5e-4, ("gp", k, err)     # encodings differ by fp32 rounding between the two sides (1e-6 of h)
+                r32, r64 = torch.tril(r32), torch.tril(r64)
+            yardstick(f"gp grad {k} {tag}", mine, r32, r64, ratio=3.0, slack=2e-5)
+            assert rel_err(mine, r32) < GP_GRAD_BAR, ("gp", k, rel_err(mine, r32))
 
 
 @pytest.mark.parametrize("model,batch,n_past,n_future", [("dcgan", 50, 5, 10), ("vgg", 50, 3, 3), ("dcgan", 64, 10, 10)])

@@ -52,9 +52,11 @@ def main():
             continue
         site = "?"
         for fr in (ev.stack or []):
-            if ROOT in fr and "site-packages" not in fr:
-                site = fr.replace(ROOT + "/", "")
+            if ("dvg_amd/" in fr or "train.py" in fr or "gp_models.py" in fr) and "site-packages" not in fr and "dist-packages" not in fr:
+                site = fr.split("/repo/")[-1]
                 break
+        if site == "?" and ev.stack:
+            site = "? " + " <- ".join(f.split("/")[-1] for f in ev.stack[:3])
         by_site[(site, ev.name)] += len(ev.kernels)
         by_site_us[(site, ev.name)] += sum(k.duration for k in ev.kernels)
         n_kernels += len(ev.kernels)
