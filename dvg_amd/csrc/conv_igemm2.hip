@@ -50,6 +50,9 @@
 #ifndef DVG_FIRST_SELECTS
 #define DVG_FIRST_SELECTS 0
 #endif
+#ifndef DVG_GEMM_NT_STORE
+#define DVG_GEMM_NT_STORE 0
+#endif
 //  DVG_GEMM_WGS_PER_CU: workgroups per CU the 64-row GEMM-mode tile is compiled for (register budget 512 / this per lane)
 #ifndef DVG_GEMM_WGS_PER_CU
 #define DVG_GEMM_WGS_PER_CU (DVG_BF16X3 ? 3 : 4)
@@ -655,8 +658,14 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                     for (int reg = 0; reg < 16; ++reg) {
                         const int mu = mbase + (reg & 3) + 8 * (reg >> 2);       // the uniform part of m (4 hh is in lane_off)
                         // (DVG_ABLATE 8 / 9, timing only: one product value per lane instead of the tile's 16)
-                        if (DVG_ABLATE < 8 || reg == 0)
-                            (yb + (size_t)((y0 + mu / TW) * p.W + x0 + mu % TW) * p.Cout + nt * 32)[lane_off] = acc[mt * NT + nt][reg];
+                        if (DVG_ABLATE < 8 || reg == 0) {
+                            float* const dst = (yb + (size_t)((y0 + mu / TW) * p.W + x0 + mu % TW) * p.Cout + nt * 32) + lane_off;
+#if DVG_GEMM_NT_STORE      // A/B (r05): the products are written once and read once, by the next kernel
+                            __builtin_nontemporal_store(acc[mt * NT + nt][reg], dst);
+#else
+                            *dst = acc[mt * NT + nt][reg];
+#endif
+                        }
                         acc[mt * NT + nt][reg] = 0.f;
                     }
             }

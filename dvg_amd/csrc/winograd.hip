@@ -14,7 +14,30 @@
 
 #include "dvg_common.h"
 
+// A/B (r05): nontemporal hints on the transforms' read-once M loads / written-once V stores
+#ifndef DVG_WINO_NT_LOAD
+#define DVG_WINO_NT_LOAD 0
+#endif
+#ifndef DVG_WINO_NT_STORE
+#define DVG_WINO_NT_STORE 0
+#endif
+
 namespace dvg {
+
+template <typename V> __device__ __forceinline__ V wino_ld(const V* p) {
+#if DVG_WINO_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void wino_st(V* p, const V& v) {
+#if DVG_WINO_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
     // thread = (ci, co); writes the 16 transform positions of this filter
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
         for (int b = 0; b < 6; ++b) {
             V q[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const V*>(m)[((size_t)(a * 6 + b) * T + t) * CVg + cg];
+            for (int a = 0; a < 6; ++a) q[a] = wino_ld(reinterpret_cast<const V*>(m) + ((size_t)(a * 6 + b) * T + t) * CVg + cg);
             V col[4];
             at4(q, col);
 #pragma unroll
@@ -530,7 +553,7 @@ __global__ __launch_bounds__(NT) void winograd4_chain_kernel(const float* __rest
             V o[6];
             bt4(e[a], o);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) reinterpret_cast<V*>(v)[((size_t)(a * 6 + b) * T2 + t2) * CVg + cg] = o[b];
+            for (int b = 0; b < 6; ++b) wino_st(reinterpret_cast<V*>(v) + ((size_t)(a * 6 + b) * T2 + t2) * CVg + cg, o[b]);
         }
     }
 }

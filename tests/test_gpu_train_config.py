@@ -30,7 +30,9 @@ DEV = "cuda:0"
 
 VALUE_BAR = 1e-6        # closure VALUES against the oracle: measured r05 <= 2.1e-7 (HIP), <= 2.6e-7 (fp32 oracle) against fp64
 GP_VALUE_BAR = 5e-6     # the GP closure's value (-ELBO): measured r05 1.0e-6 / 7.1e-7 (the oracle's GP is fp64 in both runs)
-GP_GRAD_BAR = 5e-4      # GP / likelihood parameter gradients at the real configuration (r04's bar; see the yardstick prints)
+GP_GRAD_BAR = 6e-5      # GP / likelihood parameter gradients at the real configuration: measured r05 HIP vs fp32-encodings oracle <=
+#                         2.9e-6 (dcgan_64) / 1.8e-5 (vgg_64), HIP vs fp64 <= 1.6e-5 where fp32 rounding of the ENCODINGS alone
+#                         moves them by <= 5.9e-6 (r04's bar: 5e-4)
 LSTM_GRAD_BAR = 5e-5    # LSTM parameter gradients at the real configuration: measured r05 HIP vs fp32 oracle <= 2.9e-6 (dcgan_64,
 #                         14 steps) / 1.5e-5 (vgg_64: its encodings carry the Winograd layers' ~1e-5 rounding), 1.1-2.5 x the fp32
 #                         oracle's own deviation from fp64 (r04's bar: 1e-3)
@@ -179,7 +181,7 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
             r32, r64 = gg32[(who, k)], gg64[(who, k)]
             if k.endswith("chol_variational_covar"):
                 r32, r64 = torch.tril(r32), torch.tril(r64)
-            yardstick(f"gp grad {k} {tag}", mine, r32, r64, ratio=3.0, slack=2e-5)
+            yardstick(f"gp grad {k} {tag}", mine, r32, r64, ratio=3.5, slack=2e-6)
             assert rel_err(mine, r32) < GP_GRAD_BAR, ("gp", k, rel_err(mine, r32))
 
 

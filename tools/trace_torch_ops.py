@@ -1,16 +1,53 @@
 #!/usr/bin/env python3
-"""Which Python lines of the training iteration launch torch (at::native / rocclr) kernels: one eager iteration under
-torch.profiler with stacks, aten ops that launched a device kernel grouped by the innermost frame inside this repository.
-GPU only.  usage: trace_torch_ops.py [--model dcgan] [--batch 16] [--n_past 2] [--n_future 10] [--channels 3]"""
+"""Which Python lines of the training iteration launch torch (at::native / rocclr) kernels: one eager iteration under a
+TorchDispatchMode that records, for every aten op that is not a pure view, the innermost Python frame inside this repository
+(autograd's worker thread inherits the mode: backward nodes show up under the Function.backward that called them, built-in
+nodes - AccumulateGrad, the backward of torch ops the closures compose - under "<autograd engine>").  GPU only.
+usage: trace_torch_ops.py [--model dcgan] [--batch 16] [--n_past 2] [--n_future 10] [--channels 3]"""
 import argparse
 import collections
 import os
 import sys
+import traceback
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+VIEWS = {"view", "_unsafe_view", "reshape", "as_strided", "t", "transpose", "permute", "slice", "select", "detach", "alias",
+         "expand", "unsqueeze", "squeeze", "split", "split_with_sizes", "unbind", "narrow", "view_as", "_reshape_alias",
+         "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "set_", "is_same_size", "size", "stride",
+         "sym_size", "unsafe_split", "chunk", "lift_fresh", "_local_scalar_dense", "item", "is_nonzero", "resize_",
+         "record_stream", "_to_copy" * 0 + "numel", "dim", "is_pinned", "storage_offset", "is_contiguous", "sym_stride",
+         "sym_numel", "sym_storage_offset", "unsafe_chunk", "squeeze_", "unsqueeze_", "t_", "transpose_", "result_type"}
+
+
+class Tracer(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.count = collections.Counter()
+        self.elems = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = func.overloadpacket.__name__
+        if name in VIEWS:
+            return out
+        ts = [t for t in (list(args) + [out] + (list(out) if isinstance(out, (tuple, list)) else []))
+              if torch.is_tensor(t) and t.is_cuda]
+        if not ts:
+            return out
+        site = "<autograd engine>"
+        for fr in reversed(traceback.extract_stack()[:-1]):
+            f = fr.filename
+            if ("dvg_amd/" in f or f.endswith("train.py") or f.endswith("gp_models.py")) and "dist-packages" not in f:
+                site = f"{f.split('/repo/')[-1] if '/repo/' in f else os.path.basename(f)}:{fr.lineno} {fr.name}"
+                break
+        self.count[(site, name)] += 1
+        self.elems[(site, name)] += max(t.numel() for t in ts)
+        return out
 
 
 def main():
@@ -37,32 +74,13 @@ def main():
     for _ in range(3):
         tr.iteration(x)
     torch.cuda.synchronize()
-    from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    tracer = Tracer()
+    with tracer:
         tr.iteration(x)
         torch.cuda.synchronize()
-    by_site = collections.Counter()
-    by_site_us = collections.Counter()
-    n_kernels = 0
-    for ev in prof.events():
-        if not ev.name.startswith("aten::") or not ev.kernels:
-            continue
-        # leaf aten ops only: an op whose child also launched the same kernels would be counted twice
-        if any(c.name.startswith("aten::") and c.kernels for c in ev.cpu_children):
-            continue
-        site = "?"
-        for fr in (ev.stack or []):
-            if ("dvg_amd/" in fr or "train.py" in fr or "gp_models.py" in fr) and "site-packages" not in fr and "dist-packages" not in fr:
-                site = fr.split("/repo/")[-1]
-                break
-        if site == "?" and ev.stack:
-            site = "? " + " <- ".join(f.split("/")[-1] for f in ev.stack[:3])
-        by_site[(site, ev.name)] += len(ev.kernels)
-        by_site_us[(site, ev.name)] += sum(k.duration for k in ev.kernels)
-        n_kernels += len(ev.kernels)
-    print(f"{n_kernels} device kernels launched by aten ops in one iteration")
-    for (site, name), n in by_site.most_common(60):
-        print(f"{n:5d}  {by_site_us[(site, name)]:8.0f} us  {name:28s} {site}")
+    print(f"{sum(tracer.count.values())} non-view aten ops on device tensors in one iteration")
+    for (site, name), n in tracer.count.most_common(80):
+        print(f"{n:5d}  {tracer.elems[(site, name)] / n:12.0f} elems/op  {name:24s} {site}")
 
 
 if __name__ == "__main__":
