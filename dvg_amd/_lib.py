@@ -71,12 +71,13 @@ SIGNATURES = {
     "dvg_gp_precision": (_i, [_i, _i, _i]),
     "dvg_gp_bwd_precision": (_i, [_i, _i]),
     "dvg_gp_lds_bytes": (C.c_size_t, [_i, _i, _i]),
-    "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _p]),
+    "dvg_gp_predict": (_i, [_p] * 14 + [_i, _i, _i, _i, _f, _i, _p]),
     "dvg_gp_bwd_lds_bytes": (C.c_size_t, [_i, _i]),
     "dvg_gp_bwd_chunk": (_i, [_i, _i]),
-    "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _p]),
-    "dvg_gp_elbo": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _p]),
-    "dvg_gp_elbo_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _i, _p]),
+    "dvg_sum_steps_multi": (_i, [_p, _p, _p, _i, _i, _p]),
+    "dvg_gp_elbo": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _i, _p]),
+    "dvg_gp_elbo_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dvg_bn_act_bwd_rows": (_i, [_i, _i, _i, _i]),
     "dvg_bn_act_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dvg_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _i, _i, _i, _p]),
@@ -102,6 +103,10 @@ SIGNATURES = {
     "dvg_lstm_gates_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "dvg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dvg_zero_tick": (_i, [_p, _l, _p, _p, _p, _p, _p]),
+    "dvg_frame_losses_blocks": (_i, [_l]),
+    "dvg_frame_losses": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "dvg_mse_sum_grad": (_i, [_p, _p, _p, _p, _l, _f, _p]),
     "dvg_gp_var_norms": (_i, [_p, _p, _i, _i, _p]),
     "dvg_gp_trigger_step": (_i, [_p, _i, _i, _i, _p, _i, _f, _p, _p, _p, _p, _i, _p]),
     "dvg_gp_trigger_replay": (_i, [_p, _i, _p, _i, _f, _p, _p, _p]),

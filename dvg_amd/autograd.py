@@ -787,6 +787,22 @@ def lstm_cell_autograd(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return _LSTMCell.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
 
 
+_ZERO_STATES = {}
+
+
+def _zero_state(b, h, dev):
+    """One shared all-zero (b, h) tensor per shape: the initial (h, c) of every sequence, read only (a fill launch per closure
+    otherwise).  Created eagerly; a first call during a hipGraph capture allocates from the graph's pool instead and is not
+    cached."""
+    key = (str(dev), b, h)
+    z = _ZERO_STATES.get(key)
+    if z is None:
+        z = torch.zeros((b, h), device=dev)
+        if not torch.cuda.is_current_stream_capturing():
+            _ZERO_STATES[key] = z
+    return z
+
+
 class _LSTMSequence(torch.autograd.Function):
     """lstm.lstm (lstm.py:42-72) over a whole TEACHER-FORCED sequence (train.py:213-222,181-188: step i's input is the
     encoding of the ground-truth frame x[i-1], never a prediction), from the zero state of `init_hidden()`:
@@ -808,7 +824,7 @@ class _LSTMSequence(torch.autograd.Function):
         H = we.shape[0]
         dev = x.device
         e = ops.gemm_nt(x, we.detach(), None, be.detach())
-        zero = torch.zeros((B, H), device=dev)
+        zero = _zero_state(B, H, dev)
         inp, saved = e, []
         for l in range(L):
             wih, whh, bih, bhh = params[2 + 4 * l: 6 + 4 * l]

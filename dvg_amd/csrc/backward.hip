@@ -614,6 +614,24 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// zero_grad of one or several ADJACENT parameter groups of the gradient arena as one fill, and the device-side step counts
+// of up to four of them advanced by one in the same launch (a captured iteration replays with fresh bias corrections; the
+// increment used to be a one-element torch add_ per optimiser step).
+__global__ void zero_tick_kernel(float* __restrict__ g, long n, int* __restrict__ t0, int* __restrict__ t1, int* __restrict__ t2,
+                                 int* __restrict__ t3) {
+    const long n4 = n >> 2;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(g)[i] = z;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < (n & 3)) g[(n4 << 2) + threadIdx.x] = 0.f;
+        if (threadIdx.x == 4 && t0) *t0 += 1;
+        if (threadIdx.x == 5 && t1) *t1 += 1;
+        if (threadIdx.x == 6 && t2) *t2 += 1;
+        if (threadIdx.x == 7 && t3) *t3 += 1;
+    }
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -818,4 +836,13 @@ extern "C" int dvg_adam_step(float* param, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, step);
     return check_launch("dvg_adam_step");
+}
+
+// g[0:n] = 0 and *t_k += 1 for the non-NULL step counters (see zero_tick_kernel): optimizer.zero_grad() of adjacent groups of
+// the gradient arena (train.py:201-203) + the step-count increments of the optimiser steps that follow in a captured iteration.
+extern "C" int dvg_zero_tick(float* g, long n, int* t0, int* t1, int* t2, int* t3, void* stream) {
+    DVG_REQUIRE(g, DVG_ERR_NULL, "dvg_zero_tick: NULL pointer");
+    DVG_REQUIRE(n > 0 && aligned16(g), DVG_ERR_SHAPE, "dvg_zero_tick: n > 0 and a 16-byte aligned buffer needed");
+    hipLaunchKernelGGL(zero_tick_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, n, t0, t1, t2, t3);
+    return check_launch("dvg_zero_tick");
 }

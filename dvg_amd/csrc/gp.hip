@@ -37,6 +37,8 @@ struct GpParams {
     int B, D, M, train_mode;
     float jitter;
     int raw_hypers;  // outputscale / lengthscale / noise point at the RAW parameters: soft-plus (+ noise floor) in-kernel
+    int Dp;          // parameter period: workgroup d reads the parameters of latent dim d % Dp (D = S x Dp: the S time steps of a
+                     // training closure side by side, one parameter set - no tiled copies)
     unsigned long long* clk;  // debug only: 12 x u64 per workgroup (latent dim), for the first clk_cap workgroups
     unsigned clk_cap;
 };
@@ -300,22 +302,23 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     // (gp_models.py hyper-parameters / GaussianLikelihood noise with its GreaterThan(1e-4) floor): saves three
     // 90-element launches per GP call
     auto softplus = [](T x) { return x > T(20.) ? x : log1p_t(exp_t(x)); };
-    const T s = p.raw_hypers ? softplus(p.outputscale[d]) : p.outputscale[d];
-    const T ell = p.raw_hypers ? softplus(p.lengthscale[d]) : p.lengthscale[d];
+    const int dq = d % p.Dp;      // the latent dim whose PARAMETERS this workgroup reads
+    const T s = p.raw_hypers ? softplus(p.outputscale[dq]) : p.outputscale[dq];
+    const T ell = p.raw_hypers ? softplus(p.lengthscale[dq]) : p.lengthscale[dq];
     const T ninv = -T(0.5) / (ell * ell);
-    const T c0 = p.mean_const[d];
-    const T noise = p.noise ? (p.raw_hypers ? softplus(p.noise[d]) + T(1e-4) : p.noise[d]) : T(0.);
+    const T c0 = p.mean_const[dq];
+    const T noise = p.noise ? (p.raw_hypers ? softplus(p.noise[dq]) + T(1e-4) : p.noise[dq]) : T(0.);
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
     if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
-    for (int i = tid; i < M; i += NT) zs[i] = p.z[(size_t)d * M + i];
+    for (int i = tid; i < M; i += NT) zs[i] = p.z[(size_t)dq * M + i];
     for (int b = tid; b < B; b += NT) xs[b] = p.h[(size_t)b * p.D + d];
     __syncthreads();
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
         const T dz = zs[r] - zs[q];
         L[r * LM + q] = s * exp_t(dz * dz * ninv) + (r == q ? p.jitter : T(0.));
-        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : T(0.);
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)dq * M + r) * M + q] : T(0.);
     }
     for (int i = tid; i < M * (B + 1); i += NT) {
         const int r = i / (B + 1), b = i % (B + 1);
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
             const T dx = zs[r] - xs[b];
             v = s * exp_t(dx * dx * ninv);
         } else {
-            v = p.var_mean[(size_t)d * M + r] - c0;
+            v = p.var_mean[(size_t)dq * M + r] - c0;
         }
         AK[r * LB + b] = v;
     }
@@ -479,6 +482,7 @@ struct GpBwdParams {
     float* dh; float* dz; float* dm; float* dls; float* dc; float* ds; float* dell;
     int B, D, M;
     int Bc;                   // data points per chunk (gp_bwd_chunk): B when the whole fp64 working set fits the LDS
+    int Dp;                   // parameter period (see GpParams): gradients are still written per workgroup d
     float jitter;
     unsigned long long* clk;  // debug only (dvg_debug_set_gp_clockbuf): 12 x u64 phase stamps per workgroup
     unsigned clk_cap;
@@ -522,15 +526,16 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* gq = gv + B;
     T* red = gq + B;          // [16]
 
-    const T s = p.outputscale[d], ell = p.lengthscale[d];
-    const T ninv = -T(0.5) / (ell * ell), c0 = p.mean_const[d];
+    const int dq = d % p.Dp;      // the latent dim whose PARAMETERS this workgroup reads (gradients are written per d)
+    const T s = p.outputscale[dq], ell = p.lengthscale[dq];
+    const T ninv = -T(0.5) / (ell * ell), c0 = p.mean_const[dq];
     const T gk = p.gkl ? p.gkl[d] : T(0.);
     const int nchunk = (B + Bc - 1) / Bc;
 
     GP_STAMP(0)
     for (int i = tid; i < M; i += NT) {
-        zs[i] = p.z[(size_t)d * M + i];
-        rr[i] = p.var_mean[(size_t)d * M + i] - c0;
+        zs[i] = p.z[(size_t)dq * M + i];
+        rr[i] = p.var_mean[(size_t)dq * M + i] - c0;
         tt[i] = T(0.);
     }
     for (int b = tid; b < B; b += NT) {
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         const T v = s * exp_t(dz * dz * ninv) + (r == q ? p.jitter : T(0.));
         Kj[r * LM + q] = v;
         L[r * LM + q] = v;
-        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)d * M + r) * M + q] : T(0.);
+        Ls[r * LM + q] = (q <= r) ? p.chol_var[((size_t)dq * M + r) * M + q] : T(0.);
     }
     auto build_kzx = [&](int b0, int bc) {       // Kzx of the chunk [b0, b0 + bc)
         for (int i = tid; i < M * bc; i += NT) {
@@ -754,6 +759,7 @@ struct GpElboParams {
     const float* raw_noise; const float* gelbo;
     float* elbo; float* gmean; float* gvar; float* gkl; float* gtarget; float* graw_noise;
     int B, D; float inv_num_data;
+    int Dp;      // noise period: workgroup d reads raw_noise[d % Dp] (graw_noise is still written per d)
 };
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -762,7 +768,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void gp_elbo_kernel(const GpElboParams p) {
     __shared__ float red[4];
     const int d = blockIdx.x, tid = threadIdx.x, B = p.B;
-    const float raw = p.raw_noise[d];
+    const float raw = p.raw_noise[d % p.Dp];
     const float nz = softplus_f(raw) + 1e-4f;
     float acc = 0.f;
     for (int b = tid; b < B; b += 256) {
@@ -876,7 +882,7 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
                               const float* mean_const, const float* outputscale, const float* lengthscale,
                               const float* noise, const float* eps, float* mean, float* var, float* sample,
                               float* cov, float* kl, int B, int D, int M, int train_mode, float jitter,
-                              void* stream) {
+                              int param_period, void* stream) {
     DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
                 "dvg_gp_predict: NULL input");
     DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
@@ -886,8 +892,10 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
     const size_t lds = dvg_gp_lds_bytes(B, M, need_cov);
     DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
     DVG_REQUIRE(train_mode >= 0 && train_mode <= 3, DVG_ERR_SHAPE, "dvg_gp_predict: train_mode flags must be 0..3");
+    DVG_REQUIRE(param_period >= 0 && (param_period == 0 || D % param_period == 0), DVG_ERR_SHAPE,
+                "dvg_gp_predict: param_period=%d must divide D=%d", param_period, D);
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
-               B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, g_gp_clk, g_gp_clk_cap};
+               B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, param_period ? param_period : D, g_gp_clk, g_gp_clk_cap};
     const int nt = gp_threads(GP_PREDICT_THREADS);
     const char* who = "dvg_gp_predict";
     const int variant = gp_predict_variant(B, M, need_cov);
@@ -916,7 +924,7 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
                                 const float* mean_const, const float* outputscale, const float* lengthscale,
                                 const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
                                 float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
-                                float jitter, void* stream) {
+                                float jitter, int param_period, void* stream) {
     DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
                 "dvg_gp_train_bwd: NULL input");
     DVG_REQUIRE(dh && dz && dm && dls && dc && ds && dell, DVG_ERR_NULL, "dvg_gp_train_bwd: NULL output");
@@ -924,8 +932,11 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
                 "dvg_gp_train_bwd: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
     const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
     DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
+    DVG_REQUIRE(param_period >= 0 && (param_period == 0 || D % param_period == 0), DVG_ERR_SHAPE,
+                "dvg_gp_train_bwd: param_period=%d must divide D=%d", param_period, D);
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
-                  dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(B, M), jitter, g_gp_clk, g_gp_clk_cap};
+                  dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(B, M), param_period ? param_period : D, jitter,
+                  g_gp_clk, g_gp_clk_cap};
     const int nt = gp_threads(GP_BWD_THREADS);
     const char* who = "dvg_gp_train_bwd";
     if (dvg_gp_bwd_precision(B, M) == 64) {
@@ -950,24 +961,60 @@ static int gp_elbo_checks(const float* mean, const float* var, const float* kl, 
 }
 
 extern "C" int dvg_gp_elbo(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
-                           long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data, void* stream) {
+                           long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data, int noise_period,
+                           void* stream) {
     if (int e = gp_elbo_checks(mean, var, kl, target, raw_noise, B, D, num_data, "dvg_gp_elbo")) return e;
     DVG_REQUIRE(elbo, DVG_ERR_NULL, "dvg_gp_elbo: NULL output");
+    DVG_REQUIRE(noise_period >= 0 && (noise_period == 0 || D % noise_period == 0), DVG_ERR_SHAPE, "dvg_gp_elbo: noise_period must divide D");
     GpElboParams p{mean, var, kl, target, t_stride_d, t_stride_b, raw_noise, nullptr, elbo, nullptr, nullptr, nullptr,
-                   nullptr, nullptr, B, D, 1.f / (float)num_data};
+                   nullptr, nullptr, B, D, 1.f / (float)num_data, noise_period ? noise_period : D};
     hipLaunchKernelGGL(gp_elbo_kernel<false>, dim3(D), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dvg_gp_elbo");
 }
 
 extern "C" int dvg_gp_elbo_bwd(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
                                long t_stride_b, const float* raw_noise, const float* gelbo, float* gmean, float* gvar,
-                               float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, void* stream) {
+                               float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, int noise_period,
+                               void* stream) {
     if (int e = gp_elbo_checks(mean, var, kl, target, raw_noise, B, D, num_data, "dvg_gp_elbo_bwd")) return e;
     DVG_REQUIRE(gelbo && gmean && gvar && gkl && graw_noise, DVG_ERR_NULL, "dvg_gp_elbo_bwd: NULL gradient buffer");
+    DVG_REQUIRE(noise_period >= 0 && (noise_period == 0 || D % noise_period == 0), DVG_ERR_SHAPE, "dvg_gp_elbo_bwd: noise_period must divide D");
     GpElboParams p{mean, var, kl, target, t_stride_d, t_stride_b, raw_noise, gelbo, nullptr, gmean, gvar, gkl, gtarget,
-                   graw_noise, B, D, 1.f / (float)num_data};
+                   graw_noise, B, D, 1.f / (float)num_data, noise_period ? noise_period : D};
     hipLaunchKernelGGL(gp_elbo_kernel<true>, dim3(D), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dvg_gp_elbo_bwd");
+}
+
+// dst_k[i] = sum_s src_k[s * n_k + i] for up to 8 tensors in one launch: the per-(step, latent dim) parameter gradients of the S
+// time steps a closure ran side by side (param_period above) back to one gradient per parameter (what the backward of torch's
+// `repeat` did with a reshape + sum launch per tensor).  Fixed summation order.
+struct SumStepsParams { const float* src[8]; float* dst[8]; long n[8]; int count, S; };
+__global__ __launch_bounds__(256) void sum_steps_kernel(const SumStepsParams p) {
+    const int k = blockIdx.y;
+    if (k >= p.count) return;
+    const long n = p.n[k];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a = p.src[k][i];
+        for (int s_ = 1; s_ < p.S; ++s_) a += p.src[k][(size_t)s_ * n + i];
+        p.dst[k][i] = a;
+    }
+}
+
+extern "C" int dvg_sum_steps_multi(const float* const* src, float* const* dst, const long* n, int count, int S, void* stream) {
+    DVG_REQUIRE(src && dst && n, DVG_ERR_NULL, "dvg_sum_steps_multi: NULL pointer");
+    DVG_REQUIRE(count >= 1 && count <= 8 && S >= 1, DVG_ERR_SHAPE, "dvg_sum_steps_multi: 1..8 tensors, S >= 1");
+    SumStepsParams p{};
+    long nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        DVG_REQUIRE(src[k] && dst[k] && n[k] > 0, DVG_ERR_NULL, "dvg_sum_steps_multi: NULL tensor %d", k);
+        p.src[k] = src[k]; p.dst[k] = dst[k]; p.n[k] = n[k];
+        nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    p.count = count; p.S = S;
+    long gx = (nmax + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(sum_steps_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dvg_sum_steps_multi");
 }
 
 extern "C" void dvg_debug_set_gp_clockbuf(void* buf, unsigned records) {

@@ -483,6 +483,89 @@ __global__ __launch_bounds__(256) void gp_trigger_select_kernel(const TriggerSel
         if (i < p.elems) p.s_out[k][i] = trig ? p.s_old[k][i] : p.s_new[k][i];
 }
 
+
+// ---- the frame losses of train_model and their gradient in one pass (train.py:227-239) ---------------------------------------------
+// pred [S][K][n] (per time step the K decoder calls x_pred, x_target_pred, x_pred_gp in the reference's call order, :227-232),
+// target [S][n] (the ground-truth frame of the step).  sums[k] = sum over steps and elements of (pred - target)^2 - nn.MSELoss
+// per call, summed over the steps, times n - and dpred = 2 w[k] (pred - target): the gradient of sum_k w[k] sums[k], i.e. of
+// the frame terms of `loss` (:239) with w[k] = weight_k / n.  One read of pred / target, one write of dpred; per-workgroup
+// partial sums in a fixed order (deterministic), reduced by frame_losses_finish_kernel.
+template <int K>
+__global__ __launch_bounds__(256) void frame_losses_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           float* __restrict__ dpred, float* __restrict__ partial, long n4, int S,
+                                                           const float* __restrict__ w) {
+    __shared__ float red[4][K];
+    const long total = (long)S * n4;
+    float acc[K];
+    float w2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k] = 0.f; w2[k] = 2.f * w[k]; }
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long s = i / n4, e = i % n4;
+        const f32x4 t = reinterpret_cast<const f32x4*>(target)[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const long j = (s * K + k) * n4 + e;
+            const f32x4 p = reinterpret_cast<const f32x4*>(pred)[j];
+            f32x4 d, g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d[q] = p[q] - t[q];
+                acc[k] = fmaf(d[q], d[q], acc[k]);
+                g[q] = w2[k] * d[q];
+            }
+            reinterpret_cast<f32x4*>(dpred)[j] = g;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) partial[(size_t)blockIdx.x * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void frame_losses_finish_kernel(const float* __restrict__ partial, int blocks, int K,
+                                                                  float* __restrict__ sums) {
+    __shared__ double red[256];
+    for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += 256) a += (double)partial[(size_t)b * K + k];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = (float)red[0];
+        __syncthreads();
+    }
+}
+
+// sum (a - b)^2 and da = 2 scale (a - b) for a SMALL pair of tensors (the latent MSE of a closure: S x B x g_dim values,
+// train.py:188,223): one workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void mse_sum_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ sum, float* __restrict__ da, long n, float scale) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float d = a[i] - b[i];
+        acc += (double)d * (double)d;
+        if (da) da[i] = 2.f * scale * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *sum = (float)red[0];
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -675,4 +758,36 @@ extern "C" int dvg_gp_trigger_select(const int* flag, const float* sample_db, co
     const long n = std::max((long)B * D, state_elems);
     hipLaunchKernelGGL(gp_trigger_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dvg_gp_trigger_select");
+}
+
+// The frame terms of train_model's loss and their gradient (train.py:227-239): see frame_losses_kernel.  pred [S][K][n], target
+// [S][n], n % 4 == 0, K in {1, 2, 3}; w[K] on the device (weight_k / n); partial: workspace of dvg_frame_losses_blocks(S * n) * K
+// floats; sums[K] = raw sums of squares per call position.
+extern "C" int dvg_frame_losses_blocks(long elems) {
+    long b = (elems / 4 + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int dvg_frame_losses(const float* pred, const float* target, float* sums, float* dpred, long n, int S, int K,
+                                const float* w, float* partial, void* stream) {
+    DVG_REQUIRE(pred && target && sums && dpred && w && partial, DVG_ERR_NULL, "dvg_frame_losses: NULL pointer");
+    DVG_REQUIRE(n > 0 && n % 4 == 0 && S > 0 && K >= 1 && K <= 3, DVG_ERR_SHAPE, "dvg_frame_losses: n %% 4 == 0, K in 1..3 needed");
+    DVG_REQUIRE(aligned16(pred) && aligned16(target) && aligned16(dpred), DVG_ERR_ALIGN, "dvg_frame_losses: alignment");
+    const int blocks = dvg_frame_losses_blocks((long)S * n);
+    const hipStream_t st = (hipStream_t)stream;
+    if (K == 1) hipLaunchKernelGGL(frame_losses_kernel<1>, dim3(blocks), dim3(256), 0, st, pred, target, dpred, partial, n / 4, S, w);
+    else if (K == 2) hipLaunchKernelGGL(frame_losses_kernel<2>, dim3(blocks), dim3(256), 0, st, pred, target, dpred, partial, n / 4, S, w);
+    else hipLaunchKernelGGL(frame_losses_kernel<3>, dim3(blocks), dim3(256), 0, st, pred, target, dpred, partial, n / 4, S, w);
+    if (int e = check_launch("dvg_frame_losses")) return e;
+    hipLaunchKernelGGL(frame_losses_finish_kernel, dim3(1), dim3(256), 0, st, partial, blocks, K, sums);
+    return check_launch("dvg_frame_losses (finish)");
+}
+
+// *sum = sum (a - b)^2, da = 2 scale (a - b) (NULL: no gradient): the latent MSE of a closure and its gradient (train.py:188,
+// 223,239); small tensors (one workgroup).
+extern "C" int dvg_mse_sum_grad(const float* a, const float* b, float* sum, float* da, long n, float scale, void* stream) {
+    DVG_REQUIRE(a && b && sum, DVG_ERR_NULL, "dvg_mse_sum_grad: NULL pointer");
+    DVG_REQUIRE(n > 0 && n <= (1L << 24), DVG_ERR_SHAPE, "dvg_mse_sum_grad: 1 <= n <= 2^24 (one workgroup)");
+    hipLaunchKernelGGL(mse_sum_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, sum, da, n, scale);
+    return check_launch("dvg_mse_sum_grad");
 }

@@ -29,6 +29,44 @@ class _GPTrain(torch.autograd.Function):
             g["dell"].view_as(ell), None
 
 
+class _GPTrainSteps(torch.autograd.Function):
+    """_GPTrain for S time steps side by side: h (B, S * D), ONE parameter set of D latent dims read with period D by the
+    kernels (no tiled parameter copies); backward sums the per-(step, dim) parameter gradients over the steps in one launch."""
+
+    @staticmethod
+    def forward(ctx, h, z, m, ls, c, s, ell, jitter, S):
+        D = z.shape[0]
+        r = ops.gp_predict(h, z, m, ls, c, s, ell, want_var=True, want_kl=True, train_mode=True, jitter=jitter, param_period=D)
+        ctx.save_for_backward(h, z, m, ls, c, s, ell)
+        ctx.jitter, ctx.S = jitter, S
+        return r["mean"], r["var"], r["kl"]
+
+    @staticmethod
+    def backward(ctx, dmean, dvar, dkl):
+        h, z, m, ls, c, s, ell = ctx.saved_tensors
+        g = ops.gp_train_bwd(h, z, m, ls, c, s, ell, dmean, dvar, dkl, ctx.jitter, param_period=z.shape[0])
+        dz, dm, dls, dc, ds, dell = ops.sum_steps([g["dz"], g["dm"], g["dls"], g["dc"], g["ds"], g["dell"]], ctx.S)
+        return g["dh"], dz.view_as(z), dm.view_as(m), dls.view_as(ls), dc.view_as(c), ds.view_as(s), dell.view_as(ell), None, None
+
+
+class _GPElboSteps(torch.autograd.Function):
+    """_GPElbo on S x D rows with ONE raw-noise vector of D entries (noise period D)."""
+
+    @staticmethod
+    def forward(ctx, mean, var, kl, target, raw_noise, num_data, S):
+        ctx.save_for_backward(mean, var, kl, target, raw_noise)
+        ctx.num_data, ctx.S = num_data, S
+        return ops.gp_elbo(mean, var, kl, target, raw_noise, num_data, noise_period=raw_noise.numel())
+
+    @staticmethod
+    def backward(ctx, gelbo):
+        mean, var, kl, target, raw_noise = ctx.saved_tensors
+        gm, gv, gk, gt, gr = ops.gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, ctx.num_data,
+                                             need_gtarget=ctx.needs_input_grad[3], noise_period=raw_noise.numel())
+        (gr,) = ops.sum_steps([gr], ctx.S)
+        return gm, gv, gk.view_as(kl), gt, gr.view_as(raw_noise), None, None
+
+
 def gp_train(layer, h, noise):
     from .models.gp_models import JITTER
     vs = layer.variational_strategy
@@ -45,9 +83,10 @@ def gp_elbo_steps(layer, mll, hin, htgt):
     """The GP posterior + ELBO term of S teacher-forced time steps in ONE forward and ONE backward launch each
     (train.py:164-169 and :225-226 call `mll(gp_layer(h_i), h_target_i)` once per step; the steps share the GP's parameters
     and do not depend on each other).  hin, htgt: (S, B, D).  The S x D (step, latent dim) pairs are laid out as S * D
-    virtual latent dims - the kernels are one workgroup per dim and index every parameter by dim - with the parameters
-    tiled S times (torch `repeat`: its backward sums the S gradient copies) and the steps' codes side by side in a
-    (B, S * D) matrix.  Returns (elbo (S * D,), mean (S, B, D)): `-elbo.sum()` is the closure's sum over the steps of
+    virtual latent dims - the kernels are one workgroup per dim - whose workgroups read the ONE parameter set with period D
+    (r05; until r04 the parameters were tiled S times with torch `repeat`: 7 copies forward, 7 reshape + sum launches
+    backward per call) and whose parameter gradients are summed over the steps by one launch; the steps' codes sit side by
+    side in a (B, S * D) matrix.  Returns (elbo (S * D,), mean (S, B, D)): `-elbo.sum()` is the closure's sum over the steps of
     `-mll(...).sum()`, mean[i] what `gp_layer(h_i).mean.transpose(0, 1)` would be.  Values per (step, dim) are exactly
     the per-step calls' (same kernels, same arithmetic)."""
     from .models.gp_models import JITTER
@@ -57,12 +96,10 @@ def gp_elbo_steps(layer, mll, hin, htgt):
     vd = vs.variational_distribution
     s, ell, c = layer.hypers()
     hp = hin.permute(1, 0, 2).reshape(B, S * D)
-    mean, var, kl = _GPTrain.apply(hp, vs.inducing_points.squeeze(-1).repeat(S, 1), vd.variational_mean.repeat(S, 1),
-                                   vd.chol_variational_covar.repeat(S, 1, 1), c.repeat(S), s.repeat(S), ell.repeat(S),
-                                   JITTER)
+    mean, var, kl = _GPTrainSteps.apply(hp, vs.inducing_points.squeeze(-1), vd.variational_mean, vd.chol_variational_covar,
+                                        c, s, ell, JITTER, S)
     tgt = htgt.permute(1, 0, 2).reshape(B, S * D).transpose(0, 1)          # (S * D, B), strided like h_target.transpose(0, 1)
-    raw_noise = mll.likelihood.noise_covar.raw_noise.reshape(-1).repeat(S)
-    elbo = gp_elbo(mean, var, kl, tgt, raw_noise, mll.num_data)
+    elbo = _GPElboSteps.apply(mean, var, kl, tgt, mll.likelihood.noise_covar.raw_noise.reshape(-1), mll.num_data, S)
     return elbo, mean.view(S, D, B).transpose(1, 2)
 
 

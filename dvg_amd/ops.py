@@ -786,9 +786,11 @@ def stem_up_winograd_input(vec, w_kn, k, scale, shift, cout, *, act=ACT_LRELU, s
 # GP
 # ----------------------------------------------------------------------------------
 def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *, noise=None, eps=None,
-               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3, raw_hypers=False):
+               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3, raw_hypers=False, param_period=0):
     """h [B][D] (any strides); returns dict(mean [D][B], var, sample, cov, kl).  raw_hypers: outputscale / lengthscale /
-    noise are the RAW parameters, soft-plus'ed (noise: + 1e-4 floor) inside the kernel."""
+    noise are the RAW parameters, soft-plus'ed (noise: + 1e-4 floor) inside the kernel.
+    param_period = P > 0: h carries D = S x P columns - S time steps side by side - and column d uses the parameters of
+    latent dim d % P (the parameter tensors have P rows)."""
     _dev_f32(h, "gp_predict.h")
     h = h if h.is_contiguous() else h.contiguous()
     b, d = h.shape
@@ -804,18 +806,62 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
         if tuple(eps.shape) != (d, b):
             raise RuntimeError(f"gp_predict: eps must be ({d},{b})")
     args = [t.detach().contiguous().view(-1) for t in (z, var_mean, chol_var, mean_const, outputscale, lengthscale)]
-    if args[0].numel() != d * m or args[2].numel() != d * m * m or args[3].numel() != d:
-        raise RuntimeError("gp_predict: parameter shapes do not match (D,M)")
+    dp = param_period or d
+    if d % dp or args[0].numel() != dp * m or args[2].numel() != dp * m * m or args[3].numel() != dp:
+        raise RuntimeError("gp_predict: parameter shapes do not match (D,M) / the parameter period")
     nz = None if noise is None else noise.detach().contiguous().view(-1)
     _run("gp_predict", 0.0, 4.0 * (b * d + d * m * (m + 2) + 3 * d * b), lib().dvg_gp_predict, _p(h),
          *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov), _p(kl), b, d, m,
-         int(train_mode) | (2 if raw_hypers else 0), jitter, _stream())
+         int(train_mode) | (2 if raw_hypers else 0), jitter, int(param_period), _stream())
     return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}
 
 
 # ----------------------------------------------------------------------------------
 # backward (training) wrappers
 # ----------------------------------------------------------------------------------
+_LOSS_W = {}     # (device, weights) -> device tensor of per-call weights
+
+
+def frame_losses(pred, target, weights):
+    """pred (S, K, ...) - the K decoder calls of every step -, target (S, ...) contiguous: (sums (K,), dpred like pred) with
+    sums[k] = sum over steps and elements of (pred[:, k] - target)^2 and dpred = d(sum_k weights[k] sums[k]) / d pred, one pass
+    (dvg_frame_losses; train.py:227-239).  `weights`: K Python floats (loss weight / elements per call)."""
+    _dev_f32(pred, "frame_losses.pred")
+    _dev_f32(target, "frame_losses.target")
+    if not pred.is_contiguous() or not target.is_contiguous():
+        raise RuntimeError("frame_losses: contiguous operands expected")
+    s_, k = pred.shape[0], pred.shape[1]
+    n = target[0].numel()
+    if target.shape[0] != s_ or pred[0, 0].numel() != n or n % 4 or len(weights) != k or not 1 <= k <= 3:
+        raise RuntimeError(f"frame_losses: pred {tuple(pred.shape)} / target {tuple(target.shape)} / {len(weights)} weights")
+    key = (pred.device, tuple(float(w) for w in weights))
+    w = _LOSS_W.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("frame_losses: first call with these weights during a capture (run one eager iteration first)")
+        w = _LOSS_W[key] = torch.tensor(key[1], dtype=torch.float32, device=pred.device)
+    sums = torch.empty(k, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred)
+    partial = torch.empty(lib().dvg_frame_losses_blocks(s_ * n) * k, device=pred.device, dtype=torch.float32)
+    _run("frame_losses", 3.0 * pred.numel(), 4.0 * (2 * pred.numel() + target.numel()), lib().dvg_frame_losses, _p(pred), _p(target),
+         _p(sums), _p(dpred), n, s_, k, _p(w), _p(partial), _stream())
+    return sums, dpred
+
+
+def mse_sum_grad(a, b, scale, need_grad=True):
+    """(sum (a - b)^2 as a 0-dim tensor, 2 scale (a - b) or None) for small tensors (dvg_mse_sum_grad): a closure's latent MSE
+    and its gradient (train.py:188,223)."""
+    _dev_f32(a, "mse_sum_grad.a")
+    _dev_f32(b, "mse_sum_grad.b")
+    a, b = a.contiguous(), b.contiguous()
+    if a.shape != b.shape:
+        raise RuntimeError("mse_sum_grad: shape mismatch")
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    da = torch.empty_like(a) if need_grad else None
+    check(lib().dvg_mse_sum_grad(_p(a), _p(b), _p(out), _p(da), a.numel(), float(scale), _stream()), "mse_sum_grad")
+    return out, da
+
+
 def gp_var_norms(var: torch.Tensor) -> torch.Tensor:
     """(B,) L2 norm over the latent dims of a predictive variance (D,B): generate_frames.py:230,275's
     `np.linalg.norm(variance.cpu().numpy().transpose(), axis=1)` without the host round trip (dvg_gp_var_norms)."""
@@ -1150,23 +1196,26 @@ def lstm_gates_bwd(dh, dc, gates, c_prev, c_new):
     return dG, dcp
 
 
-def gp_elbo(mean, var, kl, target, raw_noise, num_data):
+def gp_elbo(mean, var, kl, target, raw_noise, num_data, noise_period=0):
     """VariationalELBO(combine_terms=True) with the Gaussian likelihood's expected log-probability -> (D,) (dvg_gp_elbo).
-    mean, var (D,B) contiguous, kl (D,), target (D,B) with any strides, raw_noise (D,) or (D,1)."""
+    mean, var (D,B) contiguous, kl (D,), target (D,B) with any strides, raw_noise (D,) or (D,1) - (P,) with noise_period = P:
+    row d uses raw_noise[d % P]."""
     for t, n in ((mean, "mean"), (var, "var"), (kl, "kl"), (target, "target"), (raw_noise, "raw_noise")):
         _dev_f32(t, "gp_elbo." + n)
     d, b = mean.shape
-    if tuple(var.shape) != (d, b) or tuple(target.shape) != (d, b) or kl.numel() != d or raw_noise.numel() != d:
+    if tuple(var.shape) != (d, b) or tuple(target.shape) != (d, b) or kl.numel() != d or raw_noise.numel() != (noise_period or d) \
+            or d % (noise_period or d):
         raise RuntimeError(f"gp_elbo: shapes mean {tuple(mean.shape)} var {tuple(var.shape)} target {tuple(target.shape)}")
     mean, var, kl, raw = mean.contiguous(), var.contiguous(), kl.contiguous(), raw_noise.reshape(-1).contiguous()
     out = torch.empty(d, device=mean.device, dtype=torch.float32)
     check(lib().dvg_gp_elbo(_p(mean), _p(var), _p(kl), _p(target), target.stride(0), target.stride(1), _p(raw), _p(out),
-                            b, d, int(num_data), _stream()), "gp_elbo")
+                            b, d, int(num_data), int(noise_period), _stream()), "gp_elbo")
     return out
 
 
-def gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, num_data, need_gtarget=True):
-    """Gradients of gp_elbo w.r.t. mean, var (D,B), kl (D,), target (D,B; None unless asked for), raw_noise (D,)."""
+def gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, num_data, need_gtarget=True, noise_period=0):
+    """Gradients of gp_elbo w.r.t. mean, var (D,B), kl (D,), target (D,B; None unless asked for), raw_noise (D,: one entry per
+    ROW also with a noise period - the caller sums the steps)."""
     d, b = mean.shape
     mean, var, kl, raw = mean.contiguous(), var.contiguous(), kl.contiguous(), raw_noise.reshape(-1).contiguous()
     gelbo = gelbo.contiguous()
@@ -1176,12 +1225,30 @@ def gp_elbo_bwd(mean, var, kl, target, raw_noise, gelbo, num_data, need_gtarget=
     gtarget = torch.empty((d, b), device=dev) if need_gtarget else None
     check(lib().dvg_gp_elbo_bwd(_p(mean), _p(var), _p(kl), _p(target), target.stride(0), target.stride(1), _p(raw),
                                 _p(gelbo), _p(gmean), _p(gvar), _p(gkl), _p(gtarget), _p(graw), b, d, int(num_data),
-                                _stream()), "gp_elbo_bwd")
+                                int(noise_period), _stream()), "gp_elbo_bwd")
     return gmean, gvar, gkl, gtarget, graw
 
 
-def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3):
-    """Gradients of the train-mode GP prediction (see dvg_gp_train_bwd)."""
+def sum_steps(tensors, steps):
+    """[t.view(steps, -1).sum(0) for t in tensors] as ONE launch (dvg_sum_steps_multi; up to 8 tensors): (steps * n_k,) -> (n_k,)."""
+    import ctypes as C
+    if not 1 <= len(tensors) <= 8:
+        raise RuntimeError("sum_steps: 1..8 tensors")
+    src = [t.contiguous() for t in tensors]
+    for t in src:
+        _dev_f32(t, "sum_steps")
+        if t.numel() % steps:
+            raise RuntimeError("sum_steps: tensor size is not a multiple of the step count")
+    dst = [torch.empty(t.numel() // steps, device=t.device, dtype=torch.float32) for t in src]
+    k = len(src)
+    check(lib().dvg_sum_steps_multi((C.c_void_p * k)(*[t.data_ptr() for t in src]), (C.c_void_p * k)(*[t.data_ptr() for t in dst]),
+                                    (C.c_long * k)(*[t.numel() for t in dst]), k, int(steps), _stream()), "sum_steps")
+    return dst
+
+
+def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3, param_period=0):
+    """Gradients of the train-mode GP prediction (see dvg_gp_train_bwd); with param_period = P the parameter gradients come
+    back per COLUMN of h (D = S x P rows: sum_steps adds the S copies up)."""
     h = h if h.is_contiguous() else h.contiguous()
     b, d = h.shape
     mm = z.shape[1]
@@ -1192,7 +1259,7 @@ def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3):
     g = [None if t is None else t.contiguous() for t in (gmean, gvar, gkl)]
     check(lib().dvg_gp_train_bwd(_p(h), *[_p(t) for t in args], *[_p(t) for t in g], _p(out["dh"]), _p(out["dz"]),
                                  _p(out["dm"]), _p(out["dls"]), _p(out["dc"]), _p(out["ds"]), _p(out["dell"]), b, d,
-                                 mm, jitter, _stream()), "gp_train_bwd")
+                                 mm, jitter, int(param_period), _stream()), "gp_train_bwd")
     return out
 
 

@@ -155,6 +155,11 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.grad is not gv:
                     p.grad = gv
 
+    def _restore_grad_views(self, f) -> None:
+        for p, gv in zip(f["params"], f["gviews"]):
+            if p.grad is not gv:
+                p.grad = gv
+
     # ---- hipGraph support -------------------------------------------------------------------------------
     def begin_capture(self) -> None:
         """Call right before capturing a graph that contains step(): the device step counts are synchronised with the
@@ -205,11 +210,17 @@ class FusedAdam(torch.optim.Optimizer):
                     for p, gv in zip(f["params"], f["gviews"]):
                         p.grad = gv
                 t = steps.pop() + 1
-                if not capturing:
-                    f["tdev"].fill_(t - 1)           # host and device counts agree outside a capture
-                f["tdev"].add_(1)
+                if capturing:
+                    # the count lives on the device (begin_capture synchronised it): advanced by the zero_grads() launch of
+                    # this capture when there was one since the group's last step, else by a one-element add
+                    if not f.pop("ticked", False):
+                        f["tdev"].add_(1)
+                    tdev = f["tdev"]
+                else:
+                    tdev = None                      # eager: the host count goes in as an argument, no device-side bookkeeping
+                    f.pop("ticked", None)
                 check(lib().dvg_adam_step(ops._p(f["p"]), ops._p(f["g"]), ops._p(f["m"]), ops._p(f["v"]),
-                                          f["p"].numel(), *hyper, t, ops._p(f["tdev"]), ops._stream()), "dvg_adam_step")
+                                          f["p"].numel(), *hyper, t, ops._p(tdev), ops._stream()), "dvg_adam_step")
                 touched = f["params"]
                 if capturing:
                     self._captured_groups.append(gi)
@@ -235,3 +246,36 @@ class FusedAdam(torch.optim.Optimizer):
                 if not capturing:                # a capture executes nothing: after_graph_replay() counts the replays
                     self.state[p]["step"] += 1
         return loss
+
+
+@torch.no_grad()
+def zero_grads(optimizers) -> None:
+    """`zero_grad()` of several FusedAdam optimisers whose groups live in ONE arena (train.py:201-203: encoder, decoder and
+    frame predictor at the top of train_model): adjacent ranges of the gradient arena are zeroed by one launch
+    (dvg_zero_tick), and during a hipGraph capture the same launch advances the device-side step counts of those groups
+    (step() then skips its one-element increment).  Optimisers without flat arena storage fall back to their own zero_grad."""
+    spans = []
+    for o in optimizers:
+        fl = getattr(o, "_flat", None)
+        if not isinstance(o, FusedAdam) or o.arena is None or not fl or any(not f for f in fl.values()):
+            o.zero_grad()
+            continue
+        for f in fl.values():
+            spans.append((o.arena, f["lo"], f["hi"], f, o))
+    capturing = torch.cuda.is_current_stream_capturing()
+    spans.sort(key=lambda s_: (id(s_[0]), s_[1]))
+    i = 0
+    while i < len(spans):
+        arena, lo, hi = spans[i][0], spans[i][1], spans[i][2]
+        group = [spans[i]]
+        while (i + 1 < len(spans) and spans[i + 1][0] is arena and spans[i + 1][1] == hi and len(group) < 4):
+            i += 1
+            hi = spans[i][2]
+            group.append(spans[i])
+        ticks = [ops._p(s_[3]["tdev"]) if capturing else None for s_ in group] + [None] * (4 - len(group))
+        check(lib().dvg_zero_tick(ops._p(arena.g[lo:hi]), hi - lo, *ticks, ops._stream()), "dvg_zero_tick")
+        for s_ in group:
+            if capturing:
+                s_[3]["ticked"] = True
+            s_[4]._restore_grad_views(s_[3])
+        i += 1

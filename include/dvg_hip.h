@@ -411,7 +411,11 @@ int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
                    const float* outputscale, const float* lengthscale,
                    const float* noise, const float* eps, float* mean, float* var,
                    float* sample, float* cov, float* kl, int B, int D, int M,
-                   int train_mode, float jitter, void* stream);
+                   int train_mode, float jitter,
+                   int param_period /* ABI 8; 0 = D.  Workgroup d reads the parameters (z, var_mean, chol_var, mean_const,
+                                       outputscale, lengthscale, noise) of latent dim d % param_period: the S time steps of a
+                                       training closure side by side as D = S * g_dim dims on ONE parameter set */,
+                   void* stream);
 
 /* ------------------------------------------------------------------ *
  * Backward (training) entry points: what `loss.backward()` (train.py:170,194,240)
@@ -566,7 +570,11 @@ int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, cons
                      const float* mean_const, const float* outputscale, const float* lengthscale,
                      const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
                      float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
-                     float jitter, void* stream);
+                     float jitter, int param_period /* ABI 8, as dvg_gp_predict; gradients are written per workgroup d
+                                                       (dvg_sum_steps_multi adds the S copies up) */, void* stream);
+/* dst_k[i] = sum over s < S of src_k[s * n_k + i] for count <= 8 tensors in one launch (host arrays of device pointers / sizes):
+ * the per-(step, latent dim) parameter gradients of a closure's S side-by-side time steps -> one gradient per parameter.  ABI 8. */
+int dvg_sum_steps_multi(const float* const* src, float* const* dst, const long* n, int count, int S, void* stream);
 
 /* VariationalELBO(likelihood, gp_layer, num_data, combine_terms=True)(pred, target) with the GaussianLikelihood's
  * expected log-probability (train.py:102,112; called at train.py:164-169,225-226): per latent dim d
@@ -577,10 +585,12 @@ int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, cons
  * dvg_gp_elbo_bwd: given gelbo [D] -> gmean, gvar [D][B], gkl [D], gtarget [D][B] (may be NULL), graw_noise [D]
  * (soft-plus chain included).  ABI 5. */
 int dvg_gp_elbo(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
-                long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data, void* stream);
+                long t_stride_b, const float* raw_noise, float* elbo, int B, int D, int num_data,
+                int noise_period /* ABI 8; 0 = D: workgroup d reads raw_noise[d % noise_period] */, void* stream);
 int dvg_gp_elbo_bwd(const float* mean, const float* var, const float* kl, const float* target, long t_stride_d,
                     long t_stride_b, const float* raw_noise, const float* gelbo, float* gmean, float* gvar,
-                    float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, void* stream);
+                    float* gkl, float* gtarget, float* graw_noise, int B, int D, int num_data, int noise_period,
+                    void* stream);
 
 /* ------------------------------------------------------------------ *
  * Small elementwise helpers on the path
@@ -623,6 +633,23 @@ int dvg_gp_trigger_replay(const float* values, int n, const float* ctx0, int win
 int dvg_gp_trigger_select(const int* flag, const float* sample_db, const float* h_pred, float* vec, int D, int B, int n_state,
                           long state_elems, const float* const* state_old, const float* const* state_new,
                           float* const* state_out, void* stream);
+
+/* ---- losses of the step closures and their gradients in one pass (train.py:188,223,227-239; ABI 8) ---------------------------
+ * dvg_frame_losses: pred [S][K][n] - per time step the K decoder calls in the reference's call order (x_pred, x_target_pred,
+ * x_pred_gp, :227-232) -, target [S][n] (the step's ground-truth frame): sums[k] = sum over steps and elements of
+ * (pred - target)^2 (= n x the sum over steps of nn.MSELoss of call k) and dpred = 2 w[k] (pred - target), the gradient of
+ * sum_k w[k] sums[k] - the frame terms of `loss` (:239) with w[k] = weight_k / n - in ONE read of pred / target.  w on the
+ * device; partial: dvg_frame_losses_blocks(S * n) * K floats of workspace; n % 4 == 0, K <= 3.  Deterministic.
+ * dvg_mse_sum_grad: *sum = sum (a - b)^2, da = 2 scale (a - b) (NULL: value only) for the latent MSE terms.              */
+int dvg_frame_losses_blocks(long elems);
+int dvg_frame_losses(const float* pred, const float* target, float* sums, float* dpred, long n, int S, int K, const float* w,
+                     float* partial, void* stream);
+int dvg_mse_sum_grad(const float* a, const float* b, float* sum, float* da, long n, float scale, void* stream);
+
+/* optimizer.zero_grad() of adjacent parameter groups of the gradient arena as ONE fill (train.py:201-203 zeroes three modules),
+ * and the device-side Adam step counts t0..t3 (NULL: none) advanced by one in the same launch (dvg_adam_step's step_dev): a
+ * captured iteration needs no one-element increment launch per optimiser step.  ABI 8.                                   */
+int dvg_zero_tick(float* g, long n, int* t0, int* t1, int* t2, int* t3, void* stream);
 
 #ifdef __cplusplus
 }

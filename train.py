@@ -44,7 +44,7 @@ import utils  # noqa: E402
 from dvg_amd import fused, parallel  # noqa: E402
 from dvg_amd.data import SyntheticMovingMNIST, synthetic_video  # noqa: E402
 from dvg_amd.models.gp_models import GaussianLikelihood, GPRegressionLayer1, VariationalELBO  # noqa: E402
-from dvg_amd.optim import FlatArena, FusedAdam  # noqa: E402
+from dvg_amd.optim import FlatArena, FusedAdam, zero_grads  # noqa: E402
 
 
 def build_parser():
@@ -136,6 +136,10 @@ class Trainer:
         self.lstm_sequence = os.environ.get("DVG_LSTM_SEQ", "1") != "0"
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
         self.latent_stream = True
+        # True = the closures' losses and their gradients by dvg_frame_losses / dvg_mse_sum_grad, backward seeded with them
+        # (no scalar autograd graph of torch ops); False: the torch composition (tests compare the two)
+        self.fused_losses = True
+        self._loss_w = {}
         self._side_stream = None
         # optim.Adam(lr=0.002) x4 (train.py:95-104) as one fused HIP launch per parameter group.  All groups live in ONE
         # flat arena in the order [GP | likelihood | LSTM | decoder | encoder]: parameters, gradients (p.grad are views)
@@ -295,6 +299,16 @@ class Trainer:
     def train_GP_Frame_predictor(self, x):
         return float(self._train_gp_dev(x)) / (self.opt.n_past + self.opt.n_future)
 
+    def _loss_weights(self, dev, n_call, D):
+        """[0.001 / n, 1000 / n, 0.001 / n, 0.01, -0.0001 x D]: train.py:239's weights on (sum sq mse, ae_mse, mse_gp, mse_latent,
+        elbo_d) - max_ll = -elbo -; its tail [4:] is d loss / d elbo."""
+        key = (dev, n_call, D)
+        w = self._loss_w.get(key)
+        if w is None:
+            w = self._loss_w[key] = torch.tensor([0.001 / n_call, 1000.0 / n_call, 0.001 / n_call, 0.01] + [-0.0001] * D,
+                                                 dtype=torch.float32, device=dev)
+        return w
+
     def train_frame_predictor(self, x):
         return float(self._train_fp_dev(x)) / (self.opt.n_past + self.opt.n_future)
 
@@ -306,8 +320,9 @@ class Trainer:
 
     def _train_gp_dev(self, x):
         opt = self.opt
-        self.optimizer.zero_grad()
-        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        zero_grads([self.optimizer])
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden() if not (self.time_batched and self.gp_layer.training) \
+            else None          # (the time-batched GP closure has no recurrence: nothing reads `hidden`)
         max_ll = 0
         skip = None
         g = self.finetune_encoder_grad
@@ -323,6 +338,15 @@ class Trainer:
             from dvg_amd.gp_autograd import gp_elbo_steps
             hcat = torch.stack([e[0].detach() for e in enc_all])          # (T, B, D)
             elbo, _ = gp_elbo_steps(self.gp_layer, self.mll, hcat[:-1], hcat[1:])
+            if self.fused_losses:     # loss = (-elbo).sum(): d loss / d elbo = -1, no scalar graph
+                gneg = self._loss_w.get(("neg1", elbo.device, elbo.numel()))
+                if gneg is None:
+                    gneg = self._loss_w[("neg1", elbo.device, elbo.numel())] = torch.full((elbo.numel(),), -1.0, device=elbo.device)
+                loss = torch.dot(elbo.detach(), gneg)
+                elbo.backward(gneg)
+                self._ar(("reduce", self.rng_gp))
+                self.optimizer.step()
+                return loss
             max_ll = -elbo
         else:
             for i in range(1, opt.n_past + opt.n_future):
@@ -342,8 +366,9 @@ class Trainer:
 
     def _train_fp_dev(self, x):
         opt = self.opt
-        self.frame_predictor_optimizer.zero_grad()   # frame_predictor.zero_grad() (train.py:176): one fill of the flat range
-        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        zero_grads([self.frame_predictor_optimizer])   # frame_predictor.zero_grad() (train.py:176): one fill of the flat range
+        if not self._lstm_seq_applies():                  # (the sequence form starts from its own zero state)
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         mse_latent = 0
         skip = None
         g = self.finetune_encoder_grad   # only frame_predictor_optimizer steps (train.py:195-196)
@@ -361,6 +386,14 @@ class Trainer:
             from dvg_amd.models.lstm import forward_sequence
             hcat = torch.stack([e[0].detach() for e in enc_all])              # (T, B, D)
             pred = forward_sequence(self.frame_predictor, hcat[:-1])
+            if self.fused_losses:     # the sum of squares and its gradient in one launch; backward starts from d mse / d pred
+                from dvg_amd import ops
+                sq, d_pred = ops.mse_sum_grad(pred.detach(), hcat[1:], 1.0 / float(hcat[0].numel()))
+                mse_latent = sq / float(hcat[0].numel())
+                pred.backward(d_pred)
+                self._ar(("reduce", self.rng_fp))
+                self.frame_predictor_optimizer.step()
+                return mse_latent
             d = pred - hcat[1:]
             mse_latent = (d * d).sum() / float(hcat[0].numel())                # sum over the steps of nn.MSELoss (mean)
         else:
@@ -391,12 +424,11 @@ class Trainer:
         T = opt.n_past + opt.n_future
         S = T - 1
         B = x[0].shape[0]
-        self.encoder_optimizer.zero_grad()
-        self.decoder_optimizer.zero_grad()
-        self.frame_predictor_optimizer.zero_grad()
-        if not self.reference_gp_grad_leak:
-            self.optimizer.zero_grad()
-        self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203) - adjacent ranges of the gradient arena: one fill
+        zero_grads([self.encoder_optimizer, self.decoder_optimizer, self.frame_predictor_optimizer] +
+                   ([] if self.reference_gp_grad_leak else [self.optimizer]))
+        if not self._lstm_seq_applies():      # (the sequence form starts from its own zero state and never reads `hidden`)
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
         frames = _adjacent_view(list(x[:T]))
         if frames is None:
             frames = torch.cat(list(x[:T]), 0)
@@ -415,12 +447,17 @@ class Trainer:
         elbo, gp_means = gp_elbo_steps(self.gp_layer, self.mll, h_leaf[:S * B].view(S, B, D), h_leaf[B:].view(S, B, D))
         max_ll = -elbo
         # latent chain (the only recurrence): the LSTM steps
+        fused_losses = self._lstm_seq_applies() and self.fused_losses
         if self._lstm_seq_applies():
             from dvg_amd.models.lstm import forward_sequence
             tgt_h = h_leaf[B:].view(S, B, D)
             pred = forward_sequence(self.frame_predictor, h_leaf[:S * B].view(S, B, D))      # (S, B, D)
-            dlat = pred - tgt_h
-            mse_latent = (dlat * dlat).sum() / float(B * D)                                      # sum over the steps of nn.MSELoss
+            if fused_losses:     # sum of squares + its gradient in one launch (the scalar graph of :223,239 is not built)
+                lat_sq, d_pred = ops.mse_sum_grad(pred.detach(), tgt_h.detach(), 0.01 / float(B * D))
+                mse_latent = lat_sq / float(B * D)
+            else:
+                dlat = pred - tgt_h
+                mse_latent = (dlat * dlat).sum() / float(B * D)                                  # sum over the steps of nn.MSELoss
             vec_all = torch.stack([pred, tgt_h, gp_means], 1).reshape(3 * S * B, D)              # reference call order
         else:
             mse_latent = 0
@@ -438,13 +475,26 @@ class Trainer:
         shared = [ops.SharedBlocks(s[:nblk * B], B, mdev, gmap) for s in sk_leaf]
         with fused.bn_groups(3 * S, (1, 1, 1)):
             x_all = self.decoder([vec_all, shared])               # (3 S B, nc, H, W)
-        tgt = frames[B:].view(S, 1, B, *frames.shape[1:])
-        per = x_all.view(S, 3, B, *frames.shape[1:]) - tgt
-        # nn.MSELoss per call, summed over the steps = sum of squares / elements per call
-        sq = (per * per).sum((0, 2, 3, 4, 5)) / float(per[0, 0].numel())
-        mse, ae_mse, mse_gp = sq[0], sq[1], sq[2]
-        loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
-        loss.backward()
+        if fused_losses:
+            # loss = 1000 ae_mse + 0.001 mse + 0.01 mse_latent + 0.001 mse_gp + 0.0001 max_ll.sum() (train.py:239) WITHOUT its
+            # scalar autograd graph: the three frame terms' sums of squares and d loss / d x_all in one pass over the 3 S decoder
+            # outputs (ops.frame_losses; call order x_pred, x_target_pred, x_pred_gp = mse, ae_mse, mse_gp), the latent term's
+            # above, d loss / d elbo = -0.0001; backward starts from those seeds.  ~40 elementwise / reduction launches of torch
+            # per iteration (two of them passes over all 3 S B frames) become 3.
+            n_call = float(frames[0].numel() * B)
+            sq, d_x = ops.frame_losses(x_all.detach().view(S, 3, -1), frames[B:].view(S, -1),
+                                       (0.001 / n_call, 1000.0 / n_call, 0.001 / n_call))
+            wv = self._loss_weights(x_all.device, n_call, D)
+            loss = torch.dot(torch.cat([sq, mse_latent.view(1), elbo.detach()]), wv)
+            torch.autograd.backward([x_all, pred, tgt_h, elbo], [d_x.view_as(x_all), d_pred, -d_pred, wv[4:]])
+        else:
+            tgt = frames[B:].view(S, 1, B, *frames.shape[1:])
+            per = x_all.view(S, 3, B, *frames.shape[1:]) - tgt
+            # nn.MSELoss per call, summed over the steps = sum of squares / elements per call
+            sq = (per * per).sum((0, 2, 3, 4, 5)) / float(per[0, 0].numel())
+            mse, ae_mse, mse_gp = sq[0], sq[1], sq[2]
+            loss = 1000 * ae_mse + 0.001 * mse + 0.01 * mse_latent + 0.001 * mse_gp + 0.0001 * max_ll.sum()
+            loss.backward()
         if staged:
             self._ar(("start", "a", (self.rng_gp[0], self.rng_dec[1])))
             outs, seeds = [h_all], [h_leaf.grad]
