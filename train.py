@@ -301,7 +301,7 @@ class Trainer:
 
     def _loss_weights(self, dev, n_call, D):
         """[0.001 / n, 1000 / n, 0.001 / n, 0.01, -0.0001 x D]: train.py:239's weights on (sum sq mse, ae_mse, mse_gp, mse_latent,
-        elbo_d) - max_ll = -elbo -; its tail [4:] is d loss / d elbo."""
+        the D = S x g_dim entries of elbo) - max_ll = -elbo -; its tail [4:] is d loss / d elbo."""
         key = (dev, n_call, D)
         w = self._loss_w.get(key)
         if w is None:
@@ -484,7 +484,7 @@ class Trainer:
             n_call = float(frames[0].numel() * B)
             sq, d_x = ops.frame_losses(x_all.detach().view(S, 3, -1), frames[B:].view(S, -1),
                                        (0.001 / n_call, 1000.0 / n_call, 0.001 / n_call))
-            wv = self._loss_weights(x_all.device, n_call, D)
+            wv = self._loss_weights(x_all.device, n_call, elbo.numel())       # elbo: one entry per (step, latent dim)
             loss = torch.dot(torch.cat([sq, mse_latent.view(1), elbo.detach()]), wv)
             torch.autograd.backward([x_all, pred, tgt_h, elbo], [d_x.view_as(x_all), d_pred, -d_pred, wv[4:]])
         else:
