@@ -31,6 +31,13 @@ def main():
         eps = torch.randn(D, B, device=dev)
         smp = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, noise=s, eps=eps, jitter=1e-3), iters=100)
         print(f"B={B:4d}  gp_train_bwd {bwd:7.1f} us   gp_predict(train, KL) {fwd:7.1f} us   gp_predict(eval, sample) {smp:7.1f} us")
+    # the S time steps of a training closure side by side (gp_autograd.gp_elbo_steps): S * D workgroups on one parameter set
+    for B, S in ((16, 11), (4, 15), (64, 19)):
+        h = torch.tanh(torch.randn(B, S * D, device=dev))
+        gm, gv, gk = torch.randn(S * D, B, device=dev), torch.randn(S * D, B, device=dev), torch.randn(S * D, device=dev)
+        bwd = time_fn(lambda: ops.gp_train_bwd(h, z, m, ls, c, s, ell, gm, gv, gk, 1e-3, param_period=D), iters=50)
+        fwd = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, train_mode=True, want_kl=True, jitter=1e-3, param_period=D), iters=50)
+        print(f"B={B:4d} S={S:3d} ({S * D} workgroups)  gp_train_bwd {bwd:7.1f} us   gp_predict(train, KL) {fwd:7.1f} us")
 
 
 if __name__ == "__main__":

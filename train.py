@@ -321,8 +321,7 @@ class Trainer:
     def _train_gp_dev(self, x):
         opt = self.opt
         zero_grads([self.optimizer])
-        self.frame_predictor.hidden = self.frame_predictor.init_hidden() if not (self.time_batched and self.gp_layer.training) \
-            else None          # (the time-batched GP closure has no recurrence: nothing reads `hidden`)
+        self.frame_predictor.hidden = None      # train.py:150 re-creates it here, but this closure never steps the LSTM
         max_ll = 0
         skip = None
         g = self.finetune_encoder_grad
@@ -367,8 +366,8 @@ class Trainer:
     def _train_fp_dev(self, x):
         opt = self.opt
         zero_grads([self.frame_predictor_optimizer])   # frame_predictor.zero_grad() (train.py:176): one fill of the flat range
-        if not self._lstm_seq_applies():                  # (the sequence form starts from its own zero state)
-            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        self.frame_predictor.hidden = None               # (re-created below by the step-by-step path; the sequence form starts
+        #                                                   from its own zero state and leaves None behind)
         mse_latent = 0
         skip = None
         g = self.finetune_encoder_grad   # only frame_predictor_optimizer steps (train.py:195-196)
@@ -397,6 +396,7 @@ class Trainer:
             d = pred - hcat[1:]
             mse_latent = (d * d).sum() / float(hcat[0].numel())                # sum over the steps of nn.MSELoss (mean)
         else:
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()       # train.py:178
             for i in range(1, opt.n_past + opt.n_future):
                 h, skip = self._skip_rule(i, self._enc(enc_all, x, i - 1, g), skip)
                 h_target = self._enc(enc_all, x, i, g)[0]
@@ -427,8 +427,7 @@ class Trainer:
         # encoder / decoder / frame_predictor .zero_grad() (train.py:201-203) - adjacent ranges of the gradient arena: one fill
         zero_grads([self.encoder_optimizer, self.decoder_optimizer, self.frame_predictor_optimizer] +
                    ([] if self.reference_gp_grad_leak else [self.optimizer]))
-        if not self._lstm_seq_applies():      # (the sequence form starts from its own zero state and never reads `hidden`)
-            self.frame_predictor.hidden = self.frame_predictor.init_hidden()
+        self.frame_predictor.hidden = None    # (the step-by-step branch below re-creates it; the sequence form never reads it)
         frames = _adjacent_view(list(x[:T]))
         if frames is None:
             frames = torch.cat(list(x[:T]), 0)
@@ -460,6 +459,7 @@ class Trainer:
                 mse_latent = (dlat * dlat).sum() / float(B * D)                                  # sum over the steps of nn.MSELoss
             vec_all = torch.stack([pred, tgt_h, gp_means], 1).reshape(3 * S * B, D)              # reference call order
         else:
+            self.frame_predictor.hidden = self.frame_predictor.init_hidden()       # train.py:206
             mse_latent = 0
             vecs = []
             for i in range(1, T):
