@@ -810,7 +810,18 @@ using namespace dvg;
 #ifndef GP_BWD_THREADS
 #define GP_BWD_THREADS 1024
 #endif
-static int gp_threads(int dflt) { return dflt; }      // (256 / 512-thread instantiations exist: see the dispatch below)
+// Threads per workgroup by shape (r05, tools/bench_gp.py on lib variants built with -DGP_*_THREADS=...; us per launch):
+//   one GP call (D = 90 workgroups < 256 CUs): 1024 threads is fastest or tied for every kernel (latency of one workgroup);
+//   the S steps of a training closure side by side (D = S x 90 >= 990 workgroups, several rounds): train-mode predict
+//   B=16,S=11 171 (1024) / 152 (512) / 105 (256);  B=4,S=15 245 / 219 / 140;  B=64,S=19 322 / 322 / 242 -> 256 threads: its 38-70 KB
+//   of LDS let 2-4 small workgroups share a CU and overlap their serial Cholesky chains;
+//   backward (75-154 KB of LDS: one workgroup per CU whatever its size) B=16 379 / 342 / 420;  B=4 505 / 458 / 538;  B=64
+//   851 / 860 / 1134 -> 512 threads up to B = 32, else 1024.
+static int gp_threads(int dflt, int D, int B, bool bwd) {
+    if (D < 512) return dflt;
+    if (!bwd) return 256;
+    return B <= 32 ? 512 : dflt;
+}
 static bool gp_force_fp32() { return false; }        // fp32 variants only run where the fp64 working set does not fit the LDS
 static constexpr size_t GP_LDS_MAX = 160 * 1024;
 
@@ -896,7 +907,7 @@ extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_m
                 "dvg_gp_predict: param_period=%d must divide D=%d", param_period, D);
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
                B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, param_period ? param_period : D, g_gp_clk, g_gp_clk_cap};
-    const int nt = gp_threads(GP_PREDICT_THREADS);
+    const int nt = gp_threads(GP_PREDICT_THREADS, D, B, false);
     const char* who = "dvg_gp_predict";
     const int variant = gp_predict_variant(B, M, need_cov);
     if (variant == 2) {
@@ -937,7 +948,7 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
                   dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(B, M), param_period ? param_period : D, jitter,
                   g_gp_clk, g_gp_clk_cap};
-    const int nt = gp_threads(GP_BWD_THREADS);
+    const int nt = gp_threads(GP_BWD_THREADS, D, B, true);
     const char* who = "dvg_gp_train_bwd";
     if (dvg_gp_bwd_precision(B, M) == 64) {
         switch (nt) {

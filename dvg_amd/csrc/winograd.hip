@@ -17,12 +17,10 @@
 // Nontemporal hints on the transforms' read-once M loads / written-once V stores.  r05 same-box A/B on the vgg_64 rollout, each
 // twice: M loads of the chain kernels nontemporal 49.41 / 49.53 k frames/s in flight against 48.87 / 49.23 (+0.9 %), one chain
 // 15.28 against 15.34 ms -> default; V stores nontemporal 49.32 / 49.24 (noise) -> not taken; the GEMM's M store nontemporal
-// 48.86 / 49.07 (-0.3 %) -> not taken.  DVG_WINO_NT_LOAD2: the same hint in the 8 x 8 hand-over and the plain output kernels.
+// 48.86 / 49.07 (-0.3 %) -> not taken; the same load hint in the 8 x 8 hand-over and the plain output kernels 49.11 / 49.01
+// against 49.13 / 48.94 (noise) -> not taken.
 #ifndef DVG_WINO_NT_LOAD
 #define DVG_WINO_NT_LOAD 1
-#endif
-#ifndef DVG_WINO_NT_LOAD2
-#define DVG_WINO_NT_LOAD2 0
 #endif
 #ifndef DVG_WINO_NT_STORE
 #define DVG_WINO_NT_STORE 0
@@ -32,13 +30,6 @@ namespace dvg {
 
 template <typename V> __device__ __forceinline__ V wino_ld(const V* p) {
 #if DVG_WINO_NT_LOAD
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <typename V> __device__ __forceinline__ V wino_ld2(const V* p) {
-#if DVG_WINO_NT_LOAD2
     return __builtin_nontemporal_load(p);
 #else
     return *p;
@@ -343,7 +334,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
         for (int b = 0; b < 6; ++b) {
             V q[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) q[a] = wino_ld2(reinterpret_cast<const V*>(m) + ((size_t)(a * 6 + b) * T + t) * C4 + c4);
+            for (int a = 0; a < 6; ++a) q[a] = reinterpret_cast<const V*>(m)[((size_t)(a * 6 + b) * T + t) * C4 + c4];
             V col[4];
             at4(q, col);
 #pragma unroll
@@ -408,7 +399,7 @@ __global__ __launch_bounds__(256) void winograd4_out_in_kernel(const float* __re
         for (int b = 0; b < 6; ++b) {
             float q[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) q[a] = wino_ld2(m + ((size_t)(a * 6 + b) * T + t) * C + c);
+            for (int a = 0; a < 6; ++a) q[a] = m[((size_t)(a * 6 + b) * T + t) * C + c];
             float col[4];
             at4(q, col);
 #pragma unroll

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: GPU tests dominated by the CPU oracle at the reference's batch sizes (minutes); part of the "
+                                       "default `-m gpu` run, left out of the per-switch matrix (tools/test_switches.sh)")
 
 
 @pytest.fixture(scope="session")
