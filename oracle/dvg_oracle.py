@@ -605,7 +605,7 @@ def best_ssim(ssim) -> List[int]:
 def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, eps_by_step: Dict[int, torch.Tensor],
                    warmup: int = 12, total: int = 105, depth: int = 1, skip_steps: int = 5, probe: int = 3,
                    rnn_size: int = 256, n_layers: int = 2, gp_dtype=torch.float64,
-                   decisions: Optional[Dict[int, bool]] = None, guard: float = 0.0) -> dict:
+                   decisions: Optional[Dict[int, bool]] = None, guard: float = 0.0, memo: Optional[dict] = None) -> dict:
     """ONE pass of the `for index in range(batch_size)` body of GPtrigger_gen (generate_frames.py:249-298) with
     `generation` (:220-224) and `var_value` (:227-232) inlined.  The reference's bookkeeping, kept verbatim:
       * the rollout is autoregressive from x[0] alone (x_in = x_out, :280,297) - no ground-truth frame after the first;
@@ -621,6 +621,9 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
     |threshold| is of that size, and untrained networks roll out towards a fixed point where it is.  With `decisions`
     ({step: bool}, the branches another implementation took) a step whose OWN margin is below `guard` follows that implementation's
     branch and is reported in `forced`; every other step decides for itself.  All arithmetic stays this function's.
+    memo (tests): a dict shared by calls on the SAME inputs / parameters / eps: the rollout is a deterministic function of the
+    decisions taken so far, so a step already computed under the same decision prefix (another batch index) is looked up -
+    frame, recurrent state, per-sample variance norms - instead of recomputed.
     Returns dict(frames, triggers, values, thresholds, margins, forced)."""
     import numpy as np
     hidden = lstm_init_hidden(x[0].shape[0], rnn_size, n_layers, dtype=x[0].dtype)
@@ -637,18 +640,31 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
     context, values, thresholds, triggers, gen_seq, margins, forced = [], [], [], [], [], [], []
     x_in, skip = x[0], None
     for i in range(warmup):                                                # :266-280
-        h, sk = enc(x_in)
-        if i < skip_steps:
-            skip = sk
-        value = var_norms(h)[0][index]                                     # :275
+        hit = None if memo is None else memo.get(("warm", i))
+        if hit is None:
+            h, sk = enc(x_in)
+            if i < skip_steps:
+                skip = sk
+            norms = var_norms(h)[0]
+            x_in = generation(x_in, skip)
+            if memo is not None:
+                memo[("warm", i)] = (norms, x_in, list(hidden), skip)
+        else:
+            norms, x_in, hidden[:], skip = hit[0], hit[1], list(hit[2]), hit[3]
+        value = norms[index]                                               # :275
         context.append(value)
         values.append(float(value))
-        x_in = generation(x_in, skip)
         gen_seq.append(x_in)
     context = np.array(context)                                            # :283
     for i in range(warmup, total):                                         # :285-297
-        h = enc(x_in)[0]
-        norms, p = var_norms(h)
+        pre = None if memo is None else memo.get(("pre", i, tuple(triggers)))
+        if pre is None:
+            h = enc(x_in)[0]
+            norms, p = var_norms(h)
+            if memo is not None:
+                memo[("pre", i, tuple(triggers))] = (h, norms, p)
+        else:
+            h, norms, p = pre
         value = norms[probe]                                               # :230 - sample 3, not `index`
         context = np.concatenate([context[1:], [value]])                   # :231
         threshold = np.mean(context) + (2 + 0.01 * depth) * np.std(context)   # :288
@@ -657,11 +673,17 @@ def gp_trigger_gen(x, enc, dec, lstm_sd: SD, gp_sd: SD, lik_sd: SD, index: int, 
         if decisions is not None and margins[-1] < guard:
             take = bool(decisions[i])
             forced.append(i)
-        if take:                                                           # :289-292
+        post = None if memo is None else memo.get(("post", i, tuple(triggers), take))
+        if post is not None:
+            x_in, hidden[:] = post[0], list(post[1])
+        elif take:                                                         # :289-292
             x_in = dec(gp_rsample(p["mean"], p["cov"], eps_by_step[i]).t().to(h.dtype), skip)
-            triggers.append(i)
         else:
-            x_in = generation(x_in, skip)                                  # :295
+            x_in = dec(lstm_step(h, lstm_sd, hidden), skip)                # :295 generation(): its encoder call is `h` above
+        if memo is not None and post is None:
+            memo[("post", i, tuple(triggers), take)] = (x_in, list(hidden))
+        if take:
+            triggers.append(i)
         values.append(float(value))
         thresholds.append(float(threshold))
         gen_seq.append(x_in)

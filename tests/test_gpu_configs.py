@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import our_module, rel_err, to64, yardstick
+from tests.common import YARDSTICK_AT_SCALE, our_module, rel_err, to64, yardstick
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -119,10 +119,12 @@ def test_train_step_at_config_shapes(model, width, nc, batch):
         enc_6, dec_6 = (lambda t: orc.dcgan_encoder(t, e64, True)), (lambda v, s: orc.dcgan_decoder(v, s, d64, True, act))
     with torch.no_grad():
         ref = float(orc.train_model_loss(xc, enc_o, dec_o, lsd, gsd, lik, 2, 2, num_data=batch)[0])
-        ref64 = float(orc.train_model_loss([t.double() for t in xc], enc_6, dec_6, l64, g64, k64, 2, 2, num_data=batch)[0])
+        ref64 = float(orc.train_model_loss([t.double() for t in xc], enc_6, dec_6, l64, g64, k64, 2, 2, num_data=batch)[0]) \
+            if YARDSTICK_AT_SCALE else None
     tr.train_model(x)
     assert math.isfinite(tr.last_loss)
-    yardstick(f"train_model loss {model}_{width} nc={nc} B={batch}", tr.last_loss, ref, ref64, ratio=1.5, slack=LOSS_BAR)
+    if ref64 is not None:
+        yardstick(f"train_model loss {model}_{width} nc={nc} B={batch}", tr.last_loss, ref, ref64, ratio=1.5, slack=LOSS_BAR)
     assert abs(tr.last_loss - ref) < LOSS_BAR * abs(ref), (tr.last_loss, ref)
     assert math.isfinite(tr.finetune_temporal_encoders(x))
 

@@ -214,13 +214,13 @@ def test_gp_trigger_generation_at_the_reference_batch(family, depth):
     idx = [0, 3, 49]
     got = g.gp_trigger_gen([xs[0].to(DEV)], indices=idx, total=total, depth=depth,
                            eps_by_step={k: v.to(DEV) for k, v in eps.items()}, keep_batch=True)
-    unforced, both = 0, [0, 0]
+    unforced, both, memo = 0, [0, 0], {}      # memo: the oracle computes a (step, decisions so far) pair once for all indices
     for res in got:
         index = res["index"]
         dec = {i: (i in res["triggers"]) for i in range(12, total)}
         with torch.no_grad():
             ref = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, index, eps, total=total, depth=depth, decisions=dec,
-                                     guard=guard)
+                                     guard=guard, memo=memo)
         # every decision the oracle took on its own is the HIP run's decision; forced ones are by construction
         assert ref["triggers"] == res["triggers"], (index, ref["triggers"], res["triggers"], ref["forced"])
         np.testing.assert_allclose(res["values"], ref["values"], rtol=2e-5)

@@ -21,7 +21,7 @@ import torch
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import rel_err, to64, yardstick
+from tests.common import YARDSTICK_AT_SCALE, rel_err, to64, yardstick
 from tests.test_gpu_rollouts import _cpu_state, _train_mode_fns, _trainer
 
 pytestmark = pytest.mark.gpu
@@ -89,13 +89,15 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
     x64 = [t.double() for t in x]
     with torch.no_grad():   # oracle: train_model's loss; esd / dsd running statistics advance like the reference's modules
         ref_loss, ref_lat = orc.train_model_loss(x, enc, dec, lsd, gsd, lik, n_past, n_future, num_data=batch)
-        r64_loss, r64_lat = orc.train_model_loss(x64, enc64, dec64, l64, g64, k64, n_past, n_future, num_data=batch)
+        if YARDSTICK_AT_SCALE:
+            r64_loss, r64_lat = orc.train_model_loss(x64, enc64, dec64, l64, g64, k64, n_past, n_future, num_data=batch)
     _zero_lrs(tr)
     got = _closure_grads(tr, xd)
     (v, _, loss), _ = got["model"]
     tag = f"{model} B={batch} {n_past}+{n_future}"
-    yardstick(f"train_model loss {tag}", loss, float(ref_loss), float(r64_loss), ratio=1.5, slack=VALUE_BAR)
-    yardstick(f"train_model latent mse {tag}", v, float(ref_lat) / T, float(r64_lat) / T, ratio=1.5, slack=VALUE_BAR)
+    if YARDSTICK_AT_SCALE:
+        yardstick(f"train_model loss {tag}", loss, float(ref_loss), float(r64_loss), ratio=1.5, slack=VALUE_BAR)
+        yardstick(f"train_model latent mse {tag}", v, float(ref_lat) / T, float(r64_lat) / T, ratio=1.5, slack=VALUE_BAR)
     assert math.isfinite(loss) and abs(loss - float(ref_loss)) < VALUE_BAR * abs(float(ref_loss)), (loss, float(ref_loss))
     assert abs(v - float(ref_lat) / T) < VALUE_BAR * abs(float(ref_lat) / T), (v, float(ref_lat) / T)
     # (2) BatchNorm side effects: 2 (T - 1) encoder calls per closure, 3 (T - 1) decoder calls in train_model, reference order
@@ -103,12 +105,14 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
     with torch.no_grad():   # the two fine-tuning closures on the oracle (same weights: lr = 0), advancing esd further
         ref_fp = orc.train_frame_predictor_loss(x, enc, lsd, n_past, n_future)
         ref_gp = orc.train_gp_loss(x, enc, gsd, lik, n_past, n_future, num_data=batch)
-        r64_fp = orc.train_frame_predictor_loss(x64, enc64, l64, n_past, n_future)
-        r64_gp = orc.train_gp_loss(x64, enc64, g64, k64, n_past, n_future, num_data=batch)
+        if YARDSTICK_AT_SCALE:
+            r64_fp = orc.train_frame_predictor_loss(x64, enc64, l64, n_past, n_future)
+            r64_gp = orc.train_gp_loss(x64, enc64, g64, k64, n_past, n_future, num_data=batch)
     (v_fp,), _ = got["fp"]
     (v_gp,), _ = got["gp"]
-    yardstick(f"train_frame_predictor value {tag}", v_fp, float(ref_fp) / T, float(r64_fp) / T, ratio=1.5, slack=VALUE_BAR)
-    yardstick(f"train_GP_Frame_predictor value {tag}", v_gp, float(ref_gp) / T, float(r64_gp) / T, ratio=1.5, slack=GP_VALUE_BAR)
+    if YARDSTICK_AT_SCALE:
+        yardstick(f"train_frame_predictor value {tag}", v_fp, float(ref_fp) / T, float(r64_fp) / T, ratio=1.5, slack=VALUE_BAR)
+        yardstick(f"train_GP_Frame_predictor value {tag}", v_gp, float(ref_gp) / T, float(r64_gp) / T, ratio=1.5, slack=GP_VALUE_BAR)
     assert abs(v_fp - float(ref_fp) / T) < VALUE_BAR * abs(float(ref_fp) / T), (v_fp, float(ref_fp) / T)
     assert abs(v_gp - float(ref_gp) / T) < GP_VALUE_BAR * abs(float(ref_gp) / T), (v_gp, float(ref_gp) / T)
     worst_bn = 0.0
@@ -143,15 +147,17 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
             lat_ = lat_ + torch.nn.functional.mse_loss(orc.lstm_step(hs_[i - 1], leaf, hid), hs_[i])
         lat_.backward()
         return {k: v.grad for k, v in leaf.items()}
-    g32, g64_ = lstm_grads(torch.float32), lstm_grads(torch.float64)
+    g32 = lstm_grads(torch.float32)
+    g64_ = lstm_grads(torch.float64) if YARDSTICK_AT_SCALE else None
     g_fp = got["fp"][1]
     worst = 0.0
     for k, p in tr.frame_predictor.named_parameters():
         lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
         mine = g_fp[lo: lo + p.numel()].view_as(p).cpu()
         # BPTT over T - 1 steps on train-mode encodings: the fp32 oracle's own deviation from fp64 is the yardstick
-        e_hip, _ = yardstick(f"lstm grad {k} {tag}", mine, g32[k], g64_[k], ratio=3.0, slack=2e-6)
-        worst = max(worst, e_hip)
+        if g64_ is not None:
+            yardstick(f"lstm grad {k} {tag}", mine, g32[k], g64_[k], ratio=3.0, slack=2e-6)
+        worst = max(worst, rel_err(mine, g32[k]))
         assert rel_err(mine, g32[k]) < LSTM_GRAD_BAR, ("lstm", k, rel_err(mine, g32[k]))
     def gp_grads(dt):   # fp64 autograd of the oracle's GP + ELBO over the S steps, on encodings computed by the oracle in `dt`
         e_ = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in esd0.items()}
@@ -172,16 +178,19 @@ def test_closures_at_the_reference_training_configuration(model, batch, n_past, 
     # yardstick: the encodings are the only fp32 quantity on the oracle's side (its GP arithmetic is fp64 either way): what
     # fp32 ROUNDING OF THE ENCODINGS does to these gradients (fp32-encodings run against the fp64-encodings run) beside what
     # the HIP path's encodings + fp64-inside GP kernels do
-    gg32, gg64 = gp_grads(torch.float32), gp_grads(torch.float64)
+    gg32 = gp_grads(torch.float32)
+    gg64 = gp_grads(torch.float64) if YARDSTICK_AT_SCALE else None
     g_gp = got["gp"][1]
     for who, mod in (("gp", tr.gp_layer), ("lik", tr.likelihood)):
         for k, p in mod.named_parameters():
             lo = (p.grad.data_ptr() - tr.arena.g.data_ptr()) // 4
             mine = g_gp[lo: lo + p.numel()].view_as(p).cpu().double()
-            r32, r64 = gg32[(who, k)], gg64[(who, k)]
+            r32 = gg32[(who, k)]
+            r64 = r32 if gg64 is None else gg64[(who, k)]
             if k.endswith("chol_variational_covar"):
                 r32, r64 = torch.tril(r32), torch.tril(r64)
-            yardstick(f"gp grad {k} {tag}", mine, r32, r64, ratio=3.5, slack=2e-6)
+            if gg64 is not None:
+                yardstick(f"gp grad {k} {tag}", mine, r32, r64, ratio=3.5, slack=2e-6)
             assert rel_err(mine, r32) < GP_GRAD_BAR, ("gp", k, rel_err(mine, r32))
 
 
