@@ -236,6 +236,7 @@ def test_module_backward_matches_reference_gradients(family, seed, golden):
     assert not bad, [tuple(f"{v:.3e}" if isinstance(v, float) else v for v in b) for b in bad[:8]]
 
 
+@pytest.mark.slow
 def test_vgg_backward_free_running_noise_is_the_fp32_noise(golden):
     """The second, statistical check of vgg_64's 22-layer backward: branches FREE on every side (HIP, the oracle in fp32, the
     oracle in fp64), seeds 210-214.  Per tensor the deviation from the fp64 run is then dominated by WHICH near-zero

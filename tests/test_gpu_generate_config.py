@@ -62,6 +62,7 @@ def test_backbone_modules_at_the_reference_generate_batch(family):
     assert rel_err(h4, h4_ref) < FRAME_BAR
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("family", ["vgg", "dcgan"])
 def test_sample_rollout_at_b50_through_two_triggers(family):
     """generate_frames.py:143-177 at the reference's batch: n_past = 5, steps 15 and 30 decode a GP sample (eps passed in),

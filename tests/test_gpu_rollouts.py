@@ -71,6 +71,7 @@ def test_finetuning_closure_values_match_oracle(model):
     assert abs(got_gp - ref_gp) < GP_CLOSURE_BAR * abs(ref_gp), (got_gp, ref_gp)
 
 
+@pytest.mark.slow
 def test_plot_rollout_and_best_of_n_match_oracle():
     """train.py:256-310: encoder / decoder stay in TRAIN mode, LSTM / GP / likelihood in eval (train.py:372-374); the one
     GP-sampled step is i == 10; best-of-N by summed squared error must pick the same sample per row."""
@@ -193,6 +194,7 @@ def test_gp_trigger_generation_matches_oracle(depth, index):
         g.gp_trigger_gen([xs[0][:2].to(DEV)], n_index=1, total=14)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("family,depth", [("dcgan", -250), ("dcgan", 1), ("vgg", -250)])
 def test_gp_trigger_generation_at_the_reference_batch(family, depth):
     """GPtrigger_gen as generate_frames.py:47-49,249-298 configures it: B = 50, the batch indices {0, 3, 49} (the warm-up reads

@@ -73,6 +73,7 @@ def _closure_grads(tr, x):
     return res
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("model,batch,n_past,n_future", [("dcgan", 50, 5, 10), ("vgg", 50, 3, 3)])
 def test_closures_at_the_reference_training_configuration(model, batch, n_past, n_future):
     T = n_past + n_future

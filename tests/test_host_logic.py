@@ -252,3 +252,31 @@ def test_batch_prefetcher_keeps_order_propagates_errors_and_ends():
     assert next(pf) == "a"
     with pytest.raises(ValueError):
         next(pf)
+
+
+def test_gp_trigger_oracle_memo_and_forced_decisions():
+    """oracle.gp_trigger_gen (generate_frames.py:249-298), the checker of the B = 50 GPU test: (1) with a memo shared by the calls
+    for several batch indices every (step, decisions so far) pair is computed once and the results equal the un-memoised calls
+    bit for bit; (2) `decisions` + `guard`: a step whose own margin is inside the guard follows the given branch (reported in
+    `forced`), every other step decides for itself - with guard = 0 the decisions are ignored."""
+    from oracle import dvg_oracle as orc
+    from oracle import params
+    from tests.test_gpu_configs import _build, _oracle_fns
+    B, total = 5, 18
+    mods, (esd, dsd, lsd, gsd, lik) = _build("dcgan", 64, 1, B, 3300)
+    xs = [params.frames(3310, B, 1, 64)]
+    eps = {i: params.normal(3320 + i, 90, B) for i in range(12, total)}
+    enc_o, dec_o = _oracle_fns("dcgan", 64, esd, dsd)
+    memo = {}
+    with torch.no_grad():
+        for index in (0, 4):
+            a = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, index, eps, total=total, depth=-250)
+            b = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, index, eps, total=total, depth=-250, memo=memo)
+            assert a["triggers"] == b["triggers"] and a["values"] == b["values"] and a["thresholds"] == b["thresholds"]
+            assert all(torch.equal(u, v) for u, v in zip(a["frames"], b["frames"]))
+        assert any(k[0] == "post" for k in memo) and any(k[0] == "warm" for k in memo)
+        flip = {i: (i not in a["triggers"]) for i in range(12, total)}           # the opposite branch everywhere
+        c = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, 4, eps, total=total, depth=-250, decisions=flip, guard=0.0)
+        assert c["triggers"] == a["triggers"] and c["forced"] == []
+        d = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, 4, eps, total=total, depth=-250, decisions=flip, guard=1e9)
+        assert d["forced"] == list(range(12, total)) and d["triggers"] == [i for i in range(12, total) if flip[i]]
