@@ -15,7 +15,7 @@ dvg_gemm_nt_bias_act / dvg_colsum with `accumulate`) adds it straight into the p
 optimiser's flat gradient arena under train.Trainer - and the Function returns None for that input.  The reference's
 `loss.backward()` (train.py:240) accumulates one gradient tensor per USE of a parameter (a decoder weight is used 3 S times
 per iteration): that was 18 468 `at::native` add launches per 4 iterations here (5.5 % of the GPU time of a vgg_64 iteration).
-DVG_DIRECT_GRADS=0 returns the gradients to autograd instead (same values; tests run both).
+autograd.DIRECT_PARAM_GRADS = False returns the gradients to autograd instead (same values; tests run both).
 """
 from __future__ import annotations
 

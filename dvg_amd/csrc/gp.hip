@@ -50,7 +50,7 @@ struct GpParams {
 // cond * 6e-8 ~ 2e-3 of the predictive covariance; assembled, factored, solved and cancelled (k(x,x) - A^T A) in fp64 the
 // kernel meets the 1e-4 bar of BASELINE.json with two decades to spare.  Inputs and outputs stay fp32.  T = float is kept
 // for shapes whose fp64 working set exceeds the 160 KB of LDS (dvg_gp_precision() tells which one a shape gets) and for
-// A/B runs (DVG_GP_FP32=1).  v_fma_f64 issues at the fp32 vector rate on gfx950; the kernels are LDS-latency chains.
+// A/B runs (until r04).  v_fma_f64 issues at the fp32 vector rate on gfx950; the kernels are LDS-latency chains.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void gp_elbo_kernel(const GpElboParams p) {
 using namespace dvg;
 
 // Threads per workgroup (= per latent dim).  One workgroup per CU and every phase a chain of LDS round trips: more waves
-// per SIMD are the only latency hiding there is (tools/diag_gp_bwd.py, tools/bench_gp.py; DVG_GP_THREADS=256|512|1024
+// per SIMD are the only latency hiding there is (tools/diag_gp_bwd.py, tools/bench_gp.py; -DGP_PREDICT_THREADS / -DGP_BWD_THREADS variant builds
 // overrides both kernels for A/B runs).
 #ifndef GP_PREDICT_THREADS
 #define GP_PREDICT_THREADS 1024

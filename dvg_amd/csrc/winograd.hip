@@ -749,7 +749,7 @@ extern "C" int dvg_winograd_output_input(const float* mm, const float* scale, co
     DVG_REQUIRE(aligned16(mm) && aligned16(v_next), DVG_ERR_ALIGN, "dvg_winograd_output_input: alignment");
     const hipStream_t st = (hipStream_t)stream;
     const int var = chain_variant();
-    // Measured per shape (tools/bench_wino_parts.py, us at B = 64 / B = 576; DVG_WINO_CHAIN_VARIANT forces one for A/B runs):
+    // Measured per shape (tools/bench_wino_parts.py, us at B = 64 / B = 576; the variants were A/B'd per shape in r03):
     //   16x16 256ch: r02 kernel (64-byte runs) 20.3 / 212; <16,64,f32x2> 15.1 / 140; <16,32,float> 13.8 / 160
     //   32x32 128ch: separate output + input passes 42.2 / 389; <32,16,f32x2> 36.5 / 388; <32,32,f32x4> (128 KB of LDS) 27.3 / 284
     //    8x8  512ch: r02 kernel 7.6 / 73 = <8,64,float> - kept
