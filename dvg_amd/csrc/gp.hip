@@ -37,8 +37,12 @@ struct GpParams {
     int B, D, M, train_mode;
     float jitter;
     int raw_hypers;  // outputscale / lengthscale / noise point at the RAW parameters: soft-plus (+ noise floor) in-kernel
-    int Dp;          // parameter period: workgroup d reads the parameters of latent dim d % Dp (D = S x Dp: the S time steps of a
+    int Dp;          // parameter period: column d of h uses the parameters of latent dim d % Dp (D = S x Dp: the S time steps of a
                      // training closure side by side, one parameter set - no tiled copies)
+    int SG;          // steps per workgroup (r05; 1 = one workgroup per column).  The points of different time steps are just more
+                     // points of the SAME GP: workgroup w = g Dp + dq takes the steps [g SG, g SG + SG) of latent dim dq as ONE
+                     // problem of up to SG x B points, i.e. K_ZZ, its Cholesky factor and the KL term - the B-independent three
+                     // quarters of a small-batch call - once per SG steps instead of once per step.  Train-mode outputs only.
     unsigned long long* clk;  // debug only: 12 x u64 per workgroup (latent dim), for the first clk_cap workgroups
     unsigned clk_cap;
 };
@@ -278,8 +282,13 @@ __device__ void block_backward_subst(const T* L, int LM, T* X, int LB, int M, in
 template <int NT, typename T, bool PACKED = false>
 __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     T* sm = reinterpret_cast<T*>(gp_lds_raw);
-    const int d = blockIdx.x, tid = threadIdx.x;
-    const int M = p.M, B = p.B;
+    const int wg = blockIdx.x, tid = threadIdx.x;
+    const int dq = wg % p.Dp;                       // the latent dim whose PARAMETERS this workgroup reads
+    const int s0 = (wg / p.Dp) * p.SG;              // its first time step (SG = 1, Dp = D: step 0 of column wg)
+    const int ns = min(p.SG, p.D / p.Dp - s0);      // its steps
+    const int Bs = p.B, M = p.M, B = ns * Bs;       // B: the POINTS of this workgroup, point b = (step s0 + b / Bs, sample b % Bs)
+    const int d = s0 * p.Dp + dq;                   // its first column of h (the only one when SG = 1)
+    auto col_of = [&](int b) { return d + (b / Bs) * p.Dp; };
     const int LM = M + 1;   // row stride of the MxM matrices
     const int LB = B + 2;   // row stride of the M x (B+1) matrices
     const int LS = B + 1;   // row stride of Sigma
@@ -302,7 +311,6 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     // (gp_models.py hyper-parameters / GaussianLikelihood noise with its GreaterThan(1e-4) floor): saves three
     // 90-element launches per GP call
     auto softplus = [](T x) { return x > T(20.) ? x : log1p_t(exp_t(x)); };
-    const int dq = d % p.Dp;      // the latent dim whose PARAMETERS this workgroup reads
     const T s = p.raw_hypers ? softplus(p.outputscale[dq]) : p.outputscale[dq];
     const T ell = p.raw_hypers ? softplus(p.lengthscale[dq]) : p.lengthscale[dq];
     const T ninv = -T(0.5) / (ell * ell);
@@ -310,9 +318,9 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     const T noise = p.noise ? (p.raw_hypers ? softplus(p.noise[dq]) + T(1e-4) : p.noise[dq]) : T(0.);
     const bool need_cov = (p.cov != nullptr) || (p.sample != nullptr);
 
-    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 0] = clock64();
+    if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 0] = clock64();
     for (int i = tid; i < M; i += NT) zs[i] = p.z[(size_t)dq * M + i];
-    for (int b = tid; b < B; b += NT) xs[b] = p.h[(size_t)b * p.D + d];
+    for (int b = tid; b < B; b += NT) xs[b] = p.h[(size_t)(b % Bs) * p.D + col_of(b)];
     __syncthreads();
     for (int i = tid; i < M * M; i += NT) {
         const int r = i / M, q = i % M;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
     }
     __syncthreads();
 
-    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 1] = clock64();
+    if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 1] = clock64();
     // W = L_S^T K_Zx (needs the un-solved K_Zx), then chol(K_ZZ) by the whole workgroup
     for (int i = tid; i < M * B; i += NT) {
         const int r = i / B, b = i % B;
@@ -342,11 +350,11 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
         Wm[r * LB + b] = acc;
     }
     block_cholesky<NT, T>(L, M, LM, tid);   // ends with __syncthreads
-    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 2] = clock64();
+    if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 2] = clock64();
 
     // L X = [K_Zx | m-c]
     block_forward_subst<NT, T>(L, LM, AK, LB, M, B + 1, tid);
-    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 3] = clock64();
+    if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 3] = clock64();
 
     // predictive mean and marginal variance
     for (int b = tid; b < B; b += NT) {
@@ -359,11 +367,12 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
         }
         m += c0;
         mu[b] = m;
-        if (p.mean) p.mean[(size_t)d * B + b] = m;
+        const size_t ob = (size_t)col_of(b) * Bs + b % Bs;
+        if (p.mean) p.mean[ob] = m;
         if (p.var) {
             T dd = s - qa;
             if (p.train_mode) dd = max_t(dd, T(0.));
-            p.var[(size_t)d * B + b] = qw + dd + noise;
+            p.var[ob] = qw + dd + noise;
         }
     }
 
@@ -384,12 +393,12 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
             part -= T(2.) * log_t(abs_t(Ls[i * LM + i]));
         }
         const T tot = block_sum<NT, T>(part, red, tid);
-        if (tid == 0) p.kl[d] = T(0.5) * (tot - (T)M);
+        if (tid < ns) p.kl[d + tid * p.Dp] = T(0.5) * (tot - (T)M);    // the same value for every step of the workgroup
     }
 
     if (need_cov) {
         __syncthreads();
-        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 4] = clock64();
+        if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 4] = clock64();
         // Sigma = W^T W - A^T A + k(x,x) (+ noise I): 4x4 register tiles (16 LDS reads per 32 FMAs instead of 4 per 2),
         // lower-triangular tiles only, mirrored on store
         {
@@ -446,10 +455,10 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
             }
         }
         __syncthreads();
-        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 5] = clock64();
+        if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 5] = clock64();
         if (p.sample != nullptr) {
             block_cholesky<NT, T, PACKED>(Sg, B, LS, tid);   // ends with __syncthreads
-        if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 6] = clock64();
+        if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 6] = clock64();
             for (int b = tid; b < B; b += NT) {
                 T acc = mu[b];
 #pragma unroll 4
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(NT) void gp_predict_kernel(const GpParams p) {
             }
         }
     }
-    if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + 7] = clock64();
+    if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + 7] = clock64();
 }
 
 
@@ -482,13 +491,15 @@ struct GpBwdParams {
     float* dh; float* dz; float* dm; float* dls; float* dc; float* ds; float* dell;
     int B, D, M;
     int Bc;                   // data points per chunk (gp_bwd_chunk): B when the whole fp64 working set fits the LDS
-    int Dp;                   // parameter period (see GpParams): gradients are still written per workgroup d
+    int Dp;                   // parameter period (see GpParams)
+    int SG;                   // steps per workgroup (see GpParams): parameter gradients are written per WORKGROUP (ceil(S / SG) x Dp
+                              // rows), summed over the workgroup's steps
     float jitter;
     unsigned long long* clk;  // debug only (dvg_debug_set_gp_clockbuf): 12 x u64 phase stamps per workgroup
     unsigned clk_cap;
 };
 
-#define GP_STAMP(k) if (p.clk && tid == 0 && (unsigned)d < p.clk_cap) p.clk[(size_t)d * 12 + (k)] = clock64();
+#define GP_STAMP(k) if (p.clk && tid == 0 && (unsigned)wg < p.clk_cap) p.clk[(size_t)wg * 12 + (k)] = clock64();
 
 // Data points in CHUNKS of Bc (r04): everything that has a B-wide row - Kzx, W / GW, G2 and the solved columns P = K^-1 Kzx - is
 // held for Bc points at a time, so that the fp64 working set fits the 160 KB of LDS up to B = 128 (M = 40: two chunks of 64,
@@ -499,12 +510,17 @@ struct GpBwdParams {
 template <int NT, typename T>
 __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* sm = reinterpret_cast<T*>(gp_lds_raw);
-    const int d = blockIdx.x, tid = threadIdx.x;
-    const int M = p.M, B = p.B, Bc = p.Bc, LM = M + 1, LB = Bc + 2;
+    const int wg = blockIdx.x, tid = threadIdx.x;
+    const int dq = wg % p.Dp;                       // the latent dim whose PARAMETERS this workgroup reads
+    const int s0 = (wg / p.Dp) * p.SG;              // first time step, steps and points of this workgroup (see gp_predict_kernel)
+    const int ns = min(p.SG, p.D / p.Dp - s0);
+    const int Bs = p.B, M = p.M, B = ns * Bs, Bc = p.Bc, LM = M + 1, LB = Bc + 2;
+    const int d = s0 * p.Dp + dq;
+    auto col_of = [&](int b) { return d + (b / Bs) * p.Dp; };
     // ONE chunk (Bc == B): P = K^-1 [Kzx | m-c | Kzx gm | I] comes out of one pair of triangular solves and K^-1 is read in
     // place from its last M columns (the r03 layout and cost).  Several chunks: the M + 2 columns that couple the points are
     // solved first, K^-1 is copied out to a buffer of its own, and P then holds K^-1 Kzx of one chunk at a time.
-    const bool single = Bc >= B;
+    const bool single = Bc >= p.SG * Bs;       // launch-uniform (a ragged last group keeps the launch's layout)
     const int LP = single ? B + M + 3 : (Bc > M + 2 ? Bc : M + 2) + 1;
     T* Kj = sm;               // [M][LM] K with jitter
     T* L = Kj + M * LM;       // chol(K)
@@ -526,10 +542,11 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     T* gq = gv + B;
     T* red = gq + B;          // [16]
 
-    const int dq = d % p.Dp;      // the latent dim whose PARAMETERS this workgroup reads (gradients are written per d)
     const T s = p.outputscale[dq], ell = p.lengthscale[dq];
     const T ninv = -T(0.5) / (ell * ell), c0 = p.mean_const[dq];
-    const T gk = p.gkl ? p.gkl[d] : T(0.);
+    T gk = T(0.);               // the KL value is shared by the workgroup's steps: its upstream gradients add up
+    if (p.gkl)
+        for (int st = 0; st < ns; ++st) gk += (T)p.gkl[d + st * p.Dp];
     const int nchunk = (B + Bc - 1) / Bc;
 
     GP_STAMP(0)
@@ -539,9 +556,10 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         tt[i] = T(0.);
     }
     for (int b = tid; b < B; b += NT) {
-        xs[b] = p.h[(size_t)b * p.D + d];
-        gm[b] = p.gmean ? p.gmean[(size_t)d * B + b] : T(0.);
-        gv[b] = p.gvar ? p.gvar[(size_t)d * B + b] : T(0.);
+        const int cb = col_of(b);
+        xs[b] = p.h[(size_t)(b % Bs) * p.D + cb];
+        gm[b] = p.gmean ? p.gmean[(size_t)cb * Bs + b % Bs] : T(0.);
+        gv[b] = p.gvar ? p.gvar[(size_t)cb * Bs + b % Bs] : T(0.);
     }
     __syncthreads();
     for (int i = tid; i < M * M; i += NT) {
@@ -700,19 +718,19 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
         for (int b = tid; b < bc; b += NT) {
             T acc = T(0.);
             for (int i = 0; i < M; ++i) acc = fma_t(G2[i * LB + b] * Kzx[i * LB + b], zs[i] - xs[b0 + b], acc);
-            p.dh[(size_t)(b0 + b) * p.D + d] = acc * il2;
+            p.dh[(size_t)((b0 + b) % Bs) * p.D + col_of(b0 + b)] = acc * il2;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < EPT; ++it) {
         const int i = tid + it * NT;
-        if (i < M * M) p.dls[(size_t)d * M * M + i] = dls_acc[it];
+        if (i < M * M) p.dls[(size_t)wg * M * M + i] = dls_acc[it];
     }
     T dc_part = T(0.);
     for (int i = tid; i < M; i += NT) {
         const T dr = tau[i] + gk * al[i];
-        p.dm[(size_t)d * M + i] = dr;
+        p.dm[(size_t)wg * M + i] = dr;
         dc_part -= dr;
     }
     for (int b = tid; b < B; b += NT) dc_part += gm[b];
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
             const T kp = Kj[i * LM + j] - (i == j ? p.jitter : T(0.));
             acc = fma_t((GK[i * LM + j] + GK[j * LM + i]) * kp, -(zs[i] - zs[j]), acc);
         }
-        p.dz[(size_t)d * M + i] = acc * il2;
+        p.dz[(size_t)wg * M + i] = acc * il2;
     }
     GP_STAMP(8)
     const T ds_tot = block_sum<NT, T>(ds_acc, red, tid);
@@ -740,9 +758,9 @@ __global__ __launch_bounds__(NT) void gp_train_bwd_kernel(const GpBwdParams p) {
     const T dc_tot = block_sum<NT, T>(dc_part, red, tid);
     const T dsdir_tot = block_sum<NT, T>(ds_part, red, tid);
     if (tid == 0) {
-        p.ds[d] = ds_tot / s + dsdir_tot;
-        p.dell[d] = dl_tot * il3;
-        p.dc[d] = dc_tot;
+        p.ds[wg] = ds_tot / s + dsdir_tot;
+        p.dell[wg] = dl_tot * il3;
+        p.dc[wg] = dc_tot;
     }
     GP_STAMP(9)
 }
@@ -889,27 +907,51 @@ extern "C" int dvg_gp_bwd_chunk(int B, int M) {
     return bc > 0 ? bc : B;
 }
 
+// Steps per workgroup for a time-batched train-mode call (S steps x P latent dims x B points each; see GpParams::SG).  One
+// workgroup per (step, dim) repeats K_ZZ, its factor and the KL term S times per dim and, with 40-155 KB of LDS each, runs the
+// S x P workgroups in ceil(S P / 256 r) residency rounds.  The smallest group that brings the launch down to ONE workgroup per
+// CU (P ceil(S / k) <= 256) wins when its points still fit: B=16,S=11: k=6, B=4,S=15: k=8 (tools/bench_gp.py, r05); at
+// B = 64 no group fits and the call stays one workgroup per column.
+extern "C" int dvg_gp_step_group(int B, int S, int P, int M) {
+    if (B <= 0 || S <= 1 || P <= 0 || M <= 0 || M > 64 || (long)S * P <= 256) return 1;
+    for (int k = 2; k <= S; ++k) {
+        if ((long)P * ((S + k - 1) / k) > 256) continue;
+        const long bw = (long)k * B;
+        if (bw > 256 || gp_predict_variant((int)bw, M, 0) != 1 || gp_bwd_chunk((int)bw, M, 8) <= 0) return 1;
+        return k;
+    }
+    return 1;
+}
+
 extern "C" int dvg_gp_predict(const float* h, const float* z, const float* var_mean, const float* chol_var,
                               const float* mean_const, const float* outputscale, const float* lengthscale,
                               const float* noise, const float* eps, float* mean, float* var, float* sample,
                               float* cov, float* kl, int B, int D, int M, int train_mode, float jitter,
-                              int param_period, void* stream) {
+                              int param_period, int step_group, void* stream) {
     DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
                 "dvg_gp_predict: NULL input");
     DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
                 "dvg_gp_predict: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
     DVG_REQUIRE(sample == nullptr || eps != nullptr, DVG_ERR_NULL, "dvg_gp_predict: sample needs eps");
     const int need_cov = (cov != nullptr) || (sample != nullptr);
-    const size_t lds = dvg_gp_lds_bytes(B, M, need_cov);
-    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
     DVG_REQUIRE(train_mode >= 0 && train_mode <= 3, DVG_ERR_SHAPE, "dvg_gp_predict: train_mode flags must be 0..3");
     DVG_REQUIRE(param_period >= 0 && (param_period == 0 || D % param_period == 0), DVG_ERR_SHAPE,
                 "dvg_gp_predict: param_period=%d must divide D=%d", param_period, D);
+    const int Dp = param_period ? param_period : D, S = D / Dp;
+    const int SG = step_group > 1 ? step_group : 1;
+    DVG_REQUIRE(SG == 1 || (SG <= S && !need_cov), DVG_ERR_SHAPE,
+                "dvg_gp_predict: step_group=%d needs 1..S=%d steps and neither cov nor sample", step_group, S);
+    const int Bw = SG * B, G = (S + SG - 1) / SG, nwg = G * Dp;      // points per workgroup, workgroups
+    const size_t lds = dvg_gp_lds_bytes(Bw, M, need_cov);
+    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_predict: %zu bytes of LDS needed (> 160 KiB)", lds);
     GpParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, noise, eps, mean, var, sample, cov, kl,
-               B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, param_period ? param_period : D, g_gp_clk, g_gp_clk_cap};
-    const int nt = gp_threads(GP_PREDICT_THREADS, D, B, false);
+               B, D, M, train_mode & 1, jitter, (train_mode >> 1) & 1, Dp, SG, g_gp_clk, g_gp_clk_cap};
+    const int nt = gp_threads(GP_PREDICT_THREADS, nwg, Bw, false);
     const char* who = "dvg_gp_predict";
-    const int variant = gp_predict_variant(B, M, need_cov);
+    const int variant = gp_predict_variant(Bw, M, need_cov);
+    DVG_REQUIRE(SG == 1 || variant == 1, DVG_ERR_SHAPE,
+                "dvg_gp_predict: step_group=%d x B=%d points do not fit the LDS in fp64", SG, B);   // never trade precision for it
+    D = nwg;        // the grid
     if (variant == 2) {
         switch (nt) {
             case 256: return gp_launch(gp_predict_kernel<256, double, true>, 256, p, D, lds, stream, who);
@@ -935,22 +977,29 @@ extern "C" int dvg_gp_train_bwd(const float* h, const float* z, const float* var
                                 const float* mean_const, const float* outputscale, const float* lengthscale,
                                 const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
                                 float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
-                                float jitter, int param_period, void* stream) {
+                                float jitter, int param_period, int step_group, void* stream) {
     DVG_REQUIRE(h && z && var_mean && chol_var && mean_const && outputscale && lengthscale, DVG_ERR_NULL,
                 "dvg_gp_train_bwd: NULL input");
     DVG_REQUIRE(dh && dz && dm && dls && dc && ds && dell, DVG_ERR_NULL, "dvg_gp_train_bwd: NULL output");
     DVG_REQUIRE(B > 0 && D > 0 && M > 0 && M <= 64 && B <= 128, DVG_ERR_SHAPE,
                 "dvg_gp_train_bwd: need 1<=M<=64, 1<=B<=128 (got M=%d B=%d)", M, B);
-    const size_t lds = dvg_gp_bwd_lds_bytes(B, M);
-    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
     DVG_REQUIRE(param_period >= 0 && (param_period == 0 || D % param_period == 0), DVG_ERR_SHAPE,
                 "dvg_gp_train_bwd: param_period=%d must divide D=%d", param_period, D);
+    const int Dp = param_period ? param_period : D, S = D / Dp;
+    const int SG = step_group > 1 ? step_group : 1;
+    DVG_REQUIRE(SG <= S, DVG_ERR_SHAPE, "dvg_gp_train_bwd: step_group=%d exceeds the %d steps", step_group, S);
+    const int Bw = SG * B, G = (S + SG - 1) / SG, nwg = G * Dp;      // points per workgroup, workgroups (= gradient rows)
+    const size_t lds = dvg_gp_bwd_lds_bytes(Bw, M);
+    DVG_REQUIRE(lds <= GP_LDS_MAX, DVG_ERR_SHAPE, "dvg_gp_train_bwd: %zu bytes of LDS needed (> 160 KiB)", lds);
     GpBwdParams p{h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, gmean, gvar, gkl,
-                  dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(B, M), param_period ? param_period : D, jitter,
+                  dh, dz, dm, dls, dc, ds, dell, B, D, M, dvg_gp_bwd_chunk(Bw, M), Dp, SG, jitter,
                   g_gp_clk, g_gp_clk_cap};
-    const int nt = gp_threads(GP_BWD_THREADS, D, B, true);
+    const int nt = gp_threads(GP_BWD_THREADS, nwg, Bw, true);
     const char* who = "dvg_gp_train_bwd";
-    if (dvg_gp_bwd_precision(B, M) == 64) {
+    D = nwg;        // the grid
+    DVG_REQUIRE(SG == 1 || dvg_gp_bwd_precision(Bw, M) == 64, DVG_ERR_SHAPE,
+                "dvg_gp_train_bwd: step_group=%d x B=%d points do not fit the LDS in fp64", SG, B);
+    if (dvg_gp_bwd_precision(Bw, M) == 64) {
         switch (nt) {
             case 256: return gp_launch(gp_train_bwd_kernel<256, double>, 256, p, D, lds, stream, who);
             case 512: return gp_launch(gp_train_bwd_kernel<512, double>, 512, p, D, lds, stream, who);

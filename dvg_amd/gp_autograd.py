@@ -29,23 +29,31 @@ class _GPTrain(torch.autograd.Function):
             g["dell"].view_as(ell), None
 
 
+STEP_GROUPS = True   # several time steps of a latent dim per workgroup where dvg_gp_step_group says so (tests switch it off to
+                     # compare with one workgroup per (step, dim))
+
+
 class _GPTrainSteps(torch.autograd.Function):
     """_GPTrain for S time steps side by side: h (B, S * D), ONE parameter set of D latent dims read with period D by the
-    kernels (no tiled parameter copies); backward sums the per-(step, dim) parameter gradients over the steps in one launch."""
+    kernels (no tiled parameter copies).  The workgroups take one step or - small batches - a group of steps each
+    (ops.gp_step_group); backward sums the per-workgroup parameter gradients over the groups in one launch."""
 
     @staticmethod
     def forward(ctx, h, z, m, ls, c, s, ell, jitter, S):
         D = z.shape[0]
-        r = ops.gp_predict(h, z, m, ls, c, s, ell, want_var=True, want_kl=True, train_mode=True, jitter=jitter, param_period=D)
+        k = ops.gp_step_group(h.shape[0], S, D, z.shape[1]) if STEP_GROUPS else 1
+        r = ops.gp_predict(h, z, m, ls, c, s, ell, want_var=True, want_kl=True, train_mode=True, jitter=jitter, param_period=D,
+                           step_group=k)
         ctx.save_for_backward(h, z, m, ls, c, s, ell)
-        ctx.jitter, ctx.S = jitter, S
+        ctx.jitter, ctx.S, ctx.k = jitter, S, k
         return r["mean"], r["var"], r["kl"]
 
     @staticmethod
     def backward(ctx, dmean, dvar, dkl):
         h, z, m, ls, c, s, ell = ctx.saved_tensors
-        g = ops.gp_train_bwd(h, z, m, ls, c, s, ell, dmean, dvar, dkl, ctx.jitter, param_period=z.shape[0])
-        dz, dm, dls, dc, ds, dell = ops.sum_steps([g["dz"], g["dm"], g["dls"], g["dc"], g["ds"], g["dell"]], ctx.S)
+        g = ops.gp_train_bwd(h, z, m, ls, c, s, ell, dmean, dvar, dkl, ctx.jitter, param_period=z.shape[0], step_group=ctx.k)
+        grads = [g["dz"], g["dm"], g["dls"], g["dc"], g["ds"], g["dell"]]
+        dz, dm, dls, dc, ds, dell = ops.sum_steps(grads, g["groups"]) if g["groups"] > 1 else grads
         return g["dh"], dz.view_as(z), dm.view_as(m), dls.view_as(ls), dc.view_as(c), ds.view_as(s), dell.view_as(ell), None, None
 
 

@@ -786,11 +786,13 @@ def stem_up_winograd_input(vec, w_kn, k, scale, shift, cout, *, act=ACT_LRELU, s
 # GP
 # ----------------------------------------------------------------------------------
 def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *, noise=None, eps=None,
-               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3, raw_hypers=False, param_period=0):
+               want_var=True, want_cov=False, want_kl=False, train_mode=False, jitter=1e-3, raw_hypers=False, param_period=0,
+               step_group=1):
     """h [B][D] (any strides); returns dict(mean [D][B], var, sample, cov, kl).  raw_hypers: outputscale / lengthscale /
     noise are the RAW parameters, soft-plus'ed (noise: + 1e-4 floor) inside the kernel.
     param_period = P > 0: h carries D = S x P columns - S time steps side by side - and column d uses the parameters of
-    latent dim d % P (the parameter tensors have P rows)."""
+    latent dim d % P (the parameter tensors have P rows).  step_group = k > 1: k consecutive steps of a latent dim are one
+    workgroup's problem (dvg_hip.h; train-mode outputs only) - same outputs."""
     _dev_f32(h, "gp_predict.h")
     h = h if h.is_contiguous() else h.contiguous()
     b, d = h.shape
@@ -812,7 +814,7 @@ def gp_predict(h, z, var_mean, chol_var, mean_const, outputscale, lengthscale, *
     nz = None if noise is None else noise.detach().contiguous().view(-1)
     _run("gp_predict", 0.0, 4.0 * (b * d + d * m * (m + 2) + 3 * d * b), lib().dvg_gp_predict, _p(h),
          *[_p(t) for t in args], _p(nz), _p(eps), _p(mean), _p(var), _p(sample), _p(cov), _p(kl), b, d, m,
-         int(train_mode) | (2 if raw_hypers else 0), jitter, int(param_period), _stream())
+         int(train_mode) | (2 if raw_hypers else 0), jitter, int(param_period), int(step_group), _stream())
     return {"mean": mean, "var": var, "sample": sample, "cov": cov, "kl": kl}
 
 
@@ -1246,20 +1248,31 @@ def sum_steps(tensors, steps):
     return dst
 
 
-def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3, param_period=0):
+def gp_step_group(b, steps, period, m):
+    """Steps per workgroup of a time-batched train-mode GP call (dvg_gp_step_group; 1 = one workgroup per (step, dim))."""
+    return lib().dvg_gp_step_group(int(b), int(steps), int(period), int(m))
+
+
+def gp_train_bwd(h, z, m, ls, c, s, ell, gmean, gvar, gkl, jitter=1e-3, param_period=0, step_group=1):
     """Gradients of the train-mode GP prediction (see dvg_gp_train_bwd); with param_period = P the parameter gradients come
-    back per COLUMN of h (D = S x P rows: sum_steps adds the S copies up)."""
+    back per WORKGROUP: G x P rows, G = ceil(S / step_group) groups of the D = S x P columns of h (out["groups"] = G;
+    sum_steps adds the G copies up)."""
     h = h if h.is_contiguous() else h.contiguous()
     b, d = h.shape
     mm = z.shape[1]
     dev = h.device
     f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
-    out = {"dh": f(b, d), "dz": f(d, mm), "dm": f(d, mm), "dls": f(d, mm, mm), "dc": f(d), "ds": f(d), "dell": f(d)}
+    period = param_period or d
+    k = max(int(step_group), 1)
+    groups = -(-(d // period) // k)
+    r = groups * period
+    out = {"dh": f(b, d), "dz": f(r, mm), "dm": f(r, mm), "dls": f(r, mm, mm), "dc": f(r), "ds": f(r), "dell": f(r),
+           "groups": groups}
     args = [t.detach().contiguous().view(-1) for t in (z, m, ls, c, s, ell)]
     g = [None if t is None else t.contiguous() for t in (gmean, gvar, gkl)]
     check(lib().dvg_gp_train_bwd(_p(h), *[_p(t) for t in args], *[_p(t) for t in g], _p(out["dh"]), _p(out["dz"]),
                                  _p(out["dm"]), _p(out["dls"]), _p(out["dc"]), _p(out["ds"]), _p(out["dell"]), b, d,
-                                 mm, jitter, int(param_period), _stream()), "gp_train_bwd")
+                                 mm, jitter, int(param_period), k, _stream()), "gp_train_bwd")
     return out
 
 

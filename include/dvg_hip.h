@@ -415,7 +415,13 @@ int dvg_gp_predict(const float* h, const float* z, const float* var_mean,
                    int param_period /* ABI 8; 0 = D.  Workgroup d reads the parameters (z, var_mean, chol_var, mean_const,
                                        outputscale, lengthscale, noise) of latent dim d % param_period: the S time steps of a
                                        training closure side by side as D = S * g_dim dims on ONE parameter set */,
+                   int step_group /* ABI 8; <= 1: one workgroup per column of h.  k > 1 (train-mode outputs only, k <= S):
+                                     workgroup g * param_period + q takes the steps [g k, g k + k) of latent dim q as ONE
+                                     problem of up to k * B points - K_ZZ, its factor and the KL term once per k steps.
+                                     Same outputs, same layout; mean / var bit-identical to k = 1 */,
                    void* stream);
+/* the step_group the host side uses for a time-batched training call of S steps x P latent dims x B points (1 = no grouping) */
+int dvg_gp_step_group(int B, int S, int P, int M);
 
 /* ------------------------------------------------------------------ *
  * Backward (training) entry points: what `loss.backward()` (train.py:170,194,240)
@@ -570,8 +576,12 @@ int dvg_gp_train_bwd(const float* h, const float* z, const float* var_mean, cons
                      const float* mean_const, const float* outputscale, const float* lengthscale,
                      const float* gmean, const float* gvar, const float* gkl, float* dh, float* dz,
                      float* dm, float* dls, float* dc, float* ds, float* dell, int B, int D, int M,
-                     float jitter, int param_period /* ABI 8, as dvg_gp_predict; gradients are written per workgroup d
-                                                       (dvg_sum_steps_multi adds the S copies up) */, void* stream);
+                     float jitter, int param_period /* ABI 8, as dvg_gp_predict */,
+                     int step_group /* ABI 8, as dvg_gp_predict.  The PARAMETER gradients are written per workgroup:
+                                       dz, dm [G * P][M], dls [G * P][M][M], dc, ds, dell [G * P] with P = param_period (or D)
+                                       and G = ceil(S / max(step_group, 1)) - each row already summed over its workgroup's
+                                       steps; dvg_sum_steps_multi adds the G rows per latent dim up (G = 1: nothing left) */,
+                     void* stream);
 /* dst_k[i] = sum over s < S of src_k[s * n_k + i] for count <= 8 tensors in one launch (host arrays of device pointers / sizes):
  * the per-(step, latent dim) parameter gradients of a closure's S side-by-side time steps -> one gradient per parameter.  ABI 8. */
 int dvg_sum_steps_multi(const float* const* src, float* const* dst, const long* n, int count, int S, void* stream);

@@ -60,7 +60,7 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     assert rc == 1 and b"16" in lib.dvg_last_error(), lib.dvg_last_error()
     rc = lib.dvg_lstm_cell(one, one, one, one, one, one, one, one, one, None, 4, 100, None)
     assert rc == 1
-    rc = lib.dvg_gp_predict(*([one] * 7), None, None, one, None, None, None, None, 200, 90, 40, 0, 1e-3, 0, None)
+    rc = lib.dvg_gp_predict(*([one] * 7), None, None, one, None, None, None, None, 200, 90, 40, 0, 1e-3, 0, 1, None)
     assert rc == 1
     with pytest.raises(RuntimeError):
         _lib.check(rc, "gp")

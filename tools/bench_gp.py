@@ -38,6 +38,20 @@ def main():
         bwd = time_fn(lambda: ops.gp_train_bwd(h, z, m, ls, c, s, ell, gm, gv, gk, 1e-3, param_period=D), iters=50)
         fwd = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, train_mode=True, want_kl=True, jitter=1e-3, param_period=D), iters=50)
         print(f"B={B:4d} S={S:3d} ({S * D} workgroups)  gp_train_bwd {bwd:7.1f} us   gp_predict(train, KL) {fwd:7.1f} us")
+        # groups of k steps per workgroup (dvg_gp_step_group's choice is marked *)
+        auto = ops.gp_step_group(B, S, D, M)
+        for k in sorted({2, 3, 4, 6, 8, S, auto} - {1}):
+            if k > S:
+                continue
+            try:
+                bwd = time_fn(lambda: ops.gp_train_bwd(h, z, m, ls, c, s, ell, gm, gv, gk, 1e-3, param_period=D, step_group=k), iters=50)
+                fwd = time_fn(lambda: ops.gp_predict(h, z, m, ls, c, s, ell, train_mode=True, want_kl=True, jitter=1e-3,
+                                                     param_period=D, step_group=k), iters=50)
+            except RuntimeError as e:      # the group's points do not fit the LDS
+                print(f"    k={k:2d}: {str(e)[:90]}")
+                continue
+            print(f"    k={k:2d}{'*' if k == auto else ' '} ({-(-S // k) * D:4d} workgroups)  gp_train_bwd {bwd:7.1f} us   "
+                  f"gp_predict(train, KL) {fwd:7.1f} us")
 
 
 if __name__ == "__main__":

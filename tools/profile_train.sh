@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats of one training configuration (eager launches): tools/profile_train.sh <model> [extra bench_train args]
+# rocprofv3 kernel-trace stats of one training configuration (eager launches): [TAG=name] tools/profile_train.sh <model> [extra bench_train args]
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 m=${1:-vgg}; shift
-out=gpurun_out/prof_train_$m
+out=gpurun_out/prof_train_${TAG:-$m}
 rm -rf $out; mkdir -p $out
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o train -- python3 tools/bench_train.py --model $m --iters 2 "$@" > $out/log.txt 2>&1 < /dev/null
 tail -2 $out/log.txt | cut -c1-400
