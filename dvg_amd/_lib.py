@@ -75,6 +75,7 @@ SIGNATURES = {
     "dvg_gp_step_group": (_i, [_i, _i, _i, _i]),
     "dvg_gp_bwd_lds_bytes": (C.c_size_t, [_i, _i]),
     "dvg_gp_bwd_chunk": (_i, [_i, _i]),
+    "dvg_gemm_tn": (_i, [_p] * 5 + [_i] * 8 + [_p]),
     "dvg_gp_train_bwd": (_i, [_p] * 17 + [_i, _i, _i, _f, _i, _i, _p]),
     "dvg_sum_steps_multi": (_i, [_p, _p, _p, _i, _i, _p]),
     "dvg_gp_elbo": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _i, _i, _i, _i, _p]),

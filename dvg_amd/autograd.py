@@ -87,16 +87,16 @@ def _flush_dense(key):
     w_sinks, b_sinks, uses = ent["w"], ent["b"], ent["uses"]
     dys = [u[0] for u in uses]
     dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
-    dyt = ops.transpose2d(dy)
+    bias = [s_b for s_b in b_sinks if s_b is not None]     # ride on the first weight GEMM (column sums of dy)
     for i, s_w in enumerate(w_sinks):
         if s_w is None:
             continue
         xs = [u[1][i] for u in uses]
         x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
-        ops.gemm_nt(dyt, ops.transpose2d(x), None, None, out=s_w, accumulate=True)
-    for s_b in b_sinks:
-        if s_b is not None:
-            ops.colsum(dy, out=s_b, accumulate=True)
+        ops.gemm_tn(dy, x, out=s_w, accumulate=True, colsums=bias[:2])
+        bias = bias[2:]
+    for s_b in bias:
+        ops.colsum(dy, out=s_b, accumulate=True)
 
 
 def _dense_wgrad(w_sinks, b_sinks, dy, inputs):
@@ -632,7 +632,7 @@ class _DenseBlock(torch.autograd.Function):
                                                    sinks=(s_g, s_be, s_b) if bn_direct else None)
         if kind == "head":
             du = du4.reshape(rows, ch)                                   # [N][dim]
-            dgw = ops.gemm_nt(ops.transpose2d(du), ops.transpose2d(a), None, None)   # [dim][K]
+            dgw = ops.gemm_tn(du, a)                                     # [dim][K]
             n, c, h, wd = cfg["xshape"]
             dW = dgw.view(ch, h, wd, c).permute(0, 3, 1, 2).contiguous()
             dx = None
@@ -643,7 +643,7 @@ class _DenseBlock(torch.autograd.Function):
             dim, cout, kh, kw = cfg["wshape"]
             n = rows // (kh * kw)
             du = du4.reshape(n, kh * kw * cout)                          # [N][N_out]
-            dgw = ops.gemm_nt(ops.transpose2d(du), ops.transpose2d(a), None, None)   # [N_out][dim]
+            dgw = ops.gemm_tn(du, a)                                     # [N_out][dim]
             dW = dgw.view(kh, kw, cout, dim).permute(3, 2, 0, 1).contiguous()
             dx = None
             if ctx.needs_input_grad[0]:
@@ -734,12 +734,9 @@ class _Linear(torch.autograd.Function):
         if DENSE_BATCH > 1 and s_w is not None and (s_b0 is not None or not ctx.has_bias):
             _dense_wgrad((s_w,), (s_b0,), dpre, (x,))
             return dx, None, None, None
-        dW = ops.gemm_nt(ops.transpose2d(dpre), ops.transpose2d(x), None, None, out=s_w, accumulate=s_w is not None)
-        db = None
-        if ctx.has_bias:
-            s_b = _sink(ctx.params[1], ctx.needs_input_grad[2])
-            db = ops.colsum(dpre, out=s_b, accumulate=s_b is not None)
-            db = None if s_b is not None else db
+        s_b = _sink(ctx.params[1], ctx.needs_input_grad[2]) if ctx.has_bias else None
+        dW = ops.gemm_tn(dpre, x, out=s_w, accumulate=s_w is not None, colsums=(s_b,))
+        db = ops.colsum(dpre) if ctx.has_bias and s_b is None else None
         return dx, (None if s_w is not None else dW), db, None
 
 
@@ -767,9 +764,8 @@ class _LSTMCell(torch.autograd.Function):
         if DENSE_BATCH > 1 and all(t is not None for t in sinks):
             _dense_wgrad((sinks[0], sinks[1]), (sinks[2], sinks[3]), dG, (x, h))
             return dx, dh, (dc if ng[2] else None), None, None, None, None
-        dGt = ops.transpose2d(dG)
-        dw_ih = ops.gemm_nt(dGt, ops.transpose2d(x), None, None, out=sinks[0], accumulate=sinks[0] is not None)
-        dw_hh = ops.gemm_nt(dGt, ops.transpose2d(h), None, None, out=sinks[1], accumulate=sinks[1] is not None)
+        dw_ih = ops.gemm_tn(dG, x, out=sinks[0], accumulate=sinks[0] is not None)
+        dw_hh = ops.gemm_tn(dG, h, out=sinks[1], accumulate=sinks[1] is not None)
         dbs = []
         db = None
         for s_b in sinks[2:]:
@@ -858,29 +854,28 @@ class _LSTMSequence(torch.autograd.Function):
         pg = list(ng[2:])
         grads = [None] * len(params)
 
-        def acc_w(i, dyt, inp):              # dW_i = dy^T inp, into the parameter's .grad when that is an in-place sink
-            if not pg[i]:
-                return
-            s_ = _sink(params[i], True)
-            g = ops.gemm_nt(dyt, ops.transpose2d(inp), None, None, out=s_, accumulate=s_ is not None)
-            grads[i] = None if s_ is not None else g
-
-        def acc_b(idxs, d):                  # db_i = column sums of d
+        def acc_wb(i, d, inp, bias=()):      # dW_i = d^T inp and db_j = column sums of d (j in bias): ONE launch when the
+            sinks = []                       # gradients go into the parameters' .grad buffers (in-place sinks)
             plain = None
-            for i in idxs:
-                if not pg[i]:
+            for j in bias:
+                if not pg[j]:
                     continue
-                s_ = _sink(params[i], True)
+                s_ = _sink(params[j], True)
                 if s_ is not None:
-                    ops.colsum(d, out=s_, accumulate=True)
+                    sinks.append(s_)
                 else:
                     plain = ops.colsum(d) if plain is None else plain
-                    grads[i] = plain
+                    grads[j] = plain
+            if pg[i]:
+                s_ = _sink(params[i], True)
+                g = ops.gemm_tn(d, inp, out=s_, accumulate=s_ is not None, colsums=sinks)
+                grads[i] = None if s_ is not None else g
+            else:
+                for s_ in sinks:
+                    ops.colsum(d, out=s_, accumulate=True)
         dpre = ops.act_bwd(_c(dy), y, ops.ACT_TANH)
         top = saved[4 * (L - 1) + 1]
-        dpt = ops.transpose2d(dpre)
-        acc_w(len(params) - 2, dpt, top)
-        acc_b([len(params) - 1], dpre)
+        acc_wb(len(params) - 2, dpre, top, [len(params) - 1])
         dh_all = ops.gemm_nt(dpre, _transposed(params[-2]), None, None)          # d h^L_t for every t, (S*B, H)
         dev = x.device
         for l in reversed(range(L)):
@@ -897,16 +892,13 @@ class _LSTMSequence(torch.autograd.Function):
                 dcp, dhp = dcb[t & 1], (dhb[t & 1] if t > 0 else None)
                 ops.lstm_cell_bwd(dh_all[sl], dh_rec, dc, gs[sl], c_prev, cs[sl], whh_t, dG[sl], dcp, dhp)
                 dh_rec, dc = dhp, dcp
-            dGt = ops.transpose2d(dG)
-            acc_w(2 + 4 * l, dGt, inp)
+            acc_wb(2 + 4 * l, dG, inp, [4 + 4 * l, 5 + 4 * l])
             if S > 1:                           # h_{-1} = 0: the first step contributes nothing to dW_hh
-                acc_w(3 + 4 * l, ops.transpose2d(dG[B:]), hs[:(S - 1) * B])
-            acc_b([4 + 4 * l, 5 + 4 * l], dG)
+                acc_wb(3 + 4 * l, dG[B:], hs[:(S - 1) * B])
             if l > 0 or pg[0] or pg[1] or ng[0]:
                 dh_all = ops.gemm_nt(dG, _transposed(wih), None, None)          # gradient w.r.t. this layer's input sequence
         de = dh_all
-        acc_w(0, ops.transpose2d(de), x)
-        acc_b([1], de)
+        acc_wb(0, de, x, [1])
         dx = ops.gemm_nt(de, _transposed(params[0]), None, None) if ng[0] else None
         return (dx, None) + tuple(grads)
 

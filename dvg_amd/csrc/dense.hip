@@ -581,6 +581,94 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     if (lane < 16 && b0 + b < B) dh_prev[(size_t)(b0 + b) * H + n0 + n] = v[0];
 }
 
+
+// ------------------------------------------------------------------------------------
+// gemm_tn (r05): out[m][n] (+)= sum_r a[r][m] b[r][n] - the weight gradient dW = dY^T X of a dense layer (nn.Linear,
+// nn.LSTMCell; lstm.py:50-55) over the R = steps x batch rows of a BPTT pass - together with the bias gradients (column sums
+// of a = dY, into up to two sinks: an LSTMCell's b_ih and b_hh receive the same sums).  Until r05 this was two LDS-tiled
+// transposes, an NT GEMM and a column-sum launch per weight: 71 of the ~520 launches of a 16-clip training iteration.
+// Workgroup = 32 (m) x 64 (n) outputs, a thread owns 2 x 4 of them; the rows are walked in chunks of 32 through LDS with
+// the next chunk's loads in flight (registers) during the FMAs; both operands are read along their contiguous dimension.
+// fp32 FMAs, rows summed in order: deterministic.
+// ------------------------------------------------------------------------------------
+struct GemmTnParams {
+    const float* a; const float* b; float* out; float* cs0; float* cs1;
+    int R, M, N, lda, ldb, ldo, accumulate, cs_accumulate, vec_a, vec_b;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnParams p) {
+    constexpr int TM = 32, TN = 64, KT = 32;
+    __shared__ __attribute__((aligned(16))) float As[KT][TM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[KT][TN + 4];
+    const int tid = threadIdx.x, tn = tid & 15, tm = tid >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // loaders: a chunk = 32 rows x 32 floats (thread: row tid / 8, floats (tid % 8) * 4 ..), b chunk = 32 rows x 64 floats (two
+    // passes of 16 rows: row tid / 16 (+ 16), floats (tid % 16) * 4 ..)
+    const int ar = tid >> 3, ac = m0 + (tid & 7) * 4, br = tid >> 4, bc = n0 + (tid & 15) * 4;
+    auto ld4 = [](const float* base, int ld, int r, int c, int R, int C, int vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            const float* q = base + (size_t)r * ld + c;
+            if (vec) {
+                if (c < C) v = *reinterpret_cast<const float4*>(q);      // C % 4 == 0: whole float4s
+            } else {
+                if (c < C) v.x = q[0];
+                if (c + 1 < C) v.y = q[1];
+                if (c + 2 < C) v.z = q[2];
+                if (c + 3 < C) v.w = q[3];
+            }
+        }
+        return v;
+    };
+    float4 ra, rb0, rb1;
+    auto gload = [&](int r0) {
+        ra = ld4(p.a, p.lda, r0 + ar, ac, p.R, p.M, p.vec_a);
+        rb0 = ld4(p.b, p.ldb, r0 + br, bc, p.R, p.N, p.vec_b);
+        rb1 = ld4(p.b, p.ldb, r0 + br + 16, bc, p.R, p.N, p.vec_b);
+    };
+    auto lstore = [&]() {
+        *reinterpret_cast<float4*>(&As[ar][(tid & 7) * 4]) = ra;
+        *reinterpret_cast<float4*>(&Bs[br][(tid & 15) * 4]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[br + 16][(tid & 15) * 4]) = rb1;
+    };
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float cs[2] = {0.f, 0.f};
+    const bool do_cs = p.cs0 != nullptr && blockIdx.x == 0 && tn == 0;      // the bias gradient of this workgroup's 32 m
+    gload(0);
+    for (int r0 = 0; r0 < p.R; r0 += KT) {
+        __syncthreads();            // the previous chunk has been read
+        lstore();
+        __syncthreads();
+        if (r0 + KT < p.R) gload(r0 + KT);
+#pragma unroll 8
+        for (int k = 0; k < KT; ++k) {
+            const float a0 = As[k][tm * 2], a1 = As[k][tm * 2 + 1];
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[k][tn * 4]);
+            acc[0][0] = fmaf(a0, b4.x, acc[0][0]); acc[0][1] = fmaf(a0, b4.y, acc[0][1]);
+            acc[0][2] = fmaf(a0, b4.z, acc[0][2]); acc[0][3] = fmaf(a0, b4.w, acc[0][3]);
+            acc[1][0] = fmaf(a1, b4.x, acc[1][0]); acc[1][1] = fmaf(a1, b4.y, acc[1][1]);
+            acc[1][2] = fmaf(a1, b4.z, acc[1][2]); acc[1][3] = fmaf(a1, b4.w, acc[1][3]);
+            if (do_cs) { cs[0] += a0; cs[1] += a1; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + tm * 2 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tn * 4 + j;
+            if (n < p.N) {
+                float* o = p.out + (size_t)m * p.ldo + n;
+                *o = p.accumulate ? *o + acc[i][j] : acc[i][j];
+            }
+        }
+        if (do_cs) {
+            p.cs0[m] = p.cs_accumulate ? p.cs0[m] + cs[i] : cs[i];
+            if (p.cs1) p.cs1[m] = p.cs_accumulate ? p.cs1[m] + cs[i] : cs[i];
+        }
+    }
+}
 }  // namespace dvg
 
 using namespace dvg;
@@ -626,6 +714,17 @@ extern "C" int dvg_gemm_nt_bias_act(const float* a, const float* w, const float*
         return check_launch("dvg_gemm_nt_bias_act(reduce)");
     }
     return DVG_OK;
+}
+
+extern "C" int dvg_gemm_tn(const float* a, const float* b, float* out, float* colsum0, float* colsum1, int R, int M, int N,
+                           int lda, int ldb, int ldo, int accumulate, int colsum_accumulate, void* stream) {
+    DVG_REQUIRE(a && b && out, DVG_ERR_NULL, "dvg_gemm_tn: NULL pointer");
+    DVG_REQUIRE(R > 0 && M > 0 && N > 0 && lda >= M && ldb >= N && ldo >= N, DVG_ERR_SHAPE, "dvg_gemm_tn: bad shape");
+    DVG_REQUIRE(colsum0 != nullptr || colsum1 == nullptr, DVG_ERR_NULL, "dvg_gemm_tn: colsum1 without colsum0");
+    GemmTnParams p{a, b, out, colsum0, colsum1, R, M, N, lda, ldb, ldo, accumulate ? 1 : 0, colsum_accumulate ? 1 : 0,
+                   (M % 4 == 0 && lda % 4 == 0 && aligned16(a)) ? 1 : 0, (N % 4 == 0 && ldb % 4 == 0 && aligned16(b)) ? 1 : 0};
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N + 63) / 64, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dvg_gemm_tn");
 }
 
 extern "C" int dvg_lstm_cell(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,

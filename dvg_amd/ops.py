@@ -1187,6 +1187,39 @@ def colsum(a, out=None, accumulate=False):
     return out
 
 
+GEMM_TN_MAX_ROWS = 512     # above: two transposes + the NT kernel (its K = rows spread over lanes and split-K suit long sums)
+
+
+def gemm_tn(a, b, out=None, accumulate=False, colsums=(), colsum_accumulate=True):
+    """out (M, N) (+)= a^T b for a (R, M), b (R, N) - a dense layer's weight gradient dY^T X over the rows of a BPTT pass - in one
+    launch (dvg_gemm_tn); `colsums`: up to two (M,) buffers that receive (colsum_accumulate: are added) the column sums of `a`
+    (the bias gradients).  Returns out."""
+    _dev_f32(a, "gemm_tn.a")
+    _dev_f32(b, "gemm_tn.b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise RuntimeError(f"gemm_tn: a {tuple(a.shape)} and b {tuple(b.shape)} must share their rows")
+    a = a if a.stride(1) == 1 else a.contiguous()
+    b = b if b.stride(1) == 1 else b.contiguous()
+    r, m = a.shape
+    n = b.shape[1]
+    colsums = [c for c in colsums if c is not None]
+    if len(colsums) > 2 or any(c.numel() != m or not c.is_contiguous() for c in colsums):
+        raise RuntimeError("gemm_tn: at most two contiguous column-sum buffers of a.shape[1] entries")
+    if out is None:
+        out, accumulate = torch.empty((m, n), device=a.device, dtype=torch.float32), False
+    elif tuple(out.shape) != (m, n) or out.stride(1) != 1:
+        raise RuntimeError(f"gemm_tn: out must be ({m},{n}) with unit column stride")
+    if r > GEMM_TN_MAX_ROWS:
+        gemm_nt(transpose2d(a), transpose2d(b), None, None, out=out, accumulate=accumulate)
+        for c in colsums:
+            colsum(a, out=c, accumulate=colsum_accumulate)
+        return out
+    _run("gemm_tn", 2.0 * r * m * n, 4.0 * (r * m + r * n + m * n), lib().dvg_gemm_tn, _p(a), _p(b), _p(out),
+         _p(colsums[0]) if colsums else None, _p(colsums[1]) if len(colsums) > 1 else None, r, m, n, a.stride(0), b.stride(0),
+         out.stride(0), int(accumulate), int(colsum_accumulate), _stream())
+    return out
+
+
 def lstm_gates_bwd(dh, dc, gates, c_prev, c_new):
     b, hid = c_prev.shape
     dh = None if dh is None else (dh if dh.is_contiguous() else dh.contiguous())

@@ -559,6 +559,11 @@ int dvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* nn.LSTMCell backward, elementwise part: gate pre-activation gradients dG [B][4H] and
  * dc_prev [B][H] from dh', dc' (either may be NULL), the saved activated gates, c, c'.
  * The GEMM parts (dx = dG W_ih, dW_ih = dG^T x, ...) go through dvg_gemm_nt_bias_act. */
+/* out[m][n] (+)= sum_r a[r][m] b[r][n] (a [R][M], b [R][N], row strides lda / ldb / ldo): dW = dY^T X of nn.Linear / nn.LSTMCell
+ * (lstm.py:50-55) over the R = steps x batch rows of a BPTT pass in ONE launch, no transposed copies; colsum0 / colsum1
+ * (NULL = none) receive the column sums of a - the bias gradient(s) - overwritten or, colsum_accumulate, added to.  ABI 8. */
+int dvg_gemm_tn(const float* a, const float* b, float* out, float* colsum0, float* colsum1, int R, int M, int N,
+                int lda, int ldb, int ldo, int accumulate, int colsum_accumulate, void* stream);
 int dvg_lstm_gates_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                        const float* c_new, float* dG, float* dc_prev, int B, int H, void* stream);
 

@@ -502,6 +502,28 @@ def test_fused_elbo_equals_the_torch_composition():
         assert rel_err(ga[k], gb[k]) < 2e-4, (k, rel_err(ga[k], gb[k]))
 
 
+@pytest.mark.parametrize("R,M,N", [(176, 1024, 256), (60, 90, 256), (176, 256, 90), (1, 7, 5), (33, 31, 65), (600, 64, 36)])
+def test_gemm_tn_matches_fp64_reference(R, M, N):
+    """ops.gemm_tn (dW = dY^T X of the dense layers in one launch, bias gradients as column sums of dY riding along) against
+    fp64 matmul: fresh output, accumulation into existing buffers, row-sliced operands (the BPTT pass hands over dG[B:]),
+    widths that are not multiples of 4 (the 90-wide latent code), and the long-sum fallback (R > ops.GEMM_TN_MAX_ROWS)."""
+    from dvg_amd import ops
+    a = params.normal(570, R + 3, M).to(dev())[3:]
+    b = params.normal(571, R + 3, N).to(dev())[3:]
+    ref = a.double().t() @ b.double()
+    cref = a.double().sum(0)
+    out = ops.gemm_tn(a, b)
+    assert out.shape == (M, N) and rel_err(out, ref) < 2e-6, rel_err(out, ref)
+    base, c0, c1 = params.normal(572, M, N).to(dev()), params.normal(573, M).to(dev()), params.normal(574, M).to(dev())
+    o2, k0, k1 = base.clone(), c0.clone(), c1.clone()
+    assert ops.gemm_tn(a, b, out=o2, accumulate=True, colsums=(k0, None, k1)) is o2
+    assert rel_err(o2, base.double() + ref) < 2e-6
+    assert rel_err(k0, c0.double() + cref) < 2e-6 and rel_err(k1, c1.double() + cref) < 2e-6
+    k2 = torch.full((M,), 7.0, device=dev())
+    ops.gemm_tn(a, b, out=o2, colsums=(k2,), colsum_accumulate=False)
+    assert rel_err(o2, ref) < 2e-6 and rel_err(k2, cref) < 2e-6
+
+
 @pytest.mark.parametrize("S,B,k", [(11, 16, 6), (15, 4, 8), (7, 16, 4), (3, 40, 2), (5, 8, 5), (4, 16, 3)])
 def test_gp_step_groups_equal_one_workgroup_per_step(S, B, k):
     """dvg_gp_predict / dvg_gp_train_bwd with step_group = k (k time steps of a latent dim as ONE workgroup's problem of k x B
