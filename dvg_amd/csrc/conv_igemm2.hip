@@ -140,9 +140,16 @@ struct Cfg2 {
     static constexpr int NT = NT_;
     static constexpr bool FIRST = FIRST_;
     static constexpr bool GEMM = MODE == M2_GEMM;
-    static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;
-    static constexpr int SPAN = GEMM ? 1 : ((MODE == M2_CONV4S2) ? 4 : 3);
-    static constexpr int HH = (TH - 1) * S + SPAN, HW = (TW - 1) * S + SPAN;
+    static constexpr int S = (MODE == M2_CONV4S2) ? 2 : 1;                  // stride in the IMAGE
+    // PAR4 (r05, the stride-2 conv): the 16 taps of a chunk run as FOUR stages, one per input parity (alpha, beta) = (tap row & 1,
+    // tap column & 1).  The pixels (2 y - 1 + alpha + 2 a', 2 x - 1 + beta + 2 b') a parity's taps (2 a' + alpha, 2 b' + beta)
+    // read form a stride-1 grid of (TH + 1) x (TW + 1) pixels - the space-to-depth view of the conv as a 2 x 2 stride-1 conv
+    // on 4 C channels - so a stage's A tile is a quarter of the 18 x 18 halo (14 instead of 43 KB for 8 x 8 outputs: four
+    // workgroups per CU instead of two, and the 8 x 16 tile with two accumulator tiles per wave fits in 46 KB) and its taps are
+    // whole-row offsets in LDS like the other modes'.  Same global bytes: every halo pixel is still loaded once per chunk.
+    static constexpr bool PAR4 = MODE == M2_CONV4S2;
+    static constexpr int SPAN = GEMM ? 1 : (PAR4 ? 2 : 3);
+    static constexpr int HH = (TH - 1) + SPAN, HW = (TW - 1) + SPAN;        // LDS tile (stride 1 in every mode)
     static constexpr int HP = TI * HH * HW;
     static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64 * NT;
     static constexpr int NTAPS = GEMM ? 1 : ((MODE == M2_CONV3) ? 9 : 16);
@@ -152,12 +159,7 @@ struct Cfg2 {
 #define DVG_GEMM_GT 4
 #endif
     // (NT = 2: two slabs, K = 32, so that two 48 KB workgroups share a CU)
-    // The stride-2 conv takes its 16 taps in two stages of 8 with f32 tiles (72 KB of LDS) and in four stages of 4 with bf16
-    // triples: with 8 taps the tile would be 92 KB (43 KB of halo rows at 112 B + 49 KB of weights), one workgroup per CU.
-#ifndef DVG_CONV4S2_GT
-#define DVG_CONV4S2_GT (DVG_BF16X3 ? 4 : 8)
-#endif
-    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? DVG_CONV4S2_GT : (GEMM ? (NT == 2 ? 2 : (BM == 128 ? DVG_GEMM128_GT : DVG_GEMM_GT)) : 4));  // taps (GEMM: 16-channel slabs) per stage
+    static constexpr int GT = (MODE == M2_CONV3) ? 9 : (MODE == M2_CONV4S2 ? 4 : (GEMM ? (NT == 2 ? 2 : (BM == 128 ? DVG_GEMM128_GT : DVG_GEMM_GT)) : 4));  // taps (GEMM: 16-channel slabs) per stage
     static constexpr int NG = (MODE == M2_CONV4S2) ? 16 / GT : 1;                     // stages per K chunk
     static constexpr int CHUNKS_PER_STAGE = GEMM ? GT : 1;                            // 16-channel chunks one stage consumes
     static constexpr bool X3 = DVG_BF16X3 != 0;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     for (int mt = 0; mt < MT; ++mt) {
         const int m = wm * (C::BM / 2) + mt * 32 + l31;
         const int ti = m / (TH * TW), r = m % (TH * TW);
-        const int pos = (ti * HH + (r / TW) * S) * HW + (r % TW) * S;
+        const int pos = (ti * HH + r / TW) * HW + r % TW;
         a_base[mt] = pos * LD + (X3 ? (hh ^ (GEMM ? (pos >> 3) & 1 : 0)) * 4 : hh * 8);
     }
     // LDS image of the weight tile: [64-column block][tap][64 rows][LDB]; the wave's 32-column tile nt is rows
@@ -257,15 +259,40 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     // bookkeeping, around the loads.
     // GEMM mode: the GT slabs of a stage share their row offsets (slab s = + 16 s floats): NLA1 offsets, no skip operand
     constexpr int NOFF = GEMM ? NLA1 : NLA;
-    using aoff_t = typename std::conditional<GEMM, int, long>::type;   // GEMM: offsets inside one image (host checks < 2^31)
+    // GEMM: offsets inside one image; PAR4: inside the whole activation (the host checks < 2^31 floats in both cases)
+    using aoff_t = typename std::conditional<GEMM || C::PAR4, int, long>::type;
+    // a 0 / 1 value the optimiser cannot see through: `bit * step` stays a multiply instead of becoming a select on a lane
+    // mask (a dozen hoisted masks ran the kernel out of SGPRs, and the spilled ones were re-made inside the stage loop)
+    auto opaque = [](unsigned v) { asm("" : "+v"(v)); return v; };
     aoff_t offx[NOFF], offs[GEMM ? 1 : NLA];
-    unsigned okmask = 0;
+    unsigned okmask = 0;      // PAR4: bit par * NLA + i (the parity's pixel of slot i lies inside the image), 16 + i / 24 + i (steps)
+    static_assert(!C::PAR4 || NLA <= 4, "PAR4: four validity bits and two step bits per halo slot in one word");
     if (GEMM) offs[0] = 0;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
         const int idx = tid + (i % NLA1) * 256;
         const int hp = idx >> 2, q = idx & 3;
         const int ti = hp / (HH * HW), r = hp % (HH * HW);
+        if constexpr (C::PAR4) {
+            // slot (hy, hx) of parity (alpha, beta) is image pixel (yin0 + 2 hy + alpha, xin0 + 2 hx + beta).  ONE offset per slot:
+            // parity (0, 0)'s pixel CLAMPED into the image, plus a row / column step per parity that is 0 where the step would
+            // leave the image (rows -1 -> 0 and H - 1 -> H, likewise columns).  Every load reads inside the tensor; the conv's
+            // zero padding is applied to the VALUE at the LDS store (an integer AND with 0 / ~0: no lane mask, no select, exact
+            // zeros whatever was loaded).
+            const int n = n0 + ti, yy = yin0 + 2 * (r / HW), xx = xin0 + 2 * (r % HW);
+            const bool in = idx < HP * 4 && n < p.N;
+#pragma unroll
+            for (int par_ = 0; par_ < 4; ++par_) {
+                const bool ok = in && (unsigned)(yy + (par_ >> 1)) < (unsigned)p.H && (unsigned)(xx + (par_ & 1)) < (unsigned)p.W;
+                okmask |= ok ? (1u << (par_ * NLA + i)) : 0u;
+            }
+            const int cy0 = min(max(yy, 0), p.H - 1), cy1 = min(max(yy + 1, 0), p.H - 1);
+            const int cx0 = min(max(xx, 0), p.W - 1), cx1 = min(max(xx + 1, 0), p.W - 1);
+            okmask |= (in && cy1 != cy0) ? (1u << (16 + i)) : 0u;
+            okmask |= (in && cx1 != cx0) ? (1u << (24 + i)) : 0u;
+            offx[i] = in ? (int)((((long)n * p.H + cy0) * p.W + cx0) * p.C1 + q * 4) : 0;
+            offs[i] = 0;                                                    // (no skip operand in this mode)
+        } else {
         const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
         const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         const int sh = p.upsample;
@@ -273,12 +300,13 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         if (!GEMM || i < NLA1)
             offx[GEMM ? i % NLA1 : i] = (aoff_t)(ok ? ((((long)(GEMM ? 0 : n) * (p.H >> sh) + (yy >> sh)) * (p.W >> sh) + (xx >> sh)) * p.C1 + q * 4) : 0);
         if (!GEMM) offs[i] = (ok && p.C2) ? ((((long)n * p.H + yy) * p.W + xx) * p.C2 + q * 4) : 0;
+        }
     }
     auto tap_lds = [&](int grp, int tt) -> int {
         if (GEMM) return tt * C::SLAB;
         int th, tw;
         if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
-        else if (MODE == M2_CONV4S2) { const int tap = grp * GT + tt; th = tap >> 2; tw = tap & 3; }
+        else if (MODE == M2_CONV4S2) { th = tt >> 1; tw = tt & 1; }      // PAR4: tap (2 th + alpha, 2 tw + beta) of the parity grp
         else { th = 1 + py - (tt >> 1); tw = 1 + px - (tt & 1); }
         return (th * HW + tw) * LD;
     };
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
         }
     };
-    auto gload_a = [&](int c0, f32x4 (&ra)[NLA]) {
+    auto gload_a = [&](int c0, f32x4 (&ra)[NLA], const int par_ = 0) {
         if constexpr (FIRST) {      // no activation to load: the tile is computed where it is stored (first_tile, lds_store_a)
             const float* w = p.first_w + c0 + (tid & 3) * 4;                      // [9 taps][64 channels]
 #pragma unroll
@@ -344,6 +372,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         for (int i = 0; i < NLA; ++i) {
             if (GEMM) {    // whole tiles only (host checks): every slot is valid
                 ra[i] = *reinterpret_cast<const f32x4*>(src + offx[i % NLA1] + (i / NLA1) * 16);
+            } else if (C::PAR4) {
+                int off = offx[i];
+                if (par_ >> 1) off += (int)opaque((okmask >> (16 + i)) & 1u) * (p.W * p.C1);
+                if (par_ & 1) off += (int)opaque((okmask >> (24 + i)) & 1u) * p.C1;
+                ra[i] = *reinterpret_cast<const f32x4*>(src + off);
             } else {
                 const float* a = src + (from_x ? offx[GEMM ? 0 : i] : offs[GEMM ? 0 : i]);
                 ra[i] = *reinterpret_cast<const f32x4*>(((okmask >> i) & 1u) ? a : dvg_zero_slot);
@@ -364,12 +397,20 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             rb[j] = reinterpret_cast<const f32x4*>(tile)[i + blk];
         }
     };
-    auto lds_store_a = [&](f32x4 (&ra)[NLA]) {
+    auto lds_store_a = [&](f32x4 (&ra)[NLA], const int par_ = 0) {
         if constexpr (FIRST) first_tile(ra);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
             const int hp = idx >> 2, q = idx & 3;
+            if constexpr (C::PAR4) {       // the zero padding (and the slots past the tile / the batch): value AND 0 / ~0
+                const unsigned keep = 0u - opaque((okmask >> (par_ * NLA + i)) & 1u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f = ra[i][e];      // (a copy: __builtin_bit_cast on the vector-element lvalue reads element 0)
+                    ra[i][e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & keep);
+                }
+            }
             // halo / out-of-image slots already hold zeros (gload_a read dvg_zero_slot for them); rows >= HP: padding
             if constexpr (X3) {
                 // the thread's four k-values as three bf16 quadruples, 8 bytes into each plane of the row
@@ -429,14 +470,14 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     // stores are UNCONDITIONAL.  With the loads under one runtime `if` and the stores under another, hipcc's
     // (path-insensitive) s_waitcnt insertion assumed the previous stage's loads could still be pending at the loop
     // head and emitted vmcnt(0) right after the new A loads were issued - a full memory latency exposed per stage.
-    auto stage = [&](const int chunk, auto grp_c, auto has_next_c, const int nchunk_override = -1) {
+    auto stage = [&](const int chunk, auto grp_c, auto has_next_c, const int nchunk_override = -1) __attribute__((always_inline)) {
         constexpr int grp = decltype(grp_c)::value;
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int ngrp = (grp + 1) % NG;
-        constexpr bool next_a = has_next && ngrp == 0;
+        constexpr bool next_a = has_next && (ngrp == 0 || C::PAR4);        // PAR4: every stage has its own A tile
         const int nchunk = nchunk_override >= 0 ? nchunk_override : chunk + (ngrp == 0 ? CPS : 0);
         if (DVG_ABLATE < 1 || DVG_ABLATE == 6 || DVG_ABLATE == 7) {        // 6: the weight tile stays what the prologue loaded, 7: the A tile
-            if constexpr (next_a) { if (DVG_ABLATE != 7) gload_a(nchunk * C::KC, ra); }
+            if constexpr (next_a) { if (DVG_ABLATE != 7) gload_a(nchunk * C::KC, ra, C::PAR4 ? ngrp : 0); }
             if constexpr (has_next) { if (DVG_ABLATE != 6) gload_b(nchunk, ngrp, rb); }
         }
 
@@ -492,7 +533,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 // forming an MFMA-less pass between two barriers.
                 if (DVG_ABLATE < 3 || (DVG_ABLATE >= 4 && DVG_ABLATE != 9)) __syncthreads();
                 if (DVG_ABLATE < 2 || (DVG_ABLATE >= 4 && DVG_ABLATE < 8)) {      // 4: no B stores, 5: no A stores (timing only)
-                    if constexpr (next_a) { if (DVG_ABLATE != 5 && DVG_ABLATE != 7) lds_store_a(ra); }
+                    if constexpr (next_a) { if (DVG_ABLATE != 5 && DVG_ABLATE != 7) lds_store_a(ra, C::PAR4 ? ngrp : 0); }
                     if (DVG_ABLATE != 4 && DVG_ABLATE != 6) lds_store_b(rb);
                 }
             }
@@ -596,7 +637,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         if constexpr (has_next) {
             if (!DVG_WRITE_OVERLAP) {
                 __syncthreads();  // every wave has finished reading this stage's tiles
-                if constexpr (next_a) lds_store_a(ra);
+                if constexpr (next_a) lds_store_a(ra, C::PAR4 ? ngrp : 0);
                 lds_store_b(rb);
             }
             if (DVG_ABLATE < 3 || (DVG_ABLATE >= 4 && DVG_ABLATE != 9)) __syncthreads();
@@ -672,7 +713,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         }
     } else {
     // the NG stages of a chunk, the last one of the last chunk without a successor
-    auto chunk_stages = [&](const int ch, auto last_c) {
+    auto chunk_stages = [&](const int ch, auto last_c) __attribute__((always_inline)) {
         constexpr bool last = decltype(last_c)::value;
         set_prio(st++);
         stage(ch, integral_constant<int, 0>{}, integral_constant<bool, !(last && NG == 1)>{});
@@ -1076,7 +1117,7 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
     if (Hg == 4 && Wg == 4) { *ti = 4; *th = 4; *tw = 4; return 0; }
     if (Hg % 8 || Wg % 8) return -1;
     *ti = 1; *th = 8; *tw = 8;
-    if (mode != M2_CONV4S2 && Wg % 16 == 0) {
+    if (Wg % 16 == 0) {
         const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
         if (wgs >= 512) *tw = 16;
         if (mode == M2_GEMM && *tw == 16) {
@@ -1093,9 +1134,10 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
 __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
                                 int kw, int transposed) {
     // dst[chunk][co / 64][slot][co % 64][row of 16 k-values]  <-  conv: w[co][ci][a][b]   convT: w[ci][co][KH-1-a][KW-1-b]
-    // slot = the tap t = a * kw + b, except for the 4 x 4 taps of a transposed conv (the stride-2 transposed mode): there the
-    // four taps an output parity (py, px) uses are consecutive, slot = (py * 2 + px) * 4 + tt with tap row 2 + py - 2 (tt >> 1)
-    // and tap column 2 + px - 2 (tt & 1), so that a stage's weight tile is contiguous in every mode
+    // slot = the tap t = a * kw + b, except for 4 x 4 kernels (the stride-2 modes).  Transposed conv: the four taps an output
+    // parity (py, px) uses are consecutive, slot = (py * 2 + px) * 4 + tt with tap row 2 + py - 2 (tt >> 1) and tap column
+    // 2 + px - 2 (tt & 1).  Stride-2 conv: the four taps of an INPUT parity are consecutive, slot = ((a & 1) * 2 + (b & 1)) * 4
+    // + (a >> 1) * 2 + (b >> 1).  So a stage's weight tile is contiguous in every mode
     const long total = (long)cout * cin * kh * kw;
     const int nblk = cout >> 6, taps = kh * kw;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1111,6 +1153,9 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
         if (transposed && kh == 4 && kw == 4) {
             const int py = a & 1, px = b & 1;
             slot = (py * 2 + px) * 4 + ((2 + py - a) >> 1) * 2 + ((2 + px - b) >> 1);
+        } else if (kh == 4 && kw == 4) {
+            // the stride-2 conv (PAR4): the four taps of an input parity (a & 1, b & 1) are consecutive
+            slot = ((a & 1) * 2 + (b & 1)) * 4 + (a >> 1) * 2 + (b >> 1);
         }
         wrow_store(dst, (((size_t)chunk * nblk + (co >> 6)) * taps + slot) * 64 + (co & 63), co & 63, k, src[j]);
     }
@@ -1247,9 +1292,12 @@ extern "C" int dvg_conv4x4s2_bn_act_v2(const float* x, const float* w_k16, const
                    1, 0, nullptr};
     if (int e = checks2(p, "dvg_conv4x4s2_bn_act_v2")) return e;
     DVG_REQUIRE(H % 2 == 0 && W % 2 == 0, DVG_ERR_SHAPE, "dvg_conv4x4s2_bn_act_v2: odd input");
+    DVG_REQUIRE((long)N * H * W * Cin < (1L << 31), DVG_ERR_SHAPE,
+                "dvg_conv4x4s2_bn_act_v2: input of %d x %d x %d x %d floats too large (32-bit offsets)", N, H, W, Cin);
     int Hg = H / 2, Wg = W / 2, ti, th, tw;
     DVG_REQUIRE(tile2(M2_CONV4S2, N, Hg, Wg, Cout, &ti, &th, &tw) == 0, DVG_ERR_SHAPE,
                 "dvg_conv4x4s2_bn_act_v2: unsupported map %dx%d", H, W);
+    D2(M2_CONV4S2, 1, 8, 16)
     D2(M2_CONV4S2, 1, 8, 8)
     D2(M2_CONV4S2, 4, 4, 4)
     return fail(DVG_ERR_SHAPE, "dvg_conv4x4s2_bn_act_v2: no kernel");
