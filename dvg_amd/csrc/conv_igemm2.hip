@@ -1009,6 +1009,8 @@ static int finish_units_per_block(long units) {
 }
 
 // number of K splits for a v2 launch: only when the grid would leave CUs idle and K is deep enough
+// (r05, stride-2 conv after the parity split: splitting further - 768 / 1 024 workgroup slots - or not at all measured -0.5 ... -3 % on
+// the dcgan_64 rollout, in flight and on one chain: profiles/r05_ab_conv4s2.txt)
 static int choose_splitk(long wgs, int nchunks) {
     if (wgs >= 384 || nchunks < 8) return 1;
     long s = 512 / wgs;
