@@ -123,8 +123,11 @@ def test_first_layers(nc, res):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (2, 16, 16, 128, 256), (5, 8, 8, 256, 512),
-                                            (2, 64, 64, 64, 64), (16, 8, 8, 256, 512)])
+                                            (2, 64, 64, 64, 64), (16, 8, 8, 256, 512), (128, 32, 32, 32, 128),
+                                            (3, 16, 48, 16, 64)])
 def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
+    """dvg_conv4x4s2_bn_act_v2 (one stage per input parity, r05) vs F.conv2d: 8 x 8 tiles, the 4-image 4 x 4 tile with a ragged
+    batch, the 8 x 16 tile (>= 512 workgroups: the (128, 32, 32, 32, 128) case), a non-square map with three tile columns."""
     from dvg_amd import ops
     x = params.normal(40, N, Cin, H, W)
     w = params.normal(41, Cout, Cin, 4, 4, scale=1.0 / np.sqrt(16 * Cin))
