@@ -406,7 +406,10 @@ def test_shared_encoder_passes_match_reference_structure(model):
                 assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-4, atol=1e-5), (k, float((a[k] - b[k]).abs().max()))
 
 
-@pytest.mark.parametrize("model,width,batch", [("dcgan", 64, 4), ("vgg", 64, 4), ("dcgan", 128, 2), ("dcgan", 64, 6)])
+# (the 128-wide case ran at B = 2 until r05: BatchNorm over two images makes the comparison a lottery - encoder-range deviation
+# 5e-4 ... 1e-2 depending on the data seed, with the r04 kernels as with the r05 ones (LeakyReLU branches of near-zero
+# pre-activations flip with the summation order); at B = 4 it is <= 2e-4 for every seed tried)
+@pytest.mark.parametrize("model,width,batch", [("dcgan", 64, 4), ("vgg", 64, 4), ("dcgan", 128, 4), ("dcgan", 64, 6)])
 def test_time_batched_encoder_matches_the_per_frame_path(model, width, batch):
     """Trainer.time_batched: the T encoder calls of a closure as ONE pass over T x B frames with per-frame ("grouped")
     BatchNorm - statistics, normalisation, BatchNorm backward per group of B images, running statistics advanced frame by
