@@ -145,6 +145,33 @@ def test_posterior_rollout_matches_oracle(family):
         assert rel_err(shared[t], ours[t]) < 2e-5       # same arithmetic per image; tile choices may differ with the batch
 
 
+@pytest.mark.parametrize("family,B", [("dcgan", 1), ("dcgan", 3), ("dcgan", 7), ("vgg", 1), ("vgg", 5)])
+def test_posterior_rollout_at_ragged_batches(family, B):
+    """The rollout at batch sizes that divide none of the kernels' tiles (the 4-image 4 x 4 tiles, the 8-row waves of the LSTM /
+    GEMV kernels, the GP's point chunks, Winograd tile groups): B = 1, 3, 5, 7 against the oracle at the inference bar, plain
+    and as a captured hipGraph (the reference runs whatever batch the data loader's last slice has: generate_frames.py:300-318
+    drops nothing)."""
+    from dvg_amd.rollout import GraphedRollout, posterior_rollout, sample_rollout
+    n_past, n_eval = 2, 5
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1500 + B)
+    xs = [params.frames(1520 + t, B, 1, 64) for t in range(n_eval)]
+    enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
+    with torch.no_grad():
+        ref = orc.posterior_rollout(xs, enc_o, dec_o, lsd, gsd, lik, n_past, n_eval)
+    for m in mods:
+        m.to(DEV).eval()
+    xd = [t.to(DEV) for t in xs]
+    ours = posterior_rollout(*mods, xd, n_past, n_eval)
+    for t in range(n_eval):
+        assert ours[t].shape == ref[t].shape and rel_err(ours[t], ref[t]) < 1e-4, (t, rel_err(ours[t], ref[t]))
+    with torch.no_grad():
+        eager = [f.clone() for f in sample_rollout(*mods, xd, n_past=n_past, n_eval=n_eval)]      # (no trigger step inside 2 + 3)
+        graphed = GraphedRollout(*mods, xd, n_past, n_eval)(xd)
+    assert len(graphed) == len(eager) == n_eval
+    for t in range(n_eval):
+        assert torch.equal(graphed[t], eager[t]), t
+
+
 @pytest.mark.parametrize("depth,index", [(1, 0), (1, 2), (-250, 1)])
 def test_gp_trigger_generation_matches_oracle(depth, index):
     """generate_frames.py:249-298 per batch index: variance norms (float32, host-side like the reference), thresholds, the
