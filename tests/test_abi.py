@@ -69,6 +69,18 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     assert lib.dvg_conv_splitk_v2(0, 64, 8, 8, 512, 256) == 2          # 256 workgroups, K = 32 chunks
     assert lib.dvg_conv_splitk_v2(0, 16, 8, 8, 512, 512) == 4          # per-GPU batch 16
     assert lib.dvg_gp_lds_bytes(64, 40, 1) <= 160 * 1024 and lib.dvg_gp_precision(64, 40, 1) == 64
+    # r05 entry points: the checks fire before anything is launched
+    assert lib.dvg_gemm_tn(one, one, None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, None) == 2                  # no output (DVG_ERR_NULL)
+    assert lib.dvg_gemm_tn(one, one, one, None, one, 8, 8, 8, 8, 8, 8, 0, 0, None) == 2                    # second sink without first
+    assert lib.dvg_gemm_tn(one, one, one, None, None, 8, 16, 8, 8, 8, 8, 0, 0, None) == 1                  # lda < M
+    assert lib.dvg_conv4x4s2_bn_act_v2(one, one, None, None, one, None, 40000, 128, 128, 64, 64, 0, 0.2, None, 0, None) == 1
+    assert b"32-bit offsets" in lib.dvg_last_error()
+    gp = [one] * 7 + [None, None, one, one, None, None, one]                # h .. lengthscale, noise, eps, mean, var, sample, cov, kl
+    assert lib.dvg_gp_predict(*gp, 16, 990, 40, 1, 1e-3, 90, 12, None) == 1                                 # step_group > S = 11
+    assert lib.dvg_gp_predict(*gp, 64, 1710, 40, 1, 1e-3, 90, 4, None) == 1 and b"fp64" in lib.dvg_last_error()   # 256 points: no fp64 fit
+    # the host side's choice of steps per workgroup for a time-batched GP call (dvg_gp_step_group: B, S, latent dims, M)
+    assert [lib.dvg_gp_step_group(*a) for a in ((16, 11, 90, 40), (4, 15, 90, 40), (64, 19, 90, 40), (16, 2, 90, 40),
+                                               (50, 14, 90, 40), (16, 1, 90, 40))] == [6, 8, 1, 1, 1, 1]
 
 
 def test_product_has_no_cpu_fallback():
