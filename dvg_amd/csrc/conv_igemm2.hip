@@ -47,6 +47,9 @@
 #ifndef DVG_ABLATE
 #define DVG_ABLATE 0
 #endif
+#ifndef DVG_X3_TERMS
+#define DVG_X3_TERMS 6
+#endif
 #ifndef DVG_FIRST_SELECTS
 #define DVG_FIRST_SELECTS 0
 #endif
@@ -548,19 +551,21 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                                 __builtin_bit_cast(bf16x8_t, fa[cur][mt][pa]), __builtin_bit_cast(bf16x8_t, fb[cur][nt][pb]),
                                 acc[mt * NT + nt], 0, 0, 0);
                 };
+                // DVG_X3_TERMS (timing experiments only, WRONG results below 6): 3 keeps (m,h) (h,m) (h,h) - what a two-piece
+                // operand split would issue - to measure how the rollout rate follows the MFMA count (notes r05 §8)
                 if constexpr (LEAN) {
-                    mm(2, 0);
-                    mm(0, 2);
+                    if (DVG_X3_TERMS >= 6) mm(2, 0);
+                    if (DVG_X3_TERMS >= 6) mm(0, 2);
                     if (tt + 1 < GT) read_plane(2);
-                    mm(1, 1);
+                    if (DVG_X3_TERMS >= 6) mm(1, 1);
                     mm(1, 0);
                     mm(0, 1);
                     if (tt + 1 < GT) read_plane(1);
                     mm(0, 0);
                 } else {
-                    mm(2, 0);
-                    mm(1, 1);
-                    mm(0, 2);
+                    if (DVG_X3_TERMS >= 6) mm(2, 0);
+                    if (DVG_X3_TERMS >= 6) mm(1, 1);
+                    if (DVG_X3_TERMS >= 6) mm(0, 2);
                     mm(1, 0);
                     mm(0, 1);
                     mm(0, 0);
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             // Pin the software pipeline: hipcc otherwise sinks the next tap's ds_reads down to their first use
             // (ds_read x3 -> s_waitcnt -> mfma x8), exposing the LDS latency every 8 MFMAs.  One ds_read_b128 per two
             // MFMAs, issued a full tap (16 / 8 MFMAs) ahead of its consumer.
-            constexpr int NREAD = NP * (MT + NT), NMFMA = (X3 ? 6 : 8) * MT * NT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
+            constexpr int NREAD = NP * (MT + NT), NMFMA = (X3 ? DVG_X3_TERMS : 8) * MT * NT, MPR = NMFMA >= 2 * NREAD ? 2 : 1;
             // next stage's global loads: two per tap behind the first taps' MFMAs.  Left free, hipcc sinks them to
             // the end of the stage (latency exposed at their ds_write); all at the top they delay the first MFMAs.
             constexpr int NVMEM = (next_a ? (FIRST ? 11 : NLA) : 0) + (has_next ? NLB : 0);
