@@ -114,8 +114,9 @@ int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
  * schedule and its un-suffixed entry points were retired in ABI 3).  Weights are packed by
  * dvg_pack_conv_weight_k16 (transposed != 0: ConvTranspose2d weight (Cin,Cout,KH,KW), flipped) into
  * Cin/16 * KH*KW * Cout rows of dvg_packed_row_floats() floats, [Cin/16][Cout/64][tap slot][64][row]
- * (a 4x4 transposed pack orders the slots by output parity: it feeds dvg_convT4x4s2_bn_act_v2, a 4x4
- * plain pack dvg_conv4x4s2_bn_act_v2, a 3x3 pack dvg_conv3x3_bn_act_v2), and `stats` has
+ * (a 4x4 transposed pack orders the slots by OUTPUT parity: it feeds dvg_convT4x4s2_bn_act_v2; a 4x4
+ * plain pack orders them by INPUT parity (r05): it feeds dvg_conv4x4s2_bn_act_v2, which runs one stage per
+ * parity and needs N * H * W * Cin < 2^31; a 3x3 pack feeds dvg_conv3x3_bn_act_v2), and `stats` has
  * dvg_conv_stats_rows_v2(...) rows.  C1, C2 multiples of 16; Cout multiple of 64.
  *
  * ABI 7 - arithmetic of the implicit-GEMM kernels.  dvg_mfma_mode() == 1 (the default build): every fp32
