@@ -86,6 +86,13 @@ def parse_args(argv=None):
     ap.add_argument("--n_future", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the oracle check of the frames the timed region produced (rank 0; `check` in the JSON line)")
+    ap.add_argument("--sustained-s", type=float, default=5.0,
+                    help="seconds of back-to-back rollouts (same graphs) for the `sustained` figure beside `value`; 0 = skip")
+    ap.add_argument("--allow-variant", action="store_true",
+                    help="emit a line although DVG_HIP_LIB points at another build of the library or the loaded build is a "
+                         "timing experiment (X3_TERMS != 6, ABLATE != 0, ...): the line then says so in `build`")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--inflight", type=int, default=3,
                     help="complete rollouts in flight at once (independent samples of the make_gifs loop, one hipGraph and one "
@@ -187,9 +194,52 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int, budget_s: float = 10.0):
+CHECK_BAR = 1e-4   # BASELINE.json north_star: "outputs match the reference CPU path within 1e-4 relative on fp32 frames"
+
+
+def snapshot_case(model, mods, x, chains, n_past, n_eval):
+    """What the oracle needs to redo the rollouts the timed graphs just ran, copied to the host: the modules' state_dicts (the
+    SAME weights, BatchNorm running statistics and GP state the GPU path used), the input clips, and per chain the GP base
+    samples eps its last replay drew and the frames that replay produced."""
+    import torch
+    torch.cuda.synchronize()
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}   # noqa: E731
+    enc, dec, fp, gp, lik = mods
+    return {"model": model, "n_past": n_past, "n_eval": n_eval, "batch": int(x[0].shape[0]),
+            "sds": (cpu(enc.state_dict()), cpu(dec.state_dict()), cpu(fp.state_dict()), cpu(gp.state_dict()), cpu(lik.state_dict())),
+            "x": [t.detach().cpu().clone() for t in x],
+            "chains": [{"eps": {i: e.detach().cpu().clone() for i, e in eps.items()},
+                        "frames": [f.detach().cpu().clone() for f in frames]} for eps, frames in chains]}
+
+
+def check_against_oracle(case, oracle_frames):
+    """max |a - b| / max |b| per frame (tests/common.rel_err) of the frames the TIMED graphs produced against the oracle's
+    rollout of the same weights, clips and GP base samples, over every predicted frame of every chain the oracle re-ran."""
+    n_past, n_eval = case["n_past"], case["n_eval"]
+    per_chain = []
+    for k, ref in sorted(oracle_frames.items()):
+        got = case["chains"][k]["frames"]
+        errs = []
+        for t in range(n_past, n_eval):
+            a, b = got[t].double(), ref[t].double()
+            errs.append(float((a - b).abs().max() / max(float(b.abs().max()), 1e-12)))
+        per_chain.append(max(errs))
+    worst = max(per_chain) if per_chain else None
+    return {"rel_err_vs_oracle": None if worst is None else float(f"{worst:.3e}"), "bar": CHECK_BAR,
+            "ok": bool(worst is not None and worst < CHECK_BAR),
+            "frames_compared": len(per_chain) * (n_eval - n_past) * case["batch"],
+            "chains_compared": len(per_chain), "per_chain": [float(f"{e:.3e}") for e in per_chain],
+            "what": "the predicted frames left in the static buffers by the LAST replay of each timed hipGraph chain against "
+                    "oracle.rollout (generate_frames.py:143-177 restated on torch-CPU fp32, GP in fp64) with the same weights, "
+                    "clips and GP base samples; rel_err = max|a-b| / max|b| per frame, worst frame reported"}
+
+
+def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int, budget_s: float = 10.0, case=None,
+                 max_chains=None):
     """The oracle (CPU restatement, parity-checked against the reference's modules) timed on the host
-    cores of this box: whole rollouts of the same workload until `budget_s` of CPU work have been timed."""
+    cores of this box: whole rollouts of the same workload until `budget_s` of CPU work have been timed.
+    With `case` (snapshot_case) the rollouts are the ones the timed GPU graphs ran - same weights, clips and GP base samples,
+    one chain after the other - and their frames are returned as the checker's reference (second value)."""
     import importlib
     import torch
     from oracle import dvg_oracle as orc
@@ -197,35 +247,45 @@ def cpu_baseline(model: str, batch: int, n_past: int, n_eval: int, seed: int, bu
     from dvg_amd.data import SyntheticMovingMNIST
     cores = usable_cores()
     torch.set_num_threads(cores)
-    m = importlib.import_module(f"dvg_amd.models.{model}_64")
-    esd = params.fill_state_dict(m.encoder(90, 1).state_dict(), 1)
-    dsd = params.fill_state_dict(m.decoder(90, 1).state_dict(), 2,
-                                 params.decoder_transposed_keys(m.decoder(90, 1).state_dict(), model))
-    from dvg_amd.models.lstm import lstm
-    lsd = params.fill_state_dict(lstm(90, 90, 256, 2, batch).state_dict(), 3)
-    gsd, lik = params.gp_state(4)
-    seq = SyntheticMovingMNIST(seq_len=n_eval, seed=seed).batch(batch)
-    x = orc.normalize_data(seq)
+    if case is not None:
+        esd, dsd, lsd, gsd, lik = case["sds"]
+        x = case["x"]
+        eps_list = [c["eps"] for c in case["chains"]][:max_chains]
+    else:
+        m = importlib.import_module(f"dvg_amd.models.{model}_64")
+        esd = params.fill_state_dict(m.encoder(90, 1).state_dict(), 1)
+        dsd = params.fill_state_dict(m.decoder(90, 1).state_dict(), 2,
+                                     params.decoder_transposed_keys(m.decoder(90, 1).state_dict(), model))
+        from dvg_amd.models.lstm import lstm
+        lsd = params.fill_state_dict(lstm(90, 90, 256, 2, batch).state_dict(), 3)
+        gsd, lik = params.gp_state(4)
+        seq = SyntheticMovingMNIST(seq_len=n_eval, seed=seed).batch(batch)
+        x = orc.normalize_data(seq)
+        eps_list = [{i: params.normal(50 + i, 90, batch) for i in orc.gp_trigger_steps(n_past, n_eval)}]
     if model == "vgg":
         enc = lambda t: orc.vgg_encoder(t, esd, False)          # noqa: E731
         dec = lambda v, s: orc.vgg_decoder(v, s, dsd, False)    # noqa: E731
     else:
         enc = lambda t: orc.dcgan_encoder(t, esd, False)        # noqa: E731
         dec = lambda v, s: orc.dcgan_decoder(v, s, dsd, False)  # noqa: E731
-    eps = {i: params.normal(50 + i, 90, batch) for i in orc.gp_trigger_steps(n_past, n_eval)}
+    frames = {}
     with torch.no_grad():
         enc(x[0])  # warm the thread pool / allocator
         n, t0 = 0, time.perf_counter()
-        while True:   # bounded sample: whole rollouts until ~budget_s of CPU work have been timed
-            orc.rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps)
+        while True:   # bounded sample: whole rollouts until ~budget_s of CPU work have been timed (and every chain once)
+            k = n % len(eps_list)
+            out = orc.rollout(x, enc, dec, lsd, gsd, lik, n_past, n_eval, eps_list[k])
+            frames.setdefault(k, out)
             n += 1
             dt = time.perf_counter() - t0
-            if dt >= budget_s or n >= 40:
+            if (dt >= budget_s and n >= len(eps_list)) or n >= 40:
                 break
-    return {"value": round(n * batch * (n_eval - n_past) / dt, 2), "unit": "frames/s", "cores": cores,
-            "kind": "port", "sample": f"{n} rollout(s) of the same workload ({model}_64, B={batch}, "
-                                      f"{n_past}-in/{n_eval - n_past}-out) = {dt:.1f} s of CPU work, torch-CPU fp32, "
-                                      f"{cores} threads"}
+    res = {"value": round(n * batch * (n_eval - n_past) / dt, 2), "unit": "frames/s", "cores": cores,
+           "kind": "port", "sample": f"{n} rollout(s) of the same workload ({model}_64, B={batch}, "
+                                     f"{n_past}-in/{n_eval - n_past}-out) = {dt:.1f} s of CPU work, torch-CPU fp32, "
+                                     f"{cores} threads" + ("; the weights, clips and GP draws of the timed GPU chains "
+                                                           "(their frames are the `check` reference)" if case is not None else "")}
+    return (res, frames) if case is not None else res
 
 
 class Ctx:
@@ -308,8 +368,14 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     x = SyntheticMovingMNIST(seq_len=n_eval, seed=args.seed + ctx.rank).batch_device(args.batch, ctx.dev)
     calibrate_batchnorm(enc, dec, x[0])
 
+    # eager launches (--no-graph, the HIP-event leg): the GP base samples come from a static buffer refilled per step, so that
+    # the oracle check can redo the last step's draw
+    eager_eps = {i: torch.randn(90, args.batch, device=ctx.dev) for i in range(args.n_past, n_eval) if i % 15 == 0}
+
     def eager_step():
-        return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
+        for e in eager_eps.values():
+            e.normal_()
+        return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval, eps_by_step=eager_eps)
 
     # A step = one COMPLETE rollout (conditioning + prediction, B clips).  The rollouts of the make_gifs sample loop are
     # independent: `inflight` of them run at once, each as its own hipGraph on its own stream (rollout.ConcurrentRollouts);
@@ -336,6 +402,25 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     res = {"value": round(frames / dt, 1), "ms_per_step": round(1000 * dt / steps, 3), "rollouts_in_flight": inflight,
            # wall time of the K timed steps on every rank, rank order (the reported time is the max)
            "per_rank_ms_per_step": [round(1000 * t / steps, 3) for t in per_rank]}
+    if ctx.rank == 0 and not args.no_check:
+        # the frames the TIMED region left behind (every chain's last replay) and what the oracle needs to redo them; the
+        # comparison itself runs later, on the host, outside every timed region (main: cpu_baseline / check)
+        chains = [(r.eps, r.frames) for r in cr.rollouts] if cr is not None else [(eager_eps, out)]
+        res["_case"] = snapshot_case(model, (enc, dec, fp, gp, lik), x, chains, args.n_past, n_eval)
+    if args.sustained_s > 0 and steps >= 2:
+        # the same graphs for >= sustained_s seconds: the chip is power / clock-managed and the K timed steps of the contract
+        # are a fraction of a second ("nobody knows whether the figure holds for 10 s")
+        n_sus = max(steps, int(args.sustained_s / (dt / steps)) + 1)
+        if ctx.dist is not None:     # every rank must run the same count (the barrier pairs bracket it)
+            n_sus = int(max(ctx.all_ranks(float(n_sus))))
+        ctx.barrier()
+        t0 = time.perf_counter()
+        run(n_sus)
+        ctx.barrier()
+        dts = ctx.max_over_ranks(time.perf_counter() - t0)
+        res["sustained"] = {"value": round(args.batch * args.n_future * n_sus * ctx.world / dts, 1), "steps": n_sus,
+                            "seconds": round(dts, 2), "ms_per_step": round(1000 * dts / n_sus, 3),
+                            "ratio_to_value": round((args.batch * args.n_future * n_sus * ctx.world / dts) / (frames / dt), 4)}
     if inflight > 1:   # the same K rollouts as ONE serial chain of launches (one graph, one stream), for comparison
         ctx.barrier()
         t0 = time.perf_counter()
@@ -523,13 +608,19 @@ def c1_leg(ctx: Ctx, args) -> dict:
     a = copy.copy(args)
     a.batch, a.n_past, a.n_future = 8, 5, 5
     a.no_roofline = True
+    a.sustained_s = 0.0
     r = measure_rollout(ctx, a, "vgg", max(20, args.steps), args.warmup)
     out = {"workload": "Moving-MNIST 64x64 rollout, vgg_64 + lstm + GP (no trigger step inside 5 + 5), batch 8 per GPU, 5-in/5-out "
                        "(BASELINE.json configs[0])",
            "value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "single_chain": r.get("single_chain"),
            "rollouts_in_flight": r["rollouts_in_flight"]}
+    case = r.pop("_case", None)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline("vgg", 8, 5, 10, args.seed, budget_s=4.0)
+        if case is not None:
+            out["cpu_baseline"], ref = cpu_baseline("vgg", 8, 5, 10, args.seed, budget_s=4.0, case=case)
+            out["check"] = check_against_oracle(case, ref)
+        else:
+            out["cpu_baseline"] = cpu_baseline("vgg", 8, 5, 10, args.seed, budget_s=4.0)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     return out
 
@@ -666,7 +757,8 @@ def f32mfma_leg(args) -> dict:
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--model", args.model, "--batch", str(args.batch), "--n_past", str(args.n_past), "--n_future", str(args.n_future),
            "--seed", str(args.seed), "--inflight", str(args.inflight), "--no-families", "--no-cpu-baseline", "--no-train-leg",
-           "--no-f32mfma-leg", "--no-make-gifs-leg"] + (["--no-graph"] if args.no_graph else [])
+           "--no-f32mfma-leg", "--no-make-gifs-leg", "--no-extra-legs", "--sustained-s", "0"] + (["--no-graph"] if args.no_graph else []) + \
+        (["--no-check"] if args.no_check else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["DVG_HIP_LIB"] = F32MFMA_LIB
     try:
@@ -679,7 +771,7 @@ def f32mfma_leg(args) -> dict:
     d = json.loads(lines[-1])
     rf = d.get("roofline", {})
     return {"library": "dvg_amd/csrc/libdvg_hip_f32mfma.so (-DDVG_BF16X3=0)", "value": d["value"], "ms_per_step": d["ms_per_step"],
-            "single_chain": d.get("single_chain"),
+            "single_chain": d.get("single_chain"), "build": (d.get("build") or {}).get("raw"), "check": d.get("check"),
             "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us", "launches_per_step",
                                                 "kernel_time_sum_ms", "transform_share")}}
 
@@ -836,13 +928,25 @@ def main():
     ctx = Ctx(args)
 
     from dvg_amd import _lib, fused as fused_mod
+    # WHICH build of the library is loaded, before anything is measured: a headline only from the product build (the default
+    # path - or, in the f32-MFMA comparison child, the in-tree f32 build - with no timing-experiment knob)
+    build = _lib.build_info()
+    if not build["product"] and not args.allow_variant:
+        print(f"bench.py: refusing to measure {build['path']} ({build['raw']}): not the product build of libdvg_hip.so "
+              "(DVG_HIP_LIB set to a variant, or a timing-experiment build).  --allow-variant to run anyway.", file=sys.stderr)
+        sys.exit(4)
     main_res = measure_rollout(ctx, args, args.model, args.steps, args.warmup)
+    main_case = main_res.pop("_case", None)
     result = {
         "metric": "predicted frames/sec at 64x64, batch 64, 10-in/10-out",
         "value": main_res["value"], "unit": "frames/s", "n_gpus": ctx.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
         "single_chain": main_res.get("single_chain"), "per_rank_ms_per_step": main_res.get("per_rank_ms_per_step"),
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # the same graphs for >= 5 s (the chip is power-managed; the K timed steps are a fraction of a second)
+        "sustained": main_res.get("sustained"),
+        # dvg_build_info() of the loaded library: arithmetic, timing-experiment knobs (must be 6 / 0 / 0 / 0), source hash
+        "build": {k: build[k] for k in ("raw", "product", "from_env")} | {"path": os.path.relpath(build["path"], ROOT)},
         # how the implicit-GEMM kernels form their fp32 products (dvg_mfma_mode(), include/dvg_hip.h): inputs, outputs, weights,
         # accumulators and every other kernel are fp32 in both builds
         "arithmetic": ("fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per K=16 slab, fp32 accumulate "
@@ -885,6 +989,7 @@ def main():
     if not args.no_families:
         other = "dcgan" if args.model == "vgg" else "vgg"
         fam = measure_rollout(ctx, args, other, args.steps, args.warmup)
+        fam_case = fam.pop("_case", None)
         fam["workload"] = result["config"]["workload"].replace(f"{args.model}_64", f"{other}_64")
         result["families"] = {other: fam}
     if not args.no_make_gifs_leg and not args.no_graph:
@@ -898,11 +1003,27 @@ def main():
         if ctx.rank == 0 and "roofline" in result:
             result["roofline"]["hbm_bound_layers"] = hbm_bound_layers(ctx, args)
     n_eval = args.n_past + args.n_future
-    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.model, args.batch, args.n_past, n_eval, args.seed)
+    # cpu_baseline + check: the oracle re-runs, on the host and outside every timed region, the very rollouts the timed graphs
+    # ran (same weights, clips, GP draws).  Its wall time is the CPU baseline (rank 0, N = 1), its frames the checker of the
+    # frames the timed region left in the graphs' static buffers.  N > 1: one chain of rank 0, untimed.
+    checks_ok = True
+    if ctx.rank == 0:
+        timed_cpu = ctx.world == 1 and not args.no_cpu_baseline
+        jobs = [(args.model, main_case, result, 10.0)]
         if "families" in result:
-            for other, fam in result["families"].items():
-                fam["cpu_baseline"] = cpu_baseline(other, args.batch, args.n_past, n_eval, args.seed, budget_s=4.0)
+            jobs += [(other, fam_case, fam, 4.0) for other, fam in result["families"].items()]
+        for model, case, sink, budget in jobs:
+            if case is None and timed_cpu:
+                sink["cpu_baseline"] = cpu_baseline(model, args.batch, args.n_past, n_eval, args.seed, budget_s=budget)
+            elif case is not None:
+                base, ref = cpu_baseline(model, args.batch, args.n_past, n_eval, args.seed, budget_s=budget if timed_cpu else 0.0,
+                                         case=case, max_chains=None if timed_cpu else 1)
+                if timed_cpu:
+                    sink["cpu_baseline"] = base
+                sink["check"] = check_against_oracle(case, ref)
+                checks_ok = checks_ok and sink["check"]["ok"]
+    if "c1" in result and "check" in result["c1"]:
+        checks_ok = checks_ok and result["c1"]["check"]["ok"]
     # under rocprofv3 the child would inherit the preloaded tool: its f32-MFMA kernels would land in the same output
     # directory and pollute the per-kernel statistics / PMC sums of THIS command - skipped there
     profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
@@ -918,6 +1039,9 @@ def main():
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
+    if not checks_ok:      # the line is out (with check.ok = false in it); a wrong-frames run is not a measurement
+        print("bench.py: the timed frames differ from the oracle's by more than 1e-4 (see `check` in the JSON line)", file=sys.stderr)
+        sys.exit(5)
 
 
 if __name__ == "__main__":

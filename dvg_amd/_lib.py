@@ -27,6 +27,7 @@ SIGNATURES = {
     "dvg_last_error": (C.c_char_p, []),
     "dvg_stream_capture_id": (_l, [_p]),
     "dvg_mfma_mode": (_i, []),
+    "dvg_build_info": (C.c_char_p, []),
     "dvg_packed_row_floats": (_i, []),
     "dvg_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_pack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -164,6 +165,25 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = handle
         return _lib
+
+
+def build_info() -> dict:
+    """dvg_build_info() parsed: {"abi": 9, "bf16x3": 1, "x3_terms": 6, "ablate": 0, "first_selects": 0, "timing_experiments": 0,
+    "variant": "", "src": "<sha256[:12] of the sources>"} plus "path" (the file loaded), "from_env" (DVG_HIP_LIB was set) and
+    "product": True only for the library the repository ships - the default path or the in-tree f32-MFMA comparison build,
+    no timing-experiment knob, no variant name."""
+    raw = lib().dvg_build_info().decode()
+    d = {}
+    for tok in raw.split():
+        k, _, v = tok.partition("=")
+        d[k] = int(v) if v.lstrip("-").isdigit() else v
+    d["raw"] = raw
+    d["path"] = LIB_PATH
+    d["from_env"] = bool(os.environ.get("DVG_HIP_LIB"))
+    shipped = {os.path.join(_HERE, "csrc", "libdvg_hip.so"), os.path.join(_HERE, "csrc", "libdvg_hip_f32mfma.so")}
+    d["product"] = (os.path.abspath(LIB_PATH) in shipped and d.get("x3_terms") == 6 and d.get("ablate") == 0 and
+                    d.get("first_selects") == 0 and d.get("timing_experiments") == 0 and d.get("variant", "") == "")
+    return d
 
 
 def check(code: int, what: str = "") -> None:

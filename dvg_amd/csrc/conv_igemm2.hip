@@ -39,20 +39,14 @@
 #define DVG_STAGE_PRIO 1
 #endif
 
-//  DVG_ABLATE (timing experiments only, WRONG results): 1 = the stage loop issues no global loads (the next stage's LDS
-//  stores write stale registers), 2 = and no LDS stores, 3 = and no workgroup barriers - what the staging costs the loop;
-//  4 / 5 = no weight / activation LDS stores; 6 / 7 = neither loads nor stores of the weight / activation tile in the loop
-//  (6: what a weight-stationary workgroup would save at most); 8 = 2 + the GEMM mode stores one product value per lane
-//  instead of 16; 9 = 8 without the workgroup barriers: the bare fragment-read + MFMA loop
-#ifndef DVG_ABLATE
-#define DVG_ABLATE 0
-#endif
-#ifndef DVG_X3_TERMS
-#define DVG_X3_TERMS 6
-#endif
-#ifndef DVG_FIRST_SELECTS
-#define DVG_FIRST_SELECTS 0
-#endif
+//  DVG_ABLATE / DVG_X3_TERMS / DVG_FIRST_SELECTS (timing experiments, WRONG results): declared in dvg_common.h, which refuses
+//  to compile them unless the build says -DDVG_TIMING_EXPERIMENTS=1 (only `make variant` can pass that; dvg_build_info()
+//  reports it and bench.py refuses to print a headline from such a library).
+//  DVG_ABLATE: 1 = the stage loop issues no global loads (the next stage's LDS stores write stale registers), 2 = and no LDS
+//  stores, 3 = and no workgroup barriers - what the staging costs the loop; 4 / 5 = no weight / activation LDS stores;
+//  6 / 7 = neither loads nor stores of the weight / activation tile in the loop (6: what a weight-stationary workgroup would
+//  save at most); 8 = 2 + the GEMM mode stores one product value per lane instead of 16; 9 = 8 without the workgroup
+//  barriers: the bare fragment-read + MFMA loop
 #ifndef DVG_GEMM_NT_STORE
 #define DVG_GEMM_NT_STORE 0
 #endif

@@ -44,6 +44,28 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #endif
 #define DVG_WROW (DVG_BF16X3 ? 24 : 16)   // floats per packed weight row (16 k-values of one output channel)
 
+// ---- timing experiments (WRONG results) ---------------------------------------------------------------------------------
+// conv_igemm2.hip carries three knobs that change what the kernels COMPUTE, for pricing experiments only: DVG_ABLATE (parts
+// of the stage loop removed), DVG_X3_TERMS (< 6: fewer of the six bf16 MFMAs per product slab), DVG_FIRST_SELECTS (diagnostic
+// forms of the fused first layer).  They exist only in builds that say -DDVG_TIMING_EXPERIMENTS=1: `make all` / `make
+// f32mfma` never pass it (the Makefile hands DEFS to the `variant` target alone), anything else fails to compile here, and
+// dvg_build_info() carries the values so that a loaded library can be told from the product (bench.py refuses such a build).
+#ifndef DVG_TIMING_EXPERIMENTS
+#define DVG_TIMING_EXPERIMENTS 0
+#endif
+#ifndef DVG_ABLATE
+#define DVG_ABLATE 0
+#endif
+#ifndef DVG_X3_TERMS
+#define DVG_X3_TERMS 6
+#endif
+#ifndef DVG_FIRST_SELECTS
+#define DVG_FIRST_SELECTS 0
+#endif
+#if !DVG_TIMING_EXPERIMENTS && (DVG_ABLATE != 0 || DVG_X3_TERMS != 6 || DVG_FIRST_SELECTS != 0)
+#error "DVG_ABLATE / DVG_X3_TERMS / DVG_FIRST_SELECTS give WRONG results: timing builds only (-DDVG_TIMING_EXPERIMENTS=1 via `make variant`)"
+#endif
+
 // two fp32 values -> their three bf16 terms, each pair packed into one dword (low half = the first value).  Nine VALU
 // instructions: v_cvt_pk_bf16_f32 (round to nearest even) x 3, the two halves of a packed pair back to fp32 (shift / mask) x 2,
 // v_pk_add_f32 x 2.  (A truncating split - mask instead of convert - costs the same and leaves dropped terms of up to

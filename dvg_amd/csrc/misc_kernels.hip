@@ -388,6 +388,13 @@ __global__ __launch_bounds__(64) void gp_var_norms_kernel(const float* __restric
 // (`np.concatenate([ctx[1:], [value]])`); threshold = mean + coef * std (numpy population std) with float32 results at the
 // points where the reference's float32 arrays round (mean, std, coef * std, the sum); flag = value > threshold.  ctx (W floats)
 // is updated in place; value / threshold / flag are logged at `slot` for ONE read-back after the rollout.  One wave.
+// TOLERANCE: the norm, the mean and the variance are accumulated in fp64 and rounded once to float32; the
+// reference's np.linalg.norm / np.mean / np.std run on float32 arrays with float32 pairwise accumulation and can land 1 ulp
+// (6e-8 relative) away, and whether `coef * std` is a float32 or a float64 product depends on the NumPy version (1.x value-based
+// casting vs NumPy 2 scalar promotion; float32 here).  A decision can therefore differ from the reference's only where
+// |value - threshold| is within a few ulp of the threshold; the parity tests (tests/test_gpu_rollouts.py,
+// test_gpu_generate_config.py) compare decisions where the oracle's margin exceeds 1e-4 relative - ~1 000 ulp - and the logged
+// values / thresholds everywhere to 1e-5.
 // the slid window's statistics and the decision, one wave: lane i < W holds window element w; returns value > threshold
 __device__ __forceinline__ bool trigger_window_decide(int lane, float w, int W, float coef, float value, float& thr_out) {
     double m = lane < W ? (double)w : 0.0;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(1024) void mse_sum_grad_kernel(const float* __restr
 
 using namespace dvg;
 
-extern "C" int dvg_abi_version(void) { return 8; }  // 8: y_from (skip tensors of part of a batch), r05 entry points; 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
+extern "C" int dvg_abi_version(void) { return 9; }  // 9: + dvg_build_info, sync-BN partial rows (r06); 8: y_from (skip tensors of part of a batch), r05 entry points; 3: first igemm schedule retired; 4: + dvg_winograd_wgrad_*; 5: + dvg_gp_elbo(_bwd); 6: GP kernels fp64-internal, + dvg_gp_(bwd_)precision; 7: blocked packed weights, dvg_mfma_mode / dvg_packed_row_floats
 extern "C" const char* dvg_last_error(void) { return err_buf(); }
 
 extern "C" long dvg_stream_capture_id(void* stream) {

@@ -416,9 +416,12 @@ def precompute_skip_half(conv, skip, kind: str) -> None:
     _skip_seen[(id(conv), id(skip))] = [weakref.ref(skip), skip._version, _ver(conv.weight), 1, s]
 
 
-def _hoisted_skip(conv, x, skip, partial_fn):
-    """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None."""
-    if not SKIP_HOIST or skip is None:
+def _hoisted_skip(conv, x, skip, partial_fn, force=False):
+    """Returns (wp_x, S) when the skip half of this block is available as a precomputed addend, else None.
+    force: the caller HAS to have the skip half (its x operand exists only as an upsampled WinoV, because _hoist_ready said
+    yes when the producer ran): S is computed now even on what looks like a first sighting - the entry _hoist_ready saw may
+    have been evicted in between (the 64-entry bound below, a dead weakref sweep)."""
+    if skip is None or (not SKIP_HOIST and not force):
         return None
     k = (id(conv), id(skip))
     wkey = _ver(conv.weight)
@@ -430,7 +433,7 @@ def _hoisted_skip(conv, x, skip, partial_fn):
             _skip_seen.clear()
         _skip_seen[k] = ent = [weakref.ref(skip), skip._version, wkey, 1, None]
         fz = _frozen.get(id(skip))
-        if fz is None or fz[0]() is not skip or fz[1] != skip._version:
+        if not force and (fz is None or fz[0]() is not skip or fz[1] != skip._version):
             return None                    # first sighting of an undeclared skip: the ordinary fused concat conv
     else:
         ent[3] += 1
@@ -517,7 +520,7 @@ def conv3_bn_act(conv, bn, x, skip=None, *, upsample=False, pool=False, act=ACT_
     if isinstance(x, ops.WinoV) and x.up:
         # first conv of a decoder block fed by the previous block's last layer through the upsampling (_chain_up_to held there)
         hs = None if (bn.training or not upsample or pool) else \
-            _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE))
+            _hoisted_skip(conv, x, skip, lambda ps: ops.conv3x3(skip, None, ps, None, None, act=ACT_NONE), force=True)
         if hs is None:
             raise RuntimeError("conv3_bn_act: an upsampled WinoV needs the eval-mode concat conv with its skip half hoisted")
         sc, sh = folded_affine(conv, bn)

@@ -417,6 +417,8 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
     mt = {16: 2, 36: 4}.get(npos, 0)
     if mt == 0 or tuple(u.shape) != (npos, c // 16, 1, cout, packed_row_floats()) or not winograd_ok(n, c, h, w, cout, mt):
         raise RuntimeError(f"conv3x3_winograd: unsupported shape x {tuple(x.shape)} u {tuple(u.shape)}")
+    if not 0 <= y_from <= n or (y_from and not pool):      # (all argument checks BEFORE the first launch: ADVICE r05)
+        raise RuntimeError("conv3x3_winograd: y_from needs the pooled output and 0 <= y_from <= N")
     if (from_v or to_v or upsample or addend is not None) and (mt != 4 or return_v):
         raise RuntimeError("conv3x3_winograd: WinoV hand-over / upsample / addend need F(4x4,3x3) and no return_v")
     if addend is not None and pool:
@@ -442,8 +444,6 @@ def conv3x3_winograd(x, u, scale, shift, *, act=ACT_LRELU, slope=0.2, pool=False
              int(upsample), _stream())
     _run("winograd_gemm", 2.0 * npos * t * c * cout, 4.0 * (v.numel() + m.numel() + u.numel()), lib().dvg_gemm_batched_k16,
          _p(v), _p(u), _p(m), npos, t // 16, 16, c, cout, _stream(), alg_flops=2.0 * n * h * w * cout * 9 * c)
-    if not 0 <= y_from <= n or (y_from and not pool):
-        raise RuntimeError("conv3x3_winograd: y_from needs the pooled output and 0 <= y_from <= N")
     if to_v and pool:
         y = nhwc_empty(n - y_from, cout, h, w, dev) if y_from < n else None
         vn = torch.empty((npos, t // 4, cout), device=dev, dtype=torch.float32)
@@ -530,6 +530,9 @@ def convT3x3_last(x, w, bias, nc, *, act=ACT_SIGMOID):
     return y
 
 
+CONV4S2_MAX_FLOATS = 1 << 31     # dvg_conv4x4s2_bn_act_v2: N * H * W * Cin must stay below (32-bit activation offsets)
+
+
 def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     _dev_f32(x, "conv4x4s2.x")
     assert is_nhwc(x)
@@ -538,6 +541,28 @@ def conv4x4s2(x, wp, scale, shift, *, act=ACT_LRELU, slope=0.2, stats=False):
     if taps != 16 or cin_w != cin:
         raise RuntimeError(f"conv4x4s2: packed weight {tuple(wp.shape)} does not match Cin={cin}")
     y = nhwc_empty(n, cout, h // 2, w // 2, x.device)
+    if x.numel() >= CONV4S2_MAX_FLOATS:
+        # The parity-split kernel addresses the activation with 32-bit offsets (dvg_conv4x4s2_bn_act_v2 refuses N*H*W*Cin >=
+        # 2^31): run the batch as several launches over runs of images (large time-batched 128 x 128 batches).
+        # Statistics rows are per tile in image-major order (launches this large never split K), so the runs' rows
+        # concatenate to the rows of the whole batch.
+        per = (CONV4S2_MAX_FLOATS - 1) // (cin * h * w)
+        per -= per % 8
+        if per <= 0:
+            raise RuntimeError(f"conv4x4s2: one image of {cin} x {h} x {w} exceeds the kernel's 32-bit offsets")
+        sts = []
+        for lo in range(0, n, per):
+            r = conv4x4s2(x[lo:lo + per], wp, scale, shift, act=act, slope=slope, stats=stats)
+            y[lo:lo + per].copy_(r[0] if stats else r)
+            if stats:
+                if r[1].tile_images == 0:
+                    raise RuntimeError("conv4x4s2: a split-K run inside a batch split (unexpected at this size)")
+                sts.append(r[1])
+        if not stats:
+            return y
+        st = torch.cat(sts)
+        st.tile_images = sts[0].tile_images
+        return y, st
     ws = _splitk_ws(MODE_CONV4S2, n, h, w, cin, cout, y.numel(), x.device)
     if stats:
         rows = lib().dvg_conv_stats_rows_v2(MODE_CONV4S2, n, h, w, cin, cout, 0, int(ws is not None))

@@ -163,15 +163,34 @@ class FusedAdam(torch.optim.Optimizer):
     # ---- hipGraph support -------------------------------------------------------------------------------
     def begin_capture(self) -> None:
         """Call right before capturing a graph that contains step(): the device step counts are synchronised with the
-        host ones (the captured kernels then increment and read them on the device)."""
+        host ones (the captured kernels then increment and read them on the device).
+        INVARIANT: the device counts `tdev` are valid only from here through the replays of the graph captured
+        next.  An EAGER step() in between advances the host count only (it passes the count as an argument), so a replay
+        after it would apply stale bias corrections: step() marks the captured graph stale and after_graph_replay() raises.
+        Re-capture (begin_capture again) to continue with graphs after eager steps."""
         self._captured_groups = []
+        self._graph_stale = False
         for gi, f in self._flat.items():
             if f:
+                f.pop("ticked", None)
                 f["tdev"].fill_(int(self.state[f["params"][0]]["step"]))
+
+    def end_capture(self) -> None:
+        """Call after the capture: every group whose device step count a captured zero_grads() launch advanced (`ticked`)
+        must also have been stepped inside the same capture - otherwise each replay would advance the count without a step
+        and later bias corrections would be wrong without any error."""
+        for gi, f in self._flat.items():
+            if f and f.pop("ticked", False):
+                raise RuntimeError(f"FusedAdam: group {gi} had its device step count advanced by a captured zero_grads() "
+                                   "but was not stepped in the same capture")
 
     def after_graph_replay(self) -> None:
         """The replayed kernels stepped the parameters through raw pointers: advance the host-side step counts (state_dict,
-        torch.optim compatibility) and the version counters the packed-weight caches key on."""
+        torch.optim compatibility) and the version counters the packed-weight caches key on.  Raises when an eager step()
+        ran since the capture (see begin_capture: the replay just applied stale bias corrections)."""
+        if getattr(self, "_graph_stale", False) and self._captured_groups:
+            raise RuntimeError("FusedAdam: a captured graph was replayed after an eager step(): its device-side step counts "
+                               "are stale (wrong Adam bias corrections were applied).  Re-capture after eager steps.")
         for gi in self._captured_groups:
             for p in self._flat[gi]["params"]:
                 torch.autograd.graph.increment_version(p)
@@ -219,6 +238,8 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     tdev = None                      # eager: the host count goes in as an argument, no device-side bookkeeping
                     f.pop("ticked", None)
+                    if gi in self._captured_groups:  # a captured graph holds this group's device count: now behind the host's
+                        self._graph_stale = True
                 check(lib().dvg_adam_step(ops._p(f["p"]), ops._p(f["g"]), ops._p(f["m"]), ops._p(f["v"]),
                                           f["p"].numel(), *hyper, t, ops._p(tdev), ops._stream()), "dvg_adam_step")
                 touched = f["params"]

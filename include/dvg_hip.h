@@ -129,6 +129,13 @@ int dvg_conv_first_stats_rows(int ks, int N, int H, int W);
  * dvg_packed_row_floats() and are otherwise unaffected.                                          */
 int dvg_mfma_mode(void);
 int dvg_packed_row_floats(void);
+/* ABI 9 - which BUILD of the library is loaded: a static string "abi=9 bf16x3=1 x3_terms=6 ablate=0 first_selects=0
+ * timing_experiments=0 variant= src=<12 hex digits>".  `src` = sha256 over the library's sources at build time (`make -C
+ * dvg_amd/csrc srcid` prints the tree's); x3_terms / ablate / first_selects / timing_experiments != 6 / 0 / 0 / 0 mark a
+ * TIMING-ONLY build whose results are wrong by construction (conv_igemm2.hip), `variant` an A/B build (`make variant`).
+ * The reference has no counterpart (one torch build per process); the host side (bench.py, dvg_amd/_lib.build_info) uses it
+ * to refuse a headline measurement from anything but the product build.                                                 */
+const char* dvg_build_info(void);
 int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cout, int cin, int kh, int kw,
                              int transposed, void* stream);
 /* Split-K: when a layer would launch < 384 workgroups (deep, narrow layers; small per-GPU batches) and the caller

@@ -33,7 +33,7 @@ def test_binding_table_covers_header():
     from dvg_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dvg_abi_version() == 8
+    assert lib.dvg_abi_version() == 9
 
 
 def test_both_builds_of_the_library_load_and_say_which_arithmetic_they_run():
@@ -47,7 +47,30 @@ def test_both_builds_of_the_library_load_and_say_which_arithmetic_they_run():
     h = ctypes.CDLL(native)
     for s in header_symbols():
         assert hasattr(h, s), f"{s} missing from the f32-MFMA build"
-    assert h.dvg_abi_version() == 8 and h.dvg_mfma_mode() == 0 and h.dvg_packed_row_floats() == 16
+    assert h.dvg_abi_version() == 9 and h.dvg_mfma_mode() == 0 and h.dvg_packed_row_floats() == 16
+
+
+def test_build_info_identifies_the_product_build():
+    """dvg_build_info() (ABI 9): both shipped libraries say which arithmetic they run, carry no timing-experiment knob and
+    were built from THIS tree (src = sha256 over the sources, as `make srcid` computes it); a timing-experiment knob without
+    -DDVG_TIMING_EXPERIMENTS=1 does not compile (dvg_common.h), so `make all` cannot produce a wrong-results library."""
+    import subprocess
+    from dvg_amd import _lib
+    info = _lib.build_info()
+    assert info["abi"] == 9 and info["bf16x3"] == 1 and info["x3_terms"] == 6 and info["ablate"] == 0
+    assert info["first_selects"] == 0 and info["timing_experiments"] == 0 and info["variant"] == "" and info["product"]
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    srcid = subprocess.run(["make", "-s", "-C", csrc, "srcid"], capture_output=True, text=True, check=True).stdout.split()[-1]
+    assert info["src"] == srcid, "libdvg_hip.so is older than its sources: rebuild (make -C dvg_amd/csrc all f32mfma)"
+    h = ctypes.CDLL(os.path.join(csrc, "libdvg_hip_f32mfma.so"))
+    h.dvg_build_info.restype = ctypes.c_char_p
+    raw = h.dvg_build_info().decode()
+    assert "bf16x3=0" in raw and "timing_experiments=0" in raw and f"src={srcid}" in raw
+    common = open(os.path.join(csrc, "dvg_common.h")).read()
+    assert "#error" in common and "DVG_TIMING_EXPERIMENTS" in common
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    product_rules = mk[:mk.index("# A/B builds")]
+    assert "$(DEFS)" not in product_rules, "DEFS must reach the `variant` objects only"
 
 
 def test_host_side_checks_reject_bad_shapes_without_gpu():

@@ -1,0 +1,122 @@
+"""The HEADLINE configuration directly under the oracle (BASELINE.json configs[1], C2: Moving-MNIST 64x64, batch 64,
+10-in/10-out, vgg_64 | dcgan_64 + lstm + GP sample at step 15) - the exact workload bench.py times.
+
+Until r05 the full-size run was tied to the oracle through size-independent properties only
+(tests/test_gpu_configs.py::test_full_size_rollout_properties); bench.py's `cpu_baseline` leg shows the oracle finishes that
+rollout in seconds on the GPU box, so here it is the checker:
+  * `sample_rollout` (the eager launch sequence), `GraphedRollout` (one hipGraph) and `ConcurrentRollouts` (three graphs in
+    flight on three streams, bench.py's default) against `oracle.rollout` (generate_frames.py:143-177) with the GP base
+    sample eps of step 15 passed in: every one of the 20 frames within 1e-4 (max-norm), the element-wise figure (1 % floor)
+    printed beside the fp32 oracle's own deviation from the fp64 oracle (truth);
+  * the three forms are bit-identical to each other;
+  * the three chains of `ConcurrentRollouts` are given DIFFERENT eps: each must match its own oracle rollout (the oracle re-runs
+    only steps 15..19 for the other two - the steps before the trigger do not depend on eps).
+"""
+import pytest
+import torch
+
+from oracle import dvg_oracle as orc
+from oracle import params
+from tests.common import rel_err, rel_err_elem, to64
+from tests.test_gpu_configs import _build, _oracle_fns
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FRAME_BAR = 1e-4      # BASELINE.json north_star: "within 1e-4 relative on fp32 frames"
+ELEM_BAR = 6e-4       # element-wise (1 % floor), as tests/test_gpu_generate_config.py
+B, N_PAST, N_EVAL = 64, 10, 20
+
+
+def _oracle_tail(frames15, x_in, hidden, skip, enc_o, dec_o, lsd, gsd, lik, eps15):
+    """Steps 15..19 of oracle.rollout from its state before step 15 (same statements, generate_frames.py:163-176): what a
+    different GP base sample changes."""
+    noise = orc.likelihood_noise(lik)
+    frames = list(frames15)
+    hidden = [tuple(t.clone() for t in hc) for hc in hidden]
+    for i in range(15, N_EVAL):
+        h, _ = enc_o(x_in)
+        h_pred = orc.lstm_step(h, lsd, hidden)
+        if i % 15 == 0:
+            p = orc.gp_predict(h, gsd, training=False, noise=noise, dtype=torch.float64)
+            x_in = dec_o(orc.gp_rsample(p["mean"], p["cov"], eps15).t().to(h.dtype), skip)
+        else:
+            x_in = dec_o(h_pred, skip)
+        frames.append(x_in)
+    return frames
+
+
+def _oracle_rollout_with_state(xs, enc_o, dec_o, lsd, gsd, lik, eps15):
+    """oracle.rollout, but also returning the state before step 15 (frames 0..14, x_in, LSTM state, skip)."""
+    hidden = orc.lstm_init_hidden(B, 256, 2, dtype=xs[0].dtype)
+    frames, x_in, skip = [xs[0]], xs[0], None
+    for i in range(1, 15):
+        h, sk = enc_o(x_in)
+        if i < N_PAST:
+            skip = sk
+            orc.lstm_step(h, lsd, hidden)
+            x_in = xs[i]
+        else:
+            x_in = dec_o(orc.lstm_step(h, lsd, hidden), skip)
+        frames.append(x_in)
+    state = (list(frames), x_in, [tuple(t.clone() for t in hc) for hc in hidden], skip)
+    return _oracle_tail(*state, enc_o, dec_o, lsd, gsd, lik, eps15), state
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("family", ["vgg", "dcgan"])
+def test_headline_rollout_matches_the_oracle(family):
+    from dvg_amd.rollout import ConcurrentRollouts, GraphedRollout, sample_rollout
+    mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 3100)
+    xs = [params.frames(3110 + t, B, 1, 64) for t in range(N_EVAL)]
+    eps = [params.normal(3140 + k, 90, B) for k in range(3)]
+    enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
+    with torch.no_grad():
+        # the statement-for-statement oracle and the split form used for the other two eps agree exactly
+        ref0 = orc.rollout(xs, enc_o, dec_o, lsd, gsd, lik, N_PAST, N_EVAL, {15: eps[0]})
+        ref0b, state = _oracle_rollout_with_state(xs, enc_o, dec_o, lsd, gsd, lik, eps[0])
+        assert all(torch.equal(a, b) for a, b in zip(ref0, ref0b))
+        refs = [ref0] + [_oracle_tail(*state, enc_o, dec_o, lsd, gsd, lik, e) for e in eps[1:]]
+        # fp64 yardstick for the element-wise figure: the oracle in fp64 = truth
+        enc_6, dec_6 = _oracle_fns(family, 64, to64(esd), to64(dsd))
+        ref64 = orc.rollout([t.double() for t in xs], enc_6, dec_6, to64(lsd), to64(gsd), to64(lik), N_PAST, N_EVAL,
+                            {15: eps[0].double()})
+    for m in mods:
+        m.to(DEV).eval()
+    xd = [t.to(DEV) for t in xs]
+    ed = [{15: e.to(DEV)} for e in eps]
+
+    eager = sample_rollout(*mods, xd, N_PAST, N_EVAL, eps_by_step=ed[0])
+    assert len(eager) == N_EVAL
+    errs = [rel_err(eager[t], ref0[t]) for t in range(N_EVAL)]
+    assert max(errs) < FRAME_BAR, [f"{e:.1e}" for e in errs]
+    e_hip = max(rel_err_elem(eager[t], ref64[t]) for t in range(N_PAST, N_EVAL))
+    e_32 = max(rel_err_elem(ref0[t], ref64[t]) for t in range(N_PAST, N_EVAL))
+    m_hip = max(rel_err(eager[t], ref64[t]) for t in range(N_PAST, N_EVAL))
+    m_32 = max(rel_err(ref0[t], ref64[t]) for t in range(N_PAST, N_EVAL))
+    print(f"headline {family}_64 B=64 10/10: HIP vs fp32 oracle max-norm {max(errs):.2e}; vs fp64 max-norm {m_hip:.2e} "
+          f"(fp32 oracle {m_32:.2e}); element-wise {e_hip:.2e} (fp32 oracle {e_32:.2e})")
+    assert e_hip < ELEM_BAR, (e_hip, e_32)
+
+    g = GraphedRollout(*mods, xd, N_PAST, N_EVAL)
+    replay = [f.clone() for f in g(xd, ed[0])]
+    for t in range(N_EVAL):
+        assert torch.equal(replay[t], eager[t]), t
+
+    # bench.py's form: three complete rollouts in flight, one hipGraph + stream each, here with three different GP draws
+    cr = ConcurrentRollouts(*mods, xd, N_PAST, N_EVAL, inflight=3)
+    cur = torch.cuda.current_stream()
+    for k, (r, s) in enumerate(zip(cr.rollouts, cr.streams)):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            r(xd, ed[k])
+    for s in cr.streams:
+        cur.wait_stream(s)
+    torch.cuda.synchronize()
+    for k, r in enumerate(cr.rollouts):
+        errs = [rel_err(r.frames[t], refs[k][t]) for t in range(N_EVAL)]
+        assert max(errs) < FRAME_BAR, (k, [f"{e:.1e}" for e in errs])
+        if k == 0:
+            assert all(torch.equal(r.frames[t], eager[t]) for t in range(N_EVAL))
+        else:   # the other draws really changed the GP-decoded frame and what follows
+            assert all(torch.equal(r.frames[t], eager[t]) for t in range(15))
+            assert rel_err(r.frames[15], ref0[15]) > 10 * FRAME_BAR

@@ -87,7 +87,7 @@ def test_library_loaded_before_torch_touches_the_gpu_still_launches():
     runtime; the library links the system runtime, and in that order every launch used to fail with "no ROCm-capable
     device is detected".  `_lib.lib()` now brings torch's runtime up first."""
     code = ("from dvg_amd import _lib\n"
-            "assert _lib.lib().dvg_abi_version() == 8\n"
+            "assert _lib.lib().dvg_abi_version() == 9\n"
             "import torch\n"
             "from dvg_amd import ops\n"
             "x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32, device='cuda').reshape(2, 3, 4, 5)\n"

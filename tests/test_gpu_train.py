@@ -307,6 +307,43 @@ def test_graphed_iteration_matches_eager(model):
     assert torch.allclose(ha, hb, rtol=2e-3, atol=2e-5)
 
 
+def test_graph_replay_after_an_eager_step_is_refused():
+    """the captured Adam launches read their step count from the device (FusedAdam.begin_capture); an eager
+    step() between two replays advances only the host count, so the next replay would apply stale bias corrections without
+    any error.  FusedAdam marks the graph stale and after_graph_replay() raises; a fresh capture works again.  Also: a group
+    whose count a captured zero_grads() advanced must be stepped in that capture (end_capture)."""
+    import train
+    import utils
+    from dvg_amd.data import SyntheticMovingMNIST
+    from dvg_amd.optim import zero_grads
+    torch.manual_seed(12)
+    opt = _opt("dcgan")
+    tr = train.Trainer(opt, torch.device("cuda:0"))
+    tr.train_mode()
+    gen = SyntheticMovingMNIST(seq_len=4, seed=9)
+    step = train.GraphedIteration(tr, warmup=1)
+    x, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(4))
+    for _ in range(3):
+        step(x)                                  # eager warm-up, capture + replay, replay
+    assert step.graph is not None and not step.failed
+    tr.iteration(x)                              # an eager iteration on the same trainer
+    with pytest.raises(RuntimeError, match="stale"):
+        step(x)
+    step.graph = None                            # re-capture: begin_capture re-synchronises the device counts
+    step(x)
+    assert float(tr.encoder_optimizer.state_dict()["state"][0]["step"]) == 6.0
+    # a ticked group that is never stepped inside the capture
+    o = tr.encoder_optimizer
+    o.begin_capture()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        zero_grads([o])
+    with pytest.raises(RuntimeError, match="not stepped"):
+        o.end_capture()
+    o.begin_capture()                            # leaves no tick behind
+    assert not any(f.get("ticked") for f in o._flat.values() if f)
+
+
 def test_segmented_iteration_cuts_at_the_allreduces_and_matches_eager():
     """train.SegmentedIteration (the data-parallel form: a chain of hipGraphs cut at the gradient all-reduces, which run
     eagerly between the segments) on a 1-rank process group with the all-reduces forced: five graph segments, four

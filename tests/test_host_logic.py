@@ -280,3 +280,52 @@ def test_gp_trigger_oracle_memo_and_forced_decisions():
         assert c["triggers"] == a["triggers"] and c["forced"] == []
         d = orc.gp_trigger_gen(xs, enc_o, dec_o, lsd, gsd, lik, 4, eps, total=total, depth=-250, decisions=flip, guard=1e9)
         assert d["forced"] == list(range(12, total)) and d["triggers"] == [i for i in range(12, total) if flip[i]]
+
+
+def test_hoist_ready_and_hoisted_skip_agree_across_evictions(monkeypatch):
+    """a decoder block's producer asks fused._hoist_ready(conv, skip) and, on yes, hands its consumer an upsampled
+    WinoV - the consumer then MUST get the skip half from fused._hoisted_skip.  The two agree in every cache state (frozen
+    declaration, second sighting, weight change, dead skips), and where the entry is evicted between the two calls (the
+    64-entry bound) the consumer's `force=True` still yields the skip half instead of raising.  Host logic only: the packing
+    and the conv launch are stubbed."""
+    from dvg_amd import fused
+    monkeypatch.setattr(fused, "_split_packed", lambda conv, c1: ("px", "ps"))
+    calls = []
+    part = lambda ps: calls.append(ps) or "S"      # noqa: E731
+    fused.clear_skip_hoist_cache()
+    conv = torch.nn.Conv2d(8, 4, 3, 1, 1)
+    x, skip = torch.zeros(1, 4, 2, 2), torch.zeros(1, 4, 2, 2)
+
+    def agree(force=False):
+        ready = fused._hoist_ready(conv, skip)
+        got = fused._hoisted_skip(conv, x, skip, part, force=force)
+        assert ready == (got is not None) or force, (ready, got)
+        return got
+    assert agree() is None                       # first sighting, undeclared: the ordinary concat conv
+    assert agree() == ("px", "S")                # second sighting
+    skip.add_(1.0)                               # the skip changed: a new first sighting
+    assert agree() is None
+    fused.declare_frozen_skips([skip])           # declared loop-invariant: ready at once
+    fused._skip_seen.clear()
+    assert agree() == ("px", "S")
+    with torch.no_grad():
+        conv.weight.add_(1.0)                    # new weight version: entry stale, but the skip is still declared frozen
+    assert agree() == ("px", "S")
+    # eviction between producer and consumer of an UNDECLARED skip
+    fused.clear_skip_hoist_cache()
+    assert fused._hoisted_skip(conv, x, skip, part) is None and fused._hoisted_skip(conv, x, skip, part) is not None
+    assert fused._hoist_ready(conv, skip)        # the producer sees the entry ...
+    keep = [torch.zeros(1) for _ in range(70)]
+    for t in keep:                               # ... 70 other (conv, skip) pairs pass through the 64-entry table ...
+        fused._hoisted_skip(conv, x, t, part)
+    assert not fused._hoist_ready(conv, skip)    # ... and it is gone when the consumer asks
+    assert fused._hoisted_skip(conv, x, skip, part) is None
+    fused._skip_seen.clear()
+    assert fused._hoisted_skip(conv, x, skip, part, force=True) == ("px", "S")    # the consumer's call: never None
+    del keep
+    import gc
+    gc.collect()
+    alive = torch.zeros(1)
+    fused._hoisted_skip(conv, x, alive, part)              # a miss sweeps the dead entries
+    assert all(e[0]() is not None for e in fused._skip_seen.values())
+    fused.clear_skip_hoist_cache()

@@ -305,8 +305,9 @@ class Trainer:
         key = (dev, n_call, D)
         w = self._loss_w.get(key)
         if w is None:
-            w = self._loss_w[key] = torch.tensor([0.001 / n_call, 1000.0 / n_call, 0.001 / n_call, 0.01] + [-0.0001] * D,
-                                                 dtype=torch.float32, device=dev)
+            w = torch.tensor([0.001 / n_call, 1000.0 / n_call, 0.001 / n_call, 0.01] + [-0.0001] * D, dtype=torch.float32, device=dev)
+            if not torch.cuda.is_current_stream_capturing():    # a tensor made during a capture lives in the graph's pool
+                self._loss_w[key] = w                           # (ADVICE r05): never handed to later eager iterations
         return w
 
     def train_frame_predictor(self, x):
@@ -340,7 +341,9 @@ class Trainer:
             if self.fused_losses:     # loss = (-elbo).sum(): d loss / d elbo = -1, no scalar graph
                 gneg = self._loss_w.get(("neg1", elbo.device, elbo.numel()))
                 if gneg is None:
-                    gneg = self._loss_w[("neg1", elbo.device, elbo.numel())] = torch.full((elbo.numel(),), -1.0, device=elbo.device)
+                    gneg = torch.full((elbo.numel(),), -1.0, device=elbo.device)
+                    if not torch.cuda.is_current_stream_capturing():   # as autograd._zero_state: a tensor first made during a
+                        self._loss_w[("neg1", elbo.device, elbo.numel())] = gneg   # capture is written only when that graph replays
                 loss = torch.dot(elbo.detach(), gneg)
                 elbo.backward(gneg)
                 self._ar(("reduce", self.rng_gp))
@@ -721,6 +724,8 @@ class GraphedIteration:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._capture_body(self.static_x)
+        for o in tr.optimizers():
+            o.end_capture()                          # every group a captured zero_grads() ticked was stepped in the capture
         self._keepalive = snapshot_eager_caches()    # eager tensors the graph reads by raw pointer stay alive with it
         self.sig = self._signature(x)
 
@@ -820,6 +825,8 @@ class SegmentedIteration(GraphedIteration):
             raise
         finally:
             tr._segmenter = None
+        for o in tr.optimizers():
+            o.end_capture()
         self.graph = [g for kind, g in self.items if kind == "graph"]   # (truthy: "captured"; replay goes through items)
         self._keepalive = snapshot_eager_caches()
         self.sig = self._signature(x)
