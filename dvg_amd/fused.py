@@ -276,13 +276,42 @@ def replay_bn_trace(entries) -> None:
         for bn, stats, count, passes, groups in entries:
             _BN_GROUPS = groups
             with bn_passes(passes):
-                _train_bn(bn, stats, count)
+                _train_bn(bn, stats, count, synced=True)     # (recorded AFTER the cross-rank reduction: no collective here)
     finally:
         _BN_TRACE, _BN_GROUPS = prev, prev_g
 
 
-def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False):
-    """count = elements per channel of the WHOLE batch; with groups every group has count / G of them."""
+# ---- synchronised BatchNorm (train.py --sync_bn; SURVEY 8(e)'s "SyncBN variant") -------------------------------------------
+# The reference is ONE process whose BatchNorm statistics cover the whole batch (train.py:89-91,342-346).  Data-parallel
+# training normally takes them per replica (DDP semantics, the documented deviation); with sync-BN every train-mode BatchNorm
+# call sums its per-channel partial rows locally ([G][2][C]: sum and sum of squares per group), all-reduces those 2 C floats
+# per group across the ranks and finalises with the GLOBAL count - N ranks x B/N clips then compute exactly what one process
+# computes on B clips (tests/test_gpu_multirank.py: parameters equal after 3 iterations).  The backward pass mirrors it
+# (ops.bn_act_bwd: the two per-channel sums of the BatchNorm backward are all-reduced, the parameter gradients stay local
+# sums - the gradient all-reduce averages those).  Collectives cannot be captured in a hipGraph: sync-BN runs eager.
+_SYNC_BN = None      # (torch.distributed module, process group, world size) or None
+
+
+def set_sync_bn(dist=None, group=None) -> None:
+    """Switch synchronised BatchNorm on (dist = torch.distributed with an initialised group of > 1 rank) or off (None)."""
+    global _SYNC_BN
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        _SYNC_BN = None
+    else:
+        _SYNC_BN = (dist, group, dist.get_world_size(group))
+    ops.SYNC_BN = _SYNC_BN
+
+
+def sync_bn_world() -> int:
+    return _SYNC_BN[2] if _SYNC_BN is not None else 1
+
+
+def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False, synced=False):
+    """count = elements per channel of the WHOLE (local) batch; with groups every group has count / G of them.
+    sync-BN: `stats` becomes one all-reduced row per group and `count` the global count (`synced`: that has happened)."""
+    if _SYNC_BN is not None and not synced:
+        stats = ops.sync_partial_rows(stats, _BN_GROUPS[0] if _BN_GROUPS else 1)
+        count = count * _SYNC_BN[2]
     if _BN_TRACE is not None:
         _BN_TRACE.append((bn, stats, count, _BN_PASSES, _BN_GROUPS))
     if _BN_GROUPS is not None:

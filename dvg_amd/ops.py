@@ -651,6 +651,23 @@ def channel_stats(u2d: torch.Tensor, groups: int = 1) -> torch.Tensor:
     return st
 
 
+SYNC_BN = None    # fused.set_sync_bn: (torch.distributed, group, world) while synchronised BatchNorm is on
+
+
+def sync_partial_rows(partial: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """[groups * r][2][C] per-tile partial sums of this rank -> [groups][2][C] sums over ALL ranks (sync-BN): the rows of a
+    group are added up in fp64 (what dvg_bn_finalize itself does with them), all-reduced in fp64 and rounded once."""
+    dist, group, _ = SYNC_BN
+    rows, two, c = partial.shape
+    if rows % groups:
+        raise RuntimeError(f"sync_partial_rows: {rows} partial rows do not split into {groups} groups")
+    tot = partial.view(groups, rows // groups, two, c).sum(1, dtype=torch.float64)
+    dist.all_reduce(tot, group=group)
+    out = tot.to(torch.float32)
+    out.grouped = groups
+    return out
+
+
 def bn_finalize(stats_partial, gamma, beta, running_mean, running_var, count, eps, momentum, save=False,
                 num_batches_tracked=None, passes=0, groups=1, group_momenta=None):
     """`num_batches_tracked` (int64 device scalar of nn.BatchNorm2d) is advanced by `passes` inside the same launch.
@@ -978,6 +995,17 @@ def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=T
     _run("bn_act_bwd_reduce", 0.0, 4.0 * 4 * y.numel(), lib().dvg_bn_act_bwd_reduce, _p(dy), _p(dyp), _p(y), _p(u),
          _p(dp), _p(partial), n, h, w, c, act, slope, groups, _stream())
     coef = torch.empty((3, groups, c), device=dev, dtype=torch.float32)
+    if train and SYNC_BN is not None:
+        # sync-BN (mean / invstd are statistics of the GLOBAL batch): the coefficients of du need the two per-channel sums over
+        # all ranks and the global count; dgamma / dbeta / dbias stay LOCAL sums below - the gradient all-reduce averages them
+        # over the ranks like every other parameter gradient (each rank's dy carries its own 1 / local-batch factor).
+        glob = sync_partial_rows(partial, groups)
+        check(lib().dvg_bn_bwd_finalize(_p(glob), 1, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                        None, None, None, c, float(count) * SYNC_BN[2], 1, 0, groups, _stream()),
+              "bn_bwd_finalize")
+        coef_keep, coef = coef, torch.empty((3, groups, c), device=dev, dtype=torch.float32)   # the local pass's: discarded
+    else:
+        coef_keep = None
     if groups > 1:
         pg = torch.empty((3, groups, c), device=dev, dtype=torch.float32)       # per-group dgamma, dbeta, dbias
         check(lib().dvg_bn_bwd_finalize(_p(partial), rows, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]),
@@ -1003,6 +1031,8 @@ def bn_act_bwd(dy, dyp, y, u, gamma, mean, invstd, count, *, act, slope, train=T
         check(lib().dvg_bn_bwd_finalize(_p(partial), rows, _p(gamma), _p(mean), _p(invstd), _p(coef[0]), _p(coef[1]),
                                         _p(coef[2]), _p(outs[0]), _p(outs[1]), _p(outs[2]), c, float(count), int(train),
                                         acc, 1, _stream()), "bn_bwd_finalize")
+    if coef_keep is not None:
+        coef = coef_keep
     sum_t, sum_mode = (None, 0) if du_sum is None else du_sum
     if sum_t is not None and (sum_t.shape != dp.shape or sum_t.stride() != dp.stride()):
         raise RuntimeError("bn_act_bwd: du_sum must have du's shape and layout")

@@ -184,6 +184,12 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError(f"FusedAdam: group {gi} had its device step count advanced by a captured zero_grads() "
                                    "but was not stepped in the same capture")
 
+    def check_graph_fresh(self) -> None:
+        """Call BEFORE replaying a captured graph: raises when an eager step() ran since the capture (nothing has executed yet)."""
+        if getattr(self, "_graph_stale", False) and self._captured_groups:
+            raise RuntimeError("FusedAdam: an eager step() ran since the graph was captured: its device-side step counts are "
+                               "stale (a replay would apply wrong Adam bias corrections).  Re-capture after eager steps.")
+
     def after_graph_replay(self) -> None:
         """The replayed kernels stepped the parameters through raw pointers: advance the host-side step counts (state_dict,
         torch.optim compatibility) and the version counters the packed-weight caches key on.  Raises when an eager step()

@@ -329,3 +329,47 @@ def test_hoist_ready_and_hoisted_skip_agree_across_evictions(monkeypatch):
     fused._hoisted_skip(conv, x, alive, part)              # a miss sweeps the dead entries
     assert all(e[0]() is not None for e in fused._skip_seen.values())
     fused.clear_skip_hoist_cache()
+
+
+def _sync_bn_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from dvg_amd import fused, ops, parallel
+    parallel.init_distributed("gloo")
+    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None
+    fused.set_sync_bn(dist, dist.new_group())
+    assert fused.sync_bn_world() == 2 and ops.SYNC_BN is not None
+    g = torch.Generator().manual_seed(100 + rank)
+    partial = torch.randn(3 * 5, 2, 8, generator=g)        # 3 groups x 5 per-tile rows of (sum, sum of squares) x 8 channels
+    out = ops.sync_partial_rows(partial, 3)
+    q.put({"rank": rank, "partial": partial.numpy().copy(), "out": out.numpy().copy(), "grouped": int(out.grouped)})
+    fused.set_sync_bn(None)
+    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_partial_rows_allreduce_gloo_world2():
+    """--sync_bn's collective (ops.sync_partial_rows): each rank's per-tile partial rows [G r][2][C] become ONE row per group
+    holding the sums over all rows of all ranks (fp64 accumulation, one rounding), identical on every rank; the switch turns on
+    only for a group of more than one rank and off again."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    want = (a["partial"].astype(np.float64).reshape(3, 5, 2, 8).sum(1) +
+            b["partial"].astype(np.float64).reshape(3, 5, 2, 8).sum(1)).astype(np.float32)
+    assert a["out"].shape == (3, 2, 8) and a["grouped"] == 3
+    assert np.array_equal(a["out"], b["out"]) and np.array_equal(a["out"], want)
+    # one rank: the switch stays off (nothing to synchronise)
+    from dvg_amd import fused, ops
+    fused.set_sync_bn(None)
+    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Data-parallel training == single-process training.
+
+The reference is ONE process: BatchNorm statistics, the losses' means and the ELBO cover the whole batch (train.py:89-91,
+200-248).  This worker runs `--iters` training iterations (train_model + both fine-tuning closures, eager) on ONE global batch
+sequence that every rank generates identically and of which rank r takes clips [r B/N, (r+1) B/N); rank 0 writes, per
+iteration, the loss values and - after the first backward / at the end - gradients, parameters and BatchNorm buffers to
+`--out`.  tests/test_gpu_multirank.py compares a 2-rank `--sync_bn` run with the 1-rank run (must agree to fp32 rounding) and
+with the 2-rank per-replica-BatchNorm run (must NOT: the control).
+
+  python tools/dp_equivalence.py --model dcgan --batch 8 --iters 3 --out one.pt
+  DVG_DP_SHARE_GPU=1 DVG_DP_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+      --master-port P tools/dp_equivalence.py --model dcgan --batch 8 --iters 3 --sync_bn --out two.pt
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="dcgan")
+    ap.add_argument("--batch", type=int, default=8, help="GLOBAL batch")
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--n_past", type=int, default=2)
+    ap.add_argument("--n_future", type=int, default=3)
+    ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    import torch
+    import train
+    import utils
+    from dvg_amd import parallel
+    from dvg_amd.data import SyntheticMovingMNIST
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    rank, world, local = parallel.init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    argv = ["--model", a.model, "--dataset", "smmnist", "--batch_size", str(a.batch), "--n_past", str(a.n_past),
+            "--n_future", str(a.n_future), "--no_save"] + (["--sync_bn"] if a.sync_bn else [])
+    opt = train.build_parser().parse_args(argv)
+    opt.ft, opt.rank, opt.world = True, rank, world
+    opt.local_batch = parallel.shard_batch(a.batch, world)
+    torch.manual_seed(5)
+    tr = train.Trainer(opt, dev)
+    tr.train_mode()
+    T = a.n_past + a.n_future
+    gen = SyntheticMovingMNIST(seq_len=T, seed=77)        # the SAME generator state on every rank: the global batches
+    lo, hi = rank * opt.local_batch, (rank + 1) * opt.local_batch
+    rec = {"world": world, "sync_bn": bool(tr.sync_bn), "losses": []}
+    mods = {"encoder": tr.encoder, "decoder": tr.decoder, "frame_predictor": tr.frame_predictor, "gp_layer": tr.gp_layer,
+            "likelihood": tr.likelihood}
+
+    def flat(kind):
+        out = {}
+        for name, m in mods.items():
+            src = m.named_parameters() if kind != "buffers" else m.named_buffers()
+            for k, p in src:
+                t = p.grad if kind == "grads" else p
+                if t is not None and t.is_floating_point():
+                    out[f"{name}.{k}"] = t.detach().float().cpu().clone()
+        return out
+    for it in range(a.iters):
+        xg, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(a.batch))
+        x = [t[lo:hi].contiguous() for t in xg]
+        if it == 0:
+            # the first train_model backward alone, WITHOUT its optimiser steps: the averaged gradients themselves
+            steps = [o.step for o in tr.optimizers()]
+            for o in tr.optimizers():
+                o.step = lambda *args, **kw: None
+            try:
+                tr._train_model_dev(x)
+            finally:
+                for o, s in zip(tr.optimizers(), steps):
+                    o.step = s
+            torch.cuda.synchronize()
+            rec["grads_first_backward"] = flat("grads")
+            rec["buffers_first_forward"] = flat("buffers")
+            continue                                  # (the BatchNorm buffers have advanced once on every rank alike)
+        mse, _, temp = tr.iteration(x)
+        rec["losses"].append((float(mse), float(tr.last_loss), float(temp)))
+    torch.cuda.synchronize()
+    rec["params"] = flat("params")
+    rec["buffers"] = flat("buffers")
+    if rank == 0:
+        torch.save(rec, a.out)
+        print(f"dp_equivalence: world {world} sync_bn {rec['sync_bn']} losses {rec['losses']}", flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,11 @@ def build_parser():
     p.add_argument('--no_hip_graph', action='store_true', help='eager launches for every iteration')
     p.add_argument('--print_param_checksum', action='store_true',
                    help='print a checksum of all parameters per rank at the end (multi-rank tests: every rank must agree)')
+    p.add_argument('--sync_bn', action='store_true',
+                   help='several ranks: BatchNorm statistics (and their backward sums) over the GLOBAL batch - one all-reduce of '
+                        '2 x C floats per BatchNorm call and direction - i.e. the reference\'s single-process semantics: N ranks x '
+                        'B/N clips then train exactly like one process on B clips (default: per-replica statistics, as '
+                        'DistributedDataParallel).  The collectives cannot be captured in a hipGraph: iterations run eager.')
     p.add_argument('--synthetic_data', action='store_true',
                    help='datasets other than smmnist: train on synthetic clips of the right shape (--data_root is not read)')
     return p
@@ -161,6 +166,13 @@ class Trainer:
         # every replica starts from rank 0's values: ONE broadcast of the parameter arena (all parameters are views of it by
         # now) + one packed broadcast per buffer dtype, instead of ~200 per-tensor broadcasts
         self.broadcast_collectives = parallel.broadcast_parameters(self.modules, arena_p=self.arena.p)
+        # --sync_bn: BatchNorm over the global batch (fused.set_sync_bn).  Its small collectives get their OWN process group
+        # (own RCCL communicator and stream): they must not queue behind the gradient ranges that are in flight while the
+        # encoder phase of the backward pass - which issues them - is still running
+        self.sync_bn = False
+        if getattr(opt, 'sync_bn', False) and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            fused.set_sync_bn(torch.distributed, torch.distributed.new_group())
+            self.sync_bn = True
         self.reducer = parallel.ArenaReducer(self.arena.g)
         self.rng_gp = (self.optimizer.flat_range(0)[0], self.optimizer.flat_range(1)[1])
         self.rng_fp = self.frame_predictor_optimizer.flat_range(0)
@@ -203,7 +215,7 @@ class Trainer:
         if not self.reducer.active() or not getattr(self, '_iters', 0):
             return None
         import torch.distributed as dist
-        ranges = [(self.rng_gp[0], self.rng_dec[1]), self.rng_enc, self.rng_fp, self.rng_gp] if self.opt.ft else \
+        ranges = [(self.rng_gp[0], self.rng_dec[1]), self.rng_enc, (self.rng_gp[0], self.rng_fp[1])] if self.opt.ft else \
             [(self.rng_gp[0], self.rng_dec[1]), self.rng_enc]
         scratch = torch.zeros_like(self.arena.g)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -319,7 +331,7 @@ class Trainer:
         self.last_loss = float(loss)
         return v, v
 
-    def _train_gp_dev(self, x):
+    def _train_gp_dev(self, x, defer_step=False):
         opt = self.opt
         zero_grads([self.optimizer])
         self.frame_predictor.hidden = None      # train.py:150 re-creates it here, but this closure never steps the LSTM
@@ -346,8 +358,9 @@ class Trainer:
                         self._loss_w[("neg1", elbo.device, elbo.numel())] = gneg   # capture is written only when that graph replays
                 loss = torch.dot(elbo.detach(), gneg)
                 elbo.backward(gneg)
-                self._ar(("reduce", self.rng_gp))
-                self.optimizer.step()
+                if not defer_step:
+                    self._ar(("reduce", self.rng_gp))
+                    self.optimizer.step()
                 return loss
             max_ll = -elbo
         else:
@@ -362,11 +375,12 @@ class Trainer:
                 max_ll = max_ll - self.mll(h_pred, h_target.transpose(0, 1))
         loss = max_ll.sum()
         loss.backward()
-        self._ar(("reduce", self.rng_gp))
-        self.optimizer.step()
+        if not defer_step:
+            self._ar(("reduce", self.rng_gp))
+            self.optimizer.step()
         return loss.detach()
 
-    def _train_fp_dev(self, x):
+    def _train_fp_dev(self, x, defer_step=False):
         opt = self.opt
         zero_grads([self.frame_predictor_optimizer])   # frame_predictor.zero_grad() (train.py:176): one fill of the flat range
         self.frame_predictor.hidden = None               # (re-created below by the step-by-step path; the sequence form starts
@@ -393,8 +407,9 @@ class Trainer:
                 sq, d_pred = ops.mse_sum_grad(pred.detach(), hcat[1:], 1.0 / float(hcat[0].numel()))
                 mse_latent = sq / float(hcat[0].numel())
                 pred.backward(d_pred)
-                self._ar(("reduce", self.rng_fp))
-                self.frame_predictor_optimizer.step()
+                if not defer_step:
+                    self._ar(("reduce", self.rng_fp))
+                    self.frame_predictor_optimizer.step()
                 return mse_latent
             d = pred - hcat[1:]
             mse_latent = (d * d).sum() / float(hcat[0].numel())                # sum over the steps of nn.MSELoss (mean)
@@ -406,8 +421,9 @@ class Trainer:
                 h_pred = self.frame_predictor(h)
                 mse_latent = mse_latent + self.mse_latent_criterion(h_pred, h_target)
         mse_latent.backward()
-        self._ar(("reduce", self.rng_fp))
-        self.frame_predictor_optimizer.step()
+        if not defer_step:
+            self._ar(("reduce", self.rng_fp))
+            self.frame_predictor_optimizer.step()
         return mse_latent.detach()
 
     def _train_model_batched(self, x):
@@ -597,8 +613,23 @@ class Trainer:
         self.optimizer.step()
         return mse_latent.detach(), loss.detach()
 
+    def _finetune_dev(self, x):
+        """Both fine-tuning closures of an iteration (train.py:175-198 then :146-172).  They are independent of each other: the
+        LSTM closure reads the encoder and the LSTM and steps only the LSTM, the GP closure reads the encoder and the GP and
+        steps only the GP, and neither steps the encoder.  So both backward passes run first, then ONE all-reduce over the
+        adjacent arena ranges [GP | likelihood | LSTM] (r06: was one collective - and one cut of the hipGraph chain - per
+        closure), then both Adam steps: the same arithmetic as the reference's order, three collectives and four graph
+        segments per data-parallel iteration instead of four and five."""
+        fp = self._train_fp_dev(x, defer_step=True)
+        gp = self._train_gp_dev(x, defer_step=True)
+        self._ar(("reduce", (self.rng_gp[0], self.rng_fp[1])))
+        self.frame_predictor_optimizer.step()
+        self.optimizer.step()
+        return fp, gp
+
     def finetune_temporal_encoders(self, x):
-        return self.train_frame_predictor(x) + self.train_GP_Frame_predictor(x)
+        fp, gp = self._finetune_dev(x)
+        return (float(fp) + float(gp)) / (self.opt.n_past + self.opt.n_future)
 
     def optimizers(self):
         return [self.frame_predictor_optimizer, self.encoder_optimizer, self.decoder_optimizer, self.optimizer]
@@ -735,14 +766,13 @@ class GraphedIteration:
             mse_latent, loss = tr._train_model_dev(self.static_x)
             fp = gp = None
             if tr.opt.ft:
-                fp = tr._train_fp_dev(self.static_x)
-                gp = tr._train_gp_dev(self.static_x)
+                fp, gp = tr._finetune_dev(self.static_x)
             self.outs = (mse_latent, loss, fp, gp)
 
     def __call__(self, x):
         tr = self.tr
         self.calls += 1
-        if self.calls <= self.warmup or self.failed:
+        if self.calls <= self.warmup or self.failed or fused.sync_bn_world() > 1:   # sync-BN: collectives inside every pass
             return tr.iteration(x)
         if self.graph is None or self.sig != self._signature(x):
             try:
@@ -765,6 +795,8 @@ class GraphedIteration:
                 print(f"train: hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); continuing with eager "
                       "iterations", file=sys.stderr, flush=True)
                 return tr.iteration(x)
+        for o in tr.optimizers():
+            o.check_graph_fresh()        # an eager step() since the capture left the device-side Adam step counts behind
         for dst, src in zip(self.static_x, x):
             dst.copy_(src)
         self._replay()
@@ -811,8 +843,7 @@ class SegmentedIteration(GraphedIteration):
             mse_latent, loss = tr._train_model_dev(self.static_x)
             fp = gp = None
             if tr.opt.ft:
-                fp = tr._train_fp_dev(self.static_x)
-                gp = tr._train_gp_dev(self.static_x)
+                fp, gp = tr._finetune_dev(self.static_x)
             self.outs = (mse_latent, loss, fp, gp)
             seg._end()
         except BaseException:
@@ -956,7 +987,7 @@ def main(argv=None):
     # stay eager (SegmentedIteration).  Capturing the RCCL collectives inside ONE graph instead is NOT safe
     # on this stack: the c10d watchdog thread may query a collective's event while it is "recorded in a capturing stream"
     # (hipErrorCapturedEvent) and terminate the process (1 of 5 runs with a one-rank RCCL group).
-    if opt.no_hip_graph:
+    if opt.no_hip_graph or tr.sync_bn:
         step = tr.iteration
     elif world == 1:
         step = GraphedIteration(tr)
