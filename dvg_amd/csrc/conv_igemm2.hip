@@ -147,7 +147,36 @@ struct Cfg2 {
     static constexpr bool PAR4 = MODE == M2_CONV4S2;
     static constexpr int SPAN = GEMM ? 1 : (PAR4 ? 2 : 3);
     static constexpr int HH = (TH - 1) + SPAN, HW = (TW - 1) + SPAN;        // LDS tile (stride 1 in every mode)
-    static constexpr int HP = TI * HH * HW;
+    // Conflict-free A-fragment reads of the halo-tiled modes (r06).  `ds_read_b128` is served in four fixed 16-lane groups,
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS): a group's 16 rows must hit 16
+    // distinct 16-byte slots of the 256-byte bank row.  Rows are an ODD number of slots long (112 B = 7, f32 build 80 B = 5),
+    // so slot = pos x odd + const (mod 16) and what matters is that the 16 pixels of a group are distinct mod 16 in their
+    // LDS position pos = image x IMG + row x HWP + column.  With lane l holding pixel l of the 32-row tile the halo pitches
+    // (18, 10, 17, 9, 6, 5) put 2-3 rows on a slot: 30-42 % of all LDS cycles were conflict cycles in every one of these
+    // instantiations (profiles/r05_pmc_by_kernel.json) while the LDS was busy 44-79 % of the time.  Fix = (a) WHICH pixel a
+    // lane holds: lane-quad q = l >> 2 holds pixel-quad PERM[q], PERM[2 b + h] = P0[b] ^ (h PK) (so that the C-layout row of
+    // accumulator register `reg` in lane half hh is (4 P0[reg >> 2] + (reg & 3)) ^ (4 PK hh): one XOR, no select), and (b) a
+    // padded pixel pitch where no permutation suffices (8-wide tiles: 12; the 4 x 4 x 4-image tiles: rows of 6 pixels,
+    // images 40 (3 x 3 halo) / 30 (parity-split stride-2 conv: the best that fits its 128 staged rows - 2 residual conflict
+    // cycles per 8 reads instead of 8) pixels apart).  Found by exhaustive search (tools/lds_layout_search.py, which also
+    // checks that vertical 2 x 2 pool partners stay in one lane: register blocks (0, 1) and (2, 3)).  The padding pixels are
+    // never read and cost no LDS: the staged rows were already rounded up to whole 256-thread store passes.
+    // DVG_HALO_LAYOUT=0: the r05 layout (lane l = pixel l, unpadded pitches).
+#ifndef DVG_HALO_LAYOUT
+#define DVG_HALO_LAYOUT 1
+#endif
+    static constexpr bool LAYOUT = !GEMM && DVG_HALO_LAYOUT != 0;
+    static constexpr int HWP = !LAYOUT ? HW : (TW == 16 ? HW : (TW == 8 ? 12 : 6));         // pixel pitch of a halo row
+    static constexpr int IMG = (LAYOUT && TI == 4) ? (PAR4 ? 30 : 40) : HH * HWP;           // pixel pitch of an image
+    static_assert(IMG >= HH * HWP && HWP >= HW, "halo layout");
+    static constexpr int HP = TI * IMG;
+    // P0[b] as four 4-bit fields, and PK
+    static constexpr unsigned P0PACK = !LAYOUT ? 0x6420u
+        : (PAR4 ? (TW == 16 ? 0x3650u : (TI == 4 ? 0x7430u : 0x6530u))
+                : (TW == 16 ? 0x2640u : (TI == 4 ? 0x6530u : 0x4620u)));
+    static constexpr int PK = !LAYOUT ? 1 : (PAR4 ? (TW == 16 ? 4 : 1) : (TW == 16 ? 5 : (TI == 4 ? 1 : 3)));
+    // row (0..31) of the wave's 32-row tile that accumulator register `reg` holds in lane half 0; half 1: ^ (4 * PK)
+    static constexpr int row_c(int reg) { return 4 * (int)((P0PACK >> (4 * (reg >> 2))) & 15u) + (reg & 3); }
     static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64 * NT;
     static constexpr int NTAPS = GEMM ? 1 : ((MODE == M2_CONV3) ? 9 : 16);
     // DVG_GEMM_GT: 16-channel slabs per stage of the GEMM modes.  4 (K = 64, 60 KB of LDS with the 128-row tile); 8 was
@@ -230,9 +259,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     int a_base[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = wm * (C::BM / 2) + mt * 32 + l31;
+        // the pixel this lane's A-operand row holds: lane-quad l31 >> 2 = 2 b + h -> pixel-quad P0[b] ^ (h PK) (Cfg2: LAYOUT)
+        const int lp = 4 * ((int)((C::P0PACK >> (4 * (l31 >> 3))) & 15u) ^ (((l31 >> 2) & 1) * C::PK)) + (l31 & 3);
+        const int m = wm * (C::BM / 2) + mt * 32 + lp;
         const int ti = m / (TH * TW), r = m % (TH * TW);
-        const int pos = (ti * HH + r / TW) * HW + r % TW;
+        const int pos = ti * C::IMG + (r / TW) * C::HWP + r % TW;
         a_base[mt] = pos * LD + (X3 ? (hh ^ (GEMM ? (pos >> 3) & 1 : 0)) * 4 : hh * 8);
     }
     // LDS image of the weight tile: [64-column block][tap][64 rows][LDB]; the wave's 32-column tile nt is rows
@@ -269,15 +300,18 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
     for (int i = 0; i < NLA; ++i) {
         const int idx = tid + (i % NLA1) * 256;
         const int hp = idx >> 2, q = idx & 3;
-        const int ti = hp / (HH * HW), r = hp % (HH * HW);
+        // LDS pixel row hp -> (image, halo row, halo column); rows / columns of the layout's padding are never loaded
+        const int ti = hp / C::IMG, r = hp % C::IMG;
+        const int hy = r / C::HWP, hx = r % C::HWP;
+        const bool slot = idx < HP * 4 && hy < HH && hx < HW;
         if constexpr (C::PAR4) {
             // slot (hy, hx) of parity (alpha, beta) is image pixel (yin0 + 2 hy + alpha, xin0 + 2 hx + beta).  ONE offset per slot:
             // parity (0, 0)'s pixel CLAMPED into the image, plus a row / column step per parity that is 0 where the step would
             // leave the image (rows -1 -> 0 and H - 1 -> H, likewise columns).  Every load reads inside the tensor; the conv's
             // zero padding is applied to the VALUE at the LDS store (an integer AND with 0 / ~0: no lane mask, no select, exact
             // zeros whatever was loaded).
-            const int n = n0 + ti, yy = yin0 + 2 * (r / HW), xx = xin0 + 2 * (r % HW);
-            const bool in = idx < HP * 4 && n < p.N;
+            const int n = n0 + ti, yy = yin0 + 2 * hy, xx = xin0 + 2 * hx;
+            const bool in = slot && n < p.N;
 #pragma unroll
             for (int par_ = 0; par_ < 4; ++par_) {
                 const bool ok = in && (unsigned)(yy + (par_ >> 1)) < (unsigned)p.H && (unsigned)(xx + (par_ & 1)) < (unsigned)p.W;
@@ -290,8 +324,8 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             offx[i] = in ? (int)((((long)n * p.H + cy0) * p.W + cx0) * p.C1 + q * 4) : 0;
             offs[i] = 0;                                                    // (no skip operand in this mode)
         } else {
-        const int n = n0 + ti, yy = yin0 + r / HW, xx = xin0 + r % HW;
-        const bool ok = idx < HP * 4 && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const int n = n0 + ti, yy = yin0 + hy, xx = xin0 + hx;
+        const bool ok = slot && n < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         const int sh = p.upsample;
         okmask |= ok ? (1u << i) : 0u;
         if (!GEMM || i < NLA1)
@@ -305,7 +339,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         if (MODE == M2_CONV3) { th = tt / 3; tw = tt % 3; }
         else if (MODE == M2_CONV4S2) { th = tt >> 1; tw = tt & 1; }      // PAR4: tap (2 th + alpha, 2 tw + beta) of the parity grp
         else { th = 1 + py - (tt >> 1); tw = 1 + px - (tt & 1); }
-        return (th * HW + tw) * LD;
+        return (th * C::HWP + tw) * LD;
     };
     // M2_GEMM: image (relative to n0) whose operands the NEXT loads fetch; the stage loop moves it on at image boundaries
     long ld_a_off = GEMM ? (long)n0 * p.H * p.W * p.C1 : 0;
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
                 const int hp = min((tid + i * 256) >> 2, HP - 1);
-                const float* f = Fp + (hp / HW) * C::FP_W + hp % HW;
+                const float* f = Fp + (hp / C::HWP) * C::FP_W + hp % C::HWP;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -770,7 +804,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int m = wm * (C::BM / 2) + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int m = wm * (C::BM / 2) + mt * 32 + (C::row_c(reg) ^ (hh * 4 * C::PK));
                 const int tii = m / (TH * TW), r = m % (TH * TW);
                 const int ty = r / TW, tx = r % TW;
                 const int n = n0 + tii;
@@ -806,6 +840,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
         for (int t_ = 1; t_ < TI; ++t_) v = tii == t_ ? add_shift[t_] : v;
         return v;
     };
+    const int hrow = hh * 4 * C::PK;     // C-layout row of (reg, lane half): C::row_c(reg) ^ hrow  (Cfg2: LAYOUT)
     auto epilogue = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;  // -1: generic (runtime p.act)
 #pragma unroll
@@ -818,7 +853,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
                 float av[16];
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int m = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    const int m = mbase + (C::row_c(reg) ^ hrow);
                     const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
                     const int r = m % (TH * TW);
                     const int ty = r / TW, tx = r % TW;
@@ -835,7 +870,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int row = C::row_c(reg) ^ hrow;
                 const int m = mbase + row;
                 const int tii = (TH * TW >= 32) ? ti0 : m / (TH * TW);
                 const int r = m % (TH * TW);
@@ -856,12 +891,17 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
             }
             if (MODE == M2_CONV3 && (TW == 16 || TW == 8)) {
                 if (pb != nullptr) {
-                    constexpr int RY = (TW == 16) ? 8 : 4;
+                    // a 2 x 2 window = two x-neighbours (reg, reg + 1) of two vertically adjacent rows in ONE lane.  r05
+                    // layout: the 16-wide tile has tile row 0 in register blocks 0, 1 and row 1 in blocks 2, 3 (partner: + 8),
+                    // the 8-wide one alternates (partner: + 4).  r06 layout (Cfg2::LAYOUT): the vertical partner of block
+                    // 0 / 2 is block 1 / 3 in both tiles and both lane halves (which of the two is the upper row depends on
+                    // the lane half; the window's maximum and its pooled coordinates do not).
+                    constexpr int RY = (TW == 16 && !C::LAYOUT) ? 8 : 4;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const bool ty_even = (TW == 16) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
+                        const bool ty_even = (TW == 16 && !C::LAYOUT) ? ((reg >> 2) < 2) : (((reg >> 2) & 1) == 0);
                         if ((reg & 1) == 0 && ty_even) {
-                            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                            const int row = C::row_c(reg) ^ hrow;
                             const int r = (mbase + row) % (TH * TW);
                             const int ty = r / TW, tx = r % TW;
                             const float mx = fmaxf(fmaxf(v[reg], v[reg + 1]), fmaxf(v[reg + RY], v[reg + RY + 1]));

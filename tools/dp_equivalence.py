@@ -81,8 +81,21 @@ def main():
             rec["grads_first_backward"] = flat("grads")
             rec["buffers_first_forward"] = flat("buffers")
             continue                                  # (the BatchNorm buffers have advanced once on every rank alike)
-        mse, _, temp = tr.iteration(x)
-        rec["losses"].append((float(mse), float(tr.last_loss), float(temp)))
+        if it == 1:
+            # the first iteration that steps, in its two halves (= Trainer.iteration): every run starts it from identical
+            # parameters, so train_model's loss values and the parameters right after ITS Adam steps are directly comparable;
+            # the fine-tuning closures then already run on stepped weights
+            mse, _ = tr.train_model(x)
+            torch.cuda.synchronize()
+            rec["params_first_step"] = flat("params")
+            temp = tr.finetune_temporal_encoders(x)
+        else:
+            mse, _, temp = tr.iteration(x)
+        vals = torch.tensor([float(mse), float(tr.last_loss), float(temp)], dtype=torch.float64, device=dev)
+        if world > 1:       # a rank's loss values are those of ITS clips: the mean over the ranks is the global batch's
+            torch.distributed.all_reduce(vals)
+            vals /= world
+        rec["losses"].append(tuple(float(v) for v in vals))
     torch.cuda.synchronize()
     rec["params"] = flat("params")
     rec["buffers"] = flat("buffers")
