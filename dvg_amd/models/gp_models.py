@@ -28,6 +28,63 @@ from .. import ops
 
 JITTER = 1e-3        # lazy_tensor.add_jitter() default of gpytorch 0.3.x
 NOISE_FLOOR = 1e-4   # GaussianLikelihood noise constraint GreaterThan(1e-4)
+# First-call initialisation of the variational distribution (an UNTRAINED GP's start only; a loaded state with
+# variational_params_initialized = 1 never runs it): L_S <- chol((K_ZZ + INIT_JITTER_TERMS * JITTER * I)^-1).
+# [recalled, unverifiable here - gpytorch is not installable]  gpytorch 0.3.x's WhitenedVariationalStrategy builds its prior as
+# MultivariateNormal(mean, K_ZZ.add_jitter()) and `initialize_variational_dist` inverts `prior.lazy_covariance_matrix
+# .add_jitter()`: in the releases where BOTH calls add the default 1e-3 (0.3.2 - 0.3.6 as recalled) the inverse is of K_ZZ +
+# 2e-3 I, in 0.3.0 / 0.3.1 (initialisation from `prior_dist.covariance_matrix` directly) of K_ZZ + 1e-3 I.  1 = the GP starts
+# EXACTLY at its prior under the predictive equations of record (KL = 0, variance = outputscale: what tests/test_oracle_gp.py
+# pins); 2 = the recalled later behaviour (start KL = 1/2 sum_i [r_i - 1 - ln r_i], r_i = (lam_i + j) / (lam_i + 2 j) over K_ZZ's eigenvalues:
+# ~0.5 nats per latent dim, predictive variance within a few per cent of the prior's).  One
+# constant, both tested (tests/test_oracle_gp.py, tests/test_gpu_parity.py); the oracle mirrors it (oracle.gp_prior_init).
+INIT_JITTER_TERMS = 1
+
+# gpytorch >= 0.3.3 registers its parameter constraints as modules whose bounds are buffers in the state_dict; the arithmetic
+# here hard-wires exactly these (softplus onto (0, inf) for outputscale / lengthscale, softplus + 1e-4 for the noise)
+_EXPECTED_BOUNDS = {
+    "covar_module.raw_outputscale_constraint": (0.0, math.inf),
+    "covar_module.base_kernel.raw_lengthscale_constraint": (0.0, math.inf),
+    "noise_covar.raw_noise_constraint": (NOISE_FLOOR, math.inf),
+}
+
+
+def _tolerant_state_dict(module: nn.Module, state_dict, what: str):
+    """A real gpytorch-0.3.x state_dict -> (state_dict this module loads strictly, report).  Accepted and REPORTED, never
+    silently dropped (generate_frames.py:67-72 of the reference loads `gp_layer` / `likelihood` state_dicts):
+      * shape variants of a key with the right number of elements ((90,1,1) / (90,1) / (90,) for the per-dim scalars, a
+        (90,1,40) variational mean, ...) are reshaped;
+      * `<param>_constraint.lower_bound / upper_bound` buffers are checked against the bounds this implementation hard-wires
+        and left out; DIFFERENT bounds raise (the arithmetic would differ);
+      * a missing `variational_params_initialized` is read as 1 when variational parameters are present (a trained state).
+    Anything else unknown stays in the dict, so that load_state_dict(strict=True) still names it."""
+    own = module.state_dict()
+    out, report = type(state_dict)(), {"reshaped": [], "constraints": [], "assumed": []}
+    for k, v in state_dict.items():
+        base, _, leaf = k.rpartition(".")
+        if leaf in ("lower_bound", "upper_bound") and base in _EXPECTED_BOUNDS:
+            want = _EXPECTED_BOUNDS[base][0 if leaf == "lower_bound" else 1]
+            got = float(torch.as_tensor(v).reshape(-1)[0])
+            if not (got == want or abs(got - want) <= 1e-6 * abs(want)):       # (a float32 buffer holds 1e-4 as 9.9999997e-05)
+                raise RuntimeError(f"{what}: state_dict carries {k} = {got}, this implementation hard-wires {want} "
+                                   "(softplus-positive kernel hyper-parameters, noise >= 1e-4): results would differ")
+            report["constraints"].append(f"{k} = {got:g}")
+            continue
+        if k in own and torch.is_tensor(v) and tuple(v.shape) != tuple(own[k].shape) and v.numel() == own[k].numel():
+            report["reshaped"].append(f"{k}: {tuple(v.shape)} -> {tuple(own[k].shape)}")
+            v = v.reshape(own[k].shape)
+        out[k] = v
+    flag = "variational_strategy.variational_params_initialized"
+    if flag in own and flag not in out and "variational_strategy.variational_distribution.variational_mean" in out:
+        out[flag] = torch.tensor(1)
+        report["assumed"].append(f"{flag} = 1 (absent; variational parameters present)")
+    return out, report
+
+
+def _announce(what: str, report: dict) -> None:
+    if any(report.values()):
+        import sys
+        print(f"{what}.load_state_dict: " + "; ".join(f"{k}: {', '.join(v)}" for k, v in report.items() if v), file=sys.stderr)
 
 
 class _Holder(nn.Module):
@@ -139,9 +196,13 @@ class GPRegressionLayer1(nn.Module):
         self.covar_module.base_kernel = _Holder()
         self.covar_module.base_kernel.raw_lengthscale = nn.Parameter(torch.zeros(D, 1, 1))  # RBFKernel(batch_size=D)
 
-    def load_state_dict(self, *a, **k):
+    def load_state_dict(self, state_dict, *a, **k):
+        """Strict on the gpytorch-0.3.x key set, tolerant of its shape variants and constraint buffers (_tolerant_state_dict);
+        what was adapted is kept in `self.load_report` and printed once to stderr."""
         self._init_checked = False
-        return super().load_state_dict(*a, **k)
+        sd, self.load_report = _tolerant_state_dict(self, state_dict, "GPRegressionLayer1")
+        _announce("GPRegressionLayer1", self.load_report)
+        return super().load_state_dict(sd, *a, **k)
 
     # -- hyper-parameters ---------------------------------------------------------------
     def hypers(self):
@@ -162,7 +223,7 @@ class GPRegressionLayer1(nn.Module):
         z = vs.inducing_points.squeeze(-1).double()
         diff = z.unsqueeze(-1) - z.unsqueeze(-2)
         kzz = s.view(-1, 1, 1) * torch.exp(-0.5 * diff * diff / ell.view(-1, 1, 1) ** 2)
-        kzz = kzz + JITTER * torch.eye(z.shape[1], dtype=torch.float64, device=z.device)
+        kzz = kzz + INIT_JITTER_TERMS * JITTER * torch.eye(z.shape[1], dtype=torch.float64, device=z.device)
         # one-off 40x40 fp64 inverse per latent dim at initialisation time (host of the path, not
         # on it): done on the CPU so that no BLAS/solver library is pulled onto the device
         ls = torch.linalg.cholesky(torch.linalg.inv(kzz.cpu())).to(z.device)
@@ -201,6 +262,11 @@ class GaussianLikelihood(nn.Module):
         super().__init__()
         self.noise_covar = _Holder()
         self.noise_covar.raw_noise = nn.Parameter(torch.zeros(batch_size, 1))
+
+    def load_state_dict(self, state_dict, *a, **k):
+        sd, self.load_report = _tolerant_state_dict(self, state_dict, "GaussianLikelihood")
+        _announce("GaussianLikelihood", self.load_report)
+        return super().load_state_dict(sd, *a, **k)
 
     @property
     def noise(self):

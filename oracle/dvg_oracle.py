@@ -301,13 +301,15 @@ def rbf(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, ell: torch.Tensor) ->
     return s.view(-1, 1, 1) * torch.exp(-0.5 * diff * diff / (ell.view(-1, 1, 1) ** 2))
 
 
-def gp_prior_init(sd: SD) -> None:
+def gp_prior_init(sd: SD, jitter_terms: int = 1) -> None:
     """WhitenedVariationalStrategy.initialize_variational_dist (first call):
-    m <- prior mean, L_S <- chol((K_ZZ + jitter I)^-1) computed in fp64."""
+    m <- prior mean, L_S <- chol((K_ZZ + jitter_terms * jitter I)^-1) computed in fp64.  jitter_terms: 1 = the GP starts exactly
+    at its prior; 2 = the behaviour recalled for the later gpytorch 0.3.x releases, whose initialisation adds the default
+    jitter to a prior covariance that already carries it (dvg_amd/models/gp_models.py: INIT_JITTER_TERMS)."""
     s, ell, c = gp_hypers(sd)
     z = sd["variational_strategy.inducing_points"].squeeze(-1)
     M = z.shape[1]
-    kzz = rbf(z.double(), z.double(), s.double(), ell.double()) + GP_JITTER * torch.eye(M, dtype=torch.float64)
+    kzz = rbf(z.double(), z.double(), s.double(), ell.double()) + jitter_terms * GP_JITTER * torch.eye(M, dtype=torch.float64)
     ls = torch.linalg.cholesky(torch.linalg.inv(kzz))
     sd["variational_strategy.variational_distribution.variational_mean"] = c.view(-1, 1).expand(-1, M).clone().to(
         z.dtype)

@@ -327,6 +327,48 @@ def test_gp_raw_hyper_parameters_in_kernel():
     assert float((a["sample"] - b["sample"]).abs().max()) < 1e-5 * float(a["sample"].abs().max())
 
 
+@pytest.mark.parametrize("terms", [1, 2])
+def test_gp_first_call_initialisation_on_the_device(terms):
+    """gp_models.INIT_JITTER_TERMS (DESIGN.md 3.3's open point, both readings behind one constant): an UNTRAINED layer's first
+    train-mode call initialises L_S <- chol((K_zz + terms * 1e-3 I)^-1) and the kernel's KL / variance of that state equal the
+    oracle's for the same reading (terms = 1: KL = 0 - the GP starts at its prior; 2: KL ~ 0.5 nats per latent dim); a TRAINED
+    state (variational_params_initialized = 1) gives identical predictions whatever the constant says."""
+    from dvg_amd.models import gp_models as gm
+    D, M, B = 12, 40, 16
+    h = params.normal(97, B, D, scale=0.7).tanh()
+    old = gm.INIT_JITTER_TERMS
+    try:
+        gm.INIT_JITTER_TERMS = terms
+        sd, _ = params.gp_state(96, D=D, M=M, trained=False)
+        layer = gm.GPRegressionLayer1(D, M)
+        layer.load_state_dict(sd)
+        layer.to(dev()).train()
+        with torch.no_grad():
+            pred = layer(h.to(dev()))
+            kl, var = pred.kl.double().cpu(), pred.variance.double().cpu()
+        ref = {k: v.clone() for k, v in sd.items()}
+        orc.gp_prior_init(ref, jitter_terms=terms)
+        tr = orc.gp_predict(h, ref, training=True)
+        assert float((var - tr["var"]).abs().max()) < 1e-4 * float(tr["var"].abs().max())
+        if terms == 1:
+            assert float(kl.abs().max()) < 2e-3 and float(tr["kl"].abs().max()) < 2e-3       # zero up to the fp32 storage of L_S
+        else:
+            assert float(((kl - tr["kl"]).abs() / tr["kl"]).max()) < 1e-3 and float(tr["kl"].min()) > 0.05
+        sdt, _ = params.gp_state(98, D=D, M=M, trained=True)
+        outs = []
+        for t_ in (1, 2):
+            gm.INIT_JITTER_TERMS = t_
+            trained = gm.GPRegressionLayer1(D, M)
+            trained.load_state_dict(sdt)
+            trained.to(dev()).train()
+            with torch.no_grad():
+                p_ = trained(h.to(dev()))
+                outs.append((p_.mean.clone(), p_.variance.clone(), p_.kl.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+    finally:
+        gm.INIT_JITTER_TERMS = old
+
+
 def test_gp_index_bookkeeping_is_exact():
     """(B,D) <-> (D,B,1) view bookkeeping (train.py:225): GP d must see column d of h, bit-exactly."""
     from dvg_amd.models.gp_models import GPRegressionLayer1
