@@ -69,8 +69,17 @@ _WINO_MIN_C = 64
 _WINO_MAX_HW = 32
 
 
+# (Cin, map side, Cout) -> tile size forced for that layer shape (0 = direct form, 2 = F(2x2)): tools/diag_layer_precision.py
+# attributes the rounding of the F(4x4) transforms layer by layer with it; empty in the product
+WINOGRAD_LAYER_OVERRIDE = {}
+
+
 def winograd_tile(n, c, h, w, cout) -> int:
     """Winograd output-tile size (4, 2) for this eval-mode 3x3 layer, or 0 for the direct implicit GEMM."""
+    if WINOGRAD_LAYER_OVERRIDE:
+        forced = WINOGRAD_LAYER_OVERRIDE.get((c, h, cout))
+        if forced is not None:
+            return forced if (forced == 0 or ops.winograd_ok(n, c, h, w, cout, forced)) else 0
     if WINOGRAD >= 4 and c >= _WINO_MIN_C and h <= _WINO_MAX_HW and w <= _WINO_MAX_HW and ops.winograd_ok(n, c, h, w, cout, 4):
         return 4
     if WINOGRAD >= 2 and c >= 256 and ops.winograd_ok(n, c, h, w, cout, 2) and \

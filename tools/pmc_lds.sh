@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_lds
 rm -rf $out; mkdir -p $out
 for m in vgg dcgan; do
-  timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/$m -o pmc -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --no-graph --no-families --no-train-leg --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs > $out/$m.log 2>&1 < /dev/null
+  timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/$m -o pmc -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --no-graph --no-families --no-train-leg --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --no-check --sustained-s 0 > $out/$m.log 2>&1 < /dev/null
   echo "$m rc=$?"
 done
 python3 tools/pmc_summary.py $out "*" > $out/summary.json 2> $out/summary.err

@@ -9,15 +9,15 @@ out=gpurun_out/prof_round
 rm -rf $out; mkdir -p $out
 # per-kernel durations are taken with ONE rollout in flight (--inflight 1): with several rollouts overlapping, a kernel's
 # duration includes the time it shares the chip with other chains' kernels; the default (3 in flight) is profiled beside it
-B="--steps 10 --warmup 3 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --inflight 1"
+B="--steps 10 --warmup 3 --no-check --sustained-s 0 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --inflight 1"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_vgg -o vgg -- python3 bench.py --model vgg $B > $out/bench_vgg_under_rocprof.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dcgan -o dcgan -- python3 bench.py --model dcgan $B > $out/bench_dcgan_under_rocprof.log 2>&1 < /dev/null
-B3="--steps 12 --warmup 3 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --no-roofline"
+B3="--steps 12 --warmup 3 --no-check --sustained-s 0 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --no-roofline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_vgg_inflight3 -o vgg -- python3 bench.py --model vgg $B3 > $out/bench_vgg_inflight3_under_rocprof.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dcgan_inflight3 -o dcgan -- python3 bench.py --model dcgan $B3 > $out/bench_dcgan_inflight3_under_rocprof.log 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train -o train -- python3 tools/bench_train.py --model vgg --iters 2 > $out/train_vgg_under_rocprof.log 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train_dcgan -o train -- python3 tools/bench_train.py --model dcgan --iters 2 > $out/train_dcgan_under_rocprof.log 2>&1 < /dev/null
-P="--steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs"
+P="--steps 2 --warmup 1 --no-check --sustained-s 0 --no-cpu-baseline --no-graph --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs"
 for m in vgg dcgan; do
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     tag=$(echo $c | cut -d' ' -f1)
