@@ -175,6 +175,17 @@ struct Cfg2 {
         : (PAR4 ? (TW == 16 ? 0x3650u : (TI == 4 ? 0x7430u : 0x6530u))
                 : (TW == 16 ? 0x2640u : (TI == 4 ? 0x6530u : 0x4620u)));
     static constexpr int PK = !LAYOUT ? 1 : (PAR4 ? (TW == 16 ? 4 : 1) : (TW == 16 ? 5 : (TI == 4 ? 1 : 3)));
+    // ... and the A-tile STORES: four lanes write one pixel's 32 bytes of a plane (ds_write_b64, served in groups of 16
+    // consecutive lanes = 4 pixels on a 128-byte bank window).  Consecutive pixels are 112 B apart = 7 x 16 B, so pixels p and
+    // p + 1 overlap by 16 B (2-way, on every store); pixels 2 apart are 96 B = -32 B apart (mod 128): the 4 x 32 B of pixels
+    // p, p + 2, p + 4, p + 6 tile the window exactly.  So thread slot k (= 4 lanes) of every 8-pixel block stages pixel
+    // 2 (k & 3) + (k >> 2) of it.  (The global loads do not care: a pixel's 16-channel chunk is its own 64-byte segment.)
+    // bf16-triple halo modes only: the f32 build's 80-byte rows and the GEMM mode's swizzled 96-byte rows store conflict-free
+    // as they are.  Residual SQ_LDS_BANK_CONFLICT after the read fix alone: 6-14 % (profiles/r06_pmc_lds_after_layout.txt).
+    static constexpr bool STORE_PERM = LAYOUT && DVG_BF16X3 != 0;
+    static constexpr int hp_of(int slot) {     // staged pixel row of thread slot `slot` = idx >> 2
+        return STORE_PERM ? ((slot & ~7) | (((slot & 3) << 1) | ((slot >> 2) & 1))) : slot;
+    }
     // row (0..31) of the wave's 32-row tile that accumulator register `reg` holds in lane half 0; half 1: ^ (4 * PK)
     static constexpr int row_c(int reg) { return 4 * (int)((P0PACK >> (4 * (reg >> 2))) & 15u) + (reg & 3); }
     static constexpr int BM = TI * TH * TW, MT = BM / 64, BN = 64 * NT;
@@ -299,11 +310,11 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
         const int idx = tid + (i % NLA1) * 256;
-        const int hp = idx >> 2, q = idx & 3;
+        const int hp = C::hp_of(idx >> 2), q = idx & 3;
         // LDS pixel row hp -> (image, halo row, halo column); rows / columns of the layout's padding are never loaded
         const int ti = hp / C::IMG, r = hp % C::IMG;
         const int hy = r / C::HWP, hx = r % C::HWP;
-        const bool slot = idx < HP * 4 && hy < HH && hx < HW;
+        const bool slot = hp < HP && hy < HH && hx < HW;
         if constexpr (C::PAR4) {
             // slot (hy, hx) of parity (alpha, beta) is image pixel (yin0 + 2 hy + alpha, xin0 + 2 hx + beta).  ONE offset per slot:
             // parity (0, 0)'s pixel CLAMPED into the image, plus a row / column step per parity that is 0 where the step would
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #endif
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
-                const int hp = min((tid + i * 256) >> 2, HP - 1);
+                const int hp = min(C::hp_of((tid + i * 256) >> 2), HP - 1);
                 const float* f = Fp + (hp / C::HWP) * C::FP_W + hp % C::HWP;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(256, (MODE == M2_GEMM && TW == 8) ? DVG_GEMM_WGS_PE
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int idx = tid + (i % NLA1) * 256;
-            const int hp = idx >> 2, q = idx & 3;
+            const int hp = C::hp_of(idx >> 2), q = idx & 3;
             if constexpr (C::PAR4) {       // the zero padding (and the slots past the tile / the batch): value AND 0 / ~0
                 const unsigned keep = 0u - opaque((okmask >> (par_ * NLA + i)) & 1u);
 #pragma unroll
