@@ -7,8 +7,12 @@ sprites come from a seeded in-repo generator instead of MNIST.  Frames are (T,H,
 [0,1]; a batch is (B,T,H,W,1), which `utils.normalize_data` turns into T x (B,1,H,W)."""
 from __future__ import annotations
 
+import sys
+
 import numpy as np
 import torch
+
+from .utils import normalize_data
 
 
 def _sprites(rng: np.random.Generator, n: int, size: int = 32) -> np.ndarray:
@@ -133,3 +137,29 @@ def synthetic_video(batch, seq_len, channels, res, seed=1) -> torch.Tensor:
     np.cumsum(drift, axis=1, out=drift)
     drift += base
     return torch.from_numpy(np.clip(drift, 0, 1, out=drift))
+
+
+def make_batch_generator(opt, seq_len, seed, device=None):
+    """Yields `load()` callables: the host half of a batch has been drawn when the callable is yielded, calling it (on the
+    thread that owns the GPU stream) puts the batch on the device as normalize_data's list of T x (B,C,H,W) frames.
+    smmnist: the host draws the integer trajectories, the device composites them (bit-identical to the host batch).
+    `--data_root` is NOT read: there are no dataset files (nor torchvision / network) in this environment.  smmnist is
+    the reference's trajectory generator over seeded in-repo sprites; every other dataset name must be acknowledged with
+    --synthetic_data, otherwise a reference command line would silently 'train' on noise."""
+    if opt.dataset != 'smmnist' and not getattr(opt, 'synthetic_data', False):
+        raise SystemExit(f"train.py: no loader for --dataset {opt.dataset} here (--data_root {opt.data_root!r} is not read). "
+                         "Pass --synthetic_data to train on synthetic clips of that dataset's shape.")
+    if opt.rank == 0:
+        what = ("Moving-MNIST trajectories over synthetic sprites (not MNIST digits)" if opt.dataset == 'smmnist'
+                else f"random textured clips shaped like {opt.dataset}")
+        print(f"WARNING: synthetic data - {what}; --data_root is ignored", file=sys.stderr)
+    if opt.dataset == 'smmnist':
+        ds = SyntheticMovingMNIST(seq_len=seq_len, num_digits=opt.num_digits, image_size=opt.image_width, seed=seed)
+        while True:
+            ids, pos = ds.trajectories(opt.local_batch)
+            yield lambda ids=ids, pos=pos: ds.compose_device(ids, pos, device or torch.device('cuda'))
+    k = 0
+    while True:
+        seq = synthetic_video(opt.local_batch, seq_len, opt.channels, opt.image_width, seed=seed + k)
+        yield lambda seq=seq: normalize_data(opt, torch.cuda.FloatTensor, seq)[0]
+        k += 1

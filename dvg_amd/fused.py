@@ -308,7 +308,7 @@ def set_sync_bn(dist=None, group=None) -> None:
         _SYNC_BN = None
     else:
         _SYNC_BN = (dist, group, dist.get_world_size(group))
-    ops.SYNC_BN = _SYNC_BN
+    ops.set_sync_bn_state(_SYNC_BN)
 
 
 def sync_bn_world() -> int:
@@ -317,7 +317,7 @@ def sync_bn_world() -> int:
 
 def _train_bn(bn: nn.BatchNorm2d, stats, count, save=False, synced=False):
     """count = elements per channel of the WHOLE (local) batch; with groups every group has count / G of them.
-    sync-BN: `stats` becomes one all-reduced row per group and `count` the global count (`synced`: that has happened)."""
+    sync-BN: `stats` becomes the all-reduced sums (two fp32 rows, hi + lo, per group) and `count` the global count (`synced`: that has happened)."""
     if _SYNC_BN is not None and not synced:
         stats = ops.sync_partial_rows(stats, _BN_GROUPS[0] if _BN_GROUPS else 1)
         count = count * _SYNC_BN[2]

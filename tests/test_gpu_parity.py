@@ -140,6 +140,33 @@ def test_conv4x4s2_igemm(N, H, W, Cin, Cout):
                                rtol=1e-4)
 
 
+def test_conv4x4s2_splits_a_batch_beyond_the_kernels_32_bit_offsets(monkeypatch):
+    """the parity-split stride-2 conv addresses its activation with 32-bit offsets (N H W Cin < 2^31) and the
+    wrapper used to hard-fail above that.  It now runs such a batch as several launches over runs of images; exercised here by
+    lowering the wrapper's threshold (the kernel's own limit is unchanged) so that a 200-image batch splits into three runs:
+    the output equals the single launch's bit for bit, the per-tile statistics rows sum to the same totals, ragged last run
+    included; the dgrad of the transposed conv goes through the same wrapper."""
+    from dvg_amd import ops
+    from dvg_amd.ops import conv as conv_mod
+    N, H, W, Cin, Cout = 200, 32, 32, 64, 128          # (every run stays above the split-K threshold: same kernels as one launch)
+    x = nhwc(params.normal(44, N, Cin, H, W))
+    wp = ops.pack_igemm_weight((params.normal(45, Cout, Cin, 4, 4, scale=1.0 / np.sqrt(16 * Cin))).to(dev()))
+    sc, sh = (1 + 0.1 * params.normal(46, Cout)).to(dev()), (0.1 * params.normal(47, Cout)).to(dev())
+    y0, st0 = ops.conv4x4s2(x, wp, sc, sh, stats=True)
+    assert st0.tile_images == 1
+    monkeypatch.setattr(conv_mod, "CONV4S2_MAX_FLOATS", 97 * Cin * H * W)       # at most 96 images per launch: runs of 72 + 72 + 56
+    y1, st1 = ops.conv4x4s2(x, wp, sc, sh, stats=True)
+    y2 = ops.conv4x4s2(x, wp, sc, sh)
+    # every output element is the same K-ordered sum whatever tile or launch it is part of: bit-equal outputs; the statistics
+    # rows are per tile (the runs pick 8 x 8 tiles where the whole batch picks 8 x 16): equal sums
+    assert torch.equal(y1, y0) and torch.equal(y2, y0) and ops.is_nhwc(y1)
+    assert st1.tile_images == 1 and st1.shape[1:] == st0.shape[1:]
+    np.testing.assert_allclose(st1.double().sum(0).cpu().numpy(), st0.double().sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    monkeypatch.setattr(conv_mod, "CONV4S2_MAX_FLOATS", Cin * H * W)            # not even one image fits: a clear error
+    with pytest.raises(RuntimeError, match="32-bit offsets"):
+        ops.conv4x4s2(x, wp, sc, sh)
+
+
 @pytest.mark.parametrize("N,H,W,C1,C2,Cout", [(2, 4, 4, 512, 512, 256), (3, 8, 8, 256, 256, 128),
                                               (2, 16, 16, 128, 128, 64), (2, 32, 32, 64, 0, 64),
                                               (16, 4, 4, 512, 512, 256)])

@@ -337,22 +337,22 @@ def _sync_bn_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from dvg_amd import fused, ops, parallel
     parallel.init_distributed("gloo")
-    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None
+    assert fused.sync_bn_world() == 1 and ops.sync_bn_state() is None
     fused.set_sync_bn(dist, dist.new_group())
-    assert fused.sync_bn_world() == 2 and ops.SYNC_BN is not None
+    assert fused.sync_bn_world() == 2 and ops.sync_bn_state() is not None
     g = torch.Generator().manual_seed(100 + rank)
     partial = torch.randn(3 * 5, 2, 8, generator=g)        # 3 groups x 5 per-tile rows of (sum, sum of squares) x 8 channels
     out = ops.sync_partial_rows(partial, 3)
     q.put({"rank": rank, "partial": partial.numpy().copy(), "out": out.numpy().copy(), "grouped": int(out.grouped)})
     fused.set_sync_bn(None)
-    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None
+    assert fused.sync_bn_world() == 1 and ops.sync_bn_state() is None
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_sync_bn_partial_rows_allreduce_gloo_world2():
-    """--sync_bn's collective (ops.sync_partial_rows): each rank's per-tile partial rows [G r][2][C] become ONE row per group
-    holding the sums over all rows of all ranks (fp64 accumulation, one rounding), identical on every rank; the switch turns on
+    """--sync_bn's collective (ops.sync_partial_rows): each rank's per-tile partial rows [G r][2][C] become TWO fp32 rows per
+    group (hi + lo) that add up to the fp64 sums over all rows of all ranks, identical on every rank; the switch turns on
     only for a group of more than one rank and off again."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -366,10 +366,14 @@ def test_sync_bn_partial_rows_allreduce_gloo_world2():
         assert p.exitcode == 0
     a, b = res
     want = (a["partial"].astype(np.float64).reshape(3, 5, 2, 8).sum(1) +
-            b["partial"].astype(np.float64).reshape(3, 5, 2, 8).sum(1)).astype(np.float32)
-    assert a["out"].shape == (3, 2, 8) and a["grouped"] == 3
-    assert np.array_equal(a["out"], b["out"]) and np.array_equal(a["out"], want)
+            b["partial"].astype(np.float64).reshape(3, 5, 2, 8).sum(1))
+    # two fp32 rows per group (hi, lo) whose fp64 sum is the fp64 total over both ranks
+    assert a["out"].shape == (6, 2, 8) and a["grouped"] == 3
+    assert np.array_equal(a["out"], b["out"])
+    got = a["out"].astype(np.float64).reshape(3, 2, 2, 8).sum(1)
+    assert np.array_equal(a["out"].reshape(3, 2, 2, 8)[:, 0], want.astype(np.float32))
+    np.testing.assert_allclose(got, want, rtol=1e-14, atol=0)
     # one rank: the switch stays off (nothing to synchronise)
     from dvg_amd import fused, ops
     fused.set_sync_bn(None)
-    assert fused.sync_bn_world() == 1 and ops.SYNC_BN is None
+    assert fused.sync_bn_world() == 1 and ops.sync_bn_state() is None
