@@ -28,6 +28,11 @@ def main():
     ap.add_argument("--n_past", type=int, default=2)
     ap.add_argument("--n_future", type=int, default=3)
     ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--linear_lrelu", action="store_true",
+                    help="DIAGNOSTIC: every train-mode LeakyReLU with slope 1 (forward and backward).  Two runs whose forward values "
+                         "agree to rounding still take the odd LeakyReLU branch differently (a pre-activation within ~1e-7 of "
+                         "zero), and the backward pass amplifies that seed layer by layer; without the kinks the comparison shows "
+                         "what sync-BN itself leaves")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -37,6 +42,11 @@ def main():
     from dvg_amd.data import SyntheticMovingMNIST
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    if a.linear_lrelu:
+        from dvg_amd import ops
+        apply0, bwd0 = ops.bn_act_apply, ops.bn_act_bwd
+        ops.bn_act_apply = lambda *ar, **kw: apply0(*ar, **dict(kw, slope=1.0))
+        ops.bn_act_bwd = lambda *ar, **kw: bwd0(*ar, **dict(kw, slope=1.0))
     rank, world, local = parallel.init_distributed()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
