@@ -51,7 +51,16 @@ def sync_partial_rows(partial: torch.Tensor, groups: int = 1) -> torch.Tensor:
     if rows % groups:
         raise RuntimeError(f"sync_partial_rows: {rows} partial rows do not split into {groups} groups")
     tot = partial.view(groups, rows // groups, two, c).sum(1, dtype=torch.float64)
-    dist.all_reduce(tot, group=group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(tot, group=group)        # RCCL: on its own stream, ordered after / before the current one
+    else:
+        # gloo (CPU tests, the one-GPU rehearsal): an explicit, synchronous host round trip.  Its CUDA-tensor path stages the
+        # tensor through its own side streams; called from the autograd engine's thread in the middle of a backward pass, 1 run
+        # in 5 of vgg_64 came back with a wrong sum (gradients off by 30 %, run to run different; dcgan_64 and the forward pass
+        # never) - with the round trip spelled out, none.
+        host = tot.cpu()
+        dist.all_reduce(host, group=group)
+        tot = host.to(partial.device)
     hi = tot.to(torch.float32)
     lo = (tot - hi.to(torch.float64)).to(torch.float32)
     out = torch.stack([hi, lo], 1).reshape(groups * 2, two, c)

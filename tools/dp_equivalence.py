@@ -33,6 +33,8 @@ def main():
                          "agree to rounding still take the odd LeakyReLU branch differently (a pre-activation within ~1e-7 of "
                          "zero), and the backward pass amplifies that seed layer by layer; without the kinks the comparison shows "
                          "what sync-BN itself leaves")
+    ap.add_argument("--diag", default="", help="DIAGNOSTIC: comma list of sync_ar (device synchronise before every gradient "
+                    "all-reduce action), wgrad1 (no deferred weight-gradient queues), nolatent (latent path on the main stream)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -58,6 +60,19 @@ def main():
     torch.manual_seed(5)
     tr = train.Trainer(opt, dev)
     tr.train_mode()
+    diag = set(filter(None, a.diag.split(",")))
+    if "sync_ar" in diag:
+        run0 = tr._run_ar
+
+        def run_ar(actions):
+            torch.cuda.synchronize()
+            run0(actions)
+        tr._run_ar = run_ar
+    if "wgrad1" in diag:
+        from dvg_amd import autograd as ag
+        ag.WGRAD_BATCH, ag.DENSE_BATCH = 1, 1
+    if "nolatent" in diag:
+        tr.latent_stream = False
     T = a.n_past + a.n_future
     gen = SyntheticMovingMNIST(seq_len=T, seed=77)        # the SAME generator state on every rank: the global batches
     lo, hi = rank * opt.local_batch, (rank + 1) * opt.local_batch
