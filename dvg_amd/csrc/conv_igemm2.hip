@@ -66,6 +66,20 @@
 #ifndef DVG_GEMM128_LEAN
 #define DVG_GEMM128_LEAN 1
 #endif
+//  DVG_GEMM128_MIN_WGS: the batched GEMM takes the 128-row tile from this many (128-row) workgroups on - four residency rounds
+//  (tile2 below; r06 A/B under the steady-state power cap: profiles/r06_ab_gemm128_threshold.txt)
+//  DVG_GEMM_NT2: the batched GEMM takes the 128 x 128 tile (64 x 64 per wave, NT = 2, two workgroups per CU) from this many
+//  workgroups of it on (0: never).  r06: under three rollouts in flight the board sits at its power cap (1 365 W, 1.98 GHz:
+//  profiles/r06_power_trace_vgg.txt), so what a launch costs is its ENERGY, and the 128 x 128 tile moves a quarter of the LDS
+//  bytes and half of the L2 -> LDS bytes per MFMA of the 64 x 64 one: vgg_64 rollouts in flight 49.2 -> 51.5 k frames/s (+4.6 %),
+//  while ONE chain of launches - not power-bound, the finer tiles balance the CUs better - goes 15.7 -> 16.1 ms
+//  (profiles/r06_ab_gemm_nt2.txt: thresholds 128 / 256 / 512 and 2 / 3 / 4 rollouts in flight).
+#ifndef DVG_GEMM_NT2
+#define DVG_GEMM_NT2 256
+#endif
+#ifndef DVG_GEMM128_MIN_WGS
+#define DVG_GEMM128_MIN_WGS (4 * 768)
+#endif
 
 namespace dvg {
 
@@ -1177,7 +1191,7 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
             // (r04 same-box: 365 us per pass against 381), the 128-row tile (K = 32, LEAN, 3 per CU: twice the weight-fragment
             // reuse) from about four residency rounds on (the conditioning batch: 2077 us per pass against 2267)
             // (f32 MFMA build: the 64-row tile at 4 per CU throughout, as measured in r03)
-            if (!DVG_BF16X3 || wgs < 4 * 768) *tw = 8;
+            if (!DVG_BF16X3 || wgs < DVG_GEMM128_MIN_WGS) *tw = 8;
         }
     }
     return 0;
@@ -1395,6 +1409,12 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
     int Hg = H, Wg = W, ti, th, tw;
     DVG_REQUIRE(tile2(M2_GEMM, NB, Hg, Wg, Cout, &ti, &th, &tw) == 0 && ti == 1, DVG_ERR_SHAPE,
                 "dvg_gemm_batched_k16: no tile for %dx%d", H, W);
+#if DVG_BF16X3 && DVG_GEMM_NT2
+    // 128 x 128 workgroup tile (64 x 64 per wave: half the fragment reads and half the L2 -> LDS bytes per MFMA of the 128 x 64
+    // tile) from DVG_GEMM_NT2 workgroups on: the energy-lean tile (see the knob above)
+    if (Cout % 128 == 0 && Wg % 16 == 0 && (long)NB * (Hg / 8) * (Wg / 16) * (Cout / 128) >= DVG_GEMM_NT2)
+        return launch2<M2_GEMM, 1, 8, 16, 2>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
+#endif
     D2(M2_GEMM, 1, 8, 16)
     D2(M2_GEMM, 1, 8, 8)
     return fail(DVG_ERR_SHAPE, "dvg_gemm_batched_k16: no kernel");
