@@ -77,6 +77,12 @@
 #ifndef DVG_GEMM_NT2
 #define DVG_GEMM_NT2 256
 #endif
+//  DVG_TILE16_MIN_WGS: the 8 x 16 pixel tile (two accumulator tiles per wave: a third fewer fragment reads per MFMA) from this
+//  many workgroups of it on, else 8 x 8.  512 until r05 (two workgroups per CU); 256 = one per CU, r06, for the same reason as
+//  DVG_GEMM_NT2: in flight dcgan_64 217.2 -> 219.3 k, vgg_64 50.1 -> 50.3 k frames/s, one chain unchanged (profiles/r06_ab_tile16.txt)
+#ifndef DVG_TILE16_MIN_WGS
+#define DVG_TILE16_MIN_WGS 256
+#endif
 #ifndef DVG_GEMM128_MIN_WGS
 #define DVG_GEMM128_MIN_WGS (4 * 768)
 #endif
@@ -1185,7 +1191,7 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
     *ti = 1; *th = 8; *tw = 8;
     if (Wg % 16 == 0) {
         const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
-        if (wgs >= 512) *tw = 16;
+        if (wgs >= DVG_TILE16_MIN_WGS) *tw = 16;
         if (mode == M2_GEMM && *tw == 16) {
             // batched GEMM.  The 64-row tile (K = 64 per stage, 3 workgroups per CU) is faster on every launch of a B = 64 step
             // (r04 same-box: 365 us per pass against 381), the 128-row tile (K = 32, LEAN, 3 per CU: twice the weight-fragment
