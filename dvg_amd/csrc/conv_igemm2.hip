@@ -1264,13 +1264,22 @@ static long v2_wgs(int mode, int N, int Hg, int Wg, int Cout, int ti, int th, in
     return (long)((N + ti - 1) / ti) * (Hg / th) * (Wg / tw) * (Cout / 64) * (mode == M2_CONVT4S2 ? 4 : 1);
 }
 
+// K splits of a launch with this tile: the 16-wide tiles never split (Cfg2::CAN_SPLIT: their kernels do not carry the split-K
+// epilogue).  Until r05 that was implied by their threshold (512 workgroups > choose_splitk's 384); with DVG_TILE16_MIN_WGS = 256
+// it has to be said: a host side that expected a split where the kernel made none read per-tile statistics rows as finish-block
+// rows (train-mode BatchNorm statistics off by 16 % at B = 16: caught by tests/test_gpu_backward.py).
+static int v2_splits(int mode, int N, int Hg, int Wg, int Cout, int Cin, int ti, int th, int tw) {
+    if (tw == 16) return 1;
+    return choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16);
+}
+
 // K splits the v2 launch of this shape will use when a workspace is supplied (1 = no split)
 extern "C" int dvg_conv_splitk_v2(int mode, int N, int H, int W, int Cin, int Cout) {
     int Hg = H, Wg = W;
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
     if (Cin % 16 || Cout % 64 || tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
-    return choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16);
+    return v2_splits(mode, N, Hg, Wg, Cout, Cin, ti, th, tw);
 }
 
 extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, int Cout, int pool, int with_workspace) {
@@ -1278,7 +1287,7 @@ extern "C" int dvg_conv_stats_rows_v2(int mode, int N, int H, int W, int Cin, in
     if (mode == M2_CONV4S2) { Hg = H / 2; Wg = W / 2; }
     int ti, th, tw;
     if (tile2(mode, N, Hg, Wg, Cout, &ti, &th, &tw)) return -1;
-    if (with_workspace && choose_splitk(v2_wgs(mode, N, Hg, Wg, Cout, ti, th, tw), Cin / 16) > 1) {
+    if (with_workspace && v2_splits(mode, N, Hg, Wg, Cout, Cin, ti, th, tw) > 1) {
         int Ho = H, Wo = W;
         if (mode == M2_CONV4S2) { Ho = H / 2; Wo = W / 2; }
         if (mode == M2_CONVT4S2) { Ho = 2 * H; Wo = 2 * W; }

@@ -44,8 +44,8 @@ def sync_partial_rows(partial: torch.Tensor, groups: int = 1) -> torch.Tensor:
     fp64 total over all rows of ALL ranks (sync-BN).  The rows of a group are added up in fp64 (what dvg_bn_finalize /
     dvg_bn_bwd_finalize themselves do with them) and all-reduced in fp64; the total then travels as hi = fp32(total) and
     lo = fp32(total - hi), which the finalize kernels - fp64 accumulators over fp32 rows - put back together to ~1e-15.
-    (One fp32 row is not enough: the variance E[x^2] - mean^2 and the backward's sum dp (u - mean) cancel, and the 6e-8
-    rounding of the totals came out as 1e-4 ... 1e-2 in vgg_64's gradients, growing layer by layer.)"""
+    (One fp32 row would round the total before the variance E[x^2] - mean^2 and the backward's sum dp (u - mean) take their
+    differences; the single-process path never does: its finalize kernels accumulate the fp32 partial rows in fp64.)"""
     dist, group, _ = SYNC_BN
     rows, two, c = partial.shape
     if rows % groups:
