@@ -219,10 +219,16 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     # the oracle check can redo the last step's draw
     eager_eps = {i: torch.randn(90, args.batch, device=ctx.dev) for i in range(args.n_past, n_eval) if i % 15 == 0}
 
+    # tile policy of the measured kernels (dvg_set_tile_policy): energy-lean tiles when several rollouts are in flight - also for
+    # the eager forms of the same step (--no-graph, the HIP-event leg, the PMC passes of tools/profile_round.sh), so that every
+    # figure of a line describes the same kernels
+    energy = max(1, args.inflight) > 1
+
     def eager_step():
         for e in eager_eps.values():
             e.normal_()
-        return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval, eps_by_step=eager_eps)
+        with ops.tile_policy(energy):
+            return sample_rollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval, eps_by_step=eager_eps)
 
     # A step = one COMPLETE rollout (conditioning + prediction, B clips).  The rollouts of the make_gifs sample loop are
     # independent: `inflight` of them run at once, each as its own hipGraph on its own stream (rollout.ConcurrentRollouts);
@@ -268,20 +274,35 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
         res["sustained"] = {"value": round(args.batch * args.n_future * n_sus * ctx.world / dts, 1), "steps": n_sus,
                             "seconds": round(dts, 2), "ms_per_step": round(1000 * dts / n_sus, 3),
                             "ratio_to_value": round((args.batch * args.n_future * n_sus * ctx.world / dts) / (frames / dt), 4)}
-    if inflight > 1:   # the same K rollouts as ONE serial chain of launches (one graph, one stream), for comparison
+    if inflight > 1:
+        # the same K rollouts as ONE serial chain of launches (one graph, one stream), for comparison: a graph of its own,
+        # captured under the LATENCY tile policy (what a caller with one chain gets: rollout.GraphedRollout's default; the
+        # chains above carry the energy-lean tiles, which make one chain 3 % slower and three in flight 4.6 % faster)
+        from dvg_amd.rollout import GraphedRollout
+        one = GraphedRollout(enc, dec, fp, gp, lik, x, args.n_past, n_eval)
+        one()
         ctx.barrier()
         t0 = time.perf_counter()
-        run(steps, chains=1)
+        for _ in range(steps):
+            one()
         ctx.barrier()
         dt1 = ctx.max_over_ranks(time.perf_counter() - t0)
-        res["single_chain"] = {"value": round(frames / dt1, 1), "ms_per_step": round(1000 * dt1 / steps, 3)}
+        res["single_chain"] = {"value": round(frames / dt1, 1), "ms_per_step": round(1000 * dt1 / steps, 3),
+                               "tile_policy": "latency"}
+        ctx.barrier()
+        t0 = time.perf_counter()
+        run(steps, chains=1)     # ... and one of the in-flight chains' graphs (energy-lean tiles) alone
+        ctx.barrier()
+        dt2 = ctx.max_over_ranks(time.perf_counter() - t0)
+        res["single_chain"]["energy_tiles_ms_per_step"] = round(1000 * dt2 / steps, 3)
+        del one
     if ctx.rank != 0 or args.no_roofline:
         return res
     # roofline leg: the same rollout with every launch bracketed by HIP events on the launch stream
     timer = ops.KernelTimer()
     ops.set_timer(timer)
     for _ in range(3):
-        eager_step()   # events need eager launches; same kernels, same shapes as the graphed step
+        eager_step()   # events need eager launches; same kernels (tile policy included), same shapes as the graphed step
     ops.set_timer(None)
     agg = timer.summary()
     total_ms = sum(a["ms"] for a in agg.values())
@@ -485,6 +506,9 @@ def main():
                    # independent rollouts (samples of the make_gifs loop) in flight at once, one hipGraph + stream each; every
                    # step is a complete rollout, ms_per_step = wall time / steps; `single_chain` = the same steps back to back
                    "rollouts_in_flight": main_res["rollouts_in_flight"],
+                   # dvg_set_tile_policy: several chains in flight keep the board at its power cap, their graphs carry the
+                   # energy-lean tiles (bit-identical results); `single_chain` is a graph with the latency tiles
+                   "tile_policy": "energy" if max(1, args.inflight) > 1 else "latency",
                    "step": "one COMPLETE rollout (conditioning + prediction) of one batch; K steps = K rollouts, independent of "
                            "each other (samples of make_gifs' nsample loop), issued round-robin over the chains",
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's

@@ -28,6 +28,8 @@ SIGNATURES = {
     "dvg_stream_capture_id": (_l, [_p]),
     "dvg_mfma_mode": (_i, []),
     "dvg_build_info": (C.c_char_p, []),
+    "dvg_set_tile_policy": (None, [_i]),
+    "dvg_tile_policy": (_i, []),
     "dvg_packed_row_floats": (_i, []),
     "dvg_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvg_pack_convT_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -68,8 +68,8 @@
 #endif
 //  DVG_GEMM128_MIN_WGS: the batched GEMM takes the 128-row tile from this many (128-row) workgroups on - four residency rounds
 //  (tile2 below; r06 A/B under the steady-state power cap: profiles/r06_ab_gemm128_threshold.txt)
-//  DVG_GEMM_NT2: the batched GEMM takes the 128 x 128 tile (64 x 64 per wave, NT = 2, two workgroups per CU) from this many
-//  workgroups of it on (0: never).  r06: under three rollouts in flight the board sits at its power cap (1 365 W, 1.98 GHz:
+//  DVG_GEMM_NT2: under the ENERGY tile policy (dvg_set_tile_policy) the batched GEMM takes the 128 x 128 tile (64 x 64 per wave,
+//  NT = 2, two workgroups per CU) from this many workgroups of it on (0: never).  r06: under three rollouts in flight the board sits at its power cap (1 365 W, 1.98 GHz:
 //  profiles/r06_power_trace_vgg.txt), so what a launch costs is its ENERGY, and the 128 x 128 tile moves a quarter of the LDS
 //  bytes and half of the L2 -> LDS bytes per MFMA of the 64 x 64 one: vgg_64 rollouts in flight 49.2 -> 51.5 k frames/s (+4.6 %),
 //  while ONE chain of launches - not power-bound, the finer tiles balance the CUs better - goes 15.7 -> 16.1 ms
@@ -77,8 +77,8 @@
 #ifndef DVG_GEMM_NT2
 #define DVG_GEMM_NT2 256
 #endif
-//  DVG_TILE16_MIN_WGS: the 8 x 16 pixel tile (two accumulator tiles per wave: a third fewer fragment reads per MFMA) from this
-//  many workgroups of it on, else 8 x 8.  512 until r05 (two workgroups per CU); 256 = one per CU, r06, for the same reason as
+//  DVG_TILE16_MIN_WGS: under the ENERGY tile policy the 8 x 16 pixel tile (two accumulator tiles per wave: a third fewer fragment
+//  reads per MFMA) from this many workgroups of it on, else 8 x 8 (LATENCY policy: 512, two workgroups per CU).  256 = one per CU, for the same reason as
 //  DVG_GEMM_NT2: in flight dcgan_64 217.2 -> 219.3 k, vgg_64 50.1 -> 50.3 k frames/s, one chain unchanged (profiles/r06_ab_tile16.txt)
 #ifndef DVG_TILE16_MIN_WGS
 #define DVG_TILE16_MIN_WGS 256
@@ -1078,6 +1078,16 @@ static int finish_units_per_block(long units) {
     return (int)upb;
 }
 
+// Tile policy (r06).  0 = LATENCY: the tiles that make ONE launch alone on the chip fastest (finer tiles balance the CUs: the
+// r05 chooser) - one chain of launches, GPtrigger_gen, training.  1 = ENERGY: several independent chains in flight keep the
+// board at its power cap (1 365 W, 1.98 GHz), where a launch costs its energy, not its duration - the batched GEMM takes the
+// 128 x 128 tile from DVG_GEMM_NT2 workgroups on, the halo modes the 8 x 16 tile from DVG_TILE16_MIN_WGS on (DESIGN.md 3.1e:
+// +4.6 % vgg_64 / +1 % dcgan_64 rollouts in flight, one chain 3 % slower).  Process-global host state, read when a launch (or
+// one of the dvg_conv_splitk_v2 / dvg_conv_stats_rows_v2 helpers) picks its tile; a captured hipGraph keeps what it captured.
+static int g_tile_policy = 0;
+extern "C" void dvg_set_tile_policy(int energy) { g_tile_policy = energy ? 1 : 0; }
+extern "C" int dvg_tile_policy(void) { return g_tile_policy; }
+
 // number of K splits for a v2 launch: only when the grid would leave CUs idle and K is deep enough
 // (r05, stride-2 conv after the parity split: splitting further - 768 / 1 024 workgroup slots - or not at all measured -0.5 ... -3 % on
 // the dcgan_64 rollout, in flight and on one chain: profiles/r05_ab_conv4s2.txt)
@@ -1191,7 +1201,7 @@ static int tile2(int mode, int N, int Hg, int Wg, int Cout, int* ti, int* th, in
     *ti = 1; *th = 8; *tw = 8;
     if (Wg % 16 == 0) {
         const long wgs = (long)N * (Hg / 8) * (Wg / 16) * (Cout / 64) * par;
-        if (wgs >= DVG_TILE16_MIN_WGS) *tw = 16;
+        if (wgs >= (g_tile_policy ? DVG_TILE16_MIN_WGS : 512)) *tw = 16;
         if (mode == M2_GEMM && *tw == 16) {
             // batched GEMM.  The 64-row tile (K = 64 per stage, 3 workgroups per CU) is faster on every launch of a B = 64 step
             // (r04 same-box: 365 us per pass against 381), the 128-row tile (K = 32, LEAN, 3 per CU: twice the weight-fragment
@@ -1427,7 +1437,7 @@ extern "C" int dvg_gemm_batched_k16(const float* x, const float* w_k16, float* y
 #if DVG_BF16X3 && DVG_GEMM_NT2
     // 128 x 128 workgroup tile (64 x 64 per wave: half the fragment reads and half the L2 -> LDS bytes per MFMA of the 128 x 64
     // tile) from DVG_GEMM_NT2 workgroups on: the energy-lean tile (see the knob above)
-    if (Cout % 128 == 0 && Wg % 16 == 0 && (long)NB * (Hg / 8) * (Wg / 16) * (Cout / 128) >= DVG_GEMM_NT2)
+    if (g_tile_policy && Cout % 128 == 0 && Wg % 16 == 0 && (long)NB * (Hg / 8) * (Wg / 16) * (Cout / 128) >= DVG_GEMM_NT2)
         return launch2<M2_GEMM, 1, 8, 16, 2>(p, Hg, Wg, workspace, workspace_floats, (hipStream_t)stream);
 #endif
     D2(M2_GEMM, 1, 8, 16)

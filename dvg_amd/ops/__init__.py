@@ -9,7 +9,7 @@ are re-exported objects, mutated in place).  Module STATE that is re-bound lives
 `set_sync_bn_state` / `sync_bn_state`."""
 from ._core import (  # noqa: F401
     ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, MODE_CONV3, MODE_CONV4S2, MODE_CONVT4S2, _stream, KernelTimer,
-    set_timer, _run, _p, _dev_f32, nhwc_empty, is_nhwc, to_nhwc, to_nchw,
+    set_timer, _run, _p, _dev_f32, nhwc_empty, is_nhwc, to_nhwc, to_nchw, tile_policy,
 )
 from .conv import (  # noqa: F401
     pack_conv_weight, pack_convT_weight, packed_row_floats, pack_igemm_weight, _wp_dims, unpack_conv_weight,

@@ -106,3 +106,21 @@ def to_nchw(t: torch.Tensor) -> torch.Tensor:
     out = torch.empty((n, c, h, w), device=t.device, dtype=torch.float32)
     check(lib().dvg_nhwc_to_nchw(_p(t), _p(out), n, c, h, w, _stream()), "nhwc_to_nchw")
     return out
+
+
+class tile_policy:
+    """`with ops.tile_policy(energy=True):` - the launches (and hipGraph captures) inside pick the energy-lean tiles
+    (dvg_set_tile_policy: the 128 x 128 batched-GEMM tile, 8 x 16 pixel tiles from one workgroup per CU on) that pay when several
+    independent chains keep the board at its power cap; the default (latency) tiles are what makes one chain fastest.  Results are
+    bit-identical.  rollout.ConcurrentRollouts / GraphedSampler capture their chains under it when more than one is in flight."""
+
+    def __init__(self, energy: bool = True):
+        self.energy = bool(energy)
+
+    def __enter__(self):
+        self.prev = lib().dvg_tile_policy()
+        lib().dvg_set_tile_policy(int(self.energy))
+        return self
+
+    def __exit__(self, *exc):
+        lib().dvg_set_tile_policy(self.prev)

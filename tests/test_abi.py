@@ -91,11 +91,26 @@ def test_host_side_checks_reject_bad_shapes_without_gpu():
     assert lib.dvg_conv_splitk_v2(0, 64, 64, 64, 64, 64) == 1          # 2048 workgroups: no split
     assert lib.dvg_conv_splitk_v2(0, 64, 8, 8, 512, 256) == 2          # 256 workgroups, K = 32 chunks
     assert lib.dvg_conv_splitk_v2(0, 16, 8, 8, 512, 512) == 4          # per-GPU batch 16
-    # r06: the 8 x 16 tile from 256 workgroups on, and its kernels never split K - the host helpers must say so too (256 <= 320
-    # < 384 workgroups would split on an 8-wide tile): no split, one statistics row per tile with and without a workspace
-    assert lib.dvg_conv_splitk_v2(0, 10, 64, 64, 64, 64) == 1
-    assert lib.dvg_conv_stats_rows_v2(0, 10, 64, 64, 64, 64, 0, 1) == lib.dvg_conv_stats_rows_v2(0, 10, 64, 64, 64, 64, 0, 0) == 320
-    assert lib.dvg_conv_splitk_v2(0, 7, 64, 64, 64, 64) == 1 and lib.dvg_conv_stats_rows_v2(0, 7, 64, 64, 64, 64, 0, 1) == 448   # 224 < 256: 8 x 8 tiles, 448 workgroups
+    # r06 tile policy: LATENCY (default) = the r05 chooser, ENERGY = the 8 x 16 tile from 256 workgroups on - whose kernels never
+    # split K, and the host helpers must say so too (320 workgroups would split on an 8-wide tile)
+    assert lib.dvg_tile_policy() == 0
+    assert lib.dvg_conv_splitk_v2(0, 10, 64, 64, 64, 64) == 1 and lib.dvg_conv_stats_rows_v2(0, 10, 64, 64, 64, 64, 0, 1) == 640
+    lib.dvg_set_tile_policy(1)
+    try:
+        assert lib.dvg_tile_policy() == 1
+        assert lib.dvg_conv_splitk_v2(0, 10, 64, 64, 64, 64) == 1
+        assert lib.dvg_conv_stats_rows_v2(0, 10, 64, 64, 64, 64, 0, 1) == lib.dvg_conv_stats_rows_v2(0, 10, 64, 64, 64, 64, 0, 0) == 320
+        assert lib.dvg_conv_stats_rows_v2(0, 7, 64, 64, 64, 64, 0, 1) == 448       # 224 < 256 workgroups: 8 x 8 tiles
+    finally:
+        lib.dvg_set_tile_policy(0)
+    assert lib.dvg_tile_policy() == 0
+    from dvg_amd import ops
+    with ops.tile_policy(True):
+        assert lib.dvg_tile_policy() == 1
+        with ops.tile_policy(False):
+            assert lib.dvg_tile_policy() == 0
+        assert lib.dvg_tile_policy() == 1
+    assert lib.dvg_tile_policy() == 0
     assert lib.dvg_gp_lds_bytes(64, 40, 1) <= 160 * 1024 and lib.dvg_gp_precision(64, 40, 1) == 64
     # r05 entry points: the checks fire before anything is launched
     assert lib.dvg_gemm_tn(one, one, None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, None) == 2                  # no output (DVG_ERR_NULL)

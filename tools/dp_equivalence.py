@@ -73,6 +73,90 @@ def main():
         ag.WGRAD_BATCH, ag.DENSE_BATCH = 1, 1
     if "nolatent" in diag:
         tr.latent_stream = False
+    if tr.sync_bn and ("nofwd" in diag or "nobwd" in diag or "nocomm" in diag):
+        # bisecting sync-BN: without its forward half / its backward half / its communication (the arithmetic is then not the
+        # single-process one: only run-to-run determinism is being tested)
+        from dvg_amd import fused, ops
+        from dvg_amd.ops import norm
+        if "nofwd" in diag:
+            tb0 = fused._train_bn
+            fused._train_bn = lambda bn, stats, count, save=False, synced=False: tb0(bn, stats, count, save=save, synced=True)
+        if "nobwd" in diag:
+            bwd1 = ops.bn_act_bwd
+
+            def unsynced(*ar, **kw):
+                keep, norm.SYNC_BN = norm.SYNC_BN, None
+                try:
+                    return bwd1(*ar, **kw)
+                finally:
+                    norm.SYNC_BN = keep
+            ops.bn_act_bwd = unsynced
+        if "nocomm" in diag:
+            class _NoComm:
+                @staticmethod
+                def all_reduce(t, group=None):
+                    t.mul_(2.0)
+
+                @staticmethod
+                def get_backend(group=None):
+                    return "gloo"
+            norm.SYNC_BN = (_NoComm, norm.SYNC_BN[1], norm.SYNC_BN[2])
+    for d_ in diag:
+        if d_.startswith("winoff") or d_.startswith("wino2_"):      # bisecting: 3x3 layers on h x h maps in direct / F(2x2) form
+            from dvg_amd import fused
+            h_ = int(d_.replace("winoff", "").replace("wino2_", ""))
+            for c_ in (64, 128, 256, 512, 1024):
+                for co_ in (64, 128, 256, 512):
+                    fused.WINOGRAD_LAYER_OVERRIDE[(c_, h_, co_)] = 0 if d_.startswith("winoff") else 2
+    if "dgrad_direct16" in diag or "fwd_direct16" in diag:
+        from dvg_amd import autograd as ag, fused
+        keys16 = {(c_, 16, co_): 0 for c_ in (64, 128, 256, 512, 1024) for co_ in (64, 128, 256, 512)}
+
+        def with_direct16(fn):
+            def inner(*ar, **kw):
+                fused.WINOGRAD_LAYER_OVERRIDE.update(keys16)
+                try:
+                    return fn(*ar, **kw)
+                finally:
+                    for k_ in keys16:
+                        fused.WINOGRAD_LAYER_OVERRIDE.pop(k_, None)
+            return inner
+        if "dgrad_direct16" in diag:
+            ag._dgrad3 = with_direct16(ag._dgrad3)
+        if "fwd_direct16" in diag:
+            ag._conv3_raw = with_direct16(ag._conv3_raw)
+    if "lockstep" in diag and world > 1:
+        # per-replica BatchNorm, but the ranks meet (a host-side all-reduce of one float) at every BatchNorm call, forward and
+        # backward: the lock-step that sync-BN's collectives impose, without its arithmetic
+        from dvg_amd import fused, ops
+        token = torch.zeros(1)
+        tb1, bwd2 = fused._train_bn, ops.bn_act_bwd
+
+        def meet():
+            torch.cuda.current_stream().synchronize()
+            torch.distributed.all_reduce(token)
+
+        def tb_meet(*ar, **kw):
+            meet()
+            return tb1(*ar, **kw)
+
+        def bwd_meet(*ar, **kw):
+            meet()
+            return bwd2(*ar, **kw)
+        fused._train_bn, ops.bn_act_bwd = tb_meet, bwd_meet
+    if "sync_bwd" in diag or "sleep_bwd" in diag:
+        # a host-side stall at every BatchNorm backward (what sync-BN's collective does to the timing), without any collective
+        import time
+        from dvg_amd import ops
+        bwd0 = ops.bn_act_bwd
+
+        def stalled(*ar, **kw):
+            if "sync_bwd" in diag:
+                torch.cuda.synchronize()
+            else:
+                time.sleep(0.002)
+            return bwd0(*ar, **kw)
+        ops.bn_act_bwd = stalled
     T = a.n_past + a.n_future
     gen = SyntheticMovingMNIST(seq_len=T, seed=77)        # the SAME generator state on every rank: the global batches
     lo, hi = rank * opt.local_batch, (rank + 1) * opt.local_batch
