@@ -54,10 +54,8 @@ def sync_partial_rows(partial: torch.Tensor, groups: int = 1) -> torch.Tensor:
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(tot, group=group)        # RCCL: on its own stream, ordered after / before the current one
     else:
-        # gloo (CPU tests, the one-GPU rehearsal): an explicit, synchronous host round trip.  Its CUDA-tensor path stages the
-        # tensor through its own side streams; called from the autograd engine's thread in the middle of a backward pass, 1 run
-        # in 5 of vgg_64 came back with a wrong sum (gradients off by 30 %, run to run different; dcgan_64 and the forward pass
-        # never) - with the round trip spelled out, none.
+        # gloo (CPU tests, the one-GPU rehearsal): an explicit, synchronous host round trip instead of gloo's CUDA-tensor path
+        # (worker threads and side streams of its own) - one suspect less in profiles/r06_dp_race_bisect.txt (it was not the cause)
         host = tot.cpu()
         dist.all_reduce(host, group=group)
         tot = host.to(partial.device)

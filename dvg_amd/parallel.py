@@ -75,10 +75,10 @@ class ArenaReducer:
         if dist.get_backend(self.group) == "nccl":
             return (dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None)
         if buf.is_cuda:
-            # gloo on DEVICE memory (the one-GPU rehearsal: both ranks on GPU 0): an explicit, synchronous host round trip.  gloo's
-            # own CUDA path stages through side streams from a worker thread; overlapped with a backward pass that itself stalls
-            # on collectives (--sync_bn) it produced run-to-run different gradients (1 run in 5-20, vgg_64; notes r06 section 5).
-            # The rehearsal measures nothing, so nothing is lost; RCCL (above) is the path that overlaps.
+            # gloo on DEVICE memory (the one-GPU rehearsal: both ranks on GPU 0): an explicit, synchronous host round trip rather
+            # than gloo's own CUDA path (worker threads, side streams) - a suspect removed while bisecting the rehearsal's
+            # run-to-run differences (profiles/r06_dp_race_bisect.txt; it was not the cause).  The rehearsal measures nothing, so
+            # nothing is lost; RCCL (above) is the path that overlaps.
             host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             buf.copy_(host.div_(world))
