@@ -546,7 +546,7 @@ class GraphedSampler:
     def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
                  last_frame_skip=False, period=15, inflight=3, share_prefix=None):
         # several sample chains in flight keep the board at its power cap: their graphs are captured with the energy-lean tiles
-        # (ops.tile_policy; bit-identical results); one chain at a time keeps the latency tiles
+        # (ops.tile_policy; same results to fp32 rounding); one chain at a time keeps the latency tiles
         with ops.tile_policy(max(1, inflight) >= 2):
             self._init(encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval, last_frame_skip, period,
                        inflight, share_prefix)

@@ -139,9 +139,11 @@ const char* dvg_build_info(void);
 /* r06 - tile policy of the implicit-GEMM launches: 0 (default) = LATENCY, the tiles that make one launch alone on the chip fastest
  * (one chain of launches: a training iteration, GPtrigger_gen, a single sample); 1 = ENERGY, for callers that keep several
  * independent chains in flight (the samples of generate_frames.py:143-177's loop): the board then sits at its power cap and
- * larger register tiles - fewer LDS / L2 bytes per MFMA - give more frames per joule (vgg_64 rollouts in flight +4.6 %).  Results
- * are bit-identical under both (every output element is the same K-ordered sum); per-tile statistics rows differ in number -
- * dvg_conv_splitk_v2 / dvg_conv_stats_rows_v2 answer for the policy in force.  Process-global host state: set it before the
+ * larger register tiles - fewer LDS / L2 bytes per MFMA - give more frames per joule (vgg_64 rollouts in flight +4.6 %).  Within
+ * one policy every form of a computation (eager, captured, in flight) is bit-identical; ACROSS policies results agree to fp32
+ * rounding only (a rollout's frames to < 5e-6 max-norm, tests/test_gpu_headline.py): the tile shape fixes how a layer's K sum is
+ * cut into partial sums.  Per-tile statistics rows differ in number - dvg_conv_splitk_v2 / dvg_conv_stats_rows_v2 answer for
+ * the policy in force.  Process-global host state: set it before the
  * launches (or the hipGraph capture) it shall apply to.  The reference has no counterpart (cuDNN picks its own algorithms).   */
 void dvg_set_tile_policy(int energy);
 int dvg_tile_policy(void);

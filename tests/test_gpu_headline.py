@@ -65,6 +65,7 @@ def _oracle_rollout_with_state(xs, enc_o, dec_o, lsd, gsd, lik, eps15):
 @pytest.mark.slow
 @pytest.mark.parametrize("family", ["vgg", "dcgan"])
 def test_headline_rollout_matches_the_oracle(family):
+    from dvg_amd import ops
     from dvg_amd.rollout import ConcurrentRollouts, GraphedRollout, sample_rollout
     mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 3100)
     xs = [params.frames(3110 + t, B, 1, 64) for t in range(N_EVAL)]
@@ -97,6 +98,8 @@ def test_headline_rollout_matches_the_oracle(family):
           f"(fp32 oracle {m_32:.2e}); element-wise {e_hip:.2e} (fp32 oracle {e_32:.2e})")
     assert e_hip < ELEM_BAR, (e_hip, e_32)
 
+    with ops.tile_policy(True):
+        eager_energy = sample_rollout(*mods, xd, N_PAST, N_EVAL, eps_by_step=ed[0])
     g = GraphedRollout(*mods, xd, N_PAST, N_EVAL)
     replay = [f.clone() for f in g(xd, ed[0])]
     for t in range(N_EVAL):
@@ -115,8 +118,11 @@ def test_headline_rollout_matches_the_oracle(family):
     for k, r in enumerate(cr.rollouts):
         errs = [rel_err(r.frames[t], refs[k][t]) for t in range(N_EVAL)]
         assert max(errs) < FRAME_BAR, (k, [f"{e:.1e}" for e in errs])
+        # chains in flight are captured with the energy-lean tiles (ops.tile_policy): bit-equal to the eager rollout under the same
+        # policy, and equal to the latency-tile rollout up to the order of the fp32 sums inside a tile
         if k == 0:
-            assert all(torch.equal(r.frames[t], eager[t]) for t in range(N_EVAL))
+            assert all(torch.equal(r.frames[t], eager_energy[t]) for t in range(N_EVAL))
+            assert max(rel_err(r.frames[t], eager[t]) for t in range(N_EVAL)) < 5e-6
         else:   # the other draws really changed the GP-decoded frame and what follows
-            assert all(torch.equal(r.frames[t], eager[t]) for t in range(15))
+            assert all(torch.equal(r.frames[t], eager_energy[t]) for t in range(15))
             assert rel_err(r.frames[15], ref0[15]) > 10 * FRAME_BAR

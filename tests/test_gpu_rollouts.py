@@ -367,7 +367,7 @@ def test_make_gifs_shared_prefix_equals_the_per_sample_loop(family):
     (10-in / 10-out: trigger at 15), for two batches through one sampler, and for a rollout that ends before the first
     trigger step (n_eval = 14: every sample is the prefix)."""
     import generate_frames
-    from dvg_amd import rollout
+    from dvg_amd import ops, rollout
     B, S = 8, 4
     old, rollout.SHARE_PREFIX = rollout.SHARE_PREFIX, True     # (also under DVG_SHARE_PREFIX=0: the flag is read per sampler)
     mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1900)
@@ -380,8 +380,11 @@ def test_make_gifs_shared_prefix_equals_the_per_sample_loop(family):
             opt = generate_frames.build_parser().parse_args(["--synthetic_ckpt", "--batch_size", str(B), "--model", family,
                                                              "--n_past", str(n_past), "--n_eval", str(n_eval)] + extra)
             g = generate_frames.Generator(opt, ckpt, torch.device(DEV))
-            out[name] = [g.make_gifs([params.frames(1910 + 40 * b + t, B, 1, 64).to(DEV) for t in range(n_eval)], S,
-                                     eps_by_sample=eps) for b in range(2)]
+            # the samplers with chains in flight capture under the energy tile policy; the eager loop (one chain, latency tiles by
+            # default) is run under the same policy here - across policies the frames agree to fp32 summation order only
+            with ops.tile_policy(True):
+                out[name] = [g.make_gifs([params.frames(1910 + 40 * b + t, B, 1, 64).to(DEV) for t in range(n_eval)], S,
+                                         eps_by_sample=eps) for b in range(2)]
             if name == "shared":
                 assert g._sampler.share and g._sampler.t0 == min(15, n_eval)
         for name in ("per_sample", "eager"):
