@@ -249,6 +249,7 @@ def hbm_bound_layers(ctx: Ctx, args) -> dict:
     trigger (gp_models.py:10-24)."""
     import torch
     from dvg_amd import fused, ops
+    from dvg_amd.rollout import pooled_stream
     B = args.batch
     enc, dec, fp, gp, lik = build_models("vgg", B, 1, ctx.dev, args.seed)
     x = torch.rand(B, 1, 64, 64, device=ctx.dev)
@@ -256,7 +257,7 @@ def hbm_bound_layers(ctx: Ctx, args) -> dict:
     def timed(fn, reps=20, replays=10):
         """us per call: `reps` back-to-back calls captured as ONE hipGraph (no host launch latency between them - the rollout
         itself runs as graph replays), `replays` replays between two HIP events on the launch stream."""
-        side = torch.cuda.Stream()
+        side = pooled_stream("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):

@@ -164,14 +164,24 @@ def _encode_conditioning(encoder, x, n_past, last_frame_skip):
     return hs, skip
 
 
-_side_stream = None
+# Streams are made ONCE per process and shared by every graph holder of this module.  torch hands out streams from a pool of 32
+# per device, round-robin and without telling: a process that builds many samplers (bench.py: two families x (three chains +
+# make_gifs) + C1) wraps around the pool, after which two "concurrent" chains may sit on ONE hip stream (silently serial), or a
+# chain's stream may be the one torch captures graphs on - the r06 bench died with a segmentation fault inside
+# hipGraphLaunch (hip::Graph::UpdateStreams) at exactly that point.  Work on one stream runs in order, so sharing the streams
+# between holders is safe; it only orders work that a caller issues from different holders at the same time.
+_streams = {}
+
+
+def pooled_stream(role: str, index: int = 0) -> "torch.cuda.Stream":
+    key = (torch.cuda.current_device(), role, index)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream()
+    return _streams[key]
 
 
 def _hoist_stream():
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
-    return _side_stream
+    return pooled_stream("hoist")
 
 
 def _step_discard(frame_predictor, h):
@@ -383,7 +393,7 @@ class GraphedTrigger:
         self.eps = torch.zeros(max(1, total - warmup), d, b, device=dev)
         self.ctx = torch.zeros(warmup, device=dev)
         self.log = trigger_log(total, dev)
-        side = torch.cuda.Stream()
+        side = pooled_stream("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
             st = self._warm()
@@ -454,7 +464,7 @@ class GraphedRollout:
         self.eps = {i: torch.randn(gp_layer.num_dims, x[0].shape[0], device=x[0].device)
                     for i in (trigger_steps(n_past, n_eval, period) if period else [])}
         self._kw["eps_by_step"] = self.eps
-        side = torch.cuda.Stream()
+        side = pooled_stream("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):   # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
@@ -507,7 +517,7 @@ class ConcurrentRollouts:
         with ops.tile_policy(self.energy_tiles):
             self.rollouts = [GraphedRollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
                                             last_frame_skip, period) for _ in range(inflight)]
-        self.streams = [torch.cuda.Stream() for _ in range(inflight)]
+        self.streams = [pooled_stream("chain", k) for k in range(inflight)]
         self._next = 0
 
     def run(self, n: int, x: Optional[Sequence[torch.Tensor]] = None, chains: Optional[int] = None) -> List[List[torch.Tensor]]:
@@ -569,11 +579,11 @@ class GraphedSampler:
             self.t0 = n_past
         self.b = None
         self.chains = []
-        for _ in range(max(1, inflight)):
+        for k in range(max(1, inflight)):
             self.chains.append({"eps": {i: torch.zeros(D, B, device=dev) for i in self.steps},
-                                "stream": torch.cuda.Stream()})
-        self.post_stream = torch.cuda.Stream()
-        side = torch.cuda.Stream()
+                                "stream": pooled_stream("chain", k)})
+        self.post_stream = pooled_stream("post")
+        side = pooled_stream("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # first-launch work (weight packs, LDS attributes, BN folds) must not be captured
             self.b = {"state": self._condition()}
