@@ -59,6 +59,9 @@ def parse_args(argv=None):
                     help="emit a line although DVG_HIP_LIB points at another build of the library or the loaded build is a "
                          "timing experiment (X3_TERMS != 6, ABLATE != 0, ...): the line then says so in `build`")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--tile-policy", default="auto", choices=["auto", "latency", "energy"],
+                    help="dvg_set_tile_policy of the measured kernels; auto = energy with more than one rollout in flight "
+                         "(tools/profile_round.sh: --inflight 1 --tile-policy energy = isolated durations of the headline's kernels)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="complete rollouts in flight at once (independent samples of the make_gifs loop, one hipGraph and one "
                          "stream each); 1 = one serial chain of launches")
@@ -222,7 +225,7 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     # tile policy of the measured kernels (dvg_set_tile_policy): energy-lean tiles when several rollouts are in flight - also for
     # the eager forms of the same step (--no-graph, the HIP-event leg, the PMC passes of tools/profile_round.sh), so that every
     # figure of a line describes the same kernels
-    energy = max(1, args.inflight) > 1
+    energy = max(1, args.inflight) > 1 if args.tile_policy == "auto" else args.tile_policy == "energy"
 
     def eager_step():
         for e in eager_eps.values():
@@ -234,7 +237,8 @@ def measure_rollout(ctx: Ctx, args, model: str, steps: int, warmup: int) -> dict
     # independent: `inflight` of them run at once, each as its own hipGraph on its own stream (rollout.ConcurrentRollouts);
     # K steps = K rollouts issued round-robin, per-rollout work and results unchanged.
     inflight = 1 if args.no_graph else max(1, args.inflight)
-    cr = None if args.no_graph else ConcurrentRollouts(enc, dec, fp, gp, lik, x, args.n_past, n_eval, inflight=inflight)
+    cr = None if args.no_graph else ConcurrentRollouts(enc, dec, fp, gp, lik, x, args.n_past, n_eval, inflight=inflight,
+                                                       energy_tiles=energy)
 
     def run(n, chains=None):
         if cr is None:
@@ -507,8 +511,9 @@ def main():
                    # step is a complete rollout, ms_per_step = wall time / steps; `single_chain` = the same steps back to back
                    "rollouts_in_flight": main_res["rollouts_in_flight"],
                    # dvg_set_tile_policy: several chains in flight keep the board at its power cap, their graphs carry the
-                   # energy-lean tiles (bit-identical results); `single_chain` is a graph with the latency tiles
-                   "tile_policy": "energy" if max(1, args.inflight) > 1 else "latency",
+                   # energy-lean tiles (same results to fp32 rounding); `single_chain` is a graph with the latency tiles
+                   "tile_policy": (("energy" if max(1, args.inflight) > 1 else "latency") if args.tile_policy == "auto"
+                                   else args.tile_policy),
                    "step": "one COMPLETE rollout (conditioning + prediction) of one batch; K steps = K rollouts, independent of "
                            "each other (samples of make_gifs' nsample loop), issued round-robin over the chains",
                    # the skip tensors are frozen after the conditioning frames: the skip half of each decoder block's

@@ -507,13 +507,14 @@ class ConcurrentRollouts:
     recent ones; the caller synchronises (or records events) before reading them."""
 
     def __init__(self, encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval, inflight=2,
-                 last_frame_skip=False, period=15):
+                 last_frame_skip=False, period=15, energy_tiles=None):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         # Several chains in flight keep the board at its power cap (DESIGN.md 3.1e): their graphs are captured under the ENERGY
         # tile policy (128 x 128 batched-GEMM tile, 8 x 16 pixel tiles from one workgroup per CU on: fewer LDS / L2 bytes per
-        # MFMA, +4.6 % vgg_64); one chain keeps the latency tiles.  Every output element is the same K-ordered sum either way.
-        self.energy_tiles = inflight >= 2
+        # MFMA, +4.6 % vgg_64); one chain keeps the latency tiles (`energy_tiles` overrides: profiling one chain of the in-flight
+        # kernels).  The two policies' results agree to fp32 rounding, not bit for bit.
+        self.energy_tiles = inflight >= 2 if energy_tiles is None else bool(energy_tiles)
         with ops.tile_policy(self.energy_tiles):
             self.rollouts = [GraphedRollout(encoder, decoder, frame_predictor, gp_layer, likelihood, x, n_past, n_eval,
                                             last_frame_skip, period) for _ in range(inflight)]

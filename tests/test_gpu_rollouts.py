@@ -394,6 +394,35 @@ def test_make_gifs_shared_prefix_equals_the_per_sample_loop(family):
     rollout.SHARE_PREFIX = old
 
 
+def test_many_graph_holders_in_one_process_share_their_streams():
+    """bench.py builds ~10 graph holders in one process (two families x (three chains + make_gifs) + C1).  torch hands streams out of
+    a pool of 32 per device, round-robin: with one fresh torch.cuda.Stream() per chain and warm-up (r06 until the last day) the
+    pool wrapped around, a chain landed on a stream torch also used elsewhere and hipGraphLaunch died with a segmentation
+    fault (hip::Graph::UpdateStreams).  rollout.pooled_stream makes each stream once per process: 14 holders x (3 chains + 3 warm-ups)
+    would have taken 84 streams; they must all replay, and give the eager rollout's frames."""
+    from dvg_amd import ops, rollout
+    from dvg_amd.rollout import ConcurrentRollouts, sample_rollout
+    B, n_past, n_eval = 2, 2, 5
+    mods, _ = _build("dcgan", 64, 1, B, 4100)
+    for m in mods:
+        m.to(DEV).eval()
+    xs = [params.frames(4110 + t, B, 1, 64).to(DEV) for t in range(n_eval)]
+    with ops.tile_policy(True):
+        ref = sample_rollout(*mods, xs, n_past, n_eval, period=0)
+    assert rollout.pooled_stream("chain", 1) is rollout.pooled_stream("chain", 1)
+    assert rollout.pooled_stream("chain", 1) is not rollout.pooled_stream("chain", 2)
+    holders = []
+    for _ in range(14):
+        cr = ConcurrentRollouts(*mods, xs, n_past, n_eval, inflight=3, period=0)
+        holders.append(cr)
+        assert all(a is b for a, b in zip(cr.streams, holders[0].streams))
+    for cr in holders:
+        for frames in cr.run(6):
+            torch.cuda.synchronize()
+            assert all(torch.equal(frames[t], ref[t]) for t in range(n_eval))
+    assert len(rollout._streams) <= 8
+
+
 def test_gaussian_encoder_matches_reference_golden(golden):
     """vgg_64.gaussian_encoder (vgg_64.py:108-159) on the HIP path against the outputs of the reference's own module."""
     import dvg_amd.models.vgg_64 as ours

@@ -12,8 +12,9 @@ PART=${PART:-12}
 mkdir -p $out
 if [[ $PART == *1* ]]; then
 # per-kernel durations are taken with ONE rollout in flight (--inflight 1): with several rollouts overlapping, a kernel's
-# duration includes the time it shares the chip with other chains' kernels; the default (3 in flight) is profiled beside it
-B="--steps 10 --warmup 3 --no-check --sustained-s 0 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --inflight 1"
+# duration includes the time it shares the chip with other chains' kernels; the default (3 in flight) is profiled beside it.
+# --tile-policy energy: the one chain runs the kernels the headline's chains run (bench.py's roofline leg times the same ones)
+B="--steps 10 --warmup 3 --no-check --sustained-s 0 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --inflight 1 --tile-policy energy"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_vgg -o vgg -- python3 bench.py --model vgg $B > $out/bench_vgg_under_rocprof.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dcgan -o dcgan -- python3 bench.py --model dcgan $B > $out/bench_dcgan_under_rocprof.log 2>&1 < /dev/null
 B3="--steps 12 --warmup 3 --no-check --sustained-s 0 --no-cpu-baseline --no-train-leg --no-families --no-f32mfma-leg --no-make-gifs-leg --no-extra-legs --no-roofline"
