@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""DIAGNOSTIC (r06, the rehearsal's open issue: profiles/r06_dp_race_bisect.txt): the FIRST train_model backward of one process,
+repeated `--repeats` times on the same batch from the same parameters (optimiser steps disabled), gradients compared bit for bit
+with the first repeat.  The two-rank rehearsal runs local batch 4 where the single-process control of the bisect ran batch 8: this
+tool runs the rehearsal's per-rank SHAPES in one process, optionally with the rehearsal's host-side stall at every BatchNorm call
+(`--meet sync`: stream synchronise, forward and backward), so that a shape-specific fault shows without a second process.
+
+  python tools/diag_repeat_backward.py --model vgg --batch 4 --repeats 30 --meet sync [--diag winoff16,...]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="vgg")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--n_past", type=int, default=2)
+    ap.add_argument("--n_future", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=30)
+    ap.add_argument("--meet", default="none", choices=["none", "sync", "sleep"])
+    ap.add_argument("--diag", default="", help="comma list: nolatent, wgrad1, winoffN / wino2_N (3x3 layers on N x N maps direct / F(2x2))")
+    ap.add_argument("--noise", default="none", choices=["none", "mm", "nan"],
+                    help="a background thread keeps ANOTHER stream of this process busy with 2048^2 fp32 matmuls (nan: of NaN-filled "
+                         "operands, so that whatever those waves leave behind in LDS / registers is poison) - the contention a "
+                         "second process on the device causes, without the second process")
+    ap.add_argument("--fresh_batches", action="store_true", help="a new batch per repeat pair (two repeats per batch)")
+    a = ap.parse_args()
+    import time
+    import torch
+    import train
+    import utils
+    from dvg_amd import fused, ops
+    from dvg_amd.data import SyntheticMovingMNIST
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    argv = ["--model", a.model, "--dataset", "smmnist", "--batch_size", str(a.batch), "--n_past", str(a.n_past),
+            "--n_future", str(a.n_future), "--no_save"]
+    opt = train.build_parser().parse_args(argv)
+    opt.ft, opt.rank, opt.world = True, 0, 1
+    opt.local_batch = a.batch
+    torch.manual_seed(5)
+    tr = train.Trainer(opt, dev)
+    tr.train_mode()
+    diag = set(filter(None, a.diag.split(",")))
+    if "nolatent" in diag:
+        tr.latent_stream = False
+    if "wgrad1" in diag:
+        from dvg_amd import autograd as ag
+        ag.WGRAD_BATCH, ag.DENSE_BATCH = 1, 1
+    for d_ in diag:
+        if d_.startswith("winoff") or d_.startswith("wino2_"):
+            h_ = int(d_.replace("winoff", "").replace("wino2_", ""))
+            for c_ in (64, 128, 256, 512, 1024):
+                for co_ in (64, 128, 256, 512):
+                    fused.WINOGRAD_LAYER_OVERRIDE[(c_, h_, co_)] = 0 if d_.startswith("winoff") else 2
+    if a.meet != "none":
+        tb1, bwd2 = fused._train_bn, ops.bn_act_bwd
+
+        def meet():
+            if a.meet == "sync":
+                torch.cuda.current_stream().synchronize()
+            else:
+                time.sleep(0.001)
+
+        def tb_meet(*ar, **kw):
+            meet()
+            return tb1(*ar, **kw)
+
+        def bwd_meet(*ar, **kw):
+            meet()
+            return bwd2(*ar, **kw)
+        fused._train_bn, ops.bn_act_bwd = tb_meet, bwd_meet
+    T = a.n_past + a.n_future
+    gen = SyntheticMovingMNIST(seq_len=T, seed=77)
+    mods = {"encoder": tr.encoder, "decoder": tr.decoder, "frame_predictor": tr.frame_predictor, "gp_layer": tr.gp_layer,
+            "likelihood": tr.likelihood}
+
+    def grads():
+        out = {}
+        for name, m in mods.items():
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    out[f"{name}.{k}"] = p.grad.detach().clone()
+        return out
+    for o in tr.optimizers():
+        o.step = lambda *args, **kw: None
+    stop = None
+    if a.noise != "none":
+        import threading
+        stop = threading.Event()
+        ns = torch.cuda.Stream()
+        fillv = float("nan") if a.noise == "nan" else 1.0
+        na = torch.full((2048, 2048), fillv, device=dev)
+        nb = torch.full((2048, 2048), fillv, device=dev)
+        nc = torch.empty((2048, 2048), device=dev)
+
+        def noise():
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(ns):
+                while not stop.is_set():
+                    for _ in range(4):
+                        torch.mm(na, nb, out=nc)
+                        nc.add_(na)
+                    ns.synchronize()
+        th = threading.Thread(target=noise, daemon=True)
+        th.start()
+    x = None
+    first, differ, worst = None, 0, {}
+    for r in range(a.repeats):
+        if x is None or (a.fresh_batches and r % 2 == 0):
+            xg, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(a.batch))
+            x = [t.contiguous() for t in xg]
+            first = None
+        tr.optimizer.zero_grad()      # the GP / likelihood gradients, which train_model leaves to accumulate (reference behaviour)
+        tr._train_model_dev(x)
+        torch.cuda.current_stream().synchronize()
+        g = grads()
+        if first is None:
+            first = g
+            continue
+        bad = {}
+        for k, t in g.items():
+            if not torch.equal(t, first[k]):
+                bad[k] = float((t - first[k]).abs().max() / first[k].abs().max().clamp_min(1e-30))
+        if bad:
+            differ += 1
+            top = sorted(bad.items(), key=lambda kv: -kv[1])[:4]
+            print(f"repeat {r}: {len(bad)} of {len(g)} tensors differ; worst {[(k, f'{v:.1e}') for k, v in top]}", flush=True)
+            for k, v in bad.items():
+                worst[k] = max(worst.get(k, 0.0), v)
+    if stop is not None:
+        stop.set()
+        th.join()
+    print(f"diag_repeat_backward: model {a.model} batch {a.batch} T {T} meet {a.meet} noise {a.noise} diag {sorted(diag)}: "
+          f"{differ} of {a.repeats - 1} repeats differ from the first", flush=True)
+    if worst:
+        print("tensors that ever differed:", sorted(worst.items(), key=lambda kv: -kv[1])[:12], flush=True)
+
+
+if __name__ == "__main__":
+    main()
