@@ -1220,17 +1220,19 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
     // parity (py, px) uses are consecutive, slot = (py * 2 + px) * 4 + tt with tap row 2 + py - 2 (tt >> 1) and tap column
     // 2 + px - 2 (tt & 1).  Stride-2 conv: the four taps of an INPUT parity are consecutive, slot = ((a & 1) * 2 + (b & 1)) * 4
     // + (a >> 1) * 2 + (b >> 1).  So a stage's weight tile is contiguous in every mode
-    const long total = (long)cout * cin * kh * kw;
+    // thread = (chunk, tap, co, pair of k): two adjacent k-values, one 4-byte store per plane (winograd.hip, wrow_owner_note)
+    const long total = (long)cout * cin * kh * kw / 2;
     const int nblk = cout >> 6, taps = kh * kw;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = i & 15;
-        long r = i >> 4;
+        const int k = (int)(i & 7) * 2;
+        long r = i >> 3;
         const int co = r % cout; r /= cout;
         const int t = r % taps;
         const int chunk = r / taps;
         const int ci = chunk * 16 + k, a = t / kw, b = t % kw;
         const long j = transposed ? ((((long)ci * cout + co) * kh + (kh - 1 - a)) * kw + (kw - 1 - b))
                                   : ((((long)co * cin + ci) * kh + a) * kw + b);
+        const long j1 = j + (transposed ? (long)cout * kh * kw : (long)kh * kw);        // the same tap of input channel ci + 1
         int slot = t;
         if (transposed && kh == 4 && kw == 4) {
             const int py = a & 1, px = b & 1;
@@ -1239,8 +1241,9 @@ __global__ void pack_k16_kernel(const float* __restrict__ src, float* __restrict
             // the stride-2 conv (PAR4): the four taps of an input parity (a & 1, b & 1) are consecutive
             slot = ((a & 1) * 2 + (b & 1)) * 4 + (a >> 1) * 2 + (b >> 1);
         }
-        wrow_store(dst, (((size_t)chunk * nblk + (co >> 6)) * taps + slot) * 64 + (co & 63), co & 63, k, src[j]);
+        wrow_store_pair(dst, (((size_t)chunk * nblk + (co >> 6)) * taps + slot) * 64 + (co & 63), co & 63, k, src[j], src[j1]);
     }
+    wrow_drain();
 }
 
 }  // namespace dvg
@@ -1262,7 +1265,7 @@ extern "C" int dvg_pack_conv_weight_k16(const float* w, float* w_packed, int cou
     DVG_REQUIRE(w && w_packed, DVG_ERR_NULL, "dvg_pack_conv_weight_k16: NULL pointer");
     DVG_REQUIRE(cout > 0 && cout % 64 == 0 && cin > 0 && cin % 16 == 0 && kh > 0 && kw > 0, DVG_ERR_SHAPE,
                 "dvg_pack_conv_weight_k16: Cin must be a multiple of 16, Cout of 64");
-    const long total = (long)cout * cin * kh * kw;
+    const long total = (long)cout * cin * kh * kw / 2;      // threads: one per pair of k-values
     long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_k16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, w_packed, cout, cin, kh,

@@ -43,30 +43,54 @@ template <typename V> __device__ __forceinline__ void wino_st(V* p, const V& v) 
 #endif
 }
 
+// wrow_owner_note - how the packed rows are written (r06, the open issue of profiles/r06_dp_race_bisect.txt closed).
+// A packed row (96 B: three planes of 16 bf16) used to be written with 2-byte stores (global_store_short), one thread per
+// k-value.  Alone on the device that was right in every run ever compared.  With ANOTHER PROCESS busy on the same device (the
+// one-GPU data-parallel rehearsal: two trainers) the F(4x4) weight transform lost rows: in 1-15 % of its launches a few rows of
+// U kept the previous contents of the buffer - always rows of the LAST transform position (the kernel's last three store
+// instructions) and always the rows of lanes 48-63 of a wave (tools/diag_pack_repeat.py --explain: 193 of 5 700 recomputations
+// differed, 0 without the second process; a data gradient convolved with such a U is off by 1e-2 ... 4e-1).  Not cured by
+// giving every cache line to one workgroup (thread = (chunk, co, k) instead of (co, ci)), nor by s_waitcnt vmcnt(0) before
+// s_endpgm; cured by the form below - thread = (chunk, co, PAIR of k), one 4-byte store per plane (wrow_store_pair), 32-bit index
+// arithmetic: 0 of 17 100 recomputations, 0 of 39 + 20 + 3 training runs that differed in 25-60 % before.  The mechanism below
+// the ISA was not established (the F(2x2) kernel and pack_k16_kernel had the same stores and never failed in 11 400
+// recomputations; they were converted all the same).  Rule kept from it: no sub-dword global stores in this library.
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
-    // thread = (ci, co); writes the 16 transform positions of this filter
-    const long total = (long)cout * cin;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % cin), co = (int)(i / cin);
-        const float* g = w + ((size_t)co * cin + ci) * 9;
-        float t[4][3];   // G g
+    // thread = (chunk, co, pair of k); writes the 16 transform positions of two adjacent filters (wrow_owner_note)
+    const unsigned total = (unsigned)cout * (unsigned)cin / 2;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned rr = i >> 3;
+        const int co = (int)(rr % (unsigned)cout), chunk = (int)(rr / (unsigned)cout), k = (int)(i & 7) * 2;
+        const float* g = w + ((size_t)co * cin + chunk * 16 + k) * 9;       // the two filters are adjacent: 18 floats
+        float t[2][4][3];   // G g
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const float g0 = g[s], g1 = g[3 + s], g2 = g[6 + s];
-            t[0][s] = g0;
-            t[1][s] = 0.5f * (g0 + g1 + g2);
-            t[2][s] = 0.5f * (g0 - g1 + g2);
-            t[3][s] = g2;
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const float g0 = g[9 * e + s], g1 = g[9 * e + 3 + s], g2 = g[9 * e + 6 + s];
+                t[e][0][s] = g0;
+                t[e][1][s] = 0.5f * (g0 + g1 + g2);
+                t[e][2][s] = 0.5f * (g0 - g1 + g2);
+                t[e][3][s] = g2;
+            }
+        const unsigned row0 = ((unsigned)(co >> 6) * (unsigned)(cin / 16) + (unsigned)chunk) * 64u + (unsigned)(co & 63);
+        const unsigned pos_rows = (unsigned)(cout >> 6) * (unsigned)(cin / 16) * 64u;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float r[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+            float r[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                r[e][0] = t[e][a][0];
+                r[e][1] = 0.5f * (t[e][a][0] + t[e][a][1] + t[e][a][2]);
+                r[e][2] = 0.5f * (t[e][a][0] - t[e][a][1] + t[e][a][2]);
+                r[e][3] = t[e][a][2];
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                wrow_store(u, (((size_t)(a * 4 + b) * (cout >> 6) + (co >> 6)) * (cin / 16) + ci / 16) * 64 + (co & 63), co & 63,
-                           ci & 15, r[b]);
+                wrow_store_pair(u, (size_t)(a * 4 + b) * pos_rows + row0, co & 63, k, r[0][b], r[1][b]);
         }
     }
+    wrow_drain();
 }
 
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ v, int N,
@@ -201,22 +225,31 @@ __device__ __forceinline__ void at4(const V (&q)[6], V (&o)[4]) {
 __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
     const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    const long total = (long)cout * cin;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % cin), co = (int)(i / cin);
-        const float* g = w + ((size_t)co * cin + ci) * 9;
-        float t[6][3];
+    // thread = (chunk, co, pair of k): two adjacent input channels, one 4-byte store per plane and position
+    const unsigned total = (unsigned)cout * (unsigned)cin / 2;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i >> 3;
+        const int co = (int)(r % (unsigned)cout), chunk = (int)(r / (unsigned)cout), k = (int)(i & 7) * 2;
+        const float* g = w + ((size_t)co * cin + chunk * 16 + k) * 9;       // the two filters are adjacent: 18 floats
+        float t[2][6][3];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2) t[a][s2] = G[a][0] * g[s2] + G[a][1] * g[3 + s2] + G[a][2] * g[6 + s2];
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2)
+                    t[e][a][s2] = G[a][0] * g[9 * e + s2] + G[a][1] * g[9 * e + 3 + s2] + G[a][2] * g[9 * e + 6 + s2];
+        const unsigned row0 = ((unsigned)(co >> 6) * (unsigned)(cin / 16) + (unsigned)chunk) * 64u + (unsigned)(co & 63);
+        const unsigned pos_rows = (unsigned)(cout >> 6) * (unsigned)(cin / 16) * 64u;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                wrow_store(u, (((size_t)(a * 6 + b) * (cout >> 6) + (co >> 6)) * (cin / 16) + ci / 16) * 64 + (co & 63), co & 63,
-                           ci & 15, t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+                wrow_store_pair(u, (size_t)(a * 6 + b) * pos_rows + row0, co & 63, k,
+                                t[0][a][0] * G[b][0] + t[0][a][1] * G[b][1] + t[0][a][2] * G[b][2],
+                                t[1][a][0] * G[b][0] + t[1][a][1] * G[b][1] + t[1][a][2] * G[b][2]);
     }
+    wrow_drain();
 }
 
 // V = f32x4 / f32x2 / float: channels per thread.  A thread owns a whole 6x6 patch (36 loads, 36 stores), so the grid is
@@ -669,10 +702,10 @@ extern "C" int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, 
     DVG_REQUIRE(cout > 0 && cout % 64 == 0 && cin > 0 && cin % 16 == 0 && (m == 2 || m == 4), DVG_ERR_SHAPE,
                 "dvg_winograd_weight: Cin must be a multiple of 16, Cout of 64, m 2 or 4");
     if (m == 2)
-        hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+        hipLaunchKernelGGL(winograd_weight_kernel, dim3(wgrid((long)cout * cin / 2)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            u_k16, cout, cin);
     else
-        hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wgrid((long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+        hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wgrid((long)cout * cin / 2)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            u_k16, cout, cin);
     return check_launch("dvg_winograd_weight");
 }

@@ -124,13 +124,9 @@ def test_two_ranks_with_sync_bn_train_like_one_process(model, linear, tmp_path):
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
-    if model == "vgg":
-        # KNOWN ISSUE of the REHEARSAL (profiles/r06_dp_race_bisect.txt): two training processes that share ONE GPU and meet at
-        # every BatchNorm call give run-to-run different vgg_64 gradients in ~15 % of runs when the time-batched passes contain
-        # Winograd-form layers (forward values identical; one process, two processes that do not meet, direct-form kernels and
-        # dcgan_64: 0 of 40+ runs each; cause not found).  One process per GPU never has two trainers on a device; the rehearsal
-        # of vgg_64 runs on the direct-form kernels, where it is deterministic (40 of 40).
-        env["DVG_WINOGRAD"] = "0"
+    # (Until the last day of r06 the vgg_64 case ran with DVG_WINOGRAD=0: with a second process on the device the F(4x4) weight
+    # transform lost rows of U in 1-15 % of its launches - winograd.hip, wrow_owner_note; test_packed_weights_with_a_second_process
+    # below guards the fix.)
     script = os.path.join(ROOT, "tools", "dp_equivalence.py")
     common = ["--model", model, "--batch", "8", "--iters", "3"] + (["--linear_lrelu"] if linear else [])
 
@@ -202,3 +198,16 @@ def test_two_ranks_with_sync_bn_train_like_one_process(model, linear, tmp_path):
     # the control: per-replica statistics are a different computation
     assert g_p["median"] > 100 * g_s["median"] and g_p["worst_l2"] > 20 * g_s["worst_l2"] and b_p > 1e-3, (g_p, b_p)
     assert f_p > 5 * f_s and p_p["encoder"] > 3 * p_s["encoder"], (f_p, f_s, p_p, p_s)
+
+
+def test_packed_weights_with_a_second_process_on_the_device():
+    """The per-weight-version cache entries of the training path (packed igemm weights, Winograd-domain weights of the forward
+    and of the data gradient, transposes) recomputed while ANOTHER PROCESS trains on the same device must come out bit-identical
+    every time (tools/diag_pack_repeat.py).  r06: with 2-byte stores the F(4x4) weight transform lost whole rows of U in 1-15 % of
+    its launches under exactly this contention (193 of 5 700 recomputations; 0 alone on the device) - the cause of the one-GPU
+    rehearsal's run-to-run different vgg_64 gradients (profiles/r06_dp_race_bisect.txt)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_pack_repeat.py"), "--noise", "train", "--iters", "40"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "diag_pack_repeat: noise train: 0 differing recomputations" in r.stdout, r.stdout[-2000:]

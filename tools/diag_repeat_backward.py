@@ -22,12 +22,19 @@ def main():
     ap.add_argument("--n_past", type=int, default=2)
     ap.add_argument("--n_future", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=30)
-    ap.add_argument("--meet", default="none", choices=["none", "sync", "sleep"])
+    ap.add_argument("--meet", default="none", choices=["none", "sync", "sleep", "gloo"],
+                    help="what happens at every BatchNorm call, forward and backward: sync = stream synchronise; gloo (under "
+                         "torch.distributed.run, DVG_DP_SHARE_GPU=1 DVG_DP_BACKEND=gloo) = synchronise + a host-side all-reduce of "
+                         "one float: the ranks resume at the same instant, as under --sync_bn")
+    ap.add_argument("--drop_caches", action="store_true", help="forget the per-weight-version caches (packed / Winograd-domain / "
+                    "transposed weights) before every repeat: a launch whose FIRST pass built a bad cache entry then shows it")
+    ap.add_argument("--no_allreduce", action="store_true", help="ranks > 1: gradient all-reduce off (every rank keeps its own gradients)")
     ap.add_argument("--diag", default="", help="comma list: nolatent, wgrad1, winoffN / wino2_N (3x3 layers on N x N maps direct / F(2x2))")
-    ap.add_argument("--noise", default="none", choices=["none", "mm", "nan"],
+    ap.add_argument("--noise", default="none", choices=["none", "mm", "nan", "proc", "procnan", "proctrain"],
                     help="a background thread keeps ANOTHER stream of this process busy with 2048^2 fp32 matmuls (nan: of NaN-filled "
                          "operands, so that whatever those waves leave behind in LDS / registers is poison) - the contention a "
                          "second process on the device causes, without the second process")
+    ap.add_argument("--noise_child", default="", help="(internal) run as the noise process of --noise proc / procnan / proctrain")
     ap.add_argument("--fresh_batches", action="store_true", help="a new batch per repeat pair (two repeats per batch)")
     a = ap.parse_args()
     import time
@@ -38,16 +45,44 @@ def main():
     from dvg_amd.data import SyntheticMovingMNIST
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    from dvg_amd import parallel
+    rank, world, local = parallel.init_distributed() if "RANK" in os.environ else (0, 1, 0)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    if a.noise_child in ("mm", "nan"):
+        # the noise of --noise proc / procnan: ANOTHER PROCESS on the device (own queues, own VMID), until the parent ends it
+        fillv = float("nan") if a.noise_child == "nan" else 1.0
+        na = torch.full((2048, 2048), fillv, device=dev)
+        nc = torch.empty((2048, 2048), device=dev)
+        torch.mm(na, na, out=nc)
+        torch.cuda.synchronize()
+        print("ready", flush=True)
+        t_end = time.time() + 280
+        while time.time() < t_end:
+            for _ in range(4):
+                torch.mm(na, na, out=nc)
+                nc.add_(na)
+            torch.cuda.synchronize()
+        return
+    child = None
+    if a.noise.startswith("proc"):
+        import subprocess
+        kind = {"proc": "mm", "procnan": "nan", "proctrain": "train"}[a.noise]
+        cmd = [sys.executable, os.path.abspath(__file__), "--noise_child", kind, "--model", a.model, "--batch", str(a.batch),
+               "--repeats", "100000", "--meet", a.meet]
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        line = child.stdout.readline()
+        assert line.strip() == "ready", line
     argv = ["--model", a.model, "--dataset", "smmnist", "--batch_size", str(a.batch), "--n_past", str(a.n_past),
             "--n_future", str(a.n_future), "--no_save"]
     opt = train.build_parser().parse_args(argv)
-    opt.ft, opt.rank, opt.world = True, 0, 1
-    opt.local_batch = a.batch
+    opt.ft, opt.rank, opt.world = True, rank, world
+    opt.local_batch = a.batch          # --batch is the PER-RANK batch here
     torch.manual_seed(5)
     tr = train.Trainer(opt, dev)
     tr.train_mode()
+    if a.no_allreduce:
+        tr.set_allreduce(False)
     diag = set(filter(None, a.diag.split(",")))
     if "nolatent" in diag:
         tr.latent_stream = False
@@ -63,9 +98,15 @@ def main():
     if a.meet != "none":
         tb1, bwd2 = fused._train_bn, ops.bn_act_bwd
 
+        token = torch.zeros(1)
+
         def meet():
             if a.meet == "sync":
                 torch.cuda.current_stream().synchronize()
+            elif a.meet == "gloo":
+                torch.cuda.current_stream().synchronize()
+                if world > 1:
+                    torch.distributed.all_reduce(token)
             else:
                 time.sleep(0.001)
 
@@ -92,7 +133,7 @@ def main():
     for o in tr.optimizers():
         o.step = lambda *args, **kw: None
     stop = None
-    if a.noise != "none":
+    if a.noise in ("mm", "nan"):
         import threading
         stop = threading.Event()
         ns = torch.cuda.Stream()
@@ -115,9 +156,14 @@ def main():
     first, differ, worst = None, 0, {}
     for r in range(a.repeats):
         if x is None or (a.fresh_batches and r % 2 == 0):
-            xg, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(a.batch))
-            x = [t.contiguous() for t in xg]
+            xg, _ = utils.normalize_data(opt, torch.cuda.FloatTensor, gen.batch(a.batch * world))
+            x = [t[rank * a.batch:(rank + 1) * a.batch].contiguous() for t in xg]
             first = None
+        if a.noise_child == "train" and r == 1:
+            print("ready", flush=True)
+        if a.drop_caches:
+            from dvg_amd import autograd as ag_
+            ag_._pack_cache.clear()
         tr.optimizer.zero_grad()      # the GP / likelihood gradients, which train_model leaves to accumulate (reference behaviour)
         tr._train_model_dev(x)
         torch.cuda.current_stream().synchronize()
@@ -132,16 +178,26 @@ def main():
         if bad:
             differ += 1
             top = sorted(bad.items(), key=lambda kv: -kv[1])[:4]
-            print(f"repeat {r}: {len(bad)} of {len(g)} tensors differ; worst {[(k, f'{v:.1e}') for k, v in top]}", flush=True)
+            print(f"[rank {rank}] repeat {r}: {len(bad)} of {len(g)} tensors differ; worst {[(k, f'{v:.1e}') for k, v in top]}", flush=True)
             for k, v in bad.items():
                 worst[k] = max(worst.get(k, 0.0), v)
     if stop is not None:
         stop.set()
         th.join()
-    print(f"diag_repeat_backward: model {a.model} batch {a.batch} T {T} meet {a.meet} noise {a.noise} diag {sorted(diag)}: "
+    if child is not None:
+        child.terminate()       # the exact process started above
+        child.wait()
+    print(f"diag_repeat_backward[rank {rank} of {world}, all-reduce {tr.reducer.active()}]: model {a.model} batch {a.batch} T {T} meet {a.meet} noise {a.noise} diag {sorted(diag)}: "
           f"{differ} of {a.repeats - 1} repeats differ from the first", flush=True)
+    # launch-to-launch comparison: a checksum of the LAST repeat's gradients (exact: sums of |g| in fp64, repr'd)
+    tot = sum(float(t.double().abs().sum()) for k, t in g.items() if not k.startswith(("gp_layer", "likelihood")))
+    pick = [k for k in g if k.endswith(("upc3.0.main.0.weight", "c2.0.main.0.weight", "upc5.0.main.0.weight"))][:3]
+    print(f"[rank {rank}] checksum {tot!r} " + " ".join(f"{k}={float(g[k].double().abs().sum())!r}" for k in pick), flush=True)
     if worst:
-        print("tensors that ever differed:", sorted(worst.items(), key=lambda kv: -kv[1])[:12], flush=True)
+        print(f"[rank {rank}] tensors that ever differed:", sorted(worst.items(), key=lambda kv: -kv[1])[:12], flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
