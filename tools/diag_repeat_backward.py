@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""DIAGNOSTIC (r06, the rehearsal's open issue: profiles/r06_dp_race_bisect.txt): the FIRST train_model backward of one process,
-repeated `--repeats` times on the same batch from the same parameters (optimiser steps disabled), gradients compared bit for bit
-with the first repeat.  The two-rank rehearsal runs local batch 4 where the single-process control of the bisect ran batch 8: this
-tool runs the rehearsal's per-rank SHAPES in one process, optionally with the rehearsal's host-side stall at every BatchNorm call
-(`--meet sync`: stream synchronise, forward and backward), so that a shape-specific fault shows without a second process.
+"""DIAGNOSTIC (r06, profiles/r06_dp_race_bisect.txt: how the rehearsal's run-to-run different vgg_64 gradients were traced to the
+F(4x4) weight transform).  The FIRST train_model backward, repeated `--repeats` times INSIDE one launch on the same batch from the
+same parameters (optimiser steps disabled); every repeat's encoder / decoder / LSTM gradients are compared bit for bit with the
+first, and a checksum of the last repeat is printed for launch-to-launch comparison.  Runs as one process or under
+torch.distributed.run (DVG_DP_SHARE_GPU=1 DVG_DP_BACKEND=gloo: the one-GPU rehearsal; --batch is the PER-RANK batch).
+  --meet sync | gloo   what happens at every BatchNorm call (stream synchronise; + a host-side all-reduce: ranks in lock-step)
+  --noise mm | nan     a second STREAM of the process kept busy (NaN operands: poisoned LDS / register leftovers)
+  --noise proc | procnan | proctrain   a second PROCESS on the device (matmuls / another trainer)
+  --drop_caches        forget the per-weight-version caches before every repeat (the amplifier that exposed the fault)
 
-  python tools/diag_repeat_backward.py --model vgg --batch 4 --repeats 30 --meet sync [--diag winoff16,...]
+  python tools/diag_repeat_backward.py --model vgg --batch 4 --repeats 40 --drop_caches --noise proctrain
 """
 import argparse
 import os
