@@ -215,7 +215,11 @@ def test_module_backward_matches_reference_gradients(family, seed, golden):
     with orc.forced_kinks({k: v.double() for k, v in acts.items()}):
         h64, y64, e64, d64 = _oracle_grads(family, esd, dsd, x, gy, gh, torch.float64)
     tag = f"{family}_64/grad"
-    assert rel_err(ho, torch.from_numpy(golden[f"{tag}/h"])) < 1e-4
+    # against the reference's own fp32 latent (which carries the reference's rounding through 13 train-mode BatchNorm layers):
+    # 1e-4 on the product build; the native-f32-MFMA build of the library (DVG_HIP_LIB=...f32mfma.so: the less exact arithmetic,
+    # DESIGN 3.1) measured 1.14e-4 on vgg_64 seed 210 in r06 and gets 1.5e-4.  The fp64 oracle below stays at 1e-4 for both.
+    from dvg_amd._lib import lib
+    assert rel_err(ho, torch.from_numpy(golden[f"{tag}/h"])) < (1e-4 if lib().dvg_mfma_mode() == 1 else 1.5e-4)
     assert rel_err(yo, y64) < 1e-4 and rel_err(ho, h64) < 1e-4
     bad, n, worst = [], 0, [0.0, 0.0]
     for name, r64 in (("enc", e64), ("dec", d64)):
