@@ -92,6 +92,9 @@ __device__ __forceinline__ void bf16x3_split_pair(float a0, float a1, unsigned& 
 // DVG_BF16X3 a row is [3 planes h, m, l][16 bf16], and the two 16-byte halves of every plane are swapped for rows with
 // (co % 64) & 8 (the LDS image of the tile is this memory image: b128 fragment reads of 16 consecutive rows then hit 16
 // distinct 16-byte slots).
+#ifndef DVG_WROW_SHORT_STORES
+#define DVG_WROW_SHORT_STORES 0
+#endif
 // Two adjacent k-values (k even) of a packed row as ONE 4-byte store per plane.
 __device__ __forceinline__ void wrow_store_pair(float* __restrict__ rows, size_t row, int co_local, int k, float v0, float v1) {
 #if DVG_BF16X3
@@ -99,9 +102,19 @@ __device__ __forceinline__ void wrow_store_pair(float* __restrict__ rows, size_t
     unsigned ph, pm, pl;
     bf16x3_split_pair(v0, v1, ph, pm, pl);
     const int pos2 = ((((k >> 3) ^ ((co_local >> 3) & 1)) << 3) + (k & 7)) >> 1;
+#if DVG_WROW_SHORT_STORES   // A/B knob (make variant): the same values as 2 x 2-byte stores per plane - which half of the fix matters
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(d);
+    d16[2 * pos2] = (unsigned short)(ph & 0xffffu);
+    d16[2 * pos2 + 1] = (unsigned short)(ph >> 16);
+    d16[16 + 2 * pos2] = (unsigned short)(pm & 0xffffu);
+    d16[16 + 2 * pos2 + 1] = (unsigned short)(pm >> 16);
+    d16[32 + 2 * pos2] = (unsigned short)(pl & 0xffffu);
+    d16[32 + 2 * pos2 + 1] = (unsigned short)(pl >> 16);
+#else
     d[pos2] = ph;
     d[8 + pos2] = pm;
     d[16 + pos2] = pl;
+#endif
 #else
     (void)co_local;
     rows[row * 16 + k] = v0;
