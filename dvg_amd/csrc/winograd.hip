@@ -44,17 +44,19 @@ template <typename V> __device__ __forceinline__ void wino_st(V* p, const V& v) 
 }
 
 // wrow_owner_note - how the packed rows are written (r06, the open issue of profiles/r06_dp_race_bisect.txt closed).
-// A packed row (96 B: three planes of 16 bf16) used to be written with 2-byte stores (global_store_short), one thread per
-// k-value.  Alone on the device that was right in every run ever compared.  With ANOTHER PROCESS busy on the same device (the
-// one-GPU data-parallel rehearsal: two trainers) the F(4x4) weight transform lost rows: in 1-15 % of its launches a few rows of
-// U kept the previous contents of the buffer - always rows of the LAST transform position (the kernel's last three store
-// instructions) and always the rows of lanes 48-63 of a wave (tools/diag_pack_repeat.py --explain: 193 of 5 700 recomputations
-// differed, 0 without the second process; a data gradient convolved with such a U is off by 1e-2 ... 4e-1).  Not cured by
-// giving every cache line to one workgroup (thread = (chunk, co, k) instead of (co, ci)), nor by s_waitcnt vmcnt(0) before
-// s_endpgm; cured by the form below - thread = (chunk, co, PAIR of k), one 4-byte store per plane (wrow_store_pair), 32-bit index
-// arithmetic: 0 of 17 100 recomputations, 0 of 39 + 20 + 3 training runs that differed in 25-60 % before.  The mechanism below
-// the ISA was not established (the F(2x2) kernel and pack_k16_kernel had the same stores and never failed in 11 400
-// recomputations; they were converted all the same).  Rule kept from it: no sub-dword global stores in this library.
+// Until r06 a packed row (96 B: three planes of 16 bf16) was written one k-value per thread: thread i = (co, ci), 64-bit index
+// arithmetic per store, 2-byte stores.  Alone on the device that was right in every run ever compared.  With ANOTHER PROCESS busy
+// on the same device (the one-GPU data-parallel rehearsal: two trainers) the F(4x4) weight transform lost rows: in 1-15 % of its
+// launches a few rows of U kept the previous contents of the buffer - always rows of the LAST transform position (the kernel's
+// last three store instructions) and always the rows of lanes 48-63 of a wave (tools/diag_pack_repeat.py --explain: 193 of 5 700
+// recomputations differed, 0 without the second process; a data gradient convolved with such a U is off by 1e-2 ... 4e-1).
+// Not cured by giving every cache line to one workgroup (thread = (chunk, co, k)), nor by s_waitcnt vmcnt(0) before s_endpgm.
+// Cured by the form below - thread = (chunk, co, PAIR of k), 32-bit index arithmetic, one 4-byte store per plane
+// (wrow_store_pair): 0 of 17 100 recomputations, 0 of 39 + 20 + 3 training runs that differed in 25-60 % before.  The same form
+// with 2 x 2-byte stores per plane (make variant DEFS=-DDVG_WROW_SHORT_STORES=1) also never failed (0 of 5 700): the store width
+// alone is not the trigger, and what below the ISA made the old kernel lose its last stores was not established (the F(2x2) kernel
+// and pack_k16_kernel had the old form too and never failed in 11 400 recomputations; they were converted all the same).  What
+// guards it is the test, not a theory: tests/test_gpu_multirank.py::test_packed_weights_with_a_second_process_on_the_device.
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
     // thread = (chunk, co, pair of k); writes the 16 transform positions of two adjacent filters (wrow_owner_note)
     const unsigned total = (unsigned)cout * (unsigned)cin / 2;

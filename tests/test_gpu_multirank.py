@@ -203,7 +203,7 @@ def test_two_ranks_with_sync_bn_train_like_one_process(model, linear, tmp_path):
 def test_packed_weights_with_a_second_process_on_the_device():
     """The per-weight-version cache entries of the training path (packed igemm weights, Winograd-domain weights of the forward
     and of the data gradient, transposes) recomputed while ANOTHER PROCESS trains on the same device must come out bit-identical
-    every time (tools/diag_pack_repeat.py).  r06: with 2-byte stores the F(4x4) weight transform lost whole rows of U in 1-15 % of
+    every time (tools/diag_pack_repeat.py).  r06: in its earlier form the F(4x4) weight transform lost whole rows of U in 1-15 % of
     its launches under exactly this contention (193 of 5 700 recomputations; 0 alone on the device) - the cause of the one-GPU
     rehearsal's run-to-run different vgg_64 gradients (profiles/r06_dp_race_bisect.txt)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
