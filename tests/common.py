@@ -19,6 +19,17 @@ BACKBONE_CASES = {
 }
 
 
+def dev():
+    """The device of the GPU tests (they are all marked `gpu`: run on the MI355X box only)."""
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    from dvg_amd import ops
+    return ops.to_nhwc(t.to(dev()))
+
+
 def our_module(family, res):
     return importlib.import_module(f"dvg_amd.models.{family}_{res}")
 

@@ -1,5 +1,6 @@
-"""GPU parity tests: every kernel of libdvg_hip.so, through the C ABI, against the CPU oracle on the
-same seeded inputs, and the whole modules against the golden vectors produced by the REFERENCE.
+"""GPU parity tests, kernel level: every kernel of libdvg_hip.so, through the C ABI, against the CPU oracle on the same seeded
+inputs.  (Modules against the golden vectors produced by the REFERENCE: tests/test_gpu_modules.py; the Winograd forms and their
+hand-over kernels: tests/test_gpu_winograd.py.)
 
 Tolerance: the north star asks for 1e-4 relative on fp32 frames; tests use REL = 1e-4 on
 max|a-b| / max|b| (and a tighter figure where noted).
@@ -11,25 +12,12 @@ import torch.nn.functional as F
 
 from oracle import dvg_oracle as orc
 from oracle import params
-from tests.common import BACKBONE_CASES, backbone_case, oracle_backbone, rel_err, summarize, to64, yardstick
+from tests.common import BACKBONE_CASES, backbone_case, dev, nhwc, oracle_backbone, rel_err, summarize, to64, yardstick
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
 
 
-def dev():
-    assert torch.cuda.is_available()
-    return torch.device("cuda:0")
-
-
-def nhwc(t):
-    from dvg_amd import ops
-    return ops.to_nhwc(t.to(dev()))
-
-
-# ----------------------------------------------------------------------------------------
-# kernel level
-# ----------------------------------------------------------------------------------------
 def test_layout_roundtrip():
     from dvg_amd import ops
     x = params.normal(1, 3, 70, 9, 13).to(dev())
@@ -410,102 +398,6 @@ def test_gp_index_bookkeeping_is_exact():
     assert torch.allclose(gp(h[perm]).mean, a.mean[:, perm], atol=1e-5)
 
 
-# ----------------------------------------------------------------------------------------
-# module level: HIP path vs oracle and vs the REFERENCE's golden vectors
-# ----------------------------------------------------------------------------------------
-TRAIN_BN_BAR = 1e-4      # train-mode module outputs against the fp32 references (see the yardstick in the test)
-
-
-@pytest.mark.parametrize("tag", list(BACKBONE_CASES))
-def test_backbone_modules(tag, golden):
-    enc, dec, esd, dsd, x, vec = backbone_case(tag)
-    training = BACKBONE_CASES[tag][4]
-    with torch.no_grad():
-        h_ref, skips_ref, y_ref, y_h_ref, esd2, dsd2 = oracle_backbone(tag, esd, dsd, x, vec)
-        enc.to(dev()), dec.to(dev())
-        h, skips = enc(x.to(dev()))
-        y = dec([vec.to(dev()), skips])
-        y_h = dec([h, skips])
-    assert h.shape == h_ref.shape and y.shape == y_ref.shape
-    tol = REL
-    if training:
-        # Train-mode BatchNorm divides by batch statistics of B = 2-4 images: fp32 rounding of the convolutions is amplified.
-        # By how much is MEASURED, not assumed: the oracle's arithmetic in fp64 is the truth, its fp32 run (and the
-        # reference's own fp32 outputs, the golden) show what fp32 costs; the HIP result may be no further from the truth
-        # than 4 x the fp32 oracle is (+ 3e-6).  Measured: dcgan_64 0.9-1.9 x on every output; vgg_64 2.85 x on the latent (5.6e-5
-        # against the fp32 oracle's 2.0e-5; r06, native f32-MFMA build with the 256-workgroup tile thresholds: 7.5e-5 = 3.8 x).
-        # r06 attributed the excess (docs/DESIGN_NOTES_r06.md section 4): not the Winograd transforms - every layer in direct form
-        # is noisier - but the summation order of a K-long dot product on the matrix pipe (one accumulator per output) against
-        # the host library's blocked sums, which the head's BatchNorm over four samples amplifies; it moves with the tile a
-        # launch takes.  The bar against the fp32 references stays the 1e-4 of north_star (largest HIP deviation measured: 7.5e-5).
-        with torch.no_grad():
-            h64, skips64, y64, y_h64, _, _ = oracle_backbone(tag, to64(esd), to64(dsd), x.double(), vec.double())
-        for nm, a, r32, r64 in [("h", h, h_ref, h64), ("y", y, y_ref, y64), ("y_h", y_h, y_h_ref, y_h64)] + \
-                [(f"skip{i}", s_, sr, s6) for i, (s_, sr, s6) in enumerate(zip(skips, skips_ref, skips64))]:
-            yardstick(f"{tag}/{nm}", a, r32, r64, ratio=4.0, slack=3e-6)
-        yardstick(f"{tag}/y reference golden", y, torch.from_numpy(golden[f"{tag}/y"]), y64, ratio=4.0, slack=3e-6)
-        tol = TRAIN_BN_BAR
-    assert rel_err(h, h_ref) < tol, rel_err(h, h_ref)
-    for s, sr in zip(skips, skips_ref):
-        assert s.shape == sr.shape and rel_err(s, sr) < tol
-    assert rel_err(y, y_ref) < tol and rel_err(y_h, y_h_ref) < tol
-    # against the reference's own outputs
-    assert rel_err(h, torch.from_numpy(golden[f"{tag}/h"])) < tol
-    assert rel_err(y, torch.from_numpy(golden[f"{tag}/y"])) < tol
-    assert rel_err(y_h, torch.from_numpy(golden[f"{tag}/y_h"])) < tol
-    for i, s in enumerate(skips):
-        np.testing.assert_allclose(summarize(s)[3:], golden[f"{tag}/skip{i}"][3:], rtol=0,
-                                   atol=tol * float(np.abs(golden[f"{tag}/skip{i}"][3:]).max()) + 1e-6)
-    if training:
-        sd_e, sd_d = enc.state_dict(), dec.state_dict()
-        for k in golden.files:
-            if k.startswith(f"{tag}/enc/"):
-                assert rel_err(sd_e[k.split("/enc/")[1]], torch.from_numpy(golden[k])) < 1e-4, k
-            if k.startswith(f"{tag}/dec/"):
-                assert rel_err(sd_d[k.split("/dec/")[1]], torch.from_numpy(golden[k])) < 1e-4, k
-
-
-def test_lstm_module(golden):
-    import dvg_amd.models.lstm as ours
-    B = 5
-    net = ours.lstm(90, 90, 256, 2, B)
-    net.load_state_dict(params.fill_state_dict(net.state_dict(), 300))
-    net.to(dev())
-    net.hidden = net.init_hidden()
-    with torch.no_grad():
-        ys = [net(params.normal(310 + t, B, 90, scale=0.5).to(dev())) for t in range(3)]
-    assert rel_err(torch.stack(ys), torch.from_numpy(golden["lstm/y"])) < 1e-5
-    assert rel_err(net.hidden[1][0], torch.from_numpy(golden["lstm/h1"])) < 1e-5
-    assert rel_err(net.hidden[1][1], torch.from_numpy(golden["lstm/c1"])) < 1e-5
-
-
-def test_gaussian_lstm_module(golden):
-    import dvg_amd.models.lstm as ours
-    B = 5
-    net = ours.gaussian_lstm(90, 90, 256, 2, B)
-    net.load_state_dict(params.fill_state_dict(net.state_dict(), 310))
-    net.to(dev())
-    net.hidden = net.init_hidden()
-    g = golden["gaussian_lstm/y"]
-    with torch.no_grad():
-        for t in range(3):
-            z, mu, logvar = net(params.normal(320 + t, B, 90, scale=0.5).to(dev()))
-            assert rel_err(mu, torch.from_numpy(g[t, 1])) < 1e-5 and rel_err(logvar, torch.from_numpy(g[t, 2])) < 1e-5
-            assert z.shape == mu.shape and bool(torch.isfinite(z).all())
-
-
-def test_skip_tensors_are_not_recycled():
-    """SURVEY §8(b) ownership: skips returned by the encoder stay valid across later calls."""
-    enc, dec, esd, dsd, x, vec = backbone_case("dcgan_64/eval")
-    enc.to(dev())
-    with torch.no_grad():
-        h1, s1 = enc(x.to(dev()))
-        keep = [s.clone() for s in s1]
-        for _ in range(3):
-            enc(torch.rand_like(x).to(dev()))
-    assert all(torch.equal(a, b) for a, b in zip(s1, keep))
-
-
 @pytest.mark.parametrize("B,C,H,W", [(3, 1, 64, 64), (2, 3, 128, 128), (2, 2, 9, 23)])
 def test_eval_frames(B, C, H, W):
     """dvg_eval_frames (SSIM + PSNR of utils.eval_seq) against the oracle's float64 restatement of skimage."""
@@ -564,37 +456,6 @@ def test_conv3x3_addend_equals_concat_conv(H, C1, C2, Cout, up):
                     addend=S[:, :, :-1])
 
 
-@pytest.mark.parametrize("family", ["vgg", "dcgan"])
-def test_decoder_skip_hoisting_is_transparent(family):
-    """Calling the eval-mode decoder repeatedly with the SAME skip tensors (a rollout) engages the hoisted skip
-    halves from the second call on; every call still matches the oracle, a modified skip is recomputed, and
-    DVG_SKIP_HOIST semantics (fused.SKIP_HOIST = False) give the same frames."""
-    import importlib
-    from dvg_amd import fused
-    mod = importlib.import_module(f"dvg_amd.models.{family}_64")
-    torch.manual_seed(0)
-    enc, dec = mod.encoder(90, 1).to(dev()).eval(), mod.decoder(90, 1).to(dev()).eval()
-    x = params.frames(110, 4, 1, 64).to(dev())
-    with torch.no_grad():
-        h, skip = enc(x)
-        fused.clear_skip_hoist_cache()
-        fused.SKIP_HOIST = False
-        ref = [dec([h * s, skip]).clone() for s in (1.0, 0.5, -0.25, 0.75)]
-        fused.SKIP_HOIST = True
-        got = [dec([h * s, skip]).clone() for s in (1.0, 0.5, -0.25, 0.75)]
-        engaged = [e for e in fused._skip_seen.values() if e[4] is not None]
-        nblocks = 4 if family == "vgg" else 3   # dcgan's 4th concat layer is the last one (projection cache, ops.py)
-        assert len(engaged) == nblocks and all(e[3] == 4 for e in engaged), "concat blocks hoist from the 2nd call"
-        for a, b in zip(ref, got):
-            assert rel_err(b, a) < 1e-5
-        skip[0].mul_(0.5)                                    # in-place change of one skip tensor
-        fused.SKIP_HOIST = False
-        ref2 = dec([h, skip]).clone()
-        fused.SKIP_HOIST = True
-        assert rel_err(dec([h, skip]), ref2) < 1e-5          # first sighting of the new version: ordinary path
-        assert rel_err(dec([h, skip]), ref2) < 1e-5          # second: recomputed S
-
-
 @pytest.mark.parametrize("H,C1,Cout,N", [(4, 512, 512, 4), (8, 256, 256, 3), (16, 128, 128, 2), (32, 64, 64, 2)])
 def test_upsample_conv3x3_as_transposed_conv(H, C1, Cout, N):
     """conv3x3(nearest_up2(x), W, pad 1) == convT4x4s2(x, K4) with K4 = W (*) ones(2x2) (fused._upconv_packed): the
@@ -616,310 +477,6 @@ def test_upsample_conv3x3_as_transposed_conv(H, C1, Cout, N):
     y2 = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(conv.weight.detach()[:, :C1].contiguous()), sc.to(dev()),
                      sh.to(dev()), upsample=True, addend=nhwc(S))
     assert rel_err(y2, ref) < 2e-5
-
-
-def test_lstm_folded_first_cell_and_state_only_step():
-    """Inference runs the first LSTMCell with the embedding folded in (dvg_lstm_cell_x: W_x = W_ih W_e); it must agree with
-    the unfolded path (embed GEMM + dvg_lstm_cell, what autograd mode runs) and with the oracle, for several batch sizes
-    incl. one that is not a multiple of the 8-row wave block; step_state_only() advances the state exactly like forward()."""
-    import dvg_amd.models.lstm as ours
-    for B in (5, 64):
-        net = ours.lstm(90, 90, 256, 2, B)
-        sd = params.fill_state_dict(net.state_dict(), 300)
-        net.load_state_dict(sd)
-        net.to(dev()).eval()
-        xs = [params.normal(330 + t, B, 90, scale=0.5) for t in range(3)]
-        hidden = orc.lstm_init_hidden(B, 256, 2)
-        ref = [orc.lstm_step(x, sd, hidden) for x in xs]
-        net.hidden = net.init_hidden()
-        with torch.no_grad():
-            folded = [net(x.to(dev())) for x in xs]
-        h_folded = [t.clone() for pair in net.hidden for t in pair]
-        net.hidden = net.init_hidden()
-        unfolded = [net(x.to(dev()).requires_grad_(True)) for x in xs]     # autograd mode: embed GEMM + dvg_lstm_cell
-        for a, b, r in zip(folded, unfolded, ref):
-            assert rel_err(a, r) < 1e-5 and rel_err(b, r) < 1e-5 and rel_err(a, b) < 1e-5
-        net.hidden = net.init_hidden()
-        with torch.no_grad():
-            for x in xs:
-                net.step_state_only(x.to(dev()))
-        for a, b in zip(h_folded, [t for pair in net.hidden for t in pair]):
-            assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("family", ["vgg", "dcgan"])
-def test_decoder_stem_kernel_matches_generic_gemm(family):
-    """Eval-mode decoder stem through dvg_stem_gemm (transposed, zero-padded weight) against the generic small-M GEMM."""
-    import importlib
-    from dvg_amd import fused, ops
-    mod = importlib.import_module(f"dvg_amd.models.{family}_64")
-    dec = mod.decoder(90, 1)
-    dec.load_state_dict(params.fill_state_dict(dec.state_dict(), 77, params.decoder_transposed_keys(dec.state_dict(), family)))
-    dec.to(dev()).eval()
-    conv, bn = dec.upc1[0], dec.upc1[1]
-    for B in (3, 64, 100):
-        vec = params.normal(78, B, 90, scale=0.5).to(dev())
-        with torch.no_grad():
-            got = fused.stem_bn_act(conv, bn, vec)
-            sc, sh = fused.folded_affine(conv, bn)
-            ref = ops.gemm_nt(vec, fused.gemm_weight(conv, "stem"), sc, sh, act=ops.ACT_LRELU, slope=0.2, period=512)
-        assert got.shape == (B, 512, 4, 4)
-        assert rel_err(got.permute(0, 2, 3, 1).reshape(B, -1), ref) < 1e-5
-
-
-@pytest.mark.parametrize("N,H,C1,Cout", [(32, 4, 512, 512), (8, 8, 256, 256), (2, 16, 128, 128), (64, 8, 256, 256)])
-def test_upsample_conv3x3_winograd_with_hoisted_skip_half(N, H, C1, Cout):
-    """The x half of a decoder block's first conv (vgg_64.py:93,98-105) in Winograd F(4x4,3x3) form: the input transform
-    reads x through the nearest-x2 upsampling (dvg_winograd_input(upsample=1)), the hoisted skip half S enters the output
-    transform as `addend`: y = act((conv3x3(up2(x), W_x) + S) * scale + shift) against the fp64 reference and against the
-    transposed-conv (K4) form it replaces; handed over to the next layer (to_v) it must give that layer bit-identical results."""
-    from dvg_amd import ops
-    x = params.normal(3000, N, C1, H, H)
-    w = params.normal(3001, Cout, C1, 3, 3, scale=1.2 / (3 * C1 ** 0.5))
-    w2 = params.normal(3002, Cout, Cout, 3, 3, scale=1.2 / (3 * Cout ** 0.5))
-    sc, sh = 1 + 0.1 * params.normal(3003, Cout), 0.1 * params.normal(3004, Cout)
-    S = params.normal(3005, N, Cout, 2 * H, 2 * H, scale=0.3)
-    d = lambda t: t.to(dev())   # noqa: E731
-    up = F.interpolate(x, scale_factor=2, mode="nearest").double()
-    ref = F.leaky_relu((F.conv2d(up, w.double(), padding=1) + S.double()) * sc.double().view(1, -1, 1, 1) +
-                       sh.double().view(1, -1, 1, 1), 0.2)
-    assert ops.winograd_ok(N, C1, 2 * H, 2 * H, Cout, 4)
-    u = ops.winograd_weight(d(w), 4)
-    y = ops.conv3x3_winograd(nhwc(x), u, d(sc), d(sh), upsample=True, addend=nhwc(S))
-    assert y.shape == (N, Cout, 2 * H, 2 * H) and rel_err(y, ref) < 1e-4, rel_err(y, ref)
-    # the form it replaces (fused._upconv_packed): same result up to fp32 summation order
-    k4 = torch.zeros((Cout, C1, 4, 4))
-    for ty in range(3):
-        for tx in range(3):
-            k4[:, :, 2 - ty:4 - ty, 2 - tx:4 - tx] += w[:, :, ty:ty + 1, tx:tx + 1]
-    yk = ops.convT4x4s2(nhwc(x), None, ops.pack_igemm_weight(d(k4.permute(1, 0, 2, 3).contiguous()), transposed=True), d(sc),
-                        d(sh), addend=nhwc(S))
-    assert rel_err(y, yk) < 5e-5
-    if ops.winograd_chain_ok(N, Cout, 2 * H, 2 * H):
-        u2 = ops.winograd_weight(d(w2), 4)
-        v = ops.conv3x3_winograd(nhwc(x), u, d(sc), d(sh), upsample=True, addend=nhwc(S), to_v=True)
-        assert isinstance(v, ops.WinoV)
-        assert torch.equal(ops.conv3x3_winograd(v, u2, d(sc), d(sh)), ops.conv3x3_winograd(y, u2, d(sc), d(sh)))
-
-
-def test_rollout_precomputes_frozen_skip_halves_on_a_second_stream():
-    """rollout.condition() computes the decoder's loop-invariant skip halves on a side stream while the LSTM warm-up runs;
-    the rollout must equal the one without hoisting, eager and as a hipGraph."""
-    from dvg_amd import fused
-    from dvg_amd.rollout import GraphedRollout, sample_rollout
-    from tests.test_gpu_configs import _build
-    B, n_past, n_eval = 8, 4, 9
-    for family in ("dcgan", "vgg"):
-        mods, _ = _build(family, 64, 1, B, 1900)
-        for m in mods:
-            m.to(dev()).eval()
-        xs = [params.frames(1910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
-        fused.SKIP_HOIST = False
-        try:
-            plain = sample_rollout(*mods, xs, n_past, n_eval, period=0)
-        finally:
-            fused.SKIP_HOIST = True
-        fused.clear_skip_hoist_cache()
-        hoisted = sample_rollout(*mods, xs, n_past, n_eval, period=0)
-        assert any(e[4] is not None for e in fused._skip_seen.values()), "skip halves must have been precomputed"
-        g = GraphedRollout(*mods, xs, n_past, n_eval, period=0)
-        replay = [f.clone() for f in g()]
-        for t in range(n_eval):
-            assert rel_err(hoisted[t], plain[t]) < 2e-5 and rel_err(replay[t], plain[t]) < 2e-5, (family, t)
-
-
-def test_concurrent_rollouts_equal_the_serial_chain():
-    """rollout.ConcurrentRollouts: three complete rollouts in flight (one hipGraph + one stream each) must each reproduce the
-    eager rollout bit for bit - no buffer may be shared between two graphs - also when replays of different graphs overlap
-    many times over and new inputs are handed in between runs."""
-    from dvg_amd import ops
-    from dvg_amd.rollout import ConcurrentRollouts, sample_rollout
-    from tests.test_gpu_configs import _build
-    B, n_past, n_eval = 8, 4, 9
-    for family in ("dcgan", "vgg"):
-        mods, _ = _build(family, 64, 1, B, 2900)
-        for m in mods:
-            m.to(dev()).eval()
-        xs = [params.frames(2910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
-        xs2 = [params.frames(2950 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
-        lat = sample_rollout(*mods, xs, n_past, n_eval, period=0)
-        with ops.tile_policy(True):      # chains in flight are captured with the energy-lean tiles: bit-equal under one policy
-            ref = sample_rollout(*mods, xs, n_past, n_eval, period=0)
-            ref2 = sample_rollout(*mods, xs2, n_past, n_eval, period=0)
-        # ... and the two policies differ only by the order of the fp32 sums inside a tile
-        assert max(rel_err(a, b) for a, b in zip(ref, lat)) < 5e-6
-        cr = ConcurrentRollouts(*mods, xs, n_past, n_eval, inflight=3, period=0)
-        outs = cr.run(11)
-        torch.cuda.synchronize()
-        assert len(outs) == 3
-        for frames in outs:
-            for t in range(n_eval):
-                assert torch.equal(frames[t], ref[t]), (family, t)
-        outs = cr.run(7, xs2)
-        torch.cuda.synchronize()
-        for frames in outs:
-            for t in range(n_eval):
-                assert torch.equal(frames[t], ref2[t]), (family, t)
-        one = cr.run(2, xs, chains=1)
-        torch.cuda.synchronize()
-        assert len(one) == 1 and all(torch.equal(one[0][t], ref[t]) for t in range(n_eval))
-    # with the GP trigger on (period 3: steps 6 of 4..8): every chain draws its OWN base sample per replay from the
-    # captured Philox stream - frames before the trigger step equal the deterministic rollout, frames from it on differ
-    # between chains and between replays of one chain
-    mods, _ = _build("dcgan", 64, 1, B, 2900)
-    for m in mods:
-        m.to(dev()).eval()
-    xs = [params.frames(2910 + t, B, 1, 64).to(dev()) for t in range(n_eval)]
-    with ops.tile_policy(True):
-        ref = sample_rollout(*mods, xs, n_past, n_eval, period=0)
-    cr = ConcurrentRollouts(*mods, xs, n_past, n_eval, inflight=3, period=3)
-    a = [[f.clone() for f in fr] for fr in cr.run(3)]
-    b = [[f.clone() for f in fr] for fr in cr.run(3)]
-    torch.cuda.synchronize()
-    for fr in a + b:
-        for t in range(7):              # frame 6 is the first one decoded from a GP sample (step i = 6)
-            assert torch.equal(fr[t], ref[t]) == (t < 6), t
-        assert all(bool(torch.isfinite(f).all()) for f in fr)
-    assert not torch.equal(a[0][6], a[1][6]) and not torch.equal(a[1][6], a[2][6]) and not torch.equal(a[0][6], b[0][6])
-
-
-@pytest.mark.parametrize("N,H,C,Cout,pool", [(8, 8, 64, 64, False), (8, 8, 512, 256, True), (8, 16, 256, 256, False),
-                                             (64, 8, 256, 512, True), (2, 32, 128, 64, False), (32, 8, 512, 512, True),
-                                             (96, 32, 128, 128, True)])
-def test_winograd_conv3x3_matches_direct_and_fp64(N, H, C, Cout, pool):
-    """Winograd F(2x2,3x3) path (input transform -> 16 batched GEMMs in the igemm kernel's GEMM mode -> output transform with
-    scale / shift / activation / 2x2 max-pool) against the fp64 reference and the direct implicit-GEMM kernel.  r06: cases with
-    Cout % 128 == 0 and >= 256 workgroups of it run their F(4x4) GEMMs on the 128 x 128 tile of the bf16-triple build (64 x 64 per
-    wave, K = 32 per stage, LEAN fragments, two workgroups per CU: (64, 8, 256, 512), (32, 8, 512, 512), (96, 32, 128, 128)), the
-    others on the 64 x 64 tile; the f32-MFMA build has the 64- / 128-row tiles only."""
-    from dvg_amd import ops
-    x = params.normal(2300, N, C, H, H)
-    w = params.normal(2301, Cout, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
-    sc, sh = 1 + 0.1 * params.normal(2302, Cout), 0.1 * params.normal(2303, Cout)
-    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1) +
-                       sh.double().view(1, -1, 1, 1), 0.2)
-    wd = w.to(dev())
-    assert ops.winograd_ok(N, C, H, H, Cout)
-    direct = ops.conv3x3(nhwc(x), None, ops.pack_igemm_weight(wd), sc.to(dev()), sh.to(dev()), pool=pool)
-    yd = direct[0] if pool else direct
-    for m, tol in ((2, 1e-5), (4, 4e-5)):      # F(4x4,3x3) rounds ~5x coarser than F(2x2,3x3) (its transforms scale by up to 8)
-        if not ops.winograd_ok(N, C, H, H, Cout, m):
-            assert m == 4
-            continue
-        out = ops.conv3x3_winograd(nhwc(x), ops.winograd_weight(wd, m), sc.to(dev()), sh.to(dev()), pool=pool)
-        y = out[0] if pool else out
-        assert rel_err(y, ref) < tol, (m, rel_err(y, ref))
-        assert rel_err(y, yd) < tol
-        if pool:
-            assert rel_err(out[1], F.max_pool2d(ref, 2, 2)) < tol
-            assert torch.equal(out[1], F.max_pool2d(out[0], 2, 2)), "the pooled output is the max of the stored outputs, bit for bit"
-    assert not ops.winograd_ok(4, 512, 8, 8, 512)     # 64 tiles: not a whole GEMM tile -> the caller keeps the direct kernel
-
-
-@pytest.mark.parametrize("family,B", [("vgg", 32), ("vgg", 8)])
-def test_eval_backbone_at_winograd_batch_matches_oracle(family, B):
-    """The golden cases run at B <= 4, where no layer has enough output tiles for the Winograd path; here the eval-mode
-    encoder -> decoder runs at a batch where the deep 3x3 layers DO take it (B = 32: F(4x4) on 8x8 / 16x16 / 32x32 maps; B = 8:
-    F(2x2) on 8x8, F(4x4) above) and must still match the oracle (pinned to the reference) within the 1e-4 bar."""
-    from dvg_amd import fused, ops
-    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
-    x = params.frames(2400, B, 1, 64)
-    with torch.no_grad():
-        h_ref, skips_ref = orc.vgg_encoder(x, esd, False)
-        y_ref = orc.vgg_decoder(h_ref, skips_ref, dsd, False)
-    enc.to(dev()).eval(), dec.to(dev()).eval()
-    used = []
-    real = ops.conv3x3_winograd
-    ops.conv3x3_winograd = lambda xx, u, *a, **k: (used.append((u.shape[0], tuple(xx.shape))), real(xx, u, *a, **k))[1]
-    try:
-        with torch.no_grad():
-            h, skips = enc(x.to(dev()))
-            y = dec([h, skips])
-    finally:
-        ops.conv3x3_winograd = real
-    if fused.WINOGRAD == 4:      # (under DVG_WINOGRAD=0 / 2 the same parity bars apply to whatever path runs)
-        assert len(used) >= 8 and (36 in {u for u, _ in used}), used
-        if B == 8:
-            assert 16 in {u for u, _ in used}, "8x8 maps at B = 8 have 128 F(2x2) tiles but only 32 F(4x4) tiles"
-    e_h, e_y = rel_err(h, h_ref), rel_err(y, y_ref)
-    print(f"winograd backbone B={B}: rel err latent {e_h:.2e} frame {e_y:.2e} ({len(used)} winograd layers)")
-    assert e_h < 1e-4 and e_y < 1e-4
-    for a, b in zip(skips, skips_ref):
-        assert rel_err(a, b) < 1e-4
-
-
-@pytest.mark.parametrize("N,H,C,Cmid,Cout", [(32, 8, 256, 512, 512), (8, 16, 128, 256, 256), (32, 8, 512, 512, 256),
-                                             (8, 32, 64, 128, 128), (32, 16, 128, 256, 256)])
-def test_winograd_chain_hands_over_the_input_transform(N, H, C, Cmid, Cout):
-    """dvg_winograd_output_input: two consecutive F(4x4,3x3) layers with the first layer's activation never written - the
-    second layer's result equals (bit for bit: same kernels around it, same arithmetic inside) the unchained pair's, and both
-    match the fp64 reference."""
-    from dvg_amd import ops
-    x = params.normal(2500, N, C, H, H)
-    w1 = params.normal(2501, Cmid, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
-    w2 = params.normal(2502, Cout, Cmid, 3, 3, scale=1.2 / (3 * Cmid ** 0.5))
-    s1, b1 = 1 + 0.1 * params.normal(2503, Cmid), 0.1 * params.normal(2504, Cmid)
-    s2, b2 = 1 + 0.1 * params.normal(2505, Cout), 0.1 * params.normal(2506, Cout)
-    mid = F.leaky_relu(F.conv2d(x.double(), w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1), 0.2)
-    ref = F.leaky_relu(F.conv2d(mid, w2.double(), padding=1) * s2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1), 0.2)
-    u1, u2 = ops.winograd_weight(w1.to(dev()), 4), ops.winograd_weight(w2.to(dev()), 4)
-    d = lambda t: t.to(dev())   # noqa: E731
-    y1 = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1))
-    y2 = ops.conv3x3_winograd(y1, u2, d(s2), d(b2))
-    assert ops.winograd_chain_ok(N, Cmid, H, H)
-    v = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1), to_v=True)
-    assert isinstance(v, ops.WinoV) and v.shape == (N, Cmid, H, H)
-    y2c = ops.conv3x3_winograd(v, u2, d(s2), d(b2))
-    assert torch.equal(y2c, y2)
-    assert rel_err(y2c, ref) < 1e-4
-    # three in a row, the last one pooled
-    v2 = ops.conv3x3_winograd(v, u2, d(s2), d(b2), to_v=True) if Cout == Cmid else None
-    if v2 is not None:
-        a = ops.conv3x3_winograd(v2, u2, d(s2), d(b2), pool=True)
-        b = ops.conv3x3_winograd(y2, u2, d(s2), d(b2), pool=True)
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        # ... and the pooled map handed over to the next STAGE as its input transform (dvg_winograd_output_pool_input):
-        # the skip tensor and the next stage's first layer must come out bit-identical to the unchained route
-        if ops.winograd_pool_chain_ok(N, Cout, H, H) and ops.winograd_ok(N, Cout, H // 2, H // 2, Cout, 4):
-            ysk, vp = ops.conv3x3_winograd(v2, u2, d(s2), d(b2), pool=True, to_v=True)
-            assert isinstance(vp, ops.WinoV) and vp.shape == (N, Cout, H // 2, H // 2)
-            assert torch.equal(ysk, b[0])
-            w3 = params.normal(2507, Cout, Cout, 3, 3, scale=1.2 / (3 * Cout ** 0.5))
-            u3 = ops.winograd_weight(w3.to(dev()), 4)
-            assert torch.equal(ops.conv3x3_winograd(vp, u3, d(s2), d(b2)), ops.conv3x3_winograd(b[1], u3, d(s2), d(b2)))
-
-
-def test_eval_rollout_modules_chain_equals_unchained():
-    """vgg_64 encoder -> decoder in eval mode at a Winograd batch with and without the WinoV hand-over (fused.WINOGRAD_CHAIN):
-    identical outputs, and the chained run launches dvg_winograd_output_input."""
-    from dvg_amd import fused, ops
-    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
-    x = params.frames(2600, 32, 1, 64).to(dev())
-    enc.to(dev()).eval(), dec.to(dev()).eval()
-    out = {}
-    for chain in (True, False):
-        old = fused.WINOGRAD_CHAIN
-        fused.WINOGRAD_CHAIN = chain
-        timer = ops.KernelTimer()
-        ops.set_timer(timer)
-        try:
-            with torch.no_grad():
-                h, skips = enc(x)
-                y = dec([h, skips])
-        finally:
-            ops.set_timer(None)
-            fused.WINOGRAD_CHAIN = old
-        out[chain] = (h, skips, y, timer.summary())
-    n_fused = out[True][3].get("winograd_output_input", {}).get("launches", 0)
-    n_pool = out[True][3].get("winograd_output_pool_input", {}).get("launches", 0)
-    assert "winograd_output_input" not in out[False][3] and "winograd_output_pool_input" not in out[False][3], list(out[False][3])
-    if fused.WINOGRAD == 4:
-        assert n_fused >= 5, n_fused
-        if fused._CHAIN_LEVEL >= 2:   # c2.0 -> c2.1 at 32x32 inside the block; c2 -> c3 and c3 -> c4 through the max-pool
-            assert n_fused >= 7 and n_pool == 2, (n_fused, n_pool)   # 5 in the encoder (one of them at 32x32), 2 in the decoder
-    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
-    for a, b in zip(out[True][1], out[False][1]):
-        assert torch.equal(a, b)
 
 
 _PRECISION_PROBE = r"""
@@ -989,197 +546,6 @@ def test_bf16_triple_products_are_as_accurate_as_the_f32_mfma():
         (mx, rms, bias), (mx0, rms0, _) = x3[k], f32[k]
         assert mx < 1.25 * mx0 + 1e-7 and rms < 1.25 * rms0 + 1e-8 and abs(bias) < 5e-7, (k, x3[k], f32[k])
         assert mx < 3e-5 and rms < 1e-5, (k, x3[k])          # the F(4x4) transforms' own rounding dominates: 1-2e-5 max
-
-
-@pytest.mark.parametrize("N", [16, 50])
-def test_first_stage_as_one_launch_matches_two_launches_and_fp64(N):
-    """dvg_conv3x3_first_pair: vgg_64's c1 = vgg_layer(1, 64) -> vgg_layer(64, 64) + MaxPool (vgg_64.py:23-26, 49) in eval mode
-    with the first layer's activation computed inside the second layer's kernel - against the two-launch path (same kernels'
-    arithmetic otherwise) and an fp64 torch composition, skip tensor and pooled map, at a batch that is not a multiple of 8."""
-    import torch.nn as nn
-    from dvg_amd import fused, ops
-    g = torch.Generator().manual_seed(4100 + N)
-    conv0, bn0, conv1, bn1 = nn.Conv2d(1, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.Conv2d(64, 64, 3, 1, 1), nn.BatchNorm2d(64)
-    with torch.no_grad():
-        for conv, bn, fan in ((conv0, bn0, 9), (conv1, bn1, 576)):
-            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / fan) ** 0.5)
-            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
-            bn.weight.copy_(1 + 0.2 * torch.randn(64, generator=g))
-            bn.bias.copy_(0.1 * torch.randn(64, generator=g))
-            bn.running_mean.copy_(0.1 * torch.randn(64, generator=g))
-            bn.running_var.copy_(0.5 + torch.rand(64, generator=g))
-    x = torch.rand(N, 1, 64, 64, generator=g)
-    mods = nn.Sequential(conv0, bn0, nn.LeakyReLU(0.2), conv1, bn1, nn.LeakyReLU(0.2)).double().eval()
-    with torch.no_grad():
-        ref = mods(x.double())
-        ref_pool = F.max_pool2d(ref, 2, 2)
-    for m in (conv0, bn0, conv1, bn1):
-        m.float().to("cuda:0").eval()
-    xd = x.to("cuda:0")
-    with torch.no_grad():
-        assert fused.first_pair_applies(conv0, bn0, conv1, bn1, xd) or not fused.FIRST_PAIR      # (DVG_FIRST_PAIR=0: the encoder takes two launches; the op itself is tested either way)
-        y, yp = fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)
-        h0 = fused.conv3_first_bn_act(conv0, bn0, xd)
-        y2, yp2 = fused.conv3_bn_act(conv1, bn1, h0, pool=True)
-    assert ops.is_nhwc(y) and y.shape == (N, 64, 64, 64) and yp.shape == (N, 64, 32, 32)
-    assert rel_err(y, ref) < 1e-5 and rel_err(yp, ref_pool) < 1e-5, (rel_err(y, ref), rel_err(yp, ref_pool))
-    assert rel_err(y, y2) < 5e-6 and rel_err(yp, yp2) < 5e-6, (rel_err(y, y2), rel_err(yp, yp2))
-    # pooled map == max-pool of the full map the same launch wrote, bit for bit
-    assert torch.equal(yp, F.max_pool2d(y, 2, 2))
-    # and the launch is deterministic (a first version selected the LeakyReLU branch and the zero padding with lane masks
-    # inside the MFMA-interleaved store phase and produced run-to-run different tiles with two workgroups per CU)
-    with torch.no_grad():
-        for _ in range(10):
-            assert torch.equal(fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)[0], y)
-
-
-@pytest.mark.parametrize("N,C,Cmid,Cout", [(32, 512, 256, 256), (64, 256, 128, 128)])
-def test_winograd_chain_through_the_upsampling(N, C, Cmid, Cout):
-    """dvg_winograd_output_up_input: the last layer of a decoder block (8 x 8) hands the input transform of its UPSAMPLED output to
-    the x half of the next block's concat conv (vgg_64.py:93,98-105) - bit-identical to writing the activation and letting
-    that conv transform it through the upsampling (dvg_winograd_output + dvg_winograd_input(upsample = 1)), and both match fp64."""
-    from dvg_amd import ops
-    H = 8
-    x = params.normal(2800, N, C, H, H)
-    w1 = params.normal(2801, Cmid, C, 3, 3, scale=1.2 / (3 * C ** 0.5))
-    w2 = params.normal(2802, Cout, Cmid, 3, 3, scale=1.2 / (3 * Cmid ** 0.5))     # the x half of the next block's concat conv
-    s1, b1 = 1 + 0.1 * params.normal(2803, Cmid), 0.1 * params.normal(2804, Cmid)
-    s2, b2 = 1 + 0.1 * params.normal(2805, Cout), 0.1 * params.normal(2806, Cout)
-    add = params.normal(2807, N, Cout, 2 * H, 2 * H, scale=0.3)                    # the hoisted skip half (raw sums)
-    f64 = lambda t: t.double()   # noqa: E731
-    mid = F.leaky_relu(F.conv2d(f64(x), f64(w1), padding=1) * f64(s1).view(1, -1, 1, 1) + f64(b1).view(1, -1, 1, 1), 0.2)
-    up = F.interpolate(mid, scale_factor=2, mode="nearest")
-    ref = F.leaky_relu((F.conv2d(up, f64(w2), padding=1) + f64(add)) * f64(s2).view(1, -1, 1, 1) + f64(b2).view(1, -1, 1, 1), 0.2)
-    d = lambda t: t.to(dev())   # noqa: E731
-    u1, u2 = ops.winograd_weight(d(w1), 4), ops.winograd_weight(d(w2), 4)
-    assert ops.winograd_up_chain_ok(N, Cmid, H, H)
-    y1 = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1))
-    y2 = ops.conv3x3_winograd(y1, u2, d(s2), d(b2), upsample=True, addend=nhwc(add))
-    v = ops.conv3x3_winograd(nhwc(x), u1, d(s1), d(b1), to_v="up")
-    assert isinstance(v, ops.WinoV) and v.up and v.shape == (N, Cmid, 2 * H, 2 * H)
-    y2c = ops.conv3x3_winograd(v, u2, d(s2), d(b2), upsample=True, addend=nhwc(add))
-    assert torch.equal(y2c, y2)
-    assert rel_err(y2c, ref) < 1e-4, rel_err(y2c, ref)
-    with pytest.raises(RuntimeError):      # an upsampled WinoV is not a same-resolution input transform
-        ops.conv3x3_winograd(v, u2, d(s2), d(b2))
-
-
-@pytest.mark.parametrize("M,K", [(64, 90), (50, 90), (3, 128)])
-def test_stem_hands_over_through_the_upsampling(M, K):
-    """dvg_stem_up_winograd_input == dvg_stem_gemm followed by dvg_winograd_input(upsample = 1), bit for bit (ragged batch, both
-    K paddings), and the stem map it stands for matches an fp64 composition."""
-    from dvg_amd import ops
-    C = 512
-    KP = 96 if K <= 96 else 128
-    vec = params.normal(2820, M, K, scale=0.5).tanh().to(dev())
-    w = params.normal(2821, K, C, 4, 4, scale=0.05)                      # ConvTranspose2d(K, C, 4, 1, 0).weight
-    wt = torch.zeros(KP, 16 * C)
-    wt[:K] = w.permute(0, 2, 3, 1).reshape(K, 16 * C)
-    wt = wt.to(dev())
-    sc, sh = (1 + 0.1 * params.normal(2822, C)).to(dev()), (0.1 * params.normal(2823, C)).to(dev())
-    out = ops.nhwc_empty(M, C, 4, 4, dev())
-    ops.stem_gemm(vec, wt, K, sc, sh, out.permute(0, 2, 3, 1).reshape(M, 16 * C), period=C)
-    ref = F.leaky_relu(torch.einsum("mk,kchw->mchw", vec.double().cpu(), w.double()) * sc.double().cpu().view(1, -1, 1, 1)
-                       + sh.double().cpu().view(1, -1, 1, 1), 0.2)
-    assert rel_err(out, ref) < 1e-5
-    v_ref = torch.empty(36, 4 * M, C, device=dev())
-    from dvg_amd._lib import check, lib
-    check(lib().dvg_winograd_input(out.data_ptr(), v_ref.data_ptr(), M, 8, 8, C, 4, 1, torch.cuda.current_stream().cuda_stream), "in")
-    wv = ops.stem_up_winograd_input(vec, wt, K, sc, sh, C)
-    assert wv.up and wv.shape == (M, C, 8, 8) and torch.equal(wv.v, v_ref)
-
-
-def test_decoder_blocks_hand_over_through_the_upsampling():
-    """vgg_64 decoder in eval mode with frozen skips (a rollout's prediction steps): with DVG_WINOGRAD_CHAIN >= 3 the last layer of
-    upc2 hands upc3's first conv its input transform through `up` (one launch instead of dvg_winograd_output +
-    dvg_winograd_input), and the stem hands upc2's first conv its own (dvg_stem_up_winograd_input instead of dvg_stem_gemm +
-    dvg_winograd_input); frames bit-identical to the level-2 run."""
-    from dvg_amd import fused, ops
-    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
-    enc.to(dev()).eval(), dec.to(dev()).eval()
-    x = params.frames(2810, 32, 1, 64).to(dev())
-    out = {}
-    for level in (3, 2):
-        old = fused._CHAIN_LEVEL
-        fused._CHAIN_LEVEL = level
-        fused.clear_skip_hoist_cache()
-        ops.clear_skip_proj_cache()
-        try:
-            with torch.no_grad():
-                h, skips = enc(x)
-                fused.declare_frozen_skips(skips)
-                dec([h, skips])                     # (the first call computes the hoisted skip halves)
-                timer = ops.KernelTimer()
-                ops.set_timer(timer)
-                y = dec([h, skips])
-                ops.set_timer(None)
-        finally:
-            ops.set_timer(None)
-            fused._CHAIN_LEVEL = old
-        out[level] = (y, timer.summary())
-    fused.clear_skip_hoist_cache()
-    ops.clear_skip_proj_cache()
-    assert torch.equal(out[3][0], out[2][0])
-    if fused.WINOGRAD == 4 and fused.WINOGRAD_CHAIN and fused.SKIP_HOIST and fused.UPCONV_WINOGRAD:
-        assert out[3][1].get("winograd_output_up_input", {}).get("launches", 0) == 1, list(out[3][1])
-        assert out[3][1].get("stem_up_winograd_input", {}).get("launches", 0) == 1, list(out[3][1])    # stem -> upc2 likewise
-        assert "winograd_output_up_input" not in out[2][1] and "stem_up_winograd_input" not in out[2][1]
-        n3 = sum(v["launches"] for v in out[3][1].values())
-        n2 = sum(v["launches"] for v in out[2][1].values())
-        assert n3 == n2 - 2, (n3, n2)
-
-
-def test_skip_tensors_of_part_of_a_batch_are_not_stored():
-    """ABI 8 `y_from` / encoder.encode(x, skips_from=k): a rollout reads the skip tensors of ONE conditioning frame
-    (generate_frames.py:154-157), so the kernels that write an encoder stage's full-resolution output beside its pooled map
-    store it for the images [k, N) only.  Everything that IS returned - latent, the skips of the images [k, N), and through them
-    the decoder's frames - is bit-identical to the call that stores everything, for k = 0 (all), a middle k and k = N (none);
-    memory in front of / behind the shortened skip buffers is untouched (canary)."""
-    from dvg_amd import fused, ops
-    enc, dec, esd, dsd, _, _ = backbone_case("vgg_64/eval")
-    enc.to(dev()).eval(), dec.to(dev()).eval()
-    N = 32
-    x = params.frames(2700, N, 1, 64).to(dev())
-    with torch.no_grad():
-        h_all, skips_all = enc(x)
-        for k in (0, 8, 24, N):
-            timer = ops.KernelTimer()
-            ops.set_timer(timer)
-            try:
-                h, skips = enc.encode(x, skips_from=k)
-            finally:
-                ops.set_timer(None)
-            assert torch.equal(h, h_all)
-            for a, b in zip(skips, skips_all):
-                if k == N:
-                    assert a is None
-                else:
-                    assert a.shape[0] == N - k and ops.is_nhwc(a) and torch.equal(a, b[k:])
-            if fused.WINOGRAD == 4 and fused.FIRST_PAIR and fused._CHAIN_LEVEL >= 2:
-                # the kernels really skipped the stores: algorithmic bytes of the launches shrink by the elided images
-                by = sum(v["bytes"] for v in timer.summary().values())
-                if k == 0:
-                    by0 = by
-                else:
-                    assert by < by0 - 0.9 * 4 * k * sum(s_.numel() // N for s_ in skips_all), (k, by, by0)
-        # op level with canaries around the shortened buffer (a store with the wrong image offset would hit them)
-        m = params.normal(2701, 36, N * 16, 128).to(dev())
-        sc, sh = (1 + 0.1 * params.normal(2702, 128)).to(dev()), (0.1 * params.normal(2703, 128)).to(dev())
-        from dvg_amd._lib import check, lib
-        full = ops.nhwc_empty(N, 128, 16, 16, dev())
-        v_full = torch.empty(36, N * 4, 128, device=dev())
-        check(lib().dvg_winograd_output_pool_input(m.data_ptr(), sc.data_ptr(), sh.data_ptr(), full.data_ptr(), v_full.data_ptr(),
-                                                   N, 16, 16, 128, 1, 0.2, 0, torch.cuda.current_stream().cuda_stream), "full")
-        k = 20
-        per = 16 * 16 * 128
-        buf = torch.full(((N - k + 2) * per,), 7.25, device=dev())
-        v_part = torch.empty_like(v_full)
-        check(lib().dvg_winograd_output_pool_input(m.data_ptr(), sc.data_ptr(), sh.data_ptr(), buf.data_ptr() + 4 * per,
-                                                   v_part.data_ptr(), N, 16, 16, 128, 1, 0.2, k,
-                                                   torch.cuda.current_stream().cuda_stream), "part")
-        assert torch.equal(v_part, v_full)
-        assert bool((buf[:per] == 7.25).all()) and bool((buf[-per:] == 7.25).all())
-        assert torch.equal(buf[per:-per], full.permute(0, 2, 3, 1).reshape(-1)[k * per:])
 
 
 @pytest.mark.parametrize("N,C,H,Cout", [(4, 64, 16, 128), (3, 128, 8, 64)])
