@@ -101,8 +101,8 @@ def winograd_weight(conv: nn.Module, m: int) -> torch.Tensor:
 
 
 # x half of a decoder block's upsample + concat conv in Winograd F(4x4) form when the skip half is hoisted (eval-mode
-# rollouts); DVG_UPCONV_WINOGRAD=0: the transposed-conv (K4) form
-UPCONV_WINOGRAD = os.environ.get("DVG_UPCONV_WINOGRAD", "1") != "0"
+# rollouts); UPCONV_WINOGRAD = False: the transposed-conv (K4) form (module attribute; an environment switch until r06)
+UPCONV_WINOGRAD = True
 _UPCONV_WINO_MAX = 16     # largest output map side that takes this form (32 x 32 measured slower than the K4 transposed form)
 
 
@@ -639,8 +639,8 @@ def conv3_first_bn_act(conv, bn, x_nchw, *, act=ACT_LRELU, slope=0.2):
     return ops.bn_act_apply(u, sc, sh, act=act, slope=slope, inplace=True)
 
 
-# eval mode: the encoder's first stage vgg_layer(1, 64) -> vgg_layer(64, C) (+ pool) as one launch (DVG_FIRST_PAIR=0: two)
-FIRST_PAIR = os.environ.get("DVG_FIRST_PAIR", "1") != "0"
+# eval mode: the encoder's first stage vgg_layer(1, 64) -> vgg_layer(64, C) (+ pool) as one launch (FIRST_PAIR = False: two; module attribute, an environment switch until r06)
+FIRST_PAIR = True
 
 
 def first_pair_applies(conv0, bn0, conv1, bn1, x_nchw) -> bool:

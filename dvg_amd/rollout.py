@@ -52,7 +52,7 @@ def drop_version_keyed_caches() -> None:
 
 
 # make_gifs: the prediction steps before the first GP trigger step once per batch instead of once per sample (GraphedSampler)
-SHARE_PREFIX = os.environ.get("DVG_SHARE_PREFIX", "1") != "0"
+SHARE_PREFIX = True      # module attribute (tests toggle it; generate_frames.py --no_share_prefix); an environment switch until r06
 
 
 def trigger_steps(n_past: int, n_eval: int, period: int = 15) -> List[int]:
@@ -135,8 +135,8 @@ def _zero_hidden(frame_predictor):
 
 # Skip tensors the rollout never reads are not stored (encoder.encode(x, skips_from), VggEncoder.features): of the conditioning
 # batch only the LAST frame's skips survive, and once the skip is frozen (generate_frames.py:154-157) the encoder's skips of
-# every predicted frame are discarded by the caller (`h, _ = h`).  DVG_ELIDE_SKIPS=0: every call stores all of them.
-ELIDE_SKIPS = os.environ.get("DVG_ELIDE_SKIPS", "1") != "0"
+# every predicted frame are discarded by the caller (`h, _ = h`).  ELIDE_SKIPS = False: every call stores all of them (module attribute; an environment switch until r06).
+ELIDE_SKIPS = True
 
 
 def _encode(encoder, x, skips_from=0):
@@ -548,7 +548,7 @@ class GraphedSampler:
     skip-dependent tensors (read-only during their replays); GP base samples eps (D,B) per trigger step, predicted frames
     and metrics are per chain.  `set_batch()` installs a new batch, `run()` replays.
 
-    `share_prefix` (default: DVG_SHARE_PREFIX != 0): the samples of a batch differ only from the first GP trigger step t0 on
+    `share_prefix` (default: rollout.SHARE_PREFIX): the samples of a batch differ only from the first GP trigger step t0 on
     (generate_frames.py:166-171: the draw at i % 15 == 0 is the loop's only source of randomness), so the prediction steps
     n_past ... t0 - 1 - the same kernels on the same inputs for every sample, like the conditioning frames - run ONCE per
     batch and every sample graph continues from the state they leave behind.  Results are bit-identical to the per-sample

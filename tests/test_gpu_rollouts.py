@@ -327,7 +327,7 @@ def test_make_gifs_best_ssim_matches_oracle(inflight, share):
             for j in range(i + 1, 4):
                 assert torch.equal(r[i, :15], r[j, :15]) and not torch.equal(r[i, 15], r[j, 15]), (i, j)
         from dvg_amd import rollout
-        share = share and rollout.SHARE_PREFIX           # DVG_SHARE_PREFIX=0 (the switch matrix) turns the default off
+        share = share and rollout.SHARE_PREFIX           # (the module attribute turns the default off)
         assert g._sampler.share == share and g._sampler.t0 == (15 if share else n_past)
 
 
@@ -369,7 +369,7 @@ def test_make_gifs_shared_prefix_equals_the_per_sample_loop(family):
     import generate_frames
     from dvg_amd import ops, rollout
     B, S = 8, 4
-    old, rollout.SHARE_PREFIX = rollout.SHARE_PREFIX, True     # (also under DVG_SHARE_PREFIX=0: the flag is read per sampler)
+    old, rollout.SHARE_PREFIX = rollout.SHARE_PREFIX, True     # (the flag is read per sampler)
     mods, (esd, dsd, lsd, gsd, lik) = _build(family, 64, 1, B, 1900)
     ckpt = {"encoder": mods[0], "decoder": mods[1], "frame_predictor": mods[2], "likelihood": lik, "gp_layer": gsd}
     for n_past, n_eval in ((10, 20), (10, 14)):

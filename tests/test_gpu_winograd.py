@@ -214,7 +214,7 @@ def test_first_stage_as_one_launch_matches_two_launches_and_fp64(N):
         m.float().to("cuda:0").eval()
     xd = x.to("cuda:0")
     with torch.no_grad():
-        assert fused.first_pair_applies(conv0, bn0, conv1, bn1, xd) or not fused.FIRST_PAIR      # (DVG_FIRST_PAIR=0: the encoder takes two launches; the op itself is tested either way)
+        assert fused.first_pair_applies(conv0, bn0, conv1, bn1, xd) or not fused.FIRST_PAIR      # (FIRST_PAIR off: the encoder takes two launches; the op itself is tested either way)
         y, yp = fused.conv3_first_pair(conv0, bn0, conv1, bn1, xd, pool=True)
         h0 = fused.conv3_first_bn_act(conv0, bn0, xd)
         y2, yp2 = fused.conv3_bn_act(conv1, bn1, h0, pool=True)

@@ -7,8 +7,8 @@
 mkdir -p gpurun_out/switches
 sum=gpurun_out/switches/summary_$(date +%s).txt   # one per call: gpurun merges by file name
 if [ $# -gt 0 ]; then set -- "$@"; else set -- "DVG_HIP_LIB=$PWD/dvg_amd/csrc/libdvg_hip_f32mfma.so" "DVG_WINOGRAD=0" "DVG_WINOGRAD=2" "DVG_WINOGRAD_CHAIN=0" \
-         "DVG_WINOGRAD_CHAIN=1" "DVG_WINOGRAD_CHAIN=2" "DVG_UPCONV_WINOGRAD=0" "DVG_FIRST_PAIR=0" "DVG_ELIDE_SKIPS=0" "DVG_TIME_BATCH=0" "DVG_TIME_BATCH=1" \
-         "DVG_WINOGRAD_WGRAD=0" "DVG_SKIP_HOIST=0" "DVG_UPCONV_AS_CONVT=0" "DVG_LSTM_SEQ=0" "DVG_SHARE_PREFIX=0"; fi
+         "DVG_WINOGRAD_CHAIN=1" "DVG_WINOGRAD_CHAIN=2" "DVG_TIME_BATCH=0" "DVG_TIME_BATCH=1" \
+         "DVG_WINOGRAD_WGRAD=0" "DVG_SKIP_HOIST=0" "DVG_UPCONV_AS_CONVT=0"; fi
 for v in "$@"; do
   echo "== $v" | tee -a $sum
   sel="gpu and not slow"; case "$v" in DVG_HIP_LIB=*) sel="gpu";; esac

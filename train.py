@@ -137,8 +137,8 @@ class Trainer:
         self.time_batched_decoder = os.environ.get("DVG_TIME_BATCH", "2") not in ("0", "1")
         # True (with time_batched) = the LSTM of a teacher-forced closure over the whole sequence at once: one GEMM per
         # non-recurrent product over all S x B rows, one launch per step and layer for the recurrence (models.lstm.
-        # forward_sequence); DVG_LSTM_SEQ=0: one module call per step
-        self.lstm_sequence = os.environ.get("DVG_LSTM_SEQ", "1") != "0"
+        # forward_sequence); lstm_sequence = False: one module call per step (an environment switch until r06)
+        self.lstm_sequence = True
         # True = train_model's latent path (LSTM, GP, latent losses) on a second stream, concurrent with the decoder calls
         self.latent_stream = True
         # True = the closures' losses and their gradients by dvg_frame_losses / dvg_mse_sum_grad, backward seeded with them
