@@ -124,7 +124,7 @@ class Ctx:
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         self.dist = None
-        if self.world > 1 or os.environ.get("DVG_BENCH_FORCE_PG") == "1":
+        if self.world > 1 or os.environ.get("DVG_FORCE_ALLREDUCE") == "1":      # (one rank: the 1-rank RCCL group of the training leg's check)
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

@@ -377,3 +377,29 @@ def test_sync_bn_partial_rows_allreduce_gloo_world2():
     from dvg_amd import fused, ops
     fused.set_sync_bn(None)
     assert fused.sync_bn_world() == 1 and ops.sync_bn_state() is None
+
+
+def test_environment_switches_are_the_documented_ten_and_no_file_is_a_monolith():
+    """"<= 10 switches", "no file > 800 lines outside csrc/".  Every DVG_* environment variable the product
+    reads (package, train.py, generate_frames.py, bench.py) is named in README.md's switch paragraph and there are at most ten;
+    no source file outside dvg_amd/csrc is longer than 800 lines."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "dvg_amd", "**", "*.py"), recursive=True) + \
+        [os.path.join(root, f) for f in ("train.py", "generate_frames.py", "bench.py", "utils.py", "gp_models.py")]
+    read = set()
+    for f in files:
+        read |= set(re.findall(r"environ(?:\.get|\.setdefault)?[\(\[]\s*[\"'](DVG_[A-Z0-9_]+)[\"']", open(f).read()))
+    readme = open(os.path.join(root, "README.md")).read()
+    para = readme[readme.index("Switches (environment"):readme.index("All keep the results within the parity tolerances.")]
+    documented = set(re.findall(r"DVG_[A-Z0-9_]+", para))
+    assert read <= documented, sorted(read - documented)
+    assert len(read) <= 10, sorted(read)
+    long_files = []
+    for pat in ("*.py", "dvg_amd/**/*.py", "tests/*.py", "tools/*.py", "oracle/*.py", "models/*.py", "include/*.h"):
+        for f in glob.glob(os.path.join(root, pat), recursive=True):
+            n = sum(1 for _ in open(f))
+            if n > 800:
+                long_files.append((os.path.relpath(f, root), n))
+    assert not long_files, long_files
