@@ -25,6 +25,7 @@ DEV = "cuda:0"
 FRAME_BAR = 1e-4      # BASELINE.json north_star: "within 1e-4 relative on fp32 frames"
 ELEM_BAR = 6e-4       # element-wise (1 % floor), as tests/test_gpu_generate_config.py
 B, N_PAST, N_EVAL = 64, 10, 20
+S64 = 8              # clips of the batch the fp64 yardstick is computed on
 
 
 def _oracle_tail(frames15, x_in, hidden, skip, enc_o, dec_o, lsd, gsd, lik, eps15):
@@ -72,15 +73,17 @@ def test_headline_rollout_matches_the_oracle(family):
     eps = [params.normal(3140 + k, 90, B) for k in range(3)]
     enc_o, dec_o = _oracle_fns(family, 64, esd, dsd)
     with torch.no_grad():
-        # the statement-for-statement oracle and the split form used for the other two eps agree exactly
-        ref0 = orc.rollout(xs, enc_o, dec_o, lsd, gsd, lik, N_PAST, N_EVAL, {15: eps[0]})
-        ref0b, state = _oracle_rollout_with_state(xs, enc_o, dec_o, lsd, gsd, lik, eps[0])
-        assert all(torch.equal(a, b) for a, b in zip(ref0, ref0b))
+        # the split form (state before step 15 kept, for the other two eps) and the statement-for-statement oracle agree exactly
+        # (checked on dcgan_64, where a second rollout costs a second; vgg_64's costs 6 - 10 s of the suite's time)
+        ref0, state = _oracle_rollout_with_state(xs, enc_o, dec_o, lsd, gsd, lik, eps[0])
+        if family == "dcgan":
+            assert all(torch.equal(a, b) for a, b in zip(orc.rollout(xs, enc_o, dec_o, lsd, gsd, lik, N_PAST, N_EVAL, {15: eps[0]}), ref0))
         refs = [ref0] + [_oracle_tail(*state, enc_o, dec_o, lsd, gsd, lik, e) for e in eps[1:]]
-        # fp64 yardstick for the element-wise figure: the oracle in fp64 = truth
+        # fp64 yardstick for the element-wise figure: the oracle in fp64 = truth, on the first S64 clips (eval mode: every clip is
+        # computed independently of the others - the sub-batch rollout equals the full one's rows to 2e-14 - at an eighth of the time)
         enc_6, dec_6 = _oracle_fns(family, 64, to64(esd), to64(dsd))
-        ref64 = orc.rollout([t.double() for t in xs], enc_6, dec_6, to64(lsd), to64(gsd), to64(lik), N_PAST, N_EVAL,
-                            {15: eps[0].double()})
+        ref64 = orc.rollout([t[:S64].double() for t in xs], enc_6, dec_6, to64(lsd), to64(gsd), to64(lik), N_PAST, N_EVAL,
+                            {15: eps[0][:, :S64].double()})
     for m in mods:
         m.to(DEV).eval()
     xd = [t.to(DEV) for t in xs]
@@ -90,10 +93,10 @@ def test_headline_rollout_matches_the_oracle(family):
     assert len(eager) == N_EVAL
     errs = [rel_err(eager[t], ref0[t]) for t in range(N_EVAL)]
     assert max(errs) < FRAME_BAR, [f"{e:.1e}" for e in errs]
-    e_hip = max(rel_err_elem(eager[t], ref64[t]) for t in range(N_PAST, N_EVAL))
-    e_32 = max(rel_err_elem(ref0[t], ref64[t]) for t in range(N_PAST, N_EVAL))
-    m_hip = max(rel_err(eager[t], ref64[t]) for t in range(N_PAST, N_EVAL))
-    m_32 = max(rel_err(ref0[t], ref64[t]) for t in range(N_PAST, N_EVAL))
+    e_hip = max(rel_err_elem(eager[t][:S64], ref64[t]) for t in range(N_PAST, N_EVAL))
+    e_32 = max(rel_err_elem(ref0[t][:S64], ref64[t]) for t in range(N_PAST, N_EVAL))
+    m_hip = max(rel_err(eager[t][:S64], ref64[t]) for t in range(N_PAST, N_EVAL))
+    m_32 = max(rel_err(ref0[t][:S64], ref64[t]) for t in range(N_PAST, N_EVAL))
     print(f"headline {family}_64 B=64 10/10: HIP vs fp32 oracle max-norm {max(errs):.2e}; vs fp64 max-norm {m_hip:.2e} "
           f"(fp32 oracle {m_32:.2e}); element-wise {e_hip:.2e} (fp32 oracle {e_32:.2e})")
     assert e_hip < ELEM_BAR, (e_hip, e_32)
