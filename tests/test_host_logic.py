@@ -403,3 +403,27 @@ def test_environment_switches_are_the_documented_ten_and_no_file_is_a_monolith()
             if n > 800:
                 long_files.append((os.path.relpath(f, root), n))
     assert not long_files, long_files
+
+
+def test_pooled_streams_are_made_once_per_role_and_index(monkeypatch):
+    """rollout.pooled_stream: torch hands streams out of a pool of 32 per device, round-robin; graph holders that made fresh ones
+    (six per ConcurrentRollouts) wrapped around it in bench.py and hipGraphLaunch crashed (r06).  Every (device, role, index) stream is
+    made once per process and shared by all holders - checked here without a GPU, on a stand-in for torch.cuda.Stream."""
+    import torch
+    from dvg_amd import rollout
+    made = []
+
+    class FakeStream:
+        def __init__(self):
+            made.append(self)
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(rollout, "_streams", {})
+    chains = [[rollout.pooled_stream("chain", k) for k in range(3)] for _ in range(14)]     # 14 holders x 3 chains
+    warm = [rollout.pooled_stream("warmup") for _ in range(14 * 3)]
+    assert all(c[k] is chains[0][k] for c in chains for k in range(3)) and len({id(s) for s in chains[0]}) == 3
+    assert all(w is warm[0] for w in warm) and warm[0] not in chains[0]
+    assert rollout._hoist_stream() is rollout.pooled_stream("hoist")
+    assert len(made) == 5
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)          # another device: its own streams
+    assert rollout.pooled_stream("chain", 0) is not chains[0][0] and len(made) == 6
