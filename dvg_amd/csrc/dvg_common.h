@@ -122,8 +122,8 @@ __device__ __forceinline__ void wrow_store_pair(float* __restrict__ rows, size_t
 #endif
 }
 
-// The last statement of every kernel that writes packed rows: the stores above performed before the wave ends (winograd.hip,
-// wrow_owner_note: tried against the lost rows, did not cure them, kept - these kernels run once per weight version).
+// The last statement of every kernel that writes packed rows: the stores above performed before the wave ends (tried against the
+// zero rows of winograd.hip's wrow_owner_note when they still looked like lost stores; harmless, kept - once per weight version).
 __device__ __forceinline__ void wrow_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {

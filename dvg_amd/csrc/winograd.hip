@@ -43,20 +43,25 @@ template <typename V> __device__ __forceinline__ void wino_st(V* p, const V& v) 
 #endif
 }
 
-// wrow_owner_note - how the packed rows are written (r06, the open issue of profiles/r06_dp_race_bisect.txt closed).
-// Until r06 a packed row (96 B: three planes of 16 bf16) was written one k-value per thread: thread i = (co, ci), 64-bit index
-// arithmetic per store, 2-byte stores.  Alone on the device that was right in every run ever compared.  With ANOTHER PROCESS busy
-// on the same device (the one-GPU data-parallel rehearsal: two trainers) the F(4x4) weight transform lost rows: in 1-15 % of its
-// launches a few rows of U kept the previous contents of the buffer - always rows of the LAST transform position (the kernel's
-// last three store instructions) and always the rows of lanes 48-63 of a wave (tools/diag_pack_repeat.py --explain: 193 of 5 700
-// recomputations differed, 0 without the second process; a data gradient convolved with such a U is off by 1e-2 ... 4e-1).
-// Not cured by giving every cache line to one workgroup (thread = (chunk, co, k)), nor by s_waitcnt vmcnt(0) before s_endpgm.
-// Cured by the form below - thread = (chunk, co, PAIR of k), 32-bit index arithmetic, one 4-byte store per plane
-// (wrow_store_pair): 0 of 17 100 recomputations, 0 of 39 + 20 + 3 training runs that differed in 25-60 % before.  The same form
-// with 2 x 2-byte stores per plane (make variant DEFS=-DDVG_WROW_SHORT_STORES=1) also never failed (0 of 5 700): the store width
-// alone is not the trigger, and what below the ISA made the old kernel lose its last stores was not established (the F(2x2) kernel
-// and pack_k16_kernel had the old form too and never failed in 11 400 recomputations; they were converted all the same).  What
-// guards it is the test, not a theory: tests/test_gpu_multirank.py::test_packed_weights_with_a_second_process_on_the_device.
+// wrow_owner_note - why the two weight transforms have the shape they have (r06, profiles/r06_dp_race_bisect.txt).
+// Until r06 the F(4x4) kernel ran one k-value per thread (thread i = (co, ci), 2-byte stores).  Alone on the device it was right in
+// every run ever compared.  With ANOTHER PROCESS busy on the same device (the one-GPU data-parallel rehearsal: two trainers) 1-30 %
+// of its launches produced a few rows of U that were exactly ZERO: always rows of transform position (5, 5), always the 16 lanes of
+// one VALU pass (tools/diag_pack_repeat.py, tools/diag_old_weight_kernel.py; a data gradient convolved with such a U is off by
+// 1e-2 ... 4e-1 - the rehearsal's run-to-run different vgg_64 gradients).  What the stand-alone copy of that kernel established
+// (tools/ubench/old_weight_kernel.hip, poisoned output buffers, another trainer beside it):
+//   * the zeros are WRITTEN, and the fp32 value the thread computed for position (5, 5) is already 0.0 while the g[8] it read is
+//     right: a wrong VALU result, not a lost or misdirected store (so neither one workgroup per cache line, nor s_waitcnt vmcnt(0)
+//     after every store / before s_endpgm, nor a restored EXEC mask, nor 32-bit index arithmetic changed anything);
+//   * the waves concerned were on the chip no longer than their peers (no context switch);
+//   * position (5, 5) is where G's last row {0, 0, 1} meets itself: value = 0 * t50 + 0 * t51 + 1 * t52, which the compiler
+//     emits as packed FMAs with an inline-constant 0 multiplier (v_pk_fma_f32 ..., 0, ... op_sel_hi; v_pk_add_f32 with op_sel).  With
+//     that row handed in as a kernel ARGUMENT (zeros unknown at compile time): 0 of 720 against 98 of 720 in the same run.
+// Why a packed FMA chain yields 0 for one pass only when another process loads the chip was not established.  The form below (two
+// adjacent filters per thread, so the packed operations carry two real values; 4-byte stores) never failed: 0 of 17 100
+// recomputations under the same contention, 0 of 39 + 20 + 3 training runs that differed in 25-60 % before; the F(2x2) kernel
+// (hand-written transform, no literal zeros) and pack_k16_kernel never failed in any form.  What guards it is the test, not a
+// theory: tests/test_gpu_multirank.py::test_packed_weights_with_a_second_process_on_the_device.
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin) {
     // thread = (chunk, co, pair of k); writes the 16 transform positions of two adjacent filters (wrow_owner_note)
     const unsigned total = (unsigned)cout * (unsigned)cin / 2;

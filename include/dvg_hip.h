@@ -205,8 +205,8 @@ int dvg_convT4x4s2_bn_act_v2(const float* x, const float* skip, const float* w_k
  *   dvg_gemm_batched_k16  M (P, T, Cout) = V x U: P GEMMs; the tensors are passed as P "images" of (T/16) x 16 pixels
  *   dvg_winograd_output   y NHWC (N,H,W,Cout) (+ y_pool, MaxPool2d(2,2) vgg_64.py:49: pool windows never straddle tiles)
  * H, W multiples of m; C, Cout % 64 == 0; T % 128 == 0.
- * r06: dvg_winograd_weight / dvg_pack_conv_weight_k16 were rewritten (same layout, same values) after the m = 4 transform left
- * rows of U unwritten whenever ANOTHER PROCESS was busy on the device ("Sharing a device").                */
+ * r06: dvg_winograd_weight / dvg_pack_conv_weight_k16 were rewritten (same layout, same values) after the m = 4 transform wrote
+ * zero rows into U whenever ANOTHER PROCESS was busy on the device ("Sharing a device").                */
 int dvg_winograd_weight(const float* w_oihw, float* u_k16, int cout, int cin, int m, void* stream);
 /* upsample = 1 (ABI 6, m = 4): x is stored at (N, H/2, W/2, C) and read through nn.UpsamplingNearest2d(2) (vgg_64.py:93) -
  * the x half of a decoder block's first conv in Winograd form; the upsampled tensor never exists.                       */

@@ -125,7 +125,7 @@ def test_two_ranks_with_sync_bn_train_like_one_process(model, linear, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DVG_DP_SHARE_GPU="1", DVG_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
     # (Until the last day of r06 the vgg_64 case ran with DVG_WINOGRAD=0: with a second process on the device the F(4x4) weight
-    # transform lost rows of U in 1-15 % of its launches - winograd.hip, wrow_owner_note; test_packed_weights_with_a_second_process
+    # transform wrote zero rows into U in 1-30 % of its launches - winograd.hip, wrow_owner_note; test_packed_weights_with_a_second_process
     # below guards the fix.)
     script = os.path.join(ROOT, "tools", "dp_equivalence.py")
     common = ["--model", model, "--batch", "8", "--iters", "3"] + (["--linear_lrelu"] if linear else [])
@@ -203,8 +203,8 @@ def test_two_ranks_with_sync_bn_train_like_one_process(model, linear, tmp_path):
 def test_packed_weights_with_a_second_process_on_the_device():
     """The per-weight-version cache entries of the training path (packed igemm weights, Winograd-domain weights of the forward
     and of the data gradient, transposes) recomputed while ANOTHER PROCESS trains on the same device must come out bit-identical
-    every time (tools/diag_pack_repeat.py).  r06: in its earlier form the F(4x4) weight transform lost whole rows of U in 1-15 % of
-    its launches under exactly this contention (193 of 5 700 recomputations; 0 alone on the device) - the cause of the one-GPU
+    every time (tools/diag_pack_repeat.py).  r06: in its earlier form the F(4x4) weight transform wrote whole rows of U as zeros in
+    1-30 % of its launches under exactly this contention (193 of 5 700 recomputations; 0 alone on the device; a wrong packed-FMA result) - the cause of the one-GPU
     rehearsal's run-to-run different vgg_64 gradients (profiles/r06_dp_race_bisect.txt)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_pack_repeat.py"), "--noise", "train", "--iters", "40"],

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""DIAGNOSTIC (r06, profiles/r06_dp_race_bisect.txt): does the F(4x4) weight transform of r05 lose its last stores because the wave
+ends with EXEC = 0?  tools/ubench/libold_weight.so holds that kernel as it was (mode 0) and with EXEC restored + s_waitcnt vmcnt(0)
+before s_endpgm (mode 1); both recompute U `--iters` times per shape while ANOTHER PROCESS trains on the device, every result compared
+bit for bit with the first of its mode.   (build: see the header of tools/ubench/old_weight_kernel.hip)"""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=150)
+    a = ap.parse_args()
+    import torch
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libold_weight.so"))
+    lib.old_weight_transform.restype = ctypes.c_int
+    lib.old_weight_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "diag_repeat_backward.py"), "--noise_child", "train",
+                              "--model", "vgg", "--batch", "4", "--repeats", "100000"], stdout=subprocess.PIPE, text=True)
+    assert child.stdout.readline().strip() == "ready"
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = ((128, 128), (256, 128), (256, 256), (512, 256), (512, 512), (256, 512))
+    ws = {s: torch.randn(s[0], s[1], 3, 3, generator=g).to(dev) for s in shapes}
+    torch.cuda.synchronize()
+
+    def run(mode, s):
+        w = ws[s]
+        u = torch.empty((36, s[1] // 16, 1, s[0], 24), device=dev, dtype=torch.float32)
+        u.fill_(float("nan"))       # poison: a row the kernel does not write cannot look right by holding the previous result
+        dbg = torch.zeros(2 * (s[0] * s[1] // 64), device=dev, dtype=torch.int64) if mode == 5 else (
+            torch.full((2 * s[0] * s[1],), float("nan"), device=dev) if mode == 6 else None)
+        rc = lib.old_weight_transform(w.data_ptr(), u.data_ptr(), s[0], s[1], mode, torch.cuda.current_stream().cuda_stream,
+                                      None if dbg is None else dbg.data_ptr())
+        assert rc == 0, rc
+        run.dbg = dbg
+        return u
+    try:
+        for rnd in range(2):                       # the two modes alternate, twice: same contention for both
+            for mode in (7, 0):
+                bad = n = shown = 0
+                kinds = {}
+                for s in shapes:
+                    first = run(mode, s).clone()
+                    for _ in range(a.iters):
+                        n += 1
+                        out = run(mode, s)
+                        if mode == 6 and not torch.equal(out, first) and shown < 6:
+                            shown += 1
+                            o_, f_ = out.view(torch.int32).reshape(-1, 24), first.view(torch.int32).reshape(-1, 24)
+                            r_ = int(torch.nonzero((o_ != f_).any(dim=1)).reshape(-1)[0])
+                            nch = s[1] // 16
+                            co, ch = ((r_ // 64) // nch % (s[0] // 64)) * 64 + r_ % 64, (r_ // 64) % nch
+                            i0 = co * s[1] + ch * 16
+                            d = run.dbg.reshape(-1, 2)[i0:i0 + 16].cpu()
+                            want = ws[s][co, ch * 16:ch * 16 + 16, 2, 2].cpu()
+                            print(f"   shape {s} row {r_} (position {r_ // (o_.shape[0] // 36)}): stored fp32 value of position 35 / g[8] as the "
+                                  f"kernel read it / the weight: {[(round(float(a_), 4), round(float(b_), 4), round(float(c_), 4)) for (a_, b_), c_ in zip(d.tolist(), want.tolist())][:6]} "
+                                  f"words of the row: {o_[r_].tolist()[:4]}", flush=True)
+                        if mode == 5 and not torch.equal(out, first):
+                            # the waves that wrote the wrong rows (old mapping: thread i = co * cin + ci, wave = i // 64), their time on the chip
+                            o_, f_ = out.view(torch.int32).reshape(-1, 24), first.view(torch.int32).reshape(-1, 24)
+                            rows_ = torch.nonzero((o_ != f_).any(dim=1)).reshape(-1).tolist()
+                            d = run.dbg.reshape(-1, 2)
+                            dur = (d[:, 1] - d[:, 0]).double() * 0.01          # microseconds (100 MHz)
+                            nch = s[1] // 16
+                            waves = set()
+                            for r_ in rows_:
+                                co = ((r_ // 64) // nch % (s[0] // 64)) * 64 + r_ % 64
+                                waves.add((co * s[1] + ((r_ // 64) % nch) * 16) // 64)
+                            ws_ = sorted(waves)[:8]
+                            print(f"   shape {s}: {len(rows_)} wrong rows in {len(waves)} waves; all waves: median {float(dur.median()):.1f} us, "
+                                  f"99.9 % {float(dur.quantile(0.999)):.1f}, max {float(dur.max()):.1f}; the wrong rows' waves: "
+                                  f"{[round(float(dur[w_]), 1) for w_ in ws_]} us; waves above 10 x median: "
+                                  f"{int((dur > 10 * dur.median()).sum())} of {dur.numel()}", flush=True)
+                        if not torch.equal(out, first):
+                            bad += 1
+                            o, f = out.view(torch.int32).reshape(-1, 24), first.view(torch.int32).reshape(-1, 24)
+                            rows = torch.nonzero((o != f).any(dim=1)).reshape(-1)
+                            per_pos = o.shape[0] // 36
+                            for r_ in rows[:50].tolist():
+                                got = out.reshape(-1, 24)[r_]
+                                kind = "poison (never written)" if bool(torch.isnan(got).all()) else (
+                                    "zeros" if int(o[r_].abs().sum()) == 0 else "other values")
+                                key = (kind, f"position {r_ // per_pos}", f"row%4={r_ % 4}", f"{int((o[r_] != f[r_]).sum())}/24 words")
+                                kinds[key] = kinds.get(key, 0) + 1
+                torch.cuda.synchronize()
+                names = {0: "as it was", 1: "EXEC restored + vmcnt(0) before the end", 2: "32-bit loop and index arithmetic",
+                         3: "positions in descending order", 4: "vmcnt(0) after every position's stores",
+                         5: "as it was + per-wave clocks", 6: "as it was + fp32 value of position 35 and g[8] stored as dwords",
+                         7: "G's last row {0, 0, 1} from a kernel argument (no inline-zero multipliers)"}
+                print(f"round {rnd} mode {mode} ({names[mode]}): {bad} of {n} recomputations differ; wrong rows: "
+                      f"{sorted(kinds.items(), key=lambda kv: -kv[1])[:6]}", flush=True)
+    finally:
+        child.terminate()
+        child.wait()
+
+
+if __name__ == "__main__":
+    main()
