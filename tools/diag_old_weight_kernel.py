@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""DIAGNOSTIC (r06, profiles/r06_dp_race_bisect.txt): does the F(4x4) weight transform of r05 lose its last stores because the wave
-ends with EXEC = 0?  tools/ubench/libold_weight.so holds that kernel as it was (mode 0) and with EXEC restored + s_waitcnt vmcnt(0)
-before s_endpgm (mode 1); both recompute U `--iters` times per shape while ANOTHER PROCESS trains on the device, every result compared
-bit for bit with the first of its mode.   (build: see the header of tools/ubench/old_weight_kernel.hip)"""
+"""DIAGNOSTIC (r06, profiles/r06_dp_race_bisect.txt): what makes the F(4x4) weight transform of r05 produce zero rows of U while
+ANOTHER PROCESS trains on the device?  tools/ubench/libold_weight.so holds that kernel as it was (mode 0) and in one-change variants:
+1 EXEC restored + s_waitcnt vmcnt(0) before s_endpgm, 2 32-bit loop / index arithmetic, 3 positions written in descending order,
+4 s_waitcnt vmcnt(0) after every position's stores, 5 per-wave wall clocks, 6 the fp32 value of position (5,5) and g[8] stored as
+dwords, 7 G's last row {0, 0, 1} from a kernel argument.  The modes listed in `for mode in (...)` below recompute U `--iters` times
+per shape into NaN-poisoned buffers beside a training child process; every result is compared bit for bit with the first of its
+mode and the wrong rows are classified.  As committed it runs the experiment that located the fault: mode 7 against mode 0 (0 of 720
+against 98 of 720 launches).   Build: see the header of tools/ubench/old_weight_kernel.hip; 8 s of GPU time per run."""
 import argparse
 import ctypes
 import os
